@@ -1,0 +1,379 @@
+"""TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+
+ctypes front-end of the CPU oracles (``oracle/*.c``): C restatements of the reference
+rasteriser forward pass and PhysTwin spring-mass stepper.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package; nothing under ``real2sim-eval_amd/`` does.
+
+PARITY UNPINNED: the reference has no tests or golden vectors and can be neither built
+nor imported in the authoring container.  The restatement is pinned by
+the builder-authored known-answer tests in ``tests/test_*_kat.py``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libr2s_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the C oracles with gcc (``make -C oracle``)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".inc"))]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.r2s_oracle_raster_forward_f32.restype = C.c_int64
+        _lib.r2s_oracle_raster_forward_f64.restype = C.c_int64
+        _lib.r2s_oracle_higher_msb.restype = C.c_uint32
+        _lib.r2s_oracle_higher_msb.argtypes = [C.c_uint32]
+        _lib.r2s_oracle_max_threads.restype = C.c_int
+        _lib.r2s_oracle_phys_update_collision_f32.restype = C.c_int
+        _lib.r2s_oracle_phys_update_collision_f64.restype = C.c_int
+        _lib.r2s_oracle_mesh_query_f32.restype = C.c_int
+        _lib.r2s_oracle_mesh_query_f64.restype = C.c_int
+    return _lib
+
+
+def set_threads(n: int) -> None:
+    lib().r2s_oracle_set_threads(C.c_int(int(n)))
+
+
+def max_threads() -> int:
+    return int(lib().r2s_oracle_max_threads())
+
+
+def higher_msb(n: int) -> int:
+    return int(lib().r2s_oracle_higher_msb(C.c_uint32(n)))
+
+
+def _f32(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# --------------------------------------------------------------------------------------
+# R0 — camera (sim/utils/gs/transform_utils.py:7-31), float32 like torch .float()
+def setup_camera(w, h, k, w2c, near=0.01, far=100.0, bg=(0, 0, 0), z_threshold=0.2, sh_degree=0):
+    """numpy restatement of ``setup_camera``; returns a dict with the 12 settings fields."""
+    k = np.asarray(k, dtype=np.float64).reshape(3, 3)
+    fx, fy, cx, cy = k[0, 0], k[1, 1], k[0, 2], k[1, 2]
+    w2c32 = np.asarray(w2c, dtype=np.float64).reshape(4, 4).astype(np.float32)
+    cam_center = np.linalg.inv(w2c32.astype(np.float32))[:3, 3].astype(np.float32)
+    view = np.ascontiguousarray(w2c32.T)  # (w2c)^T, i.e. column-major w2c in memory
+    opengl_proj = np.array(
+        [
+            [2 * fx / w, 0.0, -(w - 2 * cx) / w, 0.0],
+            [0.0, 2 * fy / h, -(h - 2 * cy) / h, 0.0],
+            [0.0, 0.0, far / (far - near), -(far * near) / (far - near)],
+            [0.0, 0.0, 1.0, 0.0],
+        ]
+    ).astype(np.float32)
+    full_proj = (view @ opengl_proj.T).astype(np.float32)
+    return dict(
+        image_height=int(h),
+        image_width=int(w),
+        tanfovx=float(w / (2 * fx)),
+        tanfovy=float(h / (2 * fy)),
+        bg=np.asarray(bg, dtype=np.float32),
+        scale_modifier=1.0,
+        viewmatrix=view[None],
+        projmatrix=np.ascontiguousarray(full_proj)[None],
+        sh_degree=int(sh_degree),
+        campos=cam_center,
+        prefiltered=False,
+        z_threshold=float(z_threshold),
+    )
+
+
+# --------------------------------------------------------------------------------------
+def raster_forward(
+    means3D,
+    opacities,
+    viewmatrix,
+    projmatrix,
+    campos,
+    tanfovx,
+    tanfovy,
+    image_height,
+    image_width,
+    bg,
+    shs=None,
+    colors_precomp=None,
+    scales=None,
+    rotations=None,
+    cov3D_precomp=None,
+    scale_modifier=1.0,
+    sh_degree=0,
+    prefiltered=False,
+    z_threshold=0.2,
+    f64=False,
+    debug=False,
+):
+    """Oracle for ``_C.rasterize_gaussians`` (rasterize_points.cu:36-117).
+
+    Returns ``(num_rendered, color[3,H,W], radii[P], depth[1,H,W])`` and, with
+    ``debug=True``, a dict of intermediates as the fifth element.
+    """
+    L = lib()
+    means3D = _f32(means3D).reshape(-1, 3)
+    P = means3D.shape[0]
+    H, W = int(image_height), int(image_width)
+    rt = np.float64 if f64 else np.float32
+    fn = L.r2s_oracle_raster_forward_f64 if f64 else L.r2s_oracle_raster_forward_f32
+    shs = _f32(shs)
+    M = 0
+    if shs is not None and shs.size:
+        shs = shs.reshape(P, -1, 3)
+        M = shs.shape[1]
+    else:
+        shs = None
+    colors_precomp = _f32(colors_precomp)
+    if colors_precomp is not None and colors_precomp.size == 0:
+        colors_precomp = None
+    scales = _f32(scales)
+    rotations = _f32(rotations)
+    cov3D_precomp = _f32(cov3D_precomp)
+    if cov3D_precomp is not None and cov3D_precomp.size == 0:
+        cov3D_precomp = None
+    opacities = _f32(opacities)
+    bg = _f32(bg)
+    vm = _f32(viewmatrix).reshape(16)
+    pm = _f32(projmatrix).reshape(16)
+    cp = _f32(campos).reshape(3)
+    out_color = np.zeros((3, H, W), dtype=rt)
+    out_depth = np.zeros((1, H, W), dtype=rt)
+    radii = np.zeros(P, dtype=np.int32)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    dbg = {}
+    if debug:
+        dbg = dict(
+            final_T=np.zeros((H, W), dtype=rt),
+            n_contrib=np.zeros((H, W), dtype=np.uint32),
+            depths=np.zeros(P, dtype=rt),
+            means2D=np.zeros((P, 2), dtype=rt),
+            conic_opacity=np.zeros((P, 4), dtype=rt),
+            rgb=np.zeros((P, 3), dtype=rt),
+            tiles_touched=np.zeros(P, dtype=np.uint32),
+            ranges=np.zeros((gx * gy, 2), dtype=np.uint32),
+        )
+    cap = 0
+    point_list = None
+    if debug:
+        # first pass to size the list cheaply is not worth it: bound by P * tiles
+        cap = int(min(P * gx * gy, 1 << 27))
+        point_list = np.zeros(max(cap, 1), dtype=np.uint32)
+    n = fn(
+        C.c_int(P), C.c_int(int(sh_degree)), C.c_int(M), _ptr(bg), C.c_int(W), C.c_int(H), _ptr(means3D),
+        _ptr(shs), _ptr(colors_precomp), _ptr(opacities), _ptr(scales), C.c_float(scale_modifier),
+        _ptr(rotations), _ptr(cov3D_precomp), _ptr(vm), _ptr(pm), _ptr(cp), C.c_float(tanfovx),
+        C.c_float(tanfovy), C.c_int(int(bool(prefiltered))), C.c_float(z_threshold), _ptr(out_color),
+        _ptr(out_depth), _ptr(radii), _ptr(dbg.get("final_T")), _ptr(dbg.get("n_contrib")),
+        _ptr(dbg.get("depths")), _ptr(dbg.get("means2D")), _ptr(dbg.get("conic_opacity")), _ptr(dbg.get("rgb")),
+        _ptr(dbg.get("tiles_touched")), _ptr(dbg.get("ranges")), _ptr(point_list), C.c_int64(cap),
+    )
+    n = int(n)
+    if n < 0:
+        raise RuntimeError("Point is filtered although prefiltered is set (device __trap in the reference)")
+    if debug:
+        dbg["point_list"] = point_list[:n].copy()
+        return n, out_color, radii, out_depth, dbg
+    return n, out_color, radii, out_depth
+
+
+# --------------------------------------------------------------------------------------
+def _phys_struct(rt):
+    R = C.c_double if rt == np.float64 else C.c_float
+
+    class Phys(C.Structure):
+        _fields_ = [
+            ("N", C.c_int), ("S", C.c_int), ("n_substeps", C.c_int),
+            ("dt", R), ("dashpot_damping", R), ("drag_damping", R), ("spring_Y_min", R), ("spring_Y_max", R),
+            ("collision_dist", R), ("reverse_factor", R),
+            ("self_collision", C.c_int),
+            ("collide_elas", R), ("collide_fric", R), ("collide_eef_elas", R), ("collide_eef_fric", R),
+            ("collide_self_elas", R), ("collide_self_fric", R),
+            ("springs", C.c_void_p), ("rest", C.c_void_p), ("log_Y", C.c_void_p), ("masses", C.c_void_p),
+            ("masks", C.c_void_p), ("coll_idx", C.c_void_p), ("coll_num", C.c_void_p), ("coll_cap", C.c_int),
+            ("nV", C.c_int), ("nF", C.c_int), ("n_dyn_pts", C.c_int), ("use_pusher", C.c_int),
+            ("mesh_pts", C.c_void_p), ("faces", C.c_void_p), ("mesh_map", C.c_void_p), ("face_map", C.c_void_p),
+            ("interp_pts", C.c_void_p), ("interp_center", C.c_void_p), ("dyn_vel", C.c_void_p),
+            ("dyn_omega", C.c_void_p), ("collision_forces", C.c_void_p),
+        ]
+
+    return Phys
+
+
+_PhysF32 = _phys_struct(np.float32)
+_PhysF64 = _phys_struct(np.float64)
+
+
+class PhysOracle:
+    """One environment of the reference stepper (``SpringMassSystemWarp``), on the CPU.
+
+    Mirrors the constructor contract of spring_mass_warp.py:478-726: ``spring_Y`` is the
+    per-spring LOG stiffness, masks default to ``arange(N)``, meshes are given as lists of
+    ``(vertices[nv,3], triangles[nf,3])`` tuples, dynamic first (mesh_map 0,1,..) then static
+    (-1,-2,..).  ``f64=True`` selects the double-precision shadow.
+    """
+
+    COLL_CAP = 500  # spring_mass_warp.py:545
+
+    def __init__(self, x0, springs, rest, log_Y, *, masses=None, v0=None, dt=5e-5, num_substeps=667,
+                 dashpot_damping=100.0, drag_damping=3.0, spring_Y_min=0.0, spring_Y_max=1e5,
+                 collision_dist=0.005, reverse_z=False, self_collision=True, collide_elas=0.5,
+                 collide_fric=0.3, collide_eef_elas=0.0, collide_eef_fric=1.0, collide_self_elas=0.5,
+                 collide_self_fric=0.3, masks=None, dynamic_meshes=None, static_meshes=None,
+                 use_pusher=False, f64=False):
+        self.f64 = bool(f64)
+        self.rt = np.float64 if f64 else np.float32
+        rt = self.rt
+        self.sfx = "_f64" if f64 else "_f32"
+        self.x = np.ascontiguousarray(np.asarray(x0, dtype=np.float32).astype(rt)).reshape(-1, 3).copy()
+        self.N = self.x.shape[0]
+        self.v = np.zeros_like(self.x) if v0 is None else np.ascontiguousarray(np.asarray(v0, np.float32).astype(rt)).reshape(-1, 3).copy()
+        self.springs = np.ascontiguousarray(np.asarray(springs, dtype=np.int32)).reshape(-1, 2)
+        self.S = self.springs.shape[0]
+        self.rest = np.ascontiguousarray(np.asarray(rest, np.float32).astype(rt))
+        self.log_Y = np.ascontiguousarray(np.asarray(log_Y, np.float32).astype(rt))
+        self.masses = np.ones(self.N, rt) if masses is None else np.ascontiguousarray(np.asarray(masses, np.float32).astype(rt))
+        self.masks = np.arange(self.N, dtype=np.int32) if masks is None else np.ascontiguousarray(np.asarray(masks, np.int32))
+        self.self_collision = bool(self_collision)
+        self.num_substeps = int(num_substeps)
+        self.collision_dist = float(np.float32(collision_dist))
+        self.coll_idx = np.zeros((self.N, self.COLL_CAP), np.int32)
+        self.coll_num = np.zeros(self.N, np.int32)
+        self.use_pusher = bool(use_pusher)
+        # combined mesh, spring_mass_warp.py:626-695
+        verts, faces, mesh_map = [], [], []
+        off = 0
+        n_dyn = 0
+        for mi, (vv, ff) in enumerate(dynamic_meshes or []):
+            vv = np.asarray(vv, np.float32).reshape(-1, 3); ff = np.asarray(ff, np.int32).reshape(-1, 3)
+            verts.append(vv); faces.append(ff + off); off += len(vv); n_dyn += len(vv)
+            mesh_map.append(np.full(len(ff), mi, np.int32))
+        for mi, (vv, ff) in enumerate(static_meshes or []):
+            vv = np.asarray(vv, np.float32).reshape(-1, 3); ff = np.asarray(ff, np.int32).reshape(-1, 3)
+            verts.append(vv); faces.append(ff + off); off += len(vv)
+            mesh_map.append(np.full(len(ff), -1 - mi, np.int32))
+        if verts:
+            self.mesh_pts = np.ascontiguousarray(np.concatenate(verts).astype(rt))
+            self.faces = np.ascontiguousarray(np.concatenate(faces).astype(np.int32))
+            self.mesh_map = np.ascontiguousarray(np.concatenate(mesh_map))
+        else:
+            self.mesh_pts = np.zeros((0, 3), rt); self.faces = np.zeros((0, 3), np.int32); self.mesh_map = np.zeros(0, np.int32)
+        self.nF = len(self.faces)
+        self.face_map = np.arange(self.nF, dtype=np.int32)
+        self.n_dyn_pts = n_dyn
+        self.collision_forces = np.zeros((self.nF, 3), rt)
+        dynp = self.mesh_pts[:n_dyn]
+        # spring_mass_warp.py:699-711 initial values
+        self.interp_pts = np.ascontiguousarray(np.repeat(dynp[None], self.num_substeps, 0))
+        ctr = dynp.mean(0) if n_dyn else np.zeros(3, rt)
+        self.interp_center = np.ascontiguousarray(np.repeat(ctr[None].astype(rt), self.num_substeps, 0))
+        self.dyn_vel = np.zeros((2, 3), rt)
+        self.dyn_omega = np.zeros((1, 3), rt)
+        self.resting = None
+        S = (_PhysF64 if f64 else _PhysF32)()
+        self._S = S
+        S.N, S.S, S.n_substeps = self.N, self.S, self.num_substeps
+        S.dt = float(np.float32(dt)); S.dashpot_damping = float(np.float32(dashpot_damping))
+        S.drag_damping = float(np.float32(drag_damping))
+        S.spring_Y_min = float(np.float32(spring_Y_min)); S.spring_Y_max = float(np.float32(spring_Y_max))
+        S.collision_dist = self.collision_dist
+        S.reverse_factor = -1.0 if reverse_z else 1.0
+        S.self_collision = int(self.self_collision)
+        for k, val in dict(collide_elas=collide_elas, collide_fric=collide_fric, collide_eef_elas=collide_eef_elas,
+                           collide_eef_fric=collide_eef_fric, collide_self_elas=collide_self_elas,
+                           collide_self_fric=collide_self_fric).items():
+            setattr(S, k, float(np.float32(np.asarray(val).reshape(-1)[0])))
+        S.coll_cap = self.COLL_CAP
+        S.nV, S.nF, S.n_dyn_pts, S.use_pusher = len(self.mesh_pts), self.nF, n_dyn, int(self.use_pusher)
+        self._bind()
+        if self.self_collision:
+            self.create_resting_case()
+
+    def _bind(self):
+        S = self._S
+        for name in ("springs", "rest", "log_Y", "masses", "masks", "coll_idx", "coll_num", "mesh_pts", "faces",
+                     "mesh_map", "face_map", "interp_pts", "interp_center", "dyn_vel", "dyn_omega",
+                     "collision_forces"):
+            setattr(S, name, getattr(self, name).ctypes.data)
+
+    def create_resting_case(self):
+        """spring_mass_warp.py:729-740 (N x N byte matrix like the reference)."""
+        self.resting = np.zeros((self.N, self.N), np.uint8)
+        getattr(lib(), "r2s_oracle_phys_build_resting" + self.sfx)(
+            _ptr(self.x), C.c_int(self.N), (C.c_double if self.f64 else C.c_float)(self.collision_dist), _ptr(self.resting))
+
+    def update_collision_graph(self):
+        """spring_mass_warp.py:806-821; returns the largest candidate count seen."""
+        assert self.self_collision
+        return int(getattr(lib(), "r2s_oracle_phys_update_collision" + self.sfx)(
+            _ptr(self.x), _ptr(self.masks), C.c_int(self.N), (C.c_double if self.f64 else C.c_float)(self.collision_dist),
+            _ptr(self.resting), _ptr(self.coll_idx), _ptr(self.coll_num), C.c_int(self.COLL_CAP)))
+
+    def set_mesh_interactive(self, interp_pts, interp_center, dyn_vel, dyn_omega):
+        """spring_mass_warp.py:769-804"""
+        rt = self.rt
+        self.interp_pts = np.ascontiguousarray(np.asarray(interp_pts, np.float32).astype(rt)).reshape(self.num_substeps, self.n_dyn_pts, 3)
+        self.interp_center = np.ascontiguousarray(np.asarray(interp_center, np.float32).astype(rt)).reshape(self.num_substeps, 3)
+        dv = np.asarray(dyn_vel, np.float32).astype(rt).reshape(-1, 3)
+        self.dyn_vel = np.zeros((2, 3), rt); self.dyn_vel[: len(dv)] = dv
+        self.dyn_omega = np.ascontiguousarray(np.asarray(dyn_omega, np.float32).astype(rt)).reshape(1, 3)
+        self._bind()
+
+    def step(self, n_substeps=None, first_substep=0):
+        """spring_mass_warp.py:823-943"""
+        n = self.num_substeps if n_substeps is None else int(n_substeps)
+        getattr(lib(), "r2s_oracle_phys_step" + self.sfx)(
+            C.byref(self._S), _ptr(self.x), _ptr(self.v), C.c_int(int(first_substep)), C.c_int(n))
+        return self.x
+
+
+def phys_step_batch(envs, n_substeps=None):
+    """Step several float32 ``PhysOracle`` environments side by side (OpenMP over envs)."""
+    assert all(not e.f64 for e in envs)
+    n = len(envs)
+    arr = (_PhysF32 * n)(*[e._S for e in envs])
+    xs = (C.c_void_p * n)(*[e.x.ctypes.data for e in envs])
+    vs = (C.c_void_p * n)(*[e.v.ctypes.data for e in envs])
+    ns = envs[0].num_substeps if n_substeps is None else int(n_substeps)
+    lib().r2s_oracle_phys_step_batch_f32(arr, xs, vs, C.c_int(n), C.c_int(0), C.c_int(ns))
+
+
+def mesh_query(pts, faces, p, max_dist=0.02, threshold=0.6, f64=False):
+    rt = np.float64 if f64 else np.float32
+    R = C.c_double if f64 else C.c_float
+    pts = np.ascontiguousarray(np.asarray(pts, np.float32).astype(rt)).reshape(-1, 3)
+    faces = np.ascontiguousarray(np.asarray(faces, np.int32)).reshape(-1, 3)
+    p = np.ascontiguousarray(np.asarray(p, np.float32).astype(rt)).reshape(3)
+    out = np.zeros(6, rt)
+    face = C.c_int(0)
+    fn = lib().r2s_oracle_mesh_query_f64 if f64 else lib().r2s_oracle_mesh_query_f32
+    r = fn(_ptr(pts), C.c_int(len(pts)), _ptr(faces), C.c_int(len(faces)), _ptr(p), R(max_dist), R(threshold),
+           _ptr(out), C.byref(face))
+    return dict(result=bool(r), sign=float(out[0]), u=float(out[1]), v=float(out[2]), point=out[3:6].copy(), face=face.value)

@@ -1,0 +1,677 @@
+// Gaussian-splatting rasteriser forward pass for MI355X (gfx950, wave64).
+//
+// Built from scratch against the behaviour of the reference CUDA rasteriser
+//   third-party/diff-gaussian-rasterization-w-depth/cuda_rasterizer/{forward.cu,rasterizer_impl.cu,auxiliary.h}
+// (forward only, median-depth output).  Pipeline for a batch of F frames (environment x camera view):
+//
+//   k_preprocess   one thread per (frame, Gaussian): cull, project, EWA conic, radius, tile rect, SH->RGB.
+//                  Writes ONE packed 48-byte record per Gaussian (what compositing gathers later).
+//   rocPRIM scan   inclusive sum of tiles_touched over all frames at once.
+//   k_emit_keys    (frame-extended tile id << 32 | depth bits, global Gaussian index) per overlapped tile.
+//   rocPRIM sort   radix_sort_pairs on bits [0, 32 + ceil_log2(F * tiles)) — stable, so ties keep index order.
+//   k_tile_ranges  per (frame, tile) [start, end) in the sorted list.
+//   k_composite    one 256-thread workgroup per 16x16 tile, each of its 4 wavefronts owns an 8x8 pixel
+//                  quadrant; 256 instance records per round are staged through LDS and broadcast-read.
+//
+// Reference lines are cited at each function.  No CUDA compatibility layer: wave64, HIP only.
+
+#include "r2s_common.h"
+#include <rocprim/rocprim.hpp>
+#include "../../include/r2s_raster.h"
+#include <vector>
+
+namespace {
+
+constexpr int TILE = 16;         // BLOCK_X == BLOCK_Y, cuda_rasterizer/config.h:15-16
+constexpr int TILE_THREADS = 256;
+
+struct FrameDev {
+    const float* view;
+    const float* proj;
+    const float* campos;
+    const float* bg;
+    const float* means3D;
+    const float* shs;
+    const float* colors;
+    const float* opac;
+    const float* scales;
+    const float* rots;
+    const float* cov3D;
+    float* out_color;
+    float* out_depth;
+    int* radii;
+    int P, D, M;
+    uint32_t base; // index of this frame's first Gaussian in the per-batch geometry arrays
+    float scale_mod, tan_fovx, tan_fovy, focal_x, focal_y, z_thr;
+    int prefiltered;
+};
+
+// Packed per-Gaussian record read by the compositor: 3 x 16 B.
+//   q0 = (px, py, conic_a, conic_b)   q1 = (conic_c, opacity, depth, r)   q2 = (g, b, 0, 0)
+struct __attribute__((aligned(16))) GeomRec {
+    float4 q0, q1, q2;
+};
+
+// ---- per-Gaussian math -------------------------------------------------------------------------
+
+// ndc2Pix, auxiliary.h:41-44 (double-precision literals promote the expression to double).
+__device__ __forceinline__ float ndc2pix(float v, int S)
+{
+    return (float)((((double)v + 1.0) * S - 1.0) * 0.5);
+}
+
+// getRect, auxiliary.h:46-56.
+__device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int gy, uint32_t& x0, uint32_t& y0,
+                                          uint32_t& x1, uint32_t& y1)
+{
+#pragma clang fp contract(off)
+    x0 = (uint32_t)min(gx, max(0, (int)((px - (float)r) / (float)TILE)));
+    y0 = (uint32_t)min(gy, max(0, (int)((py - (float)r) / (float)TILE)));
+    x1 = (uint32_t)min(gx, max(0, (int)((px + (float)r + (float)TILE - 1.0f) / (float)TILE)));
+    y1 = (uint32_t)min(gy, max(0, (int)((py + (float)r + (float)TILE - 1.0f) / (float)TILE)));
+}
+
+// computeColorFromSH, forward.cu:20-71.
+__device__ __forceinline__ void sh_to_rgb(int idx, int deg, int M, const float* means, const float* campos,
+                                          const float* shs, float rgb[3])
+{
+#pragma clang fp contract(off)
+    constexpr float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    constexpr float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                             0.5462742152960396f};
+    constexpr float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                             -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+    const float* sh = shs + (size_t)idx * M * 3;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (deg > 0) {
+        float dx = means[3 * idx] - campos[0], dy = means[3 * idx + 1] - campos[1], dz = means[3 * idx + 2] - campos[2];
+        float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        x = dx / len; y = dy / len; z = dz / len;
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float res = C0 * sh[ch];
+        if (deg > 0) {
+            res = res - C1 * y * sh[3 + ch] + C1 * z * sh[6 + ch] - C1 * x * sh[9 + ch];
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                res = res + C2[0] * xy * sh[12 + ch] + C2[1] * yz * sh[15 + ch] +
+                      C2[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + C2[3] * xz * sh[21 + ch] +
+                      C2[4] * (xx - yy) * sh[24 + ch];
+                if (deg > 2) {
+                    res = res + C3[0] * y * (3.0f * xx - yy) * sh[27 + ch] + C3[1] * xy * z * sh[30 + ch] +
+                          C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + ch] +
+                          C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
+                          C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + ch] + C3[5] * z * (xx - yy) * sh[42 + ch] +
+                          C3[6] * x * (xx - 3.0f * yy) * sh[45 + ch];
+                }
+            }
+        }
+        res += 0.5f;
+        rgb[ch] = res > 0.f ? res : 0.f; // clamp flags are backward-only and not produced
+    }
+}
+
+// preprocessCUDA, forward.cu:156-257 with in_frustum (auxiliary.h:139-165), computeCov3D (forward.cu:118-152)
+// and computeCov2D (forward.cu:74-113) written out as scalar formulas in GLM's evaluation order.
+__global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__ frames, int gx, int gy, int W, int H,
+                                                    float* __restrict__ depths, int* __restrict__ radii_all,
+                                                    GeomRec* __restrict__ geom, uint32_t* __restrict__ tiles_touched,
+                                                    int* __restrict__ err_flag)
+{
+#pragma clang fp contract(off)
+    const FrameDev& fr = frames[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= fr.P) return;
+    const size_t g = (size_t)fr.base + idx;
+    int radius_out = 0;
+    uint32_t tiles = 0;
+    do {
+        const float* vm = fr.view;
+        const float* pm = fr.proj;
+        const float p0 = fr.means3D[3 * idx], p1 = fr.means3D[3 * idx + 1], p2 = fr.means3D[3 * idx + 2];
+        // in_frustum: only the near/z_threshold test is live (auxiliary.h:155)
+        const float pvz = vm[2] * p0 + vm[6] * p1 + vm[10] * p2 + vm[14];
+        if (pvz <= fr.z_thr) {
+            if (fr.prefiltered) atomicOr(err_flag, 1);
+            break;
+        }
+        const float hx = pm[0] * p0 + pm[4] * p1 + pm[8] * p2 + pm[12];
+        const float hy = pm[1] * p0 + pm[5] * p1 + pm[9] * p2 + pm[13];
+        const float hw = pm[3] * p0 + pm[7] * p1 + pm[11] * p2 + pm[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float projx = hx * p_w, projy = hy * p_w;
+
+        float c3[6];
+        if (fr.cov3D) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c3[k] = fr.cov3D[6 * (size_t)idx + k];
+        } else {
+            const float sx = fr.scale_mod * fr.scales[3 * idx], sy = fr.scale_mod * fr.scales[3 * idx + 1],
+                        sz = fr.scale_mod * fr.scales[3 * idx + 2];
+            const float r = fr.rots[4 * idx], x = fr.rots[4 * idx + 1], y = fr.rots[4 * idx + 2], z = fr.rots[4 * idx + 3];
+            // columns of M = S * R (GLM column-major), M[c][r] = s_r * R[c][r]
+            const float m00 = sx * (1.f - 2.f * (y * y + z * z)), m01 = sy * (2.f * (x * y - r * z)), m02 = sz * (2.f * (x * z + r * y));
+            const float m10 = sx * (2.f * (x * y + r * z)), m11 = sy * (1.f - 2.f * (x * x + z * z)), m12 = sz * (2.f * (y * z - r * x));
+            const float m20 = sx * (2.f * (x * z - r * y)), m21 = sy * (2.f * (y * z + r * x)), m22 = sz * (1.f - 2.f * (x * x + y * y));
+            // Sigma = M^T M : Sigma[c][r] = dot(column r, column c)
+            c3[0] = m00 * m00 + m01 * m01 + m02 * m02;
+            c3[1] = m10 * m00 + m11 * m01 + m12 * m02;
+            c3[2] = m20 * m00 + m21 * m01 + m22 * m02;
+            c3[3] = m10 * m10 + m11 * m11 + m12 * m12;
+            c3[4] = m20 * m10 + m21 * m11 + m22 * m12;
+            c3[5] = m20 * m20 + m21 * m21 + m22 * m22;
+        }
+
+        // computeCov2D
+        float tx = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
+        float ty = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
+        const float tz = pvz;
+        const float limx = 1.3f * fr.tan_fovx, limy = 1.3f * fr.tan_fovy;
+        tx = fminf(limx, fmaxf(-limx, tx / tz)) * tz;
+        ty = fminf(limy, fmaxf(-limy, ty / tz)) * tz;
+        const float J00 = fr.focal_x / tz, J02 = -(fr.focal_x * tx) / (tz * tz);
+        const float J11 = fr.focal_y / tz, J12 = -(fr.focal_y * ty) / (tz * tz);
+        // T = W * J, T[c][r]; W[k][r] = vm[4*r + k]  (W's columns are the rows of the view rotation)
+        float T0[3], T1[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float w0 = vm[4 * r + 0], w1 = vm[4 * r + 1], w2 = vm[4 * r + 2];
+            T0[r] = w0 * J00 + w2 * J02;
+            T1[r] = w1 * J11 + w2 * J12;
+        }
+        // V[a][b], symmetric
+        const float V[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+        // A = T^T V^T : A[k][r] = T[r][0] V[0][k] + T[r][1] V[1][k] + T[r][2] V[2][k]   (rows r = 0,1 only)
+        float A0[3], A1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            A0[k] = T0[0] * V[0][k] + T0[1] * V[1][k] + T0[2] * V[2][k];
+            A1[k] = T1[0] * V[0][k] + T1[1] * V[1][k] + T1[2] * V[2][k];
+        }
+        float cov_xx = A0[0] * T0[0] + A0[1] * T0[1] + A0[2] * T0[2];
+        const float cov_xy = A1[0] * T0[0] + A1[1] * T0[1] + A1[2] * T0[2];
+        float cov_yy = A1[0] * T1[0] + A1[1] * T1[1] + A1[2] * T1[2];
+        cov_xx += 0.3f;
+        cov_yy += 0.3f;
+
+        const float det = cov_xx * cov_yy - cov_xy * cov_xy;
+        if (det == 0.0f) break;
+        const float det_inv = 1.f / det;
+        const float ca = cov_yy * det_inv, cb = -cov_xy * det_inv, cc = cov_xx * det_inv;
+        const float mid = 0.5f * (cov_xx + cov_yy);
+        const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lambda1 = mid + sq, lambda2 = mid - sq;
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        const float pix = ndc2pix(projx, W), piy = ndc2pix(projy, H);
+        uint32_t x0, y0, x1, y1;
+        tile_rect(pix, piy, (int)my_radius, gx, gy, x0, y0, x1, y1);
+        if ((x1 - x0) * (y1 - y0) == 0) break;
+
+        float rgb[3];
+        if (fr.colors) {
+            rgb[0] = fr.colors[3 * (size_t)idx]; rgb[1] = fr.colors[3 * (size_t)idx + 1]; rgb[2] = fr.colors[3 * (size_t)idx + 2];
+        } else {
+            sh_to_rgb(idx, fr.D, fr.M, fr.means3D, fr.campos, fr.shs, rgb);
+        }
+        depths[g] = pvz;
+        GeomRec rec;
+        rec.q0 = make_float4(pix, piy, ca, cb);
+        rec.q1 = make_float4(cc, fr.opac[idx], pvz, rgb[0]);
+        rec.q2 = make_float4(rgb[1], rgb[2], 0.f, 0.f);
+        geom[g] = rec;
+        radius_out = (int)my_radius;
+        tiles = (y1 - y0) * (x1 - x0);
+    } while (false);
+    radii_all[g] = radius_out;
+    if (fr.radii) fr.radii[idx] = radius_out;
+    tiles_touched[g] = tiles;
+}
+
+// duplicateWithKeys, rasterizer_impl.cu:70-111, with the tile id extended by the frame index.
+__global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ frames, int gx, int gy,
+                                                   const float* __restrict__ depths, const int* __restrict__ radii_all,
+                                                   const GeomRec* __restrict__ geom,
+                                                   const uint32_t* __restrict__ offsets, uint64_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals)
+{
+    const FrameDev& fr = frames[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= fr.P) return;
+    const size_t g = (size_t)fr.base + idx;
+    const int r = radii_all[g];
+    if (r <= 0) return;
+    uint32_t off = (g == 0) ? 0u : offsets[g - 1];
+    const float4 q0 = geom[g].q0;
+    uint32_t x0, y0, x1, y1;
+    tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
+    const uint32_t dbits = __float_as_uint(depths[g]);
+    const uint32_t tile_base = blockIdx.y * (uint32_t)(gx * gy);
+    for (uint32_t y = y0; y < y1; ++y)
+        for (uint32_t x = x0; x < x1; ++x) {
+            const uint64_t key = ((uint64_t)(tile_base + y * (uint32_t)gx + x) << 32) | dbits;
+            keys[off] = key;
+            vals[off] = (uint32_t)g;
+            ++off;
+        }
+}
+
+// identifyTileRanges, rasterizer_impl.cu:116-138.
+__global__ void __launch_bounds__(256) k_tile_ranges(uint32_t L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const uint32_t cur = (uint32_t)(keys[i] >> 32);
+    if (i == 0) ranges[cur].x = 0;
+    else {
+        const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+        if (cur != prev) {
+            ranges[prev].y = i;
+            ranges[cur].x = i;
+        }
+    }
+    if (i == L - 1) ranges[cur].y = L;
+}
+
+// renderCUDA, forward.cu:262-394.  One workgroup per 16x16 tile; wavefront w owns the 8x8 quadrant
+// (w&1, w>>1) so that a whole-wave skip (all 64 pixels fail the alpha test) is likely for small splats.
+// The per-pixel arithmetic and its order (power -> alpha -> test_T -> colour -> median depth) follow
+// forward.cu:339-380 exactly; rgb and depth travel through LDS with the rest of the record instead of
+// being re-read from global memory inside the pixel loop (forward.cu:362).
+__global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __restrict__ frames, int gx, int gy, int W, int H,
+                                                            const uint2* __restrict__ ranges,
+                                                            const uint32_t* __restrict__ point_list,
+                                                            const GeomRec* __restrict__ geom, float* __restrict__ aux_T,
+                                                            uint32_t* __restrict__ aux_n)
+{
+    const int tiles = gx * gy;
+    const int f = blockIdx.x / tiles;
+    const int t = blockIdx.x - f * tiles;
+    const int ty = t / gx, tx = t - ty * gx;
+    const FrameDev& fr = frames[f];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pfx = (float)px, pfy = (float)py;
+    bool done = !inside;
+
+    const uint2 range = ranges[blockIdx.x];
+    const int n = (int)(range.y - range.x);
+    const int rounds = (n + TILE_THREADS - 1) / TILE_THREADS;
+
+    __shared__ float4 s_q0[TILE_THREADS]; // px, py, conic_a, conic_b
+    __shared__ float2 s_q1[TILE_THREADS]; // conic_c, opacity
+    __shared__ float4 s_q2[TILE_THREADS]; // r, g, b, depth
+
+    float T = 1.0f;
+    uint32_t contributor = 0, last_contributor = 0;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    float D = 15.0f; // forward.cu:309
+
+    int todo = n;
+    for (int i = 0; i < rounds; ++i, todo -= TILE_THREADS) {
+        if (__syncthreads_count(done) == TILE_THREADS) break;
+        const int progress = i * TILE_THREADS + tid;
+        if (progress < n) {
+            const uint32_t id = point_list[range.x + progress];
+            const GeomRec* rec = geom + id;
+            const float4 a = rec->q0, b = rec->q1, c = rec->q2;
+            s_q0[tid] = a;
+            s_q1[tid] = make_float2(b.x, b.y);
+            s_q2[tid] = make_float4(b.w, c.x, c.y, b.z);
+        }
+        __syncthreads();
+        const int m = min(TILE_THREADS, todo);
+        for (int j = 0; !done && j < m; ++j) {
+            contributor++;
+            const float4 a = s_q0[j];
+            const float2 b = s_q1[j];
+            const float dx = a.x - pfx, dy = a.y - pfy;
+            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, b.y * expf(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float test_T = T * (1.f - alpha);
+            if (test_T < 0.0001f) {
+                done = true;
+                continue;
+            }
+            const float4 c = s_q2[j];
+            const float w = alpha * T;
+            C0 += c.x * w;
+            C1 += c.y * w;
+            C2 += c.z * w;
+            if (T > 0.5f && test_T < 0.5f) D = c.w;
+            T = test_T;
+            last_contributor = contributor;
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)W * py + px;
+        const size_t hw = (size_t)H * W;
+        fr.out_color[pix] = C0 + T * fr.bg[0];
+        fr.out_color[hw + pix] = C1 + T * fr.bg[1];
+        fr.out_color[2 * hw + pix] = C2 + T * fr.bg[2];
+        fr.out_depth[pix] = D;
+        if (aux_T) aux_T[(size_t)f * hw + pix] = T;
+        if (aux_n) aux_n[(size_t)f * hw + pix] = last_contributor;
+    }
+}
+
+// getHigherMsb, rasterizer_impl.cu:35-50.
+uint32_t higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4, step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step;
+        else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+struct CallbackAlloc {
+    r2s_alloc_fn fn[3];
+    void* user[3];
+};
+
+} // namespace
+
+struct R2SRasterCtx {
+    r2s::DevBuf buf[3]; // geometry, binning, image
+    CallbackAlloc cb{}; // when set, scratch comes from the caller (single-frame API)
+    bool use_cb = false;
+    FrameDev* d_frames = nullptr;
+    FrameDev* h_frames = nullptr; // pinned
+    int frames_cap = 0;
+    uint64_t* h_read = nullptr; // pinned: [0] last offset, [1] error flag
+    bool timing = false;
+    hipEvent_t ev[7] = {};
+    bool ev_ok = false;
+    float stage_ms[6] = {};
+    float* aux_T = nullptr;
+    uint32_t* aux_n = nullptr;
+    R2SRasterDebug dbg{};
+    std::vector<int64_t> per_frame;
+
+    char* scratch(int which, size_t bytes)
+    {
+        if (use_cb) return cb.fn[which](cb.user[which], bytes);
+        if (buf[which].reserve(bytes) != hipSuccess) return nullptr;
+        return buf[which].p;
+    }
+};
+
+namespace {
+
+int ensure_frames(R2SRasterCtx* c, int n)
+{
+    if (n > c->frames_cap) {
+        if (c->d_frames) (void)hipFree(c->d_frames);
+        if (c->h_frames) (void)hipHostFree(c->h_frames);
+        c->d_frames = nullptr;
+        c->h_frames = nullptr;
+        int cap = n < 64 ? 64 : n;
+        R2S_HIP_TRY(hipMalloc((void**)&c->d_frames, sizeof(FrameDev) * cap));
+        R2S_HIP_TRY(hipHostMalloc((void**)&c->h_frames, sizeof(FrameDev) * cap, hipHostMallocDefault));
+        c->frames_cap = cap;
+    }
+    if (!c->h_read) R2S_HIP_TRY(hipHostMalloc((void**)&c->h_read, 64, hipHostMallocDefault));
+    return R2S_OK;
+}
+
+int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, const R2SRasterFrame* frames, int F, int W, int H,
+                     int64_t* per_frame_out, hipStream_t stream)
+{
+    if (!c || F < 0 || W <= 0 || H <= 0 || (F > 0 && (!sets || !frames))) return R2S_ERR_INVALID;
+    if (F == 0) return 0;
+    int rc = ensure_frames(c, F);
+    if (rc != R2S_OK) return rc;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int tiles = gx * gy;
+
+    uint64_t total = 0;
+    int maxP = 0;
+    for (int f = 0; f < F; ++f) {
+        const R2SRasterFrame& fr = frames[f];
+        if (fr.set < 0 || fr.set >= n_sets) return R2S_ERR_INVALID;
+        const R2SGaussianSet& s = sets[fr.set];
+        if (s.P < 0 || !fr.viewmatrix || !fr.projmatrix || !fr.background || !fr.out_color || !fr.out_depth) return R2S_ERR_INVALID;
+        if (s.P > 0 && (!s.means3D || !s.opacities)) return R2S_ERR_INVALID;
+        if (s.P > 0 && !s.colors_precomp && (!s.shs || !fr.cam_pos)) return R2S_ERR_INVALID;
+        if (s.P > 0 && !s.cov3D_precomp && (!s.scales || !s.rotations)) return R2S_ERR_INVALID;
+        FrameDev& d = c->h_frames[f];
+        d.view = fr.viewmatrix; d.proj = fr.projmatrix; d.campos = fr.cam_pos; d.bg = fr.background;
+        d.means3D = s.means3D; d.shs = s.shs; d.colors = s.colors_precomp; d.opac = s.opacities;
+        d.scales = s.scales; d.rots = s.rotations; d.cov3D = s.cov3D_precomp;
+        d.out_color = fr.out_color; d.out_depth = fr.out_depth; d.radii = fr.radii;
+        d.P = s.P; d.D = s.D; d.M = s.M;
+        d.base = (uint32_t)total;
+        d.scale_mod = s.scale_modifier;
+        d.tan_fovx = fr.tan_fovx; d.tan_fovy = fr.tan_fovy;
+        d.focal_y = H / (2.0f * fr.tan_fovy); // rasterizer_impl.cu:225-226
+        d.focal_x = W / (2.0f * fr.tan_fovx);
+        d.z_thr = fr.z_threshold;
+        d.prefiltered = fr.prefiltered;
+        total += (uint64_t)s.P;
+        if (s.P > maxP) maxP = s.P;
+    }
+    if (total >= 0xFFFFFFFFull) return R2S_ERR_OVERFLOW;
+    const size_t G = (size_t)total;
+
+    if (c->timing && !c->ev_ok) {
+        for (auto& e : c->ev) R2S_HIP_TRY(hipEventCreate(&e));
+        c->ev_ok = true;
+    }
+    auto mark = [&](int k) { if (c->timing) (void)hipEventRecord(c->ev[k], stream); };
+
+    // ---- geometry scratch (GeometryState, rasterizer_impl.h:30-45) ----
+    size_t scan_bytes = 0;
+    R2S_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, G ? G : 1,
+                                        rocprim::plus<uint32_t>(), stream));
+    float* depths; int* radii_all; GeomRec* geom; uint32_t* tiles_touched; uint32_t* offsets; char* scan_tmp; int* err_flag;
+    {
+        r2s::Carver sz(nullptr);
+        sz.take<float>(G); sz.take<int>(G); sz.take<GeomRec>(G); sz.take<uint32_t>(G); sz.take<uint32_t>(G);
+        sz.take<char>(scan_bytes); sz.take<int>(4);
+        char* p = c->scratch(0, sz.bytes());
+        if (!p) return R2S_ERR_ALLOC;
+        r2s::Carver cv(p);
+        depths = cv.take<float>(G); radii_all = cv.take<int>(G); geom = cv.take<GeomRec>(G);
+        tiles_touched = cv.take<uint32_t>(G); offsets = cv.take<uint32_t>(G);
+        scan_tmp = cv.take<char>(scan_bytes); err_flag = cv.take<int>(4);
+    }
+    // ---- image scratch (ImageState: ranges; accum_alpha / n_contrib are backward-only) ----
+    uint2* ranges;
+    {
+        r2s::Carver sz(nullptr);
+        sz.take<uint2>((size_t)F * tiles);
+        char* p = c->scratch(2, sz.bytes());
+        if (!p) return R2S_ERR_ALLOC;
+        r2s::Carver cv(p);
+        ranges = cv.take<uint2>((size_t)F * tiles);
+    }
+
+    R2S_HIP_TRY(hipMemcpyAsync(c->d_frames, c->h_frames, sizeof(FrameDev) * F, hipMemcpyHostToDevice, stream));
+    R2S_HIP_TRY(hipMemsetAsync(err_flag, 0, sizeof(int) * 4, stream));
+
+    mark(0);
+    uint32_t L = 0;
+    if (G > 0) {
+        dim3 grid((maxP + 255) / 256, F);
+        hipLaunchKernelGGL(k_preprocess, grid, dim3(256), 0, stream, c->d_frames, gx, gy, W, H, depths, radii_all, geom,
+                           tiles_touched, err_flag);
+        mark(1);
+        R2S_HIP_TRY(rocprim::inclusive_scan(scan_tmp, scan_bytes, tiles_touched, offsets, G, rocprim::plus<uint32_t>(), stream));
+        mark(2);
+        // The reference's blocking read of the instance count (rasterizer_impl.cu:284), once per batch.
+        R2S_HIP_TRY(hipMemcpyAsync(&c->h_read[0], offsets + (G - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        R2S_HIP_TRY(hipMemcpyAsync(&c->h_read[1], err_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+        R2S_HIP_TRY(hipStreamSynchronize(stream));
+        L = (uint32_t)(c->h_read[0] & 0xFFFFFFFFull);
+        if ((int)(c->h_read[1] & 0xFFFFFFFFull) != 0) return R2S_ERR_PREFILTERED;
+    } else {
+        mark(1); mark(2);
+    }
+
+    // ---- binning scratch (BinningState, rasterizer_impl.h:56-67) ----
+    const uint32_t bits = higher_msb((uint32_t)F * (uint32_t)tiles);
+    uint64_t *keys_a = nullptr, *keys_b = nullptr;
+    uint32_t *vals_a = nullptr, *vals_b = nullptr;
+    const uint64_t* keys_sorted = nullptr;
+    const uint32_t* vals_sorted = nullptr;
+    if (L > 0) {
+        rocprim::double_buffer<uint64_t> dk((uint64_t*)nullptr, (uint64_t*)nullptr);
+        rocprim::double_buffer<uint32_t> dv((uint32_t*)nullptr, (uint32_t*)nullptr);
+        size_t sort_bytes = 0;
+        R2S_HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, dk, dv, (size_t)L, 0u, 32u + bits, stream));
+        r2s::Carver sz(nullptr);
+        sz.take<uint64_t>(L); sz.take<uint64_t>(L); sz.take<uint32_t>(L); sz.take<uint32_t>(L); sz.take<char>(sort_bytes);
+        char* p = c->scratch(1, sz.bytes());
+        if (!p) return R2S_ERR_ALLOC;
+        r2s::Carver cv(p);
+        keys_a = cv.take<uint64_t>(L); keys_b = cv.take<uint64_t>(L);
+        vals_a = cv.take<uint32_t>(L); vals_b = cv.take<uint32_t>(L);
+        char* sort_tmp = cv.take<char>(sort_bytes);
+
+        dim3 grid((maxP + 255) / 256, F);
+        hipLaunchKernelGGL(k_emit_keys, grid, dim3(256), 0, stream, c->d_frames, gx, gy, depths, radii_all, geom, offsets, keys_a, vals_a);
+        mark(3);
+        rocprim::double_buffer<uint64_t> dkey(keys_a, keys_b);
+        rocprim::double_buffer<uint32_t> dval(vals_a, vals_b);
+        R2S_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, dkey, dval, (size_t)L, 0u, 32u + bits, stream));
+        keys_sorted = dkey.current();
+        vals_sorted = dval.current();
+        mark(4);
+    } else {
+        mark(3); mark(4);
+    }
+    R2S_HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)F * tiles, stream));
+    if (L > 0)
+        hipLaunchKernelGGL(k_tile_ranges, dim3((L + 255) / 256), dim3(256), 0, stream, L, keys_sorted, ranges);
+    mark(5);
+    hipLaunchKernelGGL(k_composite, dim3((uint32_t)F * tiles), dim3(TILE_THREADS), 0, stream, c->d_frames, gx, gy, W, H, ranges,
+                       vals_sorted, geom, c->aux_T, c->aux_n);
+    mark(6);
+    R2S_HIP_TRY(hipGetLastError());
+
+    // per-frame instance counts: offsets at frame boundaries are not read back (that would add syncs);
+    // the caller gets the total, and per-frame counts only in timing/debug mode.
+    c->per_frame.assign(F, -1);
+    if (c->timing) {
+        R2S_HIP_TRY(hipStreamSynchronize(stream));
+        for (int k = 0; k < 6; ++k) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]);
+            c->stage_ms[k] = ms;
+        }
+    }
+    if (per_frame_out) {
+        // one small D2H per frame boundary, only when asked for
+        std::vector<uint32_t> ends(F, 0);
+        for (int f = 0; f < F; ++f) {
+            const uint64_t endg = (uint64_t)c->h_frames[f].base + (uint64_t)c->h_frames[f].P;
+            if (endg == 0) { ends[f] = 0; continue; }
+            R2S_HIP_TRY(hipMemcpyAsync(&ends[f], offsets + (endg - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        }
+        R2S_HIP_TRY(hipStreamSynchronize(stream));
+        uint32_t prev = 0;
+        for (int f = 0; f < F; ++f) {
+            per_frame_out[f] = (int64_t)(ends[f] - prev);
+            prev = ends[f];
+        }
+    }
+    c->dbg.total_gaussians = (int64_t)G;
+    c->dbg.num_rendered = (int64_t)L;
+    c->dbg.depths = depths;
+    c->dbg.radii = radii_all;
+    c->dbg.geom = reinterpret_cast<const float*>(geom);
+    c->dbg.tiles_touched = tiles_touched;
+    c->dbg.point_offsets = offsets;
+    c->dbg.keys_sorted = keys_sorted;
+    c->dbg.point_list = vals_sorted;
+    c->dbg.ranges = reinterpret_cast<const uint32_t*>(ranges);
+    return (int64_t)L;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int r2s_raster_ctx_create(R2SRasterCtx** out)
+{
+    if (!out) return R2S_ERR_INVALID;
+    *out = new (std::nothrow) R2SRasterCtx();
+    return *out ? R2S_OK : R2S_ERR_ALLOC;
+}
+
+void r2s_raster_ctx_destroy(R2SRasterCtx* c)
+{
+    if (!c) return;
+    for (auto& b : c->buf) b.release();
+    if (c->d_frames) (void)hipFree(c->d_frames);
+    if (c->h_frames) (void)hipHostFree(c->h_frames);
+    if (c->h_read) (void)hipHostFree(c->h_read);
+    if (c->ev_ok) for (auto& e : c->ev) (void)hipEventDestroy(e);
+    delete c;
+}
+
+size_t r2s_raster_ctx_scratch_bytes(const R2SRasterCtx* c)
+{
+    return c ? c->buf[0].cap + c->buf[1].cap + c->buf[2].cap : 0;
+}
+
+void r2s_raster_ctx_set_timing(R2SRasterCtx* c, int enable) { if (c) c->timing = enable != 0; }
+float r2s_raster_ctx_stage_ms(const R2SRasterCtx* c, int stage) { return (c && stage >= 0 && stage < 6) ? c->stage_ms[stage] : -1.f; }
+void r2s_raster_ctx_set_aux(R2SRasterCtx* c, float* final_T, uint32_t* n_contrib) { if (c) { c->aux_T = final_T; c->aux_n = n_contrib; } }
+
+int r2s_raster_ctx_debug(const R2SRasterCtx* c, R2SRasterDebug* out)
+{
+    if (!c || !out) return R2S_ERR_INVALID;
+    *out = c->dbg;
+    return R2S_OK;
+}
+
+int64_t r2s_raster_forward_batch(R2SRasterCtx* ctx, const R2SGaussianSet* sets, int n_sets, const R2SRasterFrame* frames, int n_frames,
+                                 int width, int height, int64_t* num_rendered_per_frame, r2s_stream_t stream)
+{
+    if (!ctx) return R2S_ERR_INVALID;
+    ctx->use_cb = false;
+    return forward_impl(ctx, sets, n_sets, frames, n_frames, width, height, num_rendered_per_frame, (hipStream_t)stream);
+}
+
+int64_t r2s_raster_forward(r2s_alloc_fn geometry_buffer, void* geometry_user, r2s_alloc_fn binning_buffer, void* binning_user,
+                           r2s_alloc_fn image_buffer, void* image_user, int P, int D, int M, const float* background, int width,
+                           int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                           const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                           int prefiltered, float z_threshold, float* out_color, float* out_depth, int* radii, r2s_stream_t stream)
+{
+    if (!geometry_buffer || !binning_buffer || !image_buffer) return R2S_ERR_INVALID;
+    if (P == 0) return 0; // rasterize_points.cu:82
+    // A per-thread context carries the pinned staging words; scratch itself comes from the callbacks.
+    static thread_local R2SRasterCtx* tl = nullptr;
+    if (!tl) {
+        tl = new (std::nothrow) R2SRasterCtx();
+        if (!tl) return R2S_ERR_ALLOC;
+    }
+    tl->use_cb = true;
+    tl->cb.fn[0] = geometry_buffer; tl->cb.user[0] = geometry_user;
+    tl->cb.fn[1] = binning_buffer; tl->cb.user[1] = binning_user;
+    tl->cb.fn[2] = image_buffer; tl->cb.user[2] = image_user;
+    R2SGaussianSet set{};
+    set.P = P; set.D = D; set.M = M; set.scale_modifier = scale_modifier;
+    set.means3D = means3D; set.shs = shs; set.colors_precomp = colors_precomp; set.opacities = opacities;
+    set.scales = scales; set.rotations = rotations; set.cov3D_precomp = cov3D_precomp;
+    R2SRasterFrame fr{};
+    fr.set = 0; fr.prefiltered = prefiltered; fr.tan_fovx = tan_fovx; fr.tan_fovy = tan_fovy; fr.z_threshold = z_threshold;
+    fr.viewmatrix = viewmatrix; fr.projmatrix = projmatrix; fr.cam_pos = cam_pos; fr.background = background;
+    fr.out_color = out_color; fr.out_depth = out_depth; fr.radii = radii;
+    return forward_impl(tl, &set, 1, &fr, 1, width, height, nullptr, (hipStream_t)stream);
+}
+
+} // extern "C"

@@ -1,0 +1,203 @@
+"""Seeded synthetic inputs of the shapes BASELINE.json names.
+
+There is no network for the real PhysTwin checkpoints / Scaniverse scans, so tests and
+``bench.py`` use these generators: Gaussian clouds (object + table plane), the two cameras of
+``cfg/env/xarm_gripper.yaml:21-49`` rescaled to the requested resolution, particle clouds with the
+reference's spring construction (``sim/physics/phystwin.py:264-286``), and box meshes for the gripper
+fingers / static obstacles.  numpy + scipy only.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# cfg/env/xarm_gripper.yaml:25-48 (848x480)
+SIDE_K = np.array([[427.2920227050781, 0.0, 429.9993591308594], [0.0, 426.7926940917969, 242.8115234375], [0.0, 0.0, 1.0]])
+SIDE_C2W = np.array([
+    [0.005258014128948334, 0.6125512321694572, -0.7904133989597472, 0.8830263898083726],
+    [0.9999860093046595, -0.0036779908994199082, 0.0038017861441641317, 0.05390846195611962],
+    [-0.000578344501100992, -0.7904223303719503, -0.6125620010799026, 0.3976033855145515],
+    [0.0, 0.0, 0.0, 1.0]])
+WRIST_K = np.array([[433.2635498046875, 0.0, 425.69775390625], [0.0, 433.2635498046875, 244.70132446289062], [0.0, 0.0, 1.0]])
+WRIST_C2EEF = np.array([
+    [-0.00621799798682332, -0.9996882472848673, -0.024181019135736517, 0.070151686668396],
+    [0.9999282360076904, -0.0059682438456119995, -0.010387018683749047, -0.006011864222586155],
+    [0.01023946, -0.02424387, 0.99965361, 0.03072427],
+    [0.0, 0.0, 0.0, 1.0]])
+CFG_W, CFG_H = 848, 480
+OBJECT_CENTER = np.array([0.37, 0.05, 0.0])  # where the side camera's optical axis meets the table
+
+
+def scaled_K(K, W, H):
+    K = np.array(K, dtype=np.float64).copy()
+    K[0] *= W / CFG_W
+    K[1] *= H / CFG_H
+    return K
+
+
+def camera_settings(K, w2c, W, H, near=0.01, far=100.0, bg=(0.0, 0.0, 0.0), z_threshold=0.05, sh_degree=0):
+    """float32 numpy version of ``setup_camera`` (sim/utils/gs/transform_utils.py:7-31).
+    Returned dict has the 12 fields of GaussianRasterizationSettings as numpy arrays / scalars."""
+    K = np.asarray(K, np.float64)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    w2c32 = np.asarray(w2c, np.float64).astype(np.float32)
+    campos = np.linalg.inv(w2c32)[:3, 3].astype(np.float32)
+    view = np.ascontiguousarray(w2c32.T)
+    proj = np.array([[2 * fx / W, 0.0, -(W - 2 * cx) / W, 0.0], [0.0, 2 * fy / H, -(H - 2 * cy) / H, 0.0],
+                     [0.0, 0.0, far / (far - near), -(far * near) / (far - near)], [0.0, 0.0, 1.0, 0.0]]).astype(np.float32)
+    full = np.ascontiguousarray((view @ proj.T).astype(np.float32))
+    return dict(image_height=int(H), image_width=int(W), tanfovx=float(W / (2 * fx)), tanfovy=float(H / (2 * fy)),
+                bg=np.asarray(bg, np.float32), scale_modifier=1.0, viewmatrix=view[None].copy(), projmatrix=full[None].copy(),
+                sh_degree=int(sh_degree), campos=campos, prefiltered=False, z_threshold=float(z_threshold))
+
+
+def side_camera(W, H, **kw):
+    return camera_settings(scaled_K(SIDE_K, W, H), np.linalg.inv(SIDE_C2W), W, H, **kw)
+
+
+def wrist_camera(W, H, eef_pos=(0.37, 0.05, 0.35), **kw):
+    """Wrist camera attached to an end effector pointing straight down at ``eef_pos``
+    (w2c = eef2c . inv(eef2base), sim/renderer/gs_renderer.py:967-985)."""
+    eef2base = np.eye(4)
+    eef2base[:3, :3] = np.array([[1.0, 0.0, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, -1.0]])  # tool z axis down
+    eef2base[:3, 3] = np.asarray(eef_pos, np.float64)
+    c2w = eef2base @ WRIST_C2EEF
+    return camera_settings(scaled_K(WRIST_K, W, H), np.linalg.inv(c2w), W, H, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+def lattice_points(shape: str, n_target: int, seed: int, spacing: float = 0.006):
+    """Jittered cubic lattice carved to a shape, resting 1 mm above z=0."""
+    rng = np.random.default_rng(seed)
+    h = spacing
+    if shape == "rope":
+        r = 0.012
+        per_len = np.pi * r * r / h**3  # particles per metre
+        length = n_target / per_len
+        ext = np.array([length / 2, r, r])
+        inside = lambda p: (p[:, 1] ** 2 + p[:, 2] ** 2) <= r * r  # noqa: E731
+    elif shape == "sloth":
+        base = np.array([0.10, 0.065, 0.135]) / 2
+        vol = 4.0 / 3.0 * np.pi * np.prod(base)
+        s = (n_target * h**3 / vol) ** (1.0 / 3.0)
+        ext = base * s
+        inside = lambda p: ((p / ext) ** 2).sum(1) <= 1.0  # noqa: E731
+    elif shape == "T":
+        # T prism: bar 0.2 x 0.05 and stem 0.05 x 0.15, thickness 0.04 (push-T block), scaled to n_target
+        area = 0.2 * 0.05 + 0.05 * 0.15
+        s = (n_target * h**3 / (area * 0.04)) ** (1.0 / 3.0)
+        bw, bh, sw, sh_, th = 0.2 * s, 0.05 * s, 0.05 * s, 0.15 * s, 0.04 * s
+        ext = np.array([bw / 2, (bh + sh_) / 2, th / 2])
+
+        def inside(p):
+            y = p[:, 1] + (bh + sh_) / 2
+            bar = (y >= sh_) & (np.abs(p[:, 0]) <= bw / 2)
+            stem = (y < sh_) & (np.abs(p[:, 0]) <= sw / 2)
+            return (bar | stem) & (np.abs(p[:, 2]) <= th / 2)
+    elif shape == "cloth":
+        side = np.sqrt(n_target) * h
+        ext = np.array([side / 2, side / 2, h * 0.49])
+        inside = lambda p: np.ones(len(p), bool)  # noqa: E731
+    else:
+        raise ValueError(shape)
+    ax = [np.arange(-e, e + 1e-9, h) for e in ext]
+    g = np.stack(np.meshgrid(*ax, indexing="ij"), -1).reshape(-1, 3)
+    g = g[inside(g)]
+    g = g + rng.uniform(-0.1 * h, 0.1 * h, g.shape)
+    g[:, 2] += -g[:, 2].min() + 0.001
+    return g.astype(np.float32)
+
+
+def build_springs(pts: np.ndarray, radius: float = 0.02, max_neighbours: int = 30):
+    """The reference's spring construction (sim/physics/phystwin.py:264-286): for each i, up to
+    ``max_neighbours`` nearest points within ``radius`` (hybrid search, self included then dropped),
+    de-duplicated, rest length > 1e-4."""
+    from scipy.spatial import cKDTree
+
+    pts64 = np.asarray(pts, np.float64)
+    tree = cKDTree(pts64)
+    d, idx = tree.query(pts64, k=min(max_neighbours, len(pts64)), distance_upper_bound=radius)
+    n = len(pts64)
+    i_idx = np.repeat(np.arange(n), idx.shape[1] - 1)
+    j_idx = idx[:, 1:].reshape(-1)
+    ok = j_idx < n
+    i_idx, j_idx = i_idx[ok], j_idx[ok]
+    rest = np.linalg.norm(pts64[i_idx] - pts64[j_idx], axis=1)
+    ok = rest > 1e-4
+    i_idx, j_idx = i_idx[ok], j_idx[ok]
+    # first occurrence of the unordered pair wins, in (i, neighbour-rank) order like the reference loop
+    lo, hi = np.minimum(i_idx, j_idx), np.maximum(i_idx, j_idx)
+    key = lo.astype(np.int64) * n + hi
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    springs = np.stack([i_idx[first], j_idx[first]], 1).astype(np.int32)
+    p32 = np.asarray(pts, np.float32)
+    rest = np.linalg.norm(p32[springs[:, 0]] - p32[springs[:, 1]], axis=1).astype(np.float32)
+    return springs, rest
+
+
+def phystwin_object(shape: str, n_target: int, seed: int, center=OBJECT_CENTER):
+    """Particles + springs + per-spring log-stiffness of one synthetic PhysTwin."""
+    rng = np.random.default_rng(seed + 7919)
+    pts = lattice_points(shape, n_target, seed)
+    pts[:, :2] += np.asarray(center, np.float32)[:2] - pts[:, :2].mean(0)
+    springs, rest = build_springs(pts)
+    Y = np.exp(rng.uniform(np.log(1e3), np.log(5e4), len(springs))).astype(np.float32)
+    return dict(points=pts, springs=springs, rest=rest, log_Y=np.log(Y).astype(np.float32))
+
+
+def box_mesh(center, size):
+    """Closed 12-triangle box, outward-facing."""
+    c, s = np.asarray(center, np.float32), np.asarray(size, np.float32) / 2
+    v = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float32) * s + c
+    f = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6],
+                  [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]], np.int32)
+    return v, f
+
+
+def finger_mesh(center, size=(0.02, 0.01, 0.05), n_faces=44):
+    """A closed box re-tessellated to ``n_faces`` triangles (the real finger collision meshes have 44,
+    assets/robots/xarm/xarm7_with_gripper_collision.urdf:425,519): the two large side faces are split
+    into strips."""
+    v, f = box_mesh(center, size)
+    v, f = list(map(list, v)), [list(t) for t in f]
+    # split triangles (longest edge midpoint) until the face count is reached
+    while len(f) < n_faces:
+        lens = []
+        for t in f:
+            p = np.array([v[t[0]], v[t[1]], v[t[2]]])
+            e = [np.linalg.norm(p[1] - p[0]), np.linalg.norm(p[2] - p[1]), np.linalg.norm(p[0] - p[2])]
+            lens.append(max(e))
+        k = int(np.argmax(lens))
+        t = f.pop(k)
+        p = np.array([v[t[0]], v[t[1]], v[t[2]]])
+        e = [np.linalg.norm(p[1] - p[0]), np.linalg.norm(p[2] - p[1]), np.linalg.norm(p[0] - p[2])]
+        a = int(np.argmax(e))
+        i0, i1, i2 = t[a], t[(a + 1) % 3], t[(a + 2) % 3]
+        v.append(list((np.array(v[i0]) + np.array(v[i1])) / 2))
+        m = len(v) - 1
+        f.append([i0, m, i2])
+        f.append([m, i1, i2])
+    return np.array(v, np.float32), np.array(f[:n_faces] if len(f) > n_faces else f, np.int32)
+
+
+# ------------------------------------------------------------------------------------------------
+def gaussian_scene(n_gaussians: int, seed: int, object_points: np.ndarray | None = None, table_frac: float = 0.35,
+                   sh_coeffs: int = 1):
+    """Object Gaussians scattered around the particle cloud + a 1.2 x 0.8 m table plane."""
+    rng = np.random.default_rng(seed + 104729)
+    n_tab = int(n_gaussians * table_frac)
+    n_obj = n_gaussians - n_tab
+    if object_points is None:
+        object_points = lattice_points("rope", 2000, seed)
+        object_points[:, :2] += OBJECT_CENTER[:2].astype(np.float32)
+    pick = rng.integers(0, len(object_points), n_obj)
+    obj = object_points[pick] + rng.normal(0, 0.002, (n_obj, 3)).astype(np.float32)
+    tab = np.stack([rng.uniform(-0.2, 1.0, n_tab), rng.uniform(-0.4, 0.4, n_tab), rng.normal(0, 0.0005, n_tab)], 1)
+    means = np.concatenate([obj, tab]).astype(np.float32)
+    P = len(means)
+    scales = np.exp(rng.normal(np.log(0.004), 0.5, (P, 3))).astype(np.float32)
+    q = rng.normal(size=(P, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    opac = (1.0 / (1.0 + np.exp(-rng.normal(2.0, 2.0, (P, 1))))).astype(np.float32)
+    shs = rng.normal(0, 1, (P, sh_coeffs, 3)).astype(np.float32)
+    return dict(means3D=means, scales=scales, rotations=q.astype(np.float32), opacities=opac, shs=shs)
