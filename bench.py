@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py — env-steps/s (physics + render) of the batched rollout on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one batched env step of the hot path over `envs` environments per GPU: collision-candidate rebuild,
+667 fused physics substeps, and 2 rasterised 640x480 frames per environment (SURVEY.md §8d Metric 1), on
+synthetic inputs of BASELINE.json configs[2] (sloth PhysTwin ~15k particles / ~80k Gaussians, 32 envs per GPU).
+Inputs are resident in HBM before the timed region.  Envs shard across GPUs with no data-path collective
+(weak scaling); the only collective is the final all-gather of per-rank result records.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the fused physics substep) and `cpu_baseline`
+(the oracle — a CPU restatement of the reference algorithm, kind "port" — on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "real2sim-eval_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(ro, budget_s=20.0):
+    """Time the oracle on a bounded sample of the same workload: `n` envs stepped side by side (OpenMP over
+    envs, the only parallelism the reference has) for a few substeps + one 2-view render; extrapolated to
+    env-steps/s.  Returns the cpu_baseline object."""
+    import numpy as np
+    import oracle
+
+    cores = len(os.sched_getaffinity(0))
+    n = max(1, min(ro.n_env, cores))
+    oracle.set_threads(n)
+    dyn = ro.fingers if ro.with_gripper else None
+    envs = []
+    x0 = ro.ob["points"]
+    sta = None
+    if ro.phys.n_faces and (ro.phys.mesh_map < 0).any():
+        from r2s_hip import synth
+        c = x0.mean(0)
+        sta = [synth.box_mesh((c[0] + 0.25, c[1] + 0.2, 0.135), (0.2, 0.13, 0.27))]
+    for e in range(n):
+        ob = dict(ro.ob)
+        ob["points"] = x0 + ro.env_shift[e]
+        envs.append(oracle.PhysOracle(ob["points"], ob["springs"], ob["rest"], ob["log_Y"], num_substeps=ro.num_substeps,
+                                      self_collision=False, dynamic_meshes=dyn, static_meshes=sta))
+    # physics: calibrate on 1 substep, then spend ~60% of the budget
+    t0 = time.perf_counter(); oracle.phys_step_batch(envs, 1); t1 = time.perf_counter()
+    per = max(t1 - t0, 1e-4)
+    nsub = int(max(2, min(ro.num_substeps, 0.6 * budget_s / per)))
+    t0 = time.perf_counter(); oracle.phys_step_batch(envs, nsub); t_phys = (time.perf_counter() - t0) / nsub
+    # raster: 2 views of env 0, all threads over tiles
+    oracle.set_threads(cores)
+    means = ro.means[0].cpu().numpy()
+    g = {k: v.cpu().numpy() for k, v in ro.g.items()}
+    t0 = time.perf_counter()
+    for cam in ro.cams:
+        oracle.raster_forward(means, g["opacities"], cam["viewmatrix"], cam["projmatrix"], cam["campos"], cam["tanfovx"],
+                              cam["tanfovy"], ro.H, ro.W, cam["bg"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
+                              z_threshold=cam["z_threshold"])
+    t_frames = time.perf_counter() - t0  # one env's 2 frames with `cores` threads
+    # n envs in parallel for physics; raster of n envs = n * t_frames (already using every core)
+    t_env_step_batch = t_phys * ro.num_substeps + n * t_frames
+    return {
+        "value": n / t_env_step_batch, "unit": "env-steps/s", "cores": int(max(n, cores)), "kind": "port",
+        "sample": f"{n} envs x {nsub} of {ro.num_substeps} substeps (OpenMP over envs, mesh+ground, no self-collision rebuild) "
+                  f"+ {len(ro.cams)} frames of env 0 at {ro.W}x{ro.H} ({cores} threads over tiles); extrapolated to full env steps",
+        "phys_ms_per_substep_batch": t_phys * 1e3, "raster_ms_per_frame": t_frames / len(ro.cams) * 1e3,
+        "cpu_threads_available": cores,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="sloth_32env")
+    ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default: the config's)")
+    ap.add_argument("--substeps", type=int, default=667)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+
+    from r2s_hip.rollout import BatchedRollout
+
+    ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps)
+    ro.phys.set_timing(True)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        ro.step()
+    barrier()
+    phys_ms, phys_kernels = 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ro.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # per-kernel time of the dominant kernel: HIP events on the launch stream around the last step's graph
+    ms, k = ro.phys.last_step_ms()
+    phys_ms, phys_kernels = ms, k
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        # the metric all-gather of north_star: one fixed-size record per rank (envs, steps, wall ms, instances)
+        rec = torch.tensor([ro.n_env, args.steps, elapsed * 1e3, float(ro.last_num_rendered)], device=dev, dtype=torch.float64)
+        allrec = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+        total_envs = int(sum(r[0].item() for r in allrec))
+    else:
+        total_envs = ro.n_env
+
+    # stage timing of the raster pipeline (separate, untimed pass)
+    ro.raster.set_timing(True)
+    ro.render()
+    torch.cuda.synchronize(dev)
+    stages = ro.raster.stage_ms()
+    ro.raster.set_timing(False)
+    frames = ro.n_env * ro.views
+    raster_ms = sum(stages.values())
+
+    if rank == 0:
+        value = total_envs * args.steps / elapsed
+        t_kernel = phys_ms * 1e-3 / max(phys_kernels, 1)
+        alg_bytes = ro.physics_algorithmic_bytes_per_substep()
+        achieved = alg_bytes / t_kernel / 1e9
+        comp_bytes = ro.composite_algorithmic_bytes()
+        comp_gbs = comp_bytes / (stages["composite"] * 1e-3) / 1e9 if stages["composite"] > 0 else 0.0
+        out = {
+            "metric": "sim env-steps/sec (phys+render) per node at 32 envs", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {ro.N} particles / {ro.S} springs / {ro.P} Gaussians per env, "
+                                   f"{ro.n_env} envs per GPU, {args.substeps} substeps + {ro.views} frames {ro.W}x{ro.H} per env step",
+                       "envs_per_gpu": ro.n_env, "parallelism": f"envs sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_substep (fused spring gather + velocity + collisions + integrate)",
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": t_kernel * 1e6, "launches": phys_kernels},
+            "raster": {"gs_raster_mpix_per_s": frames * ro.W * ro.H / (raster_ms * 1e-3) / 1e6, "frames": frames,
+                       "num_rendered": int(ro.last_num_rendered), "stage_ms": stages,
+                       "composite_roofline": {"bound": "hbm", "achieved": comp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": comp_gbs / HBM_PEAK_GBS, "algorithmic_bytes": comp_bytes}},
+            "physics_ms_per_env_step": phys_ms,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(ro, args.cpu_budget)
+            except Exception as e:  # the baseline is a report, never the product
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

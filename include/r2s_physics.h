@@ -1,0 +1,130 @@
+/*
+ * r2s_physics.h — C ABI of the MI355X (gfx950) PhysTwin spring-mass soft-body stepper.
+ *
+ * Drop-in boundary for the reference operator `SpringMassSystemWarp`
+ *   sim/physics/spring_mass_warp.py:477-995   (14 NVIDIA-Warp kernels + CUDA-graph capture)
+ * as driven by its only caller
+ *   sim/physics/phystwin.py:336-357 (constructor), :362-521 (per-env-step protocol).
+ * The reference has no FFI for this path (Warp JIT-compiles Python to CUDA); these entry points
+ * are what a ctypes/cffi binding of that operator needs, one per method the caller uses.
+ *
+ * One handle holds a BATCH of `n_env` independent environments that share one PhysTwin
+ * (same springs / stiffness / masses / meshes topology; own particle state, own mesh motion).
+ * n_env = 1 reproduces the reference object exactly.
+ *
+ * Conventions
+ *   - "host" pointers are read during the call and may be freed afterwards;
+ *     "device" pointers are HIP device memory; work on them is enqueued on `stream`;
+ *   - every call returns R2S_OK (0) or a negative R2S_ERR_* code (see r2s_raster.h);
+ *     no exceptions cross the ABI; a handle is single-owner and not thread-safe;
+ *   - all arithmetic is float32 like Warp's default; particle state is exposed in the
+ *     reference's layout (vec3 array = [n_env, N, 3] float32).
+ */
+#ifndef R2S_PHYSICS_H
+#define R2S_PHYSICS_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "r2s_raster.h" /* error codes, r2s_stream_t */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Scalar parameters (phystwin_cfg fields read at spring_mass_warp.py:501-512, 591-618 and the
+ * six collide_* arrays set through set_collide*, :955-995). */
+typedef struct R2SPhysParams {
+    float dt;                /* cfg.dt (5e-5)                       */
+    float dashpot_damping;   /* cfg.dashpot_damping (100)           */
+    float drag_damping;      /* cfg.drag_damping (3)                */
+    float spring_Y_min;      /* cfg.spring_Y_min (0)                */
+    float spring_Y_max;      /* cfg.spring_Y_max (1e5)              */
+    float collision_dist;    /* cfg.collision_dist (0.005)          */
+    float collide_elas, collide_fric;           /* ground + static meshes */
+    float collide_eef_elas, collide_eef_fric;   /* dynamic (robot) meshes */
+    float collide_self_elas, collide_self_fric; /* particle-particle      */
+    int32_t reverse_z;       /* cfg.reverse_z                       */
+    int32_t self_collision;  /* cfg.self_collision                  */
+    int32_t use_pusher;      /* ctor arg use_pusher                 */
+    int32_t num_substeps;    /* cfg.num_substeps (667): length of the captured step graph */
+} R2SPhysParams;
+
+/* Constructor arguments (spring_mass_warp.py:478-500).  All pointers are HOST memory. */
+typedef struct R2SPhysDesc {
+    R2SPhysParams params;
+    int32_t n_env;             /* batch of independent environments sharing this PhysTwin       */
+    int32_t num_object_points; /* N                                                              */
+    int32_t num_springs;       /* S                                                              */
+    const float* init_vertices;    /* [n_env, N, 3]                                              */
+    const float* init_velocities;  /* [n_env, N, 3] or NULL (zeros)                              */
+    const int32_t* init_springs;   /* [S, 2]                                                     */
+    const float* init_rest_lengths;/* [S]                                                        */
+    const float* init_spring_Y;    /* [S]  LOG stiffness (phystwin.py:344)                       */
+    const float* init_masses;      /* [N]                                                        */
+    const int32_t* init_collision_mask; /* [N] or NULL -> arange(N) (spring_mass_warp.py:529-533) */
+    /* Combined collision mesh (spring_mass_warp.py:626-695): dynamic meshes first (mesh_map 0,1,..),
+     * then static meshes (mesh_map -1,-2,..).  n_meshes == 0 means "no meshes". */
+    int32_t n_dynamic_meshes, n_static_meshes;
+    const int32_t* mesh_num_vertices; /* [n_dynamic + n_static]                                  */
+    const int32_t* mesh_num_faces;    /* [n_dynamic + n_static]                                  */
+    const float* mesh_vertices;       /* concatenated [sum nv, 3], identical for every env at t=0 */
+    const int32_t* mesh_triangles;    /* concatenated [sum nf, 3], indices local to each mesh    */
+    int32_t collision_capacity;       /* candidate slots per particle; 0 -> 500 (:545)           */
+} R2SPhysDesc;
+
+typedef struct R2SPhys R2SPhys; /* opaque */
+
+/* SpringMassSystemWarp.__init__ (:478-726): uploads topology and state, builds the combined mesh,
+ * mesh_map / face_map, the resting-pair set (create_resting_case, :729-740) when self_collision, and
+ * captures the num_substeps step graph (the reference's wp.ScopedCapture, :723-726). */
+int r2s_phys_create(const R2SPhysDesc* desc, R2SPhys** out, r2s_stream_t stream);
+void r2s_phys_destroy(R2SPhys* h);
+
+/* set_init_state (:742-767).  x, v: device [n_env, N, 3]; v may be NULL (keep). */
+int r2s_phys_set_state(R2SPhys* h, const float* x, const float* v, r2s_stream_t stream);
+/* wp.to_torch(wp_state.wp_x / wp_v) (phystwin.py:523-531).  Either pointer may be NULL. */
+int r2s_phys_get_state(R2SPhys* h, float* x, float* v, r2s_stream_t stream);
+
+/* create_resting_case (:729-740): rebuild the resting-pair set from the CURRENT positions. */
+int r2s_phys_create_resting_case(R2SPhys* h, r2s_stream_t stream);
+/* update_collision_graph (:806-821): hash-grid rebuild + candidate lists, once per env step. */
+int r2s_phys_update_collision_graph(R2SPhys* h, r2s_stream_t stream);
+
+/* set_mesh_interactive (:769-804).  Device pointers, per environment:
+ *   interp_points [n_env, num_substeps, n_dynamic_points, 3], interp_center [n_env, num_substeps, 3],
+ *   dynamic_velocity [n_env, n_dyn_vel, 3] (n_dyn_vel = 2 gripper fingers, 1 pusher),
+ *   dynamic_omega [n_env, 1, 3]. */
+int r2s_phys_set_mesh_interactive(R2SPhys* h, const float* interp_points, const float* interp_center,
+                                  const float* dynamic_velocity, const float* dynamic_omega,
+                                  r2s_stream_t stream);
+
+/* step (:823-943) / wp.capture_launch(graph) (phystwin.py:515-519).  n_substeps <= 0 or
+ * == params.num_substeps replays the captured graph; any other count runs substeps
+ * [first_substep, first_substep + n_substeps) eagerly (they index the interpolated mesh motion). */
+int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t stream);
+
+/* collision_forces (:690-695): device pointer to [n_env, n_faces, 3]; holds the LAST substep's
+ * per-face force, as in the reference which zeroes it every substep (:900). */
+int r2s_phys_collision_forces(R2SPhys* h, float** device_ptr, int32_t* n_faces);
+/* mesh_map / face_map (:677-689), copied to host arrays of n_faces ints (either may be NULL). */
+int r2s_phys_mesh_maps(R2SPhys* h, int32_t* mesh_map, int32_t* face_map);
+/* Candidate lists of update_potential_collision (:544-552): device pointers to
+ * collision_number [n_env, N] and collision_indices [n_env, N, capacity]. */
+int r2s_phys_collision_lists(R2SPhys* h, int32_t** number, int32_t** indices, int32_t* capacity);
+/* Overflow report: max candidates any particle wanted at the last update (host sync). The reference
+ * writes past its 500-wide row unchecked (:226); here extra candidates are dropped and reported. */
+int r2s_phys_collision_max_count(R2SPhys* h, int32_t* max_count, r2s_stream_t stream);
+
+/* set_spring_Y (:946-953, host [S] log stiffness) and set_collide* (:955-995). */
+int r2s_phys_set_spring_Y(R2SPhys* h, const float* log_Y, r2s_stream_t stream);
+int r2s_phys_set_params(R2SPhys* h, const R2SPhysParams* params, r2s_stream_t stream);
+
+/* Measurement hook for bench.py: HIP-event time (ms) of the last r2s_phys_step on its stream and
+ * the number of substep kernels it launched (events are recorded only when enabled). */
+void r2s_phys_set_timing(R2SPhys* h, int enable);
+int r2s_phys_last_step_ms(R2SPhys* h, float* ms, int32_t* kernels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R2S_PHYSICS_H */

@@ -1,0 +1,266 @@
+"""Python host of the physics C ABI (include/r2s_physics.h): a batch of environments that share one
+PhysTwin, stepped by the fused HIP substep kernel.  torch is used for device memory and streams only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, cur_stream
+
+
+class R2SPhysParams(C.Structure):
+    _fields_ = [
+        ("dt", C.c_float), ("dashpot_damping", C.c_float), ("drag_damping", C.c_float), ("spring_Y_min", C.c_float),
+        ("spring_Y_max", C.c_float), ("collision_dist", C.c_float), ("collide_elas", C.c_float), ("collide_fric", C.c_float),
+        ("collide_eef_elas", C.c_float), ("collide_eef_fric", C.c_float), ("collide_self_elas", C.c_float),
+        ("collide_self_fric", C.c_float), ("reverse_z", C.c_int32), ("self_collision", C.c_int32), ("use_pusher", C.c_int32),
+        ("num_substeps", C.c_int32),
+    ]
+
+
+class R2SPhysDesc(C.Structure):
+    _fields_ = [
+        ("params", R2SPhysParams), ("n_env", C.c_int32), ("num_object_points", C.c_int32), ("num_springs", C.c_int32),
+        ("init_vertices", C.c_void_p), ("init_velocities", C.c_void_p), ("init_springs", C.c_void_p),
+        ("init_rest_lengths", C.c_void_p), ("init_spring_Y", C.c_void_p), ("init_masses", C.c_void_p),
+        ("init_collision_mask", C.c_void_p), ("n_dynamic_meshes", C.c_int32), ("n_static_meshes", C.c_int32),
+        ("mesh_num_vertices", C.c_void_p), ("mesh_num_faces", C.c_void_p), ("mesh_vertices", C.c_void_p),
+        ("mesh_triangles", C.c_void_p), ("collision_capacity", C.c_int32),
+    ]
+
+
+_bound = False
+
+
+def _bind():
+    global _bound
+    L = _lib.lib()
+    if _bound:
+        return L
+    vp, i32 = C.c_void_p, C.c_int
+    L.r2s_phys_create.restype = i32
+    L.r2s_phys_create.argtypes = [C.POINTER(R2SPhysDesc), C.POINTER(vp), vp]
+    L.r2s_phys_destroy.restype = None
+    L.r2s_phys_destroy.argtypes = [vp]
+    for name, args in dict(
+        r2s_phys_set_state=[vp, vp, vp, vp], r2s_phys_get_state=[vp, vp, vp, vp], r2s_phys_create_resting_case=[vp, vp],
+        r2s_phys_update_collision_graph=[vp, vp], r2s_phys_set_mesh_interactive=[vp, vp, vp, vp, vp, vp],
+        r2s_phys_step=[vp, i32, i32, vp], r2s_phys_collision_forces=[vp, C.POINTER(vp), C.POINTER(C.c_int32)],
+        r2s_phys_mesh_maps=[vp, vp, vp], r2s_phys_collision_lists=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32)],
+        r2s_phys_collision_max_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_set_spring_Y=[vp, vp, vp],
+        r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
+    ).items():
+        fn = getattr(L, name)
+        fn.restype = i32
+        fn.argtypes = args
+    L.r2s_phys_set_timing.restype = None
+    L.r2s_phys_set_timing.argtypes = [vp, i32]
+    _bound = True
+    return L
+
+
+def _np(a, dtype):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(a, dtype=dtype))
+
+
+def mesh_tuple(m):
+    """Accept open3d-like meshes (``.vertices`` / ``.triangles``) or ``(vertices, triangles)`` tuples."""
+    if hasattr(m, "vertices") and hasattr(m, "triangles"):
+        return np.asarray(m.vertices, np.float32).reshape(-1, 3), np.asarray(m.triangles, np.int32).reshape(-1, 3)
+    v, f = m
+    return _np(v, np.float32).reshape(-1, 3), _np(f, np.int32).reshape(-1, 3)
+
+
+class PhysBatch:
+    """``n_env`` environments sharing one PhysTwin (springs, stiffness, masses, mesh topology).
+
+    Parameter names follow ``SpringMassSystemWarp.__init__`` (sim/physics/spring_mass_warp.py:478-500);
+    ``init_vertices`` is ``[n_env, N, 3]`` (or ``[N, 3]`` for one env)."""
+
+    def __init__(self, *, init_vertices, init_springs, init_rest_lengths, init_masses, init_spring_Y, dt=5e-5,
+                 num_substeps=667, dashpot_damping=100.0, drag_damping=3.0, spring_Y_min=0.0, spring_Y_max=1e5,
+                 collision_dist=0.005, reverse_z=False, self_collision=True, collide_elas=0.5, collide_fric=0.3,
+                 collide_eef_elas=0.0, collide_eef_fric=1.0, collide_self_elas=0.5, collide_self_fric=0.3,
+                 init_collision_mask=None, init_velocities=None, dynamic_meshes=None, static_meshes=None,
+                 use_pusher=False, collision_capacity=500, device="cuda:0"):
+        L = _bind()
+        self.device = torch.device(device)
+        x = _np(init_vertices, np.float32)
+        if x.ndim == 2:
+            x = x[None]
+        self.n_env, self.N = int(x.shape[0]), int(x.shape[1])
+        springs = _np(init_springs, np.int32).reshape(-1, 2)
+        self.S = int(springs.shape[0])
+        rest = _np(init_rest_lengths, np.float32).reshape(-1)
+        logy = _np(init_spring_Y, np.float32).reshape(-1)
+        masses = _np(init_masses, np.float32).reshape(-1)[: self.N]
+        vel = None if init_velocities is None else _np(init_velocities, np.float32).reshape(self.n_env, self.N, 3)
+        masks = None if init_collision_mask is None else _np(init_collision_mask, np.int32).reshape(-1)[: self.N]
+        if self_collision and masks is not None:
+            assert np.unique(masks).shape[0] > 1  # spring_mass_warp.py:534
+        dyn = [mesh_tuple(m) for m in (dynamic_meshes or [])]
+        sta = [mesh_tuple(m) for m in (static_meshes or [])]
+        meshes = dyn + sta
+        self.num_substeps = int(num_substeps)
+        self.use_pusher = bool(use_pusher)
+        self.self_collision = bool(self_collision)
+        f = lambda v: float(np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v, dtype=np.float32).reshape(-1)[0])  # noqa: E731
+        P = R2SPhysParams(f(dt), f(dashpot_damping), f(drag_damping), f(spring_Y_min), f(spring_Y_max), f(collision_dist),
+                          f(collide_elas), f(collide_fric), f(collide_eef_elas), f(collide_eef_fric), f(collide_self_elas),
+                          f(collide_self_fric), int(bool(reverse_z)), int(bool(self_collision)), int(bool(use_pusher)),
+                          int(num_substeps))
+        self.params = P
+        d = R2SPhysDesc()
+        d.params = P
+        d.n_env, d.num_object_points, d.num_springs = self.n_env, self.N, self.S
+        keep = [x, springs, rest, logy, masses, vel, masks]
+        d.init_vertices = x.ctypes.data
+        d.init_velocities = vel.ctypes.data if vel is not None else None
+        d.init_springs = springs.ctypes.data if self.S else None
+        d.init_rest_lengths = rest.ctypes.data if self.S else None
+        d.init_spring_Y = logy.ctypes.data if self.S else None
+        d.init_masses = masses.ctypes.data
+        d.init_collision_mask = masks.ctypes.data if masks is not None else None
+        d.n_dynamic_meshes, d.n_static_meshes = len(dyn), len(sta)
+        self.n_dyn_pts = int(sum(len(v) for v, _ in dyn))
+        self.n_faces = int(sum(len(t) for _, t in meshes))
+        if meshes:
+            nv = np.array([len(v) for v, _ in meshes], np.int32)
+            nf = np.array([len(t) for _, t in meshes], np.int32)
+            vv = np.ascontiguousarray(np.concatenate([v for v, _ in meshes]).astype(np.float32))
+            tt = np.ascontiguousarray(np.concatenate([t for _, t in meshes]).astype(np.int32))
+            keep += [nv, nf, vv, tt]
+            d.mesh_num_vertices, d.mesh_num_faces = nv.ctypes.data, nf.ctypes.data
+            d.mesh_vertices, d.mesh_triangles = vv.ctypes.data, tt.ctypes.data
+        d.collision_capacity = int(collision_capacity)
+        self.collision_capacity = int(collision_capacity)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(L.r2s_phys_create(C.byref(d), C.byref(h), cur_stream(self.device)), "r2s_phys_create")
+        self._h = h
+        del keep
+        # stable output tensors in the reference's layout; refreshed by sync_state()
+        self.x = torch.empty(self.n_env, self.N, 3, dtype=torch.float32, device=self.device)
+        self.v = torch.empty_like(self.x)
+        self.sync_state()
+        mm = np.zeros(self.n_faces, np.int32)
+        fm = np.zeros(self.n_faces, np.int32)
+        check(L.r2s_phys_mesh_maps(self._h, mm.ctypes.data, fm.ctypes.data), "r2s_phys_mesh_maps")
+        self.mesh_map, self.face_map = mm, fm
+
+    # -- lifetime ------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            _bind().r2s_phys_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state ---------------------------------------------------------------------------------------
+    def _s(self):
+        return cur_stream(self.device)
+
+    def sync_state(self):
+        """Refresh ``self.x`` / ``self.v`` ([n_env, N, 3]) from the device state (wp.to_torch views in the reference)."""
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_get_state(self._h, self.x.data_ptr(), self.v.data_ptr(), self._s()), "r2s_phys_get_state")
+        return self.x, self.v
+
+    def set_state(self, x: torch.Tensor, v: Optional[torch.Tensor] = None):
+        x = x.to(self.device, torch.float32).contiguous().reshape(self.n_env, self.N, 3)
+        vp = None
+        if v is not None:
+            v = v.to(self.device, torch.float32).contiguous().reshape(self.n_env, self.N, 3)
+            vp = v.data_ptr()
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_set_state(self._h, x.data_ptr(), vp, self._s()), "r2s_phys_set_state")
+        self.sync_state()
+
+    # -- per-env-step protocol (phystwin.py:362-521) ------------------------------------------------------
+    def create_resting_case(self):
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_create_resting_case(self._h, self._s()), "r2s_phys_create_resting_case")
+
+    def update_collision_graph(self):
+        assert self.self_collision
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_update_collision_graph(self._h, self._s()), "r2s_phys_update_collision_graph")
+
+    def set_mesh_interactive(self, interp_points, interp_center, dynamic_velocity, dynamic_omega):
+        E, n = self.n_env, self.num_substeps
+        ndv = 1 if self.use_pusher else 2
+        t = lambda a, shape: a.to(self.device, torch.float32).contiguous().reshape(shape)  # noqa: E731
+        ip = t(interp_points, (E, n, self.n_dyn_pts, 3))
+        ic = t(interp_center, (E, n, 3))
+        dv = t(dynamic_velocity, (E, ndv, 3))
+        om = t(dynamic_omega, (E, 1, 3))
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_set_mesh_interactive(self._h, ip.data_ptr(), ic.data_ptr(), dv.data_ptr(), om.data_ptr(), self._s()),
+                  "r2s_phys_set_mesh_interactive")
+        self._keep_mesh = (ip, ic, dv, om)
+
+    def step(self, n_substeps: int = 0, first_substep: int = 0, sync_state: bool = True):
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_step(self._h, int(n_substeps), int(first_substep), self._s()), "r2s_phys_step")
+        if sync_state:
+            self.sync_state()
+        return self.x
+
+    # -- read-backs -------------------------------------------------------------------------------------
+    def collision_forces(self) -> torch.Tensor:
+        """[n_env, n_faces, 3] copy of the last substep's per-face forces."""
+        p, n = C.c_void_p(), C.c_int32()
+        check(_bind().r2s_phys_collision_forces(self._h, C.byref(p), C.byref(n)), "r2s_phys_collision_forces")
+        out = torch.empty(self.n_env, int(n.value), 3, dtype=torch.float32, device=self.device)
+        if out.numel():
+            from .raster import _memcpy_d2d
+            _memcpy_d2d(out.data_ptr(), p.value, out.numel() * 4, self.device)
+        return out
+
+    def collision_lists(self):
+        """(collision_number [n_env,N], collision_indices [n_env,N,cap]) copies."""
+        num, idx, cap = C.c_void_p(), C.c_void_p(), C.c_int32()
+        check(_bind().r2s_phys_collision_lists(self._h, C.byref(num), C.byref(idx), C.byref(cap)), "r2s_phys_collision_lists")
+        from .raster import _memcpy_d2d
+        tn = torch.empty(self.n_env, self.N, dtype=torch.int32, device=self.device)
+        _memcpy_d2d(tn.data_ptr(), num.value, tn.numel() * 4, self.device)
+        ti = None
+        if idx.value:
+            ti = torch.empty(self.n_env, self.N, int(cap.value), dtype=torch.int32, device=self.device)
+            _memcpy_d2d(ti.data_ptr(), idx.value, ti.numel() * 4, self.device)
+        return tn, ti
+
+    def collision_max_count(self) -> int:
+        m = C.c_int32()
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_collision_max_count(self._h, C.byref(m), self._s()), "r2s_phys_collision_max_count")
+        return int(m.value)
+
+    def set_spring_Y(self, log_Y):
+        a = _np(log_Y, np.float32).reshape(-1)
+        assert a.shape[0] == self.S
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_set_spring_Y(self._h, a.ctypes.data, self._s()), "r2s_phys_set_spring_Y")
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            setattr(self.params, k, float(np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v, np.float32).reshape(-1)[0]))
+        check(_bind().r2s_phys_set_params(self._h, C.byref(self.params), self._s()), "r2s_phys_set_params")
+
+    def set_timing(self, on: bool):
+        _bind().r2s_phys_set_timing(self._h, int(on))
+
+    def last_step_ms(self):
+        ms, k = C.c_float(), C.c_int32()
+        check(_bind().r2s_phys_last_step_ms(self._h, C.byref(ms), C.byref(k)), "r2s_phys_last_step_ms")
+        return float(ms.value), int(k.value)

@@ -1,0 +1,152 @@
+"""Thin batched rollout driver: the loop the reference's ``BaseEnv.step`` + ``get_obs`` run per environment
+(sim/envs/env.py:53-94 -> PhysTwinDynamics.step, phystwin.py:362-521 -> GSRenderer.render / render_wrist,
+gs_renderer.py:924-1000), for ``n_env`` environments of one GPU at once.
+
+One env step =
+    update_collision_graph                       (once per env step, phystwin.py:365-366)
+    set_mesh_interactive(gripper motion)         (phystwin.py:455-460)
+    num_substeps fused physics substeps          (the captured graph, phystwin.py:515-519)
+    Gaussians follow their particles             (stand-in for LBS skinning, a "next" row: rigid attach)
+    2 rasterised frames per env (side + wrist)   (env.py:55-56)
+
+Synthetic inputs only: there is no network for the real PhysTwin / Scaniverse assets.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import synth
+from .physics import PhysBatch
+from .raster import RasterBatch
+
+CONFIGS = {
+    # name: (object shape, particles, gaussians per env, envs, W, H)  — BASELINE.json configs[1..3]
+    "rope_1env": ("rope", 8000, 40000, 1, 640, 480),
+    "sloth_32env": ("sloth", 15000, 80000, 32, 640, 480),
+    "T_32env": ("T", 2229, 40000, 32, 640, 480),
+    "tiny": ("rope", 600, 3000, 2, 160, 120),
+}
+
+
+class BatchedRollout:
+    def __init__(self, config="sloth_32env", device="cuda:0", seed=0, n_env=None, num_substeps=667, views=2,
+                 self_collision=True, with_gripper=True, with_static=True):
+        shape, n_particles, n_gauss, envs, W, H = CONFIGS[config]
+        self.config = config
+        self.n_env = int(n_env if n_env is not None else envs)
+        self.W, self.H, self.views = W, H, views
+        self.device = torch.device(device)
+        self.num_substeps = int(num_substeps)
+        self.dt = 5e-5
+        E = self.n_env
+        ob = synth.phystwin_object(shape, n_particles, seed)
+        self.ob = ob
+        pts = ob["points"]
+        self.N, self.S = len(pts), len(ob["springs"])
+        # per-env pose: grid randomisation stand-in — planar shifts of a few cm (cfg/gs/*.yaml patterns)
+        rng = np.random.default_rng(seed + 1)
+        self.env_shift = np.zeros((E, 3), np.float32)
+        self.env_shift[:, :2] = rng.uniform(-0.03, 0.03, (E, 2))
+        self.env_shift[0] = 0
+        x0 = pts[None] + self.env_shift[:, None]
+        c = pts.mean(0)
+        top = pts[:, 2].max()
+        dyn, sta = [], []
+        if with_gripper:
+            self.fingers = [synth.finger_mesh((c[0], c[1] - 0.03, top + 0.04)), synth.finger_mesh((c[0], c[1] + 0.03, top + 0.04))]
+            dyn = self.fingers
+        if with_static:
+            sta = [synth.box_mesh((c[0] + 0.25, c[1] + 0.2, 0.135), (0.2, 0.13, 0.27))]
+        self.phys = PhysBatch(init_vertices=x0, init_springs=ob["springs"], init_rest_lengths=ob["rest"],
+                              init_masses=np.ones(self.N, np.float32), init_spring_Y=ob["log_Y"], num_substeps=num_substeps,
+                              self_collision=self_collision, dynamic_meshes=dyn, static_meshes=sta, device=self.device)
+        self.with_gripper = with_gripper
+        # Gaussians: object splats ride on particles, table splats are static
+        sc = synth.gaussian_scene(n_gauss, seed, object_points=pts)
+        self.P = len(sc["means3D"])
+        n_tab = int(n_gauss * 0.35)
+        self.n_obj = self.P - n_tab
+        rgen = np.random.default_rng(seed + 104729)  # same stream synth.gaussian_scene used for `pick`
+        pick = rgen.integers(0, len(pts), self.n_obj)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)  # noqa: E731
+        self.pick = t(pick.astype(np.int64))
+        self.offset = t(sc["means3D"][: self.n_obj] - pts[pick])
+        self.means = torch.empty(E, self.P, 3, dtype=torch.float32, device=self.device)
+        self.means[:, self.n_obj:] = t(sc["means3D"][self.n_obj:])[None]
+        self.g = {k: t(v) for k, v in sc.items() if k != "means3D"}
+        self.raster = RasterBatch(self.device)
+        self.cams = [synth.side_camera(W, H), synth.wrist_camera(W, H, eef_pos=(c[0], c[1], top + 0.30))][:views]
+        self.cam_t = [{k: (t(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()} for cam in self.cams]
+        self.out_color = torch.empty(E, views, 3, H, W, dtype=torch.float32, device=self.device)
+        self.out_depth = torch.empty(E, views, 1, H, W, dtype=torch.float32, device=self.device)
+        self._update_means()
+        self._sets = [RasterBatch.make_set(self.means[e], self.g["opacities"], shs=self.g["shs"], scales=self.g["scales"],
+                                           rotations=self.g["rotations"]) for e in range(E)]
+        self._frames = []
+        for e in range(E):
+            for vi, cam in enumerate(self.cam_t):
+                self._frames.append(dict(set=e, viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"],
+                                         bg=cam["bg"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], z_threshold=cam["z_threshold"],
+                                         out_color=self.out_color[e, vi], out_depth=self.out_depth[e, vi]))
+        self.t = 0
+        self.last_num_rendered = 0
+        if with_gripper:
+            self._init_gripper_motion()
+
+    # ---- gripper motion: fixed Lissajous path at <= 0.1 m/s, rigid, computed on device ------------------------
+    def _init_gripper_motion(self):
+        pts0 = np.concatenate([v for v, _ in self.fingers]).astype(np.float32)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)  # noqa: E731
+        self.finger_pts0 = t(pts0)
+        self.finger_center0 = t(pts0.mean(0))
+        n = self.num_substeps
+        self.ts = (torch.arange(1, n + 1, device=self.device, dtype=torch.float32) * self.dt)
+
+    def _gripper_velocity(self, step):
+        w = 2 * np.pi * 0.25
+        tt = step / 30.0
+        return np.array([0.05 * w * np.cos(w * tt) * 0.6, 0.05 * w * np.cos(2 * w * tt + 0.5) * 0.6, -0.01 * np.sin(w * tt)], np.float32)
+
+    def _set_gripper(self, step):
+        E, n = self.n_env, self.num_substeps
+        vel = torch.from_numpy(self._gripper_velocity(step)).to(self.device)
+        disp = getattr(self, "_disp", torch.zeros(3, device=self.device))
+        base = self.finger_pts0 + disp
+        interp = base[None] + vel[None, None] * self.ts[:, None, None]               # [n, M, 3]
+        centers = (self.finger_center0 + disp)[None] + vel[None] * self.ts[:, None]   # [n, 3]
+        self._disp = disp + vel * (n * self.dt)
+        dv = torch.stack([vel * 0.5, vel * 0.5])                                       # phystwin.py:439
+        om = torch.zeros(1, 3, device=self.device)
+        self.phys.set_mesh_interactive(interp[None].expand(E, -1, -1, -1), centers[None].expand(E, -1, -1),
+                                       dv[None].expand(E, -1, -1), om[None].expand(E, -1, -1))
+
+    def _update_means(self):
+        self.means[:, : self.n_obj] = self.phys.x[:, self.pick] + self.offset[None]
+
+    # ---- one batched env step -----------------------------------------------------------------------------------
+    def physics_step(self):
+        if self.phys.self_collision:
+            self.phys.update_collision_graph()
+        if self.with_gripper:
+            self._set_gripper(self.t)
+        self.phys.step(0, 0, sync_state=True)
+
+    def render(self):
+        self._update_means()
+        self.last_num_rendered = self.raster.forward(self._sets, self._frames, self.W, self.H)
+        return self.out_color, self.out_depth
+
+    def step(self):
+        self.physics_step()
+        out = self.render()
+        self.t += 1
+        return out
+
+    # ---- accounting -------------------------------------------------------------------------------
+    def physics_algorithmic_bytes_per_substep(self):
+        return self.n_env * (16 * self.S + 48 * self.N)
+
+    def composite_algorithmic_bytes(self, num_rendered=None):
+        L = self.last_num_rendered if num_rendered is None else num_rendered
+        return 44 * L + 16 * self.W * self.H * self.n_env * self.views

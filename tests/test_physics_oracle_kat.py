@@ -1,0 +1,221 @@
+"""Known-answer tests that pin the CPU physics oracle to the reference's formulas.
+The reference (sim/physics/spring_mass_warp.py) ships no tests and cannot be imported here (warp-lang + CUDA),
+so every case is a closed form derived from the cited lines."""
+import numpy as np
+import pytest
+
+import oracle
+
+DT = np.float32(5e-5)
+G = np.float32(-9.8)
+
+
+def env(x, springs=None, rest=None, logy=None, **kw):
+    springs = np.zeros((0, 2), np.int32) if springs is None else springs
+    rest = np.zeros(0, np.float32) if rest is None else rest
+    logy = np.zeros(0, np.float32) if logy is None else logy
+    kw.setdefault("self_collision", False)
+    kw.setdefault("num_substeps", 10)
+    f64 = kw.pop("f64", True)
+    return oracle.PhysOracle(np.asarray(x, np.float32), springs, rest, logy, f64=f64, **kw)
+
+
+def test_Q1_two_particles_one_spring_with_dashpot():
+    x = [[0, 0, 1.0], [0.1, 0, 1.0]]
+    v = [[0, 0, 0], [1.0, 0, 0]]
+    o = env(x, np.array([[0, 1]]), np.array([0.08]), np.log(np.array([1000.0])), v0=v, drag_damping=3.0)
+    o.step(1)
+    k, L, rest, c = 1000.0, np.float32(0.1).astype(np.float64), np.float32(0.08).astype(np.float64), 100.0
+    F = k * (L / rest - 1.0) + c * 1.0  # eval_springs :92-101
+    drag = np.exp(-float(DT) * 3.0)
+    v1 = np.array([F * float(DT), 0, float(G) * float(DT)]) * drag        # :123-129, m = 1
+    v2 = np.array([1.0 - F * float(DT), 0, float(G) * float(DT)]) * drag  # antisymmetric (:103-104)
+    assert np.allclose(o.v[0], v1, rtol=1e-6, atol=1e-9) and np.allclose(o.v[1], v2, rtol=1e-6, atol=1e-9)
+    assert np.allclose(o.x[0], np.array(x[0]) + v1 * float(DT), atol=1e-9)  # no mesh: single advance (:473)
+
+
+def test_Q2_free_fall_with_drag_closed_form():
+    o = env([[0, 0, 5.0]], drag_damping=3.0, num_substeps=400)
+    o.step(400)
+    dt, drag = float(DT), np.exp(-float(DT) * 3.0)
+    v, z = 0.0, 5.0
+    for _ in range(400):
+        v = (v + float(G) * dt) * drag
+        z += v * dt
+    assert o.v[0, 2] == pytest.approx(v, rel=1e-9) and o.x[0, 2] == pytest.approx(z, rel=1e-12)
+
+
+def test_Q3_ground_bounce_time_of_impact_split():
+    z0, vz, vx = 1e-5, -1.0, 0.5
+    o = env([[0, 0, z0]], v0=[[vx, 0, vz]], drag_damping=0.0, collide_elas=0.5, collide_fric=0.3)
+    o.step(1)
+    dt = float(DT)
+    vz1 = vz + float(G) * dt
+    assert (np.float32(z0) + vz1 * dt) < 0 and vz1 < -1e-4  # :447
+    e, mu = 0.5, float(np.float32(0.3))  # parameters are float32 in the reference
+    a = max(0.0, 1.0 - mu * (1 + e) * abs(vz1) / abs(vx))  # :457-464
+    v_after = np.array([a * vx, 0.0, -e * vz1])
+    toi = -float(np.float32(z0)) / vz1  # :468
+    x_after = np.array([0, 0, float(np.float32(z0))]) + np.array([vx, 0, vz1]) * toi + v_after * (dt - toi)  # :473
+    assert np.allclose(o.v[0], v_after, rtol=1e-7) and np.allclose(o.x[0], x_after, atol=1e-12)
+    assert o.x[0, 2] > 0
+
+
+def test_Q3b_restitution_and_friction_are_clamped():
+    a = env([[0, 0, 1e-5]], v0=[[0.5, 0, -1.0]], collide_elas=7.0, collide_fric=9.0)
+    b = env([[0, 0, 1e-5]], v0=[[0.5, 0, -1.0]], collide_elas=1.0, collide_fric=2.0)  # clamp bounds :453-454
+    a.step(1); b.step(1)
+    assert np.array_equal(a.v, b.v)
+
+
+def test_Q4_head_on_pair_symmetric_impulse_and_averaging():
+    x = [[0, 0, 1.0], [0.004, 0, 1.0], [0, 0.004, 1.0]]
+    v = [[0, 0, 0], [-1.0, 0, 0], [0, -1.0, 0]]
+    o = env(x, v0=v, self_collision=True, drag_damping=0.0, collide_self_elas=0.5, collide_self_fric=0.0, masks=[0, 1, 2])
+    o.coll_num[:] = [2, 1, 1]
+    o.coll_idx[0, :2] = [1, 2]; o.coll_idx[1, 0] = 0; o.coll_idx[2, 0] = 0
+    o.step(1)
+    g = float(G) * float(DT)
+    e = 0.5
+    # particle 0: two valid contacts; per contact J = -(1+e) v_rel_n / 2 (+ frictionless tangential: a = 1 -> J_t = 0)
+    # contact with 1: rel v = (-1,0,0), n = (1,0,0): J = (0.75, 0, 0); contact with 2: J = (0, 0.75, 0)
+    # v0' = v0 - mean(J) / m  (:264-266) -> (-0.375, -0.375)
+    assert np.allclose(o.v[0], [-0.375, -0.375, g], atol=1e-9)
+    # particle 1 sees only particle 0: rel v = (1,0,0), n = (-1,0,0): J = -(1.5)(1,0,0)/2 -> v1' = -1 + 0.75
+    assert np.allclose(o.v[1], [-0.25, 0.0, g], atol=1e-9)
+    assert np.allclose(o.v[2], [0.0, -0.25, g], atol=1e-9)
+
+
+def test_Q4b_separating_pairs_and_equal_masks_are_ignored():
+    x = [[0, 0, 1.0], [0.004, 0, 1.0]]
+    o = env(x, v0=[[0, 0, 0], [1.0, 0, 0]], self_collision=True, drag_damping=0.0, masks=[0, 1])
+    o.coll_num[:] = [1, 1]; o.coll_idx[0, 0] = 1; o.coll_idx[1, 0] = 0
+    o.step(1)
+    assert o.v[1, 0] == pytest.approx(1.0)  # dot(dis, rel_v) > 0 -> no impulse (:166)
+    o2 = env(x, v0=[[0, 0, 0], [-1.0, 0, 0]], self_collision=True, drag_damping=0.0, masks=[0, 0, ] + [])
+    o2.masks[:] = [5, 5]; o2.coll_num[:] = [1, 1]; o2.coll_idx[0, 0] = 1; o2.coll_idx[1, 0] = 0
+    o2.step(1)
+    assert o2.v[1, 0] == pytest.approx(-1.0)  # mask1 == mask2 (:164)
+
+
+def _box(center, size):
+    from r2s_hip import synth
+    return synth.box_mesh(center, size)
+
+
+def test_Q5_static_box_margin_projection_and_reflection():
+    box = _box((0, 0, 0.5), (1.0, 1.0, 0.2))  # top face at z = 0.6
+    z0 = 0.6 + 0.0012
+    o = env([[0.01, 0.02, z0]], v0=[[0.3, 0, -10.0]], static_meshes=[box], drag_damping=0.0, collide_elas=0.5, collide_fric=0.3)
+    o.step(1)
+    dt = float(DT)
+    vz = -10.0 + float(G) * dt
+    nx = np.array([0.01, 0.02, float(np.float32(z0))]) + np.array([0.3, 0, vz]) * dt  # :321
+    dist = nx[2] - 0.6
+    err = dist - 0.001  # static margin 1 mm (:344-349)
+    assert err < 0
+    a = max(0.0, 1 - float(np.float32(0.3)) * 1.5 * abs(vz) / float(np.float32(0.3)))
+    v_new = np.array([a * float(np.float32(0.3)), 0, -0.5 * vz])
+    x_mid = nx - np.array([0, 0, 1.0]) * err  # :410 pushes out to the margin
+    x_fin = x_mid + v_new * dt  # integrate_ground_collision advances AGAIN (:473) — fact 5 of SURVEY.md
+    assert np.allclose(o.v[0], v_new, rtol=1e-6, atol=1e-7)
+    assert np.allclose(o.x[0], x_fin, atol=2e-8)
+    # force on the touched face: delta v_n / dt (:413-414); top face is one of the two z=+ triangles
+    f = o.collision_forces.sum(0)
+    assert np.allclose(f, [0, 0, (-0.5 * vz - vz) / dt], rtol=1e-5, atol=1e-3)
+    assert (np.abs(o.collision_forces).sum(1) > 0).sum() == 1
+
+
+def test_Q6_moving_finger_relative_frame_margin_and_requery():
+    n_sub = 4
+    finger = _box((0, 0, 0.5), (0.2, 0.2, 0.1))  # top at z = 0.55
+    other = _box((5.0, 0, 0.5), (0.2, 0.2, 0.1))
+    o = env([[0.0, 0.01, 0.5535]], v0=[[0, 0, 0]], dynamic_meshes=[finger, other], drag_damping=0.0, num_substeps=n_sub,
+            collide_eef_elas=0.0, collide_eef_fric=1.0)
+    pts0 = np.concatenate([finger[0], other[0]])
+    vel = np.array([0, 0, 2.0])  # the finger mesh rises at 2 m/s; the caller passes HALF of it (phystwin.py:439)
+    ts = (np.arange(1, n_sub + 1) * float(DT))[:, None, None]
+    interp = pts0[None] + vel[None, None] * ts
+    centers = pts0[:8].mean(0)[None] + vel[None] * ts[:, 0]
+    o.set_mesh_interactive(interp, centers, np.stack([vel * 0.5, vel * 0.5]), np.zeros((1, 3)))
+    o.step(1)
+    dt = float(DT)
+    vz = float(G) * dt
+    x0 = float(np.float32(0.5535))
+    top = float(np.float32(0.55)) + 2.0 * dt
+    nx = x0 + vz * dt
+    err = (nx - top) - 0.005  # gripper margin 5 mm (:344-345)
+    assert err < 0
+    # relative frame: v_rel = v - 1.0 (half the true speed); e = 0 -> normal part removed, v_new = 0 + 1.0  (:364-392)
+    v_new = 1.0
+    # position: re-query at x0 + v_new*dt (:396-408) then push out to the margin, then advanced again by v_new*dt
+    nx2 = x0 + v_new * dt
+    err2 = (nx2 - top) - 0.005
+    x_mid = nx2 - err2 if err2 < 0 else nx2
+    assert o.v[0, 2] == pytest.approx(v_new, rel=1e-6)
+    assert o.x[0, 2] == pytest.approx(x_mid + v_new * dt, abs=3e-8)
+    assert o.collision_forces[:12].sum(0)[2] == pytest.approx((0 - (vz - 1.0)) / dt, rel=1e-5)
+    assert np.abs(o.collision_forces[12:]).sum() == 0
+
+
+def test_Q7_stiffness_gate_and_clamp():
+    x = [[0, 0, 1.0], [0.1, 0, 1.0]]
+    sp, rest = np.array([[0, 1]]), np.array([0.08])
+    hi = env(x, sp, rest, np.log(np.array([1e9])), drag_damping=0.0, dashpot_damping=0.0)
+    cl = env(x, sp, rest, np.log(np.array([1e5])), drag_damping=0.0, dashpot_damping=0.0)
+    hi.step(1); cl.step(1)
+    assert np.allclose(hi.v, cl.v, rtol=1e-6)  # clamp to spring_Y_max (:93)
+    off = env(x, sp, rest, np.log(np.array([50.0])), drag_damping=0.0, spring_Y_min=100.0)
+    off.v[1, 0] = 1.0
+    off.step(1)
+    assert off.v[0, 0] == 0.0 and off.v[1, 0] == pytest.approx(1.0)  # gated off entirely incl. dashpot (:75)
+
+
+def test_Q8_position_advances_twice_when_a_mesh_exists():
+    far_box = _box((50.0, 0, 0.5), (0.1, 0.1, 0.1))
+    a = env([[0, 0, 5.0]], v0=[[1.0, 0, 0]], drag_damping=0.0)
+    b = env([[0, 0, 5.0]], v0=[[1.0, 0, 0]], drag_damping=0.0, static_meshes=[far_box])
+    a.step(1); b.step(1)
+    assert a.x[0, 0] == pytest.approx(1.0 * float(DT))
+    assert b.x[0, 0] == pytest.approx(2.0 * float(DT))  # mesh_collision :321,:420 then integrate :473
+
+
+def test_mesh_query_sign_distance_and_ties():
+    v, f = _box((0, 0, 0), (2, 2, 2))
+    q = oracle.mesh_query(v, f, [0, 0, 1.01], f64=True)
+    assert q["result"] and q["sign"] == 1.0 and np.allclose(q["point"], [0, 0, 1.0])
+    q = oracle.mesh_query(v, f, [0.2, -0.3, 0.99], f64=True)
+    assert q["result"] and q["sign"] == -1.0 and np.allclose(q["point"], [0.2, -0.3, 1.0])
+    assert not oracle.mesh_query(v, f, [0, 0, 1.03], f64=True)["result"]  # beyond max_dist = 0.02
+    assert not oracle.mesh_query(v, f, [0, 0, 0.0], f64=True)["result"]   # deep inside: no face within 2 cm either
+    # a point above the top-face diagonal is equidistant from both top triangles: lowest face index wins
+    q = oracle.mesh_query(v, f, [0.5, 0.5, 1.005], f64=True)
+    tops = [i for i, t in enumerate(f) if np.allclose(v[t][:, 2], 1.0)]
+    assert q["face"] == min(tops)
+
+
+def test_hash_grid_semantics_resting_pairs():
+    cd = 0.005
+    cell = 5 * cd
+    # particle 1 sits in the neighbouring cell but 4 cm away (> query radius is irrelevant: no distance filter, :287-291)
+    x = np.array([[0.012, 0.012, 0.012], [0.049, 0.012, 0.012], [0.012, 0.012, 0.10]], np.float32)
+    o = env(x, self_collision=True, collision_dist=cd, f64=False)
+    assert o.resting[1, 0] == 1 and o.resting[0, 1] == 1  # cells 0 and 1 both overlap [x-r, x+r] of particle 1
+    assert o.resting[2, 0] == 0                            # z cell 4 is outside particle 2's box [3, 4]... and 0's
+    # int() truncation toward zero: coordinates in (-cell, cell) share cell 0 (warp-lang hashgrid.h, unpinned)
+    y = np.array([[-0.02, 0.0, 0.0], [0.02, 0.0, 0.0]], np.float32)
+    o2 = env(y, self_collision=True, collision_dist=cd, f64=False)
+    assert o2.resting[1, 0] == 1
+    assert cell == pytest.approx(0.025)
+
+
+def test_update_collision_keeps_only_close_non_resting_pairs():
+    a = np.array([[0.0, 0, 0.1], [0.2, 0, 0.1]], np.float32)
+    o = env(a, self_collision=True, f64=False)
+    assert o.resting.sum() == 0
+    o.x[1] = [0.004, 0, 0.1]
+    assert o.update_collision_graph() == 1
+    assert list(o.coll_num) == [1, 1] and o.coll_idx[0, 0] == 1 and o.coll_idx[1, 0] == 0
+    o.x[1] = [0.0051, 0, 0.1]
+    o.update_collision_graph()
+    assert list(o.coll_num) == [0, 0]  # strict `< collision_dist` (:225)
