@@ -10,6 +10,16 @@
 //     slot-major so every load is a coalesced 256-byte run) instead of scattered with float atomics
 //     (eval_springs, :61-104) — deterministic and atomic-free.  Velocity update (:107-129), self collision
 //     (:132-268), mesh collision (:295-421) and ground integration (:424-474) run in the same thread.
+//   * Particles are re-ordered along a Morton curve at construction (the caller never sees it: set/get_state
+//     permute).  A workgroup owns 256 consecutive particles of one environment and stages their {x,v}
+//     records plus a precomputed HALO (the most-referenced outside neighbours, up to the LDS budget) in LDS
+//     with coalesced / once-per-workgroup loads; the ~31 neighbour gathers per particle are then LDS reads
+//     (ds_read_b128) instead of 64-distinct-cache-line global gathers, which the first profile showed to be
+//     the limiter (vector-L1 tag rate, not bytes).  Neighbours that do not fit the halo fall back to a
+//     global gather, so any topology works.
+//   * Workgroups are numbered so that each XCD (private 4 MiB L2) owns a contiguous chunk of particle blocks
+//     for ALL environments, environment index fastest: its slice of the adjacency and its particles' state
+//     stay resident in that XCD's L2 and most halo records were written by the same XCD.
 //   * Self collision needs the post-force velocity of the contact partner (object_collision reads
 //     v_before_collision[j]); instead of a second launch per substep the few particles that have contact
 //     candidates recompute their partners' velocity update (same code path, bit-identical result).
@@ -31,10 +41,20 @@
 #include <cmath>
 #include <vector>
 
+#ifndef R2S_EXPERIMENT
+#define R2S_EXPERIMENT 0
+#endif
+
 namespace {
 
 constexpr int SLICE = 64;
-constexpr int BLOCK = 256;
+#ifndef R2S_BLOCK
+#define R2S_BLOCK 256
+#endif
+#ifndef R2S_UNROLL
+#define R2S_UNROLL 4
+#endif
+constexpr int BLOCK = R2S_BLOCK;
 constexpr int GRID_DIM = 128;          // wp.HashGrid(128,128,128), spring_mass_warp.py:541
 constexpr int GRID_CELL_BITS = 21;     // 128^3 cells
 constexpr float MESH_MAX_DIST = 0.02f; // :323
@@ -42,12 +62,19 @@ constexpr float WIND_THRESHOLD = 0.6f; // :323
 
 struct PhysDev {
     int N, E, n_sub;
-    // topology (shared by all envs)
+    // topology (shared by all envs); all particle indices are INTERNAL (Morton order)
+    int nb, cb;                // particle blocks of BLOCK, blocks per XCD chunk
     const int* slice_off;      // [n_slices]
     const int* slice_deg;      // [n_slices]
-    const int* adj_j;          // sliced ELL, slot-major inside a slice
-    const float* adj_inv_rest;
-    const float* adj_k;
+    const int4* adj;           // sliced ELL, slot-major, 16 B per slot: {LDS record of the neighbour in the owner's
+                               // block, global particle id, bits(k), bits(1/rest)}; padding / inactive / overflowed slots
+                               // point at the owner itself (zero force)
+    const int* ovf_ptr;        // [N+1] per-particle overflow neighbours that did not fit the block's halo (normally empty)
+    const int4* ovf;           // {global id, bits(k), bits(1/rest), 0}
+    const int* halo_off;       // [nb+1]
+    const int* halo_ids;       // halo particle ids per block (LDS records BLOCK.. in this order)
+    const int* perm;           // internal -> user index
+    const int* inv;            // user -> internal index
     const float* masses;       // [N]
     const int* masks;          // [N]
     // scalars
@@ -58,6 +85,9 @@ struct PhysDev {
     const int* coll_num;       // [E,N]
     const int* coll_idx;       // [E,N,cap]
     int coll_cap;
+    float4* vbc;               // [E,N] v_before_collision published by particles that have candidates
+    const int2* cand_list;     // (env, particle) of every particle with candidates
+    const int* cand_count;
     // meshes
     int n_mesh, n_dyn_mesh, nF, nV, n_dyn_pts;
     const int* faces;          // [nF,3] global vertex ids
@@ -207,93 +237,83 @@ __device__ MeshQ mesh_query(const PhysDev& p, int e, int step, f3 q)
 // in adjacency order instead of atomic order.  The hot loop: FMA contraction allowed, 1-ulp rsq instead of
 // sqrt + three divides (the reference's own float atomics reorder sums far more than this perturbs them).
 #pragma clang fp contract(fast)
-__device__ __forceinline__ f3 spring_force(const PhysDev& p, const float4* __restrict__ xv, size_t env_base, int i, f3 xi, f3 vi)
+__device__ __forceinline__ void spring_term(float4 xj, float4 vj, f3 xi, f3 vi, float k, float inv_rest, float dashpot, float& fx,
+                                            float& fy, float& fz)
 {
+    const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    const float rinv = __builtin_amdgcn_rsqf(fmaxf(d2, 1e-12f)); // 1 / max(L, 1e-6)
+    const float L = d2 * rinv;
+    const float ux = dx * rinv, uy = dy * rinv, uz = dz * rinv;
+    const float v_rel = (vj.x - vi.x) * ux + (vj.y - vi.y) * uy + (vj.z - vi.z) * uz;
+    const float mag = k * (L * inv_rest - 1.0f) + dashpot * v_rel;
+    fx += ux * mag; fy += uy * mag; fz += uz * mag;
+}
+
+// Hot path: every neighbour slot is one coalesced 16-byte adjacency load + two ds_read_b128 from the workgroup's LDS
+// window (records = {x, v}); no branch in the loop, so the 4x-unrolled body keeps 4 adjacency loads and 8 LDS reads
+// in flight.  Neighbours that did not fit the halo (none for the benchmark objects) follow from a per-particle overflow
+// list with global gathers.
+__device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* __restrict__ xv, const float4* lds, size_t env_base,
+                                               int i, f3 xi, f3 vi)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const v4f lds_f4; // explicit LDS address space -> ds_read_b128
+    lds_f4* lds3 = (lds_f4*)lds;
     const int sl = i >> 6, ln = i & 63;
-    const int base = p.slice_off[sl] + ln;
+    const int4* __restrict__ a = p.adj + p.slice_off[sl] + ln;
     const int deg = p.slice_deg[sl];
     float fx = 0.f, fy = 0.f, fz = 0.f;
-#pragma unroll 4
+#pragma unroll R2S_UNROLL
     for (int n = 0; n < deg; ++n) {
-        const int idx = base + n * SLICE;
-        const int j = p.adj_j[idx];
-        const float inv_rest = p.adj_inv_rest[idx];
-        const float k = p.adj_k[idx];
-        const float4 xj = xv[(env_base + j) * 2];
-        const float4 vj = xv[(env_base + j) * 2 + 1];
-        const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        const float rinv = __builtin_amdgcn_rsqf(fmaxf(d2, 1e-12f)); // 1 / max(L, 1e-6)
-        const float L = d2 * rinv;
-        const float ux = dx * rinv, uy = dy * rinv, uz = dz * rinv;
-        const float v_rel = (vj.x - vi.x) * ux + (vj.y - vi.y) * uy + (vj.z - vi.z) * uz;
-        const float mag = k * (L * inv_rest - 1.0f) + p.dashpot * v_rel;
-        fx += ux * mag; fy += uy * mag; fz += uz * mag;
+#if R2S_EXPERIMENT == 2 /* no adjacency loads: synthetic entries */
+        const int4 en = make_int4((i + n * 7) & 255, 0, 0x447a0000, 0x42c80000);
+#else
+        const int4 en = a[n * SLICE];
+#endif
+#if R2S_EXPERIMENT == 1 /* no LDS reads */
+        const v4f xl = {__int_as_float(en.x) , 0.1f, 0.2f, 0.f}, vl = {0.f, __int_as_float(en.y), 0.f, 0.f};
+#else
+        const v4f xl = lds3[2 * en.x], vl = lds3[2 * en.x + 1];
+#endif
+        spring_term(make_float4(xl.x, xl.y, xl.z, 0.f), make_float4(vl.x, vl.y, vl.z, 0.f), xi, vi, __int_as_float(en.z),
+                    __int_as_float(en.w), p.dashpot, fx, fy, fz);
+    }
+    for (int t = p.ovf_ptr[i], t1 = p.ovf_ptr[i + 1]; t < t1; ++t) {
+        const int4 en = p.ovf[t];
+        const size_t g = (env_base + (size_t)en.x) * 2;
+        spring_term(xv[g], xv[g + 1], xi, vi, __int_as_float(en.y), __int_as_float(en.z), p.dashpot, fx, fy, fz);
     }
     return {fx, fy, fz};
 }
+
 #pragma clang fp contract(off)
 
-// ---- the fused substep ------------------------------------------------------------------------------
-// grid = (ceil(N/256), E); one thread per (particle, environment).
-template <bool SELF, bool MESH>
-__global__ void __launch_bounds__(BLOCK) k_substep(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out,
-                                                   int step, int write_forces)
+// ---- everything after the velocity update for ONE particle: mesh collision, ground, store -------------------
+// (shared by the fused substep and the self-collision finishing kernel)
+template <bool MESH>
+__device__ __forceinline__ void finish_particle(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v,
+                                                float4* __restrict__ xv_out)
 {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    const int e = blockIdx.y;
-    if (i >= p.N) return;
-    const size_t eb = (size_t)e * p.N;
-    const f3 x0 = xyz(xv_in[(eb + i) * 2]);
-    const f3 v0 = xyz(xv_in[(eb + i) * 2 + 1]);
-    const float m1 = p.masses[i];
-
-    // eval_springs + update_vel_from_force
-    f3 v = vel_update(p, v0, spring_force(p, xv_in, eb, i, x0, v0), m1);
-
-    // object_collision + loop, :132-193, :230-268
-    if (SELF) {
-        const int cnt = p.coll_num[eb + i];
-        if (cnt > 0) {
-            const int mask1 = p.masks[i];
-            float valid = 0.f;
-            f3 Jsum = mk(0.f, 0.f, 0.f);
-            for (int k = 0; k < cnt; ++k) {
-                const int j = p.coll_idx[(eb + i) * (size_t)p.coll_cap + k];
-                const f3 x2 = xyz(xv_in[(eb + j) * 2]);
-                const f3 dis = x2 - x0;
-                const float dis_len = len(dis);
-                if (mask1 == p.masks[j] || !(dis_len < p.cd)) continue;
-                // partner's v_before_collision: the same spring gather + velocity update its own thread performs
-                const f3 vj0 = xyz(xv_in[(eb + j) * 2 + 1]);
-                const float m2 = p.masses[j];
-                const f3 v2 = vel_update(p, vj0, spring_force(p, xv_in, eb, j, x2, vj0), m2);
-                const f3 rv = v2 - v;
-                if (dot(dis, rv) < -1e-4f) {
-                    valid += 1.f;
-                    const f3 nrm = dis / fmaxf(dis_len, 1e-6f);
-                    const f3 v_rel_n = nrm * dot(rv, nrm);
-                    const float inv = 1.f / m1 + 1.f / m2;
-                    const f3 impulse_n = (v_rel_n * (-(1.f + p.cse))) / inv;
-                    const float vnl = len(v_rel_n);
-                    const f3 v_rel_t = rv - v_rel_n;
-                    const float vtl = fmaxf(len(v_rel_t), 1e-6f);
-                    const float a = fmaxf(0.f, 1.f - p.csf * (1.f + p.cse) * vnl / vtl);
-                    const f3 impulse_t = (v_rel_t * (a - 1.f)) / inv;
-                    Jsum = Jsum + (impulse_n + impulse_t);
-                }
-            }
-            if (valid > 0.f) v = v - (Jsum / valid) / m1;
-        }
-    }
-
     f3 x = x0;
     // mesh_collision, :295-421 — advances x by v*dt for EVERY particle (:321, :420)
     if (MESH) {
         f3 vin = v;
         f3 next_x = x0 + vin * p.dt;
         f3 next_v = vin;
-        MeshQ q = mesh_query(p, e, step, next_x);
+        // Exact early-out.  The response below only fires when signed distance < margin (5 mm for gripper
+        // meshes, 1 mm otherwise).  Every collision mesh is a closed surface, so a point outside a mesh's AABB is
+        // outside the mesh (winding number 0 < 0.6, sign +1) and its distance to the mesh is at least its distance
+        // to the AABB: if that is >= the margin for every mesh, nothing can happen and the query is skipped.
+        bool need = false;
+        for (int m = 0; m < p.n_mesh; ++m) {
+            const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
+                                               : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
+            const float mg = (m < p.n_dyn_mesh && !p.use_pusher) ? 0.005f : 0.001f;
+            need = need || box_dist2(next_x, bb) < mg * mg * 1.0001f;
+        }
+        MeshQ q = {false, 0.f, 0, 0.f, 0.f};
+        if (need) q = mesh_query(p, e, step, next_x);
         if (q.result) {
             int is_gripper;
             const int mm = p.mesh_map[q.face];
@@ -381,20 +401,131 @@ __global__ void __launch_bounds__(BLOCK) k_substep(const PhysDev p, const float4
     }
 }
 
-// ---- state pack / unpack ----------------------------------------------------------------------------
-__global__ void k_pack(int total, const float* __restrict__ x, const float* __restrict__ v, float4* __restrict__ xv)
+// ---- the fused substep ------------------------------------------------------------------------------
+// One workgroup = 256 consecutive (Morton-ordered) particles of one environment.  Linear workgroup id L:
+// XCD = L % 8 (observed dispatch order; a speed assumption only), within an XCD the environment index runs
+// fastest over the XCD's contiguous chunk of particle blocks.
+template <bool SELF, bool MESH>
+__global__ void __launch_bounds__(BLOCK) k_substep(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out,
+                                                   int step, int write_forces)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    if (x) xv[2 * (size_t)t] = make_float4(x[3 * (size_t)t], x[3 * (size_t)t + 1], x[3 * (size_t)t + 2], 0.f);
-    if (v) xv[2 * (size_t)t + 1] = make_float4(v[3 * (size_t)t], v[3 * (size_t)t + 1], v[3 * (size_t)t + 2], 0.f);
+    extern __shared__ __attribute__((aligned(16))) float4 lds[]; // (BLOCK + halo) records of 2 float4
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int e = q % p.E, bq = q / p.E;
+    const int b = xcd * p.cb + bq;
+    if (bq >= p.cb || b >= p.nb) return; // whole workgroup
+    const int tid = threadIdx.x;
+    const int i = b * BLOCK + tid;
+    const size_t eb = (size_t)e * p.N;
+    // stage own records (fully coalesced: 2*BLOCK consecutive float4) and the halo
+    {
+        const int n_own = min(BLOCK, p.N - b * BLOCK) * 2;
+        const float4* src = xv_in + (eb + (size_t)b * BLOCK) * 2;
+        if (tid < n_own) lds[tid] = src[tid];
+        if (tid + BLOCK < n_own) lds[tid + BLOCK] = src[tid + BLOCK];
+        const int h0 = p.halo_off[b], h1 = p.halo_off[b + 1];
+        for (int h = h0 + tid; h < h1; h += BLOCK) {
+            const size_t g = (eb + (size_t)p.halo_ids[h]) * 2;
+            const int r = BLOCK + (h - h0);
+            lds[2 * r] = xv_in[g];
+            lds[2 * r + 1] = xv_in[g + 1];
+        }
+    }
+    __syncthreads();
+    if (i >= p.N) return;
+    const f3 x0 = xyz(lds[2 * tid]);
+    const f3 v0 = xyz(lds[2 * tid + 1]);
+    const float m1 = p.masses[i];
+
+    // eval_springs + update_vel_from_force
+    f3 v = vel_update(p, v0, spring_force_lds(p, xv_in, lds, eb, i, x0, v0), m1);
+
+    // Self collision (object_collision, :230-268) needs the partners' post-force velocities.  Particles that have
+    // contact candidates (rare; the list is rebuilt once per env step) only publish their own v_before_collision
+    // here and are finished by k_self_finish, which reads the partners' published values; everyone else is done.
+    if (SELF) {
+        if (p.coll_num[eb + i] > 0) {
+            p.vbc[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
+            return;
+        }
+    }
+    finish_particle<MESH>(p, e, i, eb, step, write_forces, x0, v, xv_out);
 }
-__global__ void k_unpack(int total, const float4* __restrict__ xv, float* __restrict__ x, float* __restrict__ v)
+
+// object_collision + loop (:132-193, :230-268) for the particles on the candidate list, then the rest of the substep.
+template <bool MESH>
+__global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
+                                                     int write_forces)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    if (x) { const float4 a = xv[2 * (size_t)t]; x[3 * (size_t)t] = a.x; x[3 * (size_t)t + 1] = a.y; x[3 * (size_t)t + 2] = a.z; }
-    if (v) { const float4 a = xv[2 * (size_t)t + 1]; v[3 * (size_t)t] = a.x; v[3 * (size_t)t + 1] = a.y; v[3 * (size_t)t + 2] = a.z; }
+    const int n = *p.cand_count;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const int2 ei = p.cand_list[t];
+        const int e = ei.x, i = ei.y;
+        const size_t eb = (size_t)e * p.N;
+        const f3 x0 = xyz(xv_in[(eb + i) * 2]);
+        f3 v = xyz(p.vbc[eb + i]);
+        const float m1 = p.masses[i];
+        const int mask1 = p.masks[i];
+        const int cnt = p.coll_num[eb + i];
+        float valid = 0.f;
+        f3 Jsum = mk(0.f, 0.f, 0.f);
+        for (int k = 0; k < cnt; ++k) {
+            const int j = p.coll_idx[(eb + i) * (size_t)p.coll_cap + k];
+            const f3 x2 = xyz(xv_in[(eb + j) * 2]);
+            const f3 v2 = xyz(p.vbc[eb + j]); // j lists i too (the candidate relation is symmetric), so it published
+            const float m2 = p.masses[j];
+            const f3 dis = x2 - x0;
+            const float dis_len = len(dis);
+            const f3 rv = v2 - v;
+            if (mask1 != p.masks[j] && dis_len < p.cd && dot(dis, rv) < -1e-4f) {
+                valid += 1.f;
+                const f3 nrm = dis / fmaxf(dis_len, 1e-6f);
+                const f3 v_rel_n = nrm * dot(rv, nrm);
+                const float inv = 1.f / m1 + 1.f / m2;
+                const f3 impulse_n = (v_rel_n * (-(1.f + p.cse))) / inv;
+                const float vnl = len(v_rel_n);
+                const f3 v_rel_t = rv - v_rel_n;
+                const float vtl = fmaxf(len(v_rel_t), 1e-6f);
+                const float a = fmaxf(0.f, 1.f - p.csf * (1.f + p.cse) * vnl / vtl);
+                const f3 impulse_t = (v_rel_t * (a - 1.f)) / inv;
+                Jsum = Jsum + (impulse_n + impulse_t);
+            }
+        }
+        if (valid > 0.f) v = v - (Jsum / valid) / m1;
+        finish_particle<MESH>(p, e, i, eb, step, write_forces, x0, v, xv_out);
+    }
+}
+
+// ---- state pack / unpack: caller order [env][user index][3]  <->  internal [env][Morton index]{x,v} -------
+__global__ void k_pack(int N, int E, const int* __restrict__ inv, const float* __restrict__ x, const float* __restrict__ v, float4* __restrict__ xv)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    if (u >= N) return;
+    const size_t src = ((size_t)e * N + u) * 3, dst = ((size_t)e * N + inv[u]) * 2;
+    if (x) xv[dst] = make_float4(x[src], x[src + 1], x[src + 2], 0.f);
+    if (v) xv[dst + 1] = make_float4(v[src], v[src + 1], v[src + 2], 0.f);
+}
+__global__ void k_unpack(int N, int E, const int* __restrict__ inv, const float4* __restrict__ xv, float* __restrict__ x, float* __restrict__ v)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    if (u >= N) return;
+    const size_t dst = ((size_t)e * N + u) * 3, src = ((size_t)e * N + inv[u]) * 2;
+    if (x) { const float4 a = xv[src]; x[dst] = a.x; x[dst + 1] = a.y; x[dst + 2] = a.z; }
+    if (v) { const float4 a = xv[src + 1]; v[dst] = a.x; v[dst + 1] = a.y; v[dst + 2] = a.z; }
+}
+// candidate lists back to the caller's indexing (debug / parity taps)
+__global__ void k_lists_to_user(int N, int E, int cap, const int* __restrict__ perm, const int* __restrict__ num, const int* __restrict__ idx,
+                                int* __restrict__ num_u, int* __restrict__ idx_u)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    if (i >= N) return;
+    const size_t src = (size_t)e * N + i, dst = (size_t)e * N + perm[i];
+    const int c = num[src];
+    num_u[dst] = c;
+    for (int k = 0; k < c; ++k) idx_u[dst * cap + k] = perm[idx[src * cap + k]];
 }
 
 // ---- mesh AABBs per (env, substep, dynamic mesh) and per (env, static mesh) ----------------------------
@@ -436,15 +567,18 @@ __device__ __forceinline__ int grid_cell(int x, int y, int z)
     return (z % GRID_DIM) * (GRID_DIM * GRID_DIM) + (y % GRID_DIM) * GRID_DIM + (x % GRID_DIM);
 }
 
-__global__ void k_grid_keys(int N, int E, const float4* __restrict__ xv, float cell_inv, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+// One (cell key, USER index) pair per particle, emitted in user order so that the stable sort leaves every cell's
+// points in ascending user index — the traversal order of warp's grid (its ids are the caller's indices).
+__global__ void k_grid_keys(int N, int E, const int* __restrict__ inv, const float4* __restrict__ xv, float cell_inv,
+                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
-    if (i >= N) return;
-    const float4 q = xv[((size_t)e * N + i) * 2];
+    if (u >= N) return;
+    const float4 q = xv[((size_t)e * N + inv[u]) * 2];
     const int c = grid_cell((int)(q.x * cell_inv), (int)(q.y * cell_inv), (int)(q.z * cell_inv));
-    keys[(size_t)e * N + i] = ((uint32_t)e << GRID_CELL_BITS) | (uint32_t)c;
-    vals[(size_t)e * N + i] = (uint32_t)i;
+    keys[(size_t)e * N + u] = ((uint32_t)e << GRID_CELL_BITS) | (uint32_t)c;
+    vals[(size_t)e * N + u] = (uint32_t)u;
 }
 
 __device__ __forceinline__ void cell_range(const uint32_t* __restrict__ keys, int lo0, int hi0, uint32_t key, int& b, int& en)
@@ -468,13 +602,16 @@ __device__ __forceinline__ QBox query_box(float4 q, float r, float cell_inv)
     return b;
 }
 
-// build_resting_collision_pairs, :272-291 (bitset instead of N x N bytes)
-__global__ void k_build_resting(int N, int E, int words, const float4* __restrict__ xv, float radius, float cell_inv,
-                                const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ids, uint32_t* __restrict__ bits)
+// build_resting_collision_pairs, :272-291 (bitset instead of N x N bytes; rows/bits are INTERNAL indices, the
+// `index < i` test is on USER indices like the reference)
+__global__ void k_build_resting(int N, int E, int words, const int* __restrict__ perm, const int* __restrict__ inv,
+                                const float4* __restrict__ xv, float radius, float cell_inv, const uint32_t* __restrict__ keys,
+                                const uint32_t* __restrict__ ids, uint32_t* __restrict__ bits)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
     if (i >= N) return;
+    const int ui = perm[i];
     const float4 q = xv[((size_t)e * N + i) * 2];
     const QBox b = query_box(q, radius, cell_inv);
     uint32_t* my = bits + ((size_t)e * N) * words;
@@ -484,8 +621,9 @@ __global__ void k_build_resting(int N, int E, int words, const float4* __restric
                 int s, t;
                 cell_range(keys, e * N, (e + 1) * N, ((uint32_t)e << GRID_CELL_BITS) | (uint32_t)grid_cell(x, y, z), s, t);
                 for (int k = s; k < t; ++k) {
-                    const int j = (int)ids[k];
-                    if (j < i) {
+                    const int uj = (int)ids[k];
+                    if (uj < ui) {
+                        const int j = inv[uj];
                         atomicOr(&my[(size_t)i * words + (j >> 5)], 1u << (j & 31));
                         atomicOr(&my[(size_t)j * words + (i >> 5)], 1u << (i & 31));
                     }
@@ -493,10 +631,11 @@ __global__ void k_build_resting(int N, int E, int words, const float4* __restric
             }
 }
 
-// update_potential_collision, :196-227 (same candidate order: cells x-fastest, ids ascending inside a cell)
-__global__ void k_candidates(int N, int E, int words, int cap, const float4* __restrict__ xv, const int* __restrict__ masks, float cd,
-                             float radius, float cell_inv, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ids,
-                             const uint32_t* __restrict__ bits, int* __restrict__ coll_idx, int* __restrict__ coll_num, int* __restrict__ max_count)
+// update_potential_collision, :196-227 (same candidate order: cells x-fastest, user ids ascending inside a cell)
+__global__ void k_candidates(int N, int E, int words, int cap, const int* __restrict__ inv, const float4* __restrict__ xv,
+                             const int* __restrict__ masks, float cd, float radius, float cell_inv, const uint32_t* __restrict__ keys,
+                             const uint32_t* __restrict__ ids, const uint32_t* __restrict__ bits, int* __restrict__ coll_idx,
+                             int* __restrict__ coll_num, int* __restrict__ max_count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
@@ -514,7 +653,7 @@ __global__ void k_candidates(int N, int E, int words, int cap, const float4* __r
                 int s, t;
                 cell_range(keys, e * N, (e + 1) * N, ((uint32_t)e << GRID_CELL_BITS) | (uint32_t)grid_cell(x, y, z), s, t);
                 for (int k = s; k < t; ++k) {
-                    const int j = (int)ids[k];
+                    const int j = inv[ids[k]];
                     if (j == i) continue;
                     const f3 dis = xyz(xv[(eb + j) * 2]) - x1;
                     if (!(len(dis) < cd)) continue;          // cheap test first; same set as the reference order
@@ -528,12 +667,22 @@ __global__ void k_candidates(int N, int E, int words, int cap, const float4* __r
     if (cnt > 0) atomicMax(max_count, cnt);
 }
 
+// compact (env, particle) list of the particles that have candidates (order irrelevant: each is independent)
+__global__ void k_cand_list(int N, int E, const int* __restrict__ coll_num, int2* __restrict__ list, int* __restrict__ count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    if (i >= N) return;
+    if (coll_num[(size_t)e * N + i] > 0) list[atomicAdd(count, 1)] = make_int2(e, i);
+}
+
 } // namespace
 
 // =========================================================================================================
 struct R2SPhys {
     R2SPhysParams prm{};
     int E = 0, N = 0, S = 0, n_slices = 0, ell_len = 0;
+    int nb = 0, cb = 0, halo_max = 0; // particle blocks, blocks per XCD chunk, largest halo (LDS sizing)
     int coll_cap = 500;
     int words = 0;
     int n_mesh = 0, n_dyn_mesh = 0, nF = 0, nV = 0, n_dyn_pts = 0;
@@ -541,16 +690,30 @@ struct R2SPhys {
     std::vector<int> h_springs;
     std::vector<float> h_rest;
     std::vector<int> h_adj_spring; // ELL slot -> spring id (or -1 for padding)
-    std::vector<int> h_adj_nbr;    // ELL slot -> neighbour particle
-    std::vector<int> h_adj_self;   // ELL slot -> owning particle (padding target)
+    std::vector<int> h_adj_nbr;    // ELL slot -> neighbour particle (internal id)
+    std::vector<int> h_adj_self;   // ELL slot -> owning particle (internal id; padding target)
+    std::vector<int> h_adj_loc;    // ELL slot -> LDS record of the neighbour in the owner's block, or ~global id
+    std::vector<int> h_perm, h_inv, h_slice_off, h_slice_deg;
     std::vector<int> h_mesh_map, h_face_map;
     // device
     float4* xv[2] = {nullptr, nullptr};
     int cur = 0;
-    int *d_slice_off = nullptr, *d_slice_deg = nullptr, *d_adj_j = nullptr;
-    float *d_adj_inv_rest = nullptr, *d_adj_k = nullptr, *d_masses = nullptr;
+    int *d_slice_off = nullptr, *d_slice_deg = nullptr, *d_ovf_ptr = nullptr;
+    int4 *d_adj = nullptr, *d_ovf = nullptr;
+    int n_ovf = 0;
+    int *d_halo_off = nullptr, *d_halo_ids = nullptr, *d_perm = nullptr, *d_inv = nullptr;
+    int *d_num_user = nullptr, *d_idx_user = nullptr;
+    float* d_masses = nullptr;
     int* d_masks = nullptr;
     int *d_coll_num = nullptr, *d_coll_idx = nullptr, *d_max_count = nullptr;
+    float4* d_vbc = nullptr;
+    int2* d_cand_list = nullptr;
+    int* d_cand_count = nullptr;
+    int* h_cand_count = nullptr; // pinned; filled asynchronously by update_collision_graph
+    hipEvent_t cand_event = nullptr;
+    bool cand_pending = false;
+    int n_cand = 0;              // particles with candidates after the last update (host view)
+    int graph_cand_cap = 0, n_cand_launch = 0;
     uint32_t *d_bits = nullptr, *d_keys[2] = {nullptr, nullptr}, *d_ids[2] = {nullptr, nullptr};
     char* d_sort_tmp = nullptr;
     size_t sort_bytes = 0;
@@ -558,9 +721,11 @@ struct R2SPhys {
     float *d_mesh_pts = nullptr, *d_interp = nullptr, *d_center = nullptr, *d_dyn_vel = nullptr, *d_dyn_omega = nullptr;
     float *d_aabb_dyn = nullptr, *d_aabb_static = nullptr, *d_coll_forces = nullptr;
     // graph
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_start_buf = -1;
+    // two captured variants of the num_substeps step: [0] no particle has candidates (one kernel per substep),
+    // [1] some do (fused kernel + self-collision finishing kernel per substep)
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    int graph_start_buf[2] = {-1, -1};
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -571,7 +736,9 @@ struct R2SPhys {
     {
         PhysDev p{};
         p.N = N; p.E = E; p.n_sub = prm.num_substeps;
-        p.slice_off = d_slice_off; p.slice_deg = d_slice_deg; p.adj_j = d_adj_j; p.adj_inv_rest = d_adj_inv_rest; p.adj_k = d_adj_k;
+        p.nb = nb; p.cb = cb;
+        p.slice_off = d_slice_off; p.slice_deg = d_slice_deg; p.adj = d_adj; p.ovf_ptr = d_ovf_ptr; p.ovf = d_ovf;
+        p.halo_off = d_halo_off; p.halo_ids = d_halo_ids; p.perm = d_perm; p.inv = d_inv;
         p.masses = d_masses; p.masks = d_masks;
         p.dt = prm.dt; p.dashpot = prm.dashpot_damping; p.drag_factor = expf(-prm.dt * prm.drag_damping);
         p.rf = prm.reverse_z ? -1.f : 1.f; p.cd = prm.collision_dist;
@@ -581,6 +748,7 @@ struct R2SPhys {
         p.cse = cl(prm.collide_self_elas, 0.f, 1.f); p.csf = cl(prm.collide_self_fric, 0.f, 2.f);
         p.self_collision = prm.self_collision; p.use_pusher = prm.use_pusher;
         p.coll_num = d_coll_num; p.coll_idx = d_coll_idx; p.coll_cap = coll_cap;
+        p.vbc = d_vbc; p.cand_list = d_cand_list; p.cand_count = d_cand_count;
         p.n_mesh = n_mesh; p.n_dyn_mesh = n_dyn_mesh; p.nF = nF; p.nV = nV; p.n_dyn_pts = n_dyn_pts;
         p.faces = d_faces; p.mesh_map = d_mesh_map; p.face_map = d_face_map; p.mesh_face_off = d_mesh_face_off;
         p.mesh_pts = d_mesh_pts; p.interp_pts = d_interp; p.interp_center = d_center; p.dyn_vel = d_dyn_vel; p.dyn_omega = d_dyn_omega;
@@ -606,6 +774,8 @@ int upload(T* d, const T* h, size_t count, hipStream_t s)
     return R2S_OK;
 }
 
+void drop_graph_fwd(R2SPhys* h);
+
 // Per-spring stiffness with the reference's gate and clamp (:75, :93); 0 => spring inactive.
 void stiffness_from_log(const R2SPhys* h, const float* log_Y, std::vector<float>& k, std::vector<char>& active)
 {
@@ -623,43 +793,72 @@ int upload_stiffness(R2SPhys* h, const float* log_Y, hipStream_t s)
     stiffness_from_log(h, log_Y, k, act);
     // Slots of inactive springs (gate exp(logY) > Ymin fails, :75) and padding slots point at the particle
     // itself with k = 0: then d = 0 and dv = 0, so neither the spring nor the dashpot term contributes.
-    std::vector<float> ell_k(h->ell_len, 0.f), ell_ir(h->ell_len, 0.f);
-    std::vector<int> ell_j(h->ell_len);
-    for (int t = 0; t < h->ell_len; ++t) {
-        const int sp = h->h_adj_spring[t];
-        if (sp >= 0 && act[sp]) { ell_k[t] = k[sp]; ell_ir[t] = 1.0f / h->h_rest[sp]; ell_j[t] = h->h_adj_nbr[t]; }
-        else ell_j[t] = h->h_adj_self[t];
+    auto fbits = [](float f) { int i; memcpy(&i, &f, 4); return i; };
+    std::vector<int4> ell(h->ell_len);
+    std::vector<int> ovf_ptr(h->N + 1, 0);
+    std::vector<int4> ovf;
+    // ELL slots are stored slot-major per slice; walk them particle by particle so the overflow CSR is in slot order
+    for (int i = 0; i < h->n_slices * SLICE; ++i) {
+        const int sl = i / SLICE, ln = i % SLICE;
+        for (int n = 0; n < h->h_slice_deg[sl]; ++n) {
+            const int t = h->h_slice_off[sl] + n * SLICE + ln;
+            const int sp = h->h_adj_spring[t];
+            const int self = h->h_adj_self[t];
+            int4 en = make_int4(self % BLOCK, self, 0, 0);
+            if (sp >= 0 && act[sp]) {
+                const int kb = fbits(k[sp]), rb = fbits(1.0f / h->h_rest[sp]);
+                if (h->h_adj_loc[t] >= 0) en = make_int4(h->h_adj_loc[t], h->h_adj_nbr[t], kb, rb);
+                else ovf.push_back(make_int4(h->h_adj_nbr[t], kb, rb, 0));
+            }
+            ell[t] = en;
+        }
+        if (i < h->N) ovf_ptr[i + 1] = (int)ovf.size();
     }
-    int rc = upload(h->d_adj_j, ell_j.data(), ell_j.size(), s);
+    for (int i = 1; i <= h->N; ++i) ovf_ptr[i] = std::max(ovf_ptr[i], ovf_ptr[i - 1]);
+    if ((int)ovf.size() > h->n_ovf || !h->d_ovf) {
+        if (h->d_ovf) (void)hipFree(h->d_ovf);
+        h->d_ovf = nullptr;
+        h->n_ovf = (int)ovf.size();
+        R2S_HIP_TRY(hipMalloc((void**)&h->d_ovf, sizeof(int4) * std::max<size_t>(ovf.size(), 1)));
+        drop_graph_fwd(h); // the pointer is baked into captured kernel arguments
+    }
+    int rc = upload(h->d_adj, ell.data(), ell.size(), s);
     if (rc) return rc;
-    rc = upload(h->d_adj_k, ell_k.data(), ell_k.size(), s);
+    rc = upload(h->d_ovf_ptr, ovf_ptr.data(), ovf_ptr.size(), s);
     if (rc) return rc;
-    return upload(h->d_adj_inv_rest, ell_ir.data(), ell_ir.size(), s);
+    return upload(h->d_ovf, ovf.data(), ovf.size(), s);
 }
 
-int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, hipStream_t s)
+int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, hipStream_t s)
 {
-    dim3 grid((h->N + BLOCK - 1) / BLOCK, h->E);
-    const bool self = h->prm.self_collision != 0, mesh = h->nF > 0;
+    dim3 grid(8u * (unsigned)h->cb * (unsigned)h->E);
+    const size_t lds = (size_t)(BLOCK + h->halo_max) * 2 * sizeof(float4);
+    const bool mesh = h->nF > 0;
     const float4* in = h->xv[in_buf];
     float4* out = h->xv[in_buf ^ 1];
-    if (self && mesh) hipLaunchKernelGGL((k_substep<true, true>), grid, dim3(BLOCK), 0, s, p, in, out, step, write_forces);
-    else if (self) hipLaunchKernelGGL((k_substep<true, false>), grid, dim3(BLOCK), 0, s, p, in, out, step, write_forces);
-    else if (mesh) hipLaunchKernelGGL((k_substep<false, true>), grid, dim3(BLOCK), 0, s, p, in, out, step, write_forces);
-    else hipLaunchKernelGGL((k_substep<false, false>), grid, dim3(BLOCK), 0, s, p, in, out, step, write_forces);
+    if (with_self && mesh) hipLaunchKernelGGL((k_substep<true, true>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
+    else if (with_self) hipLaunchKernelGGL((k_substep<true, false>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
+    else if (mesh) hipLaunchKernelGGL((k_substep<false, true>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
+    else hipLaunchKernelGGL((k_substep<false, false>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
+    if (with_self) {
+        // grid-stride over the device-side candidate list; sized for the host's view of the count
+        const unsigned blocks = (unsigned)std::min(1024, std::max(1, (h->n_cand + 255) / 256));
+        if (mesh) hipLaunchKernelGGL((k_self_finish<true>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
+        else hipLaunchKernelGGL((k_self_finish<false>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
+    }
     return R2S_OK;
 }
 
 // Enqueue substeps [first, first+n) starting from buffer `start_buf`; the final state is left in buffer
 // start_buf ^ (n & 1).
-int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, hipStream_t s)
+int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, hipStream_t s)
 {
     const PhysDev p = h->dev();
     int buf = start_buf;
     for (int k = 0; k < n; ++k) {
         const int last = (k == n - 1);
         if (last && h->nF > 0) R2S_HIP_TRY(hipMemsetAsync(h->d_coll_forces, 0, sizeof(float) * 3 * (size_t)h->E * h->nF, s));
-        int rc = launch_substep(h, p, buf, first + k, last, s);
+        int rc = launch_substep(h, p, buf, first + k, last, with_self, s);
         if (rc) return rc;
         buf ^= 1;
     }
@@ -668,26 +867,44 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, hipStream_t s)
 
 void drop_graph(R2SPhys* h)
 {
-    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    if (h->graph) (void)hipGraphDestroy(h->graph);
-    h->graph_exec = nullptr; h->graph = nullptr; h->graph_start_buf = -1;
+    for (int v = 0; v < 2; ++v) {
+        if (h->graph_exec[v]) (void)hipGraphExecDestroy(h->graph_exec[v]);
+        if (h->graph[v]) (void)hipGraphDestroy(h->graph[v]);
+        h->graph_exec[v] = nullptr; h->graph[v] = nullptr; h->graph_start_buf[v] = -1;
+    }
 }
 
-int capture_graph(R2SPhys* h, int start_buf)
+void drop_graph_fwd(R2SPhys* h) { drop_graph(h); }
+
+int capture_graph(R2SPhys* h, int variant, int start_buf)
 {
-    drop_graph(h);
+    if (h->graph_exec[variant]) (void)hipGraphExecDestroy(h->graph_exec[variant]);
+    if (h->graph[variant]) (void)hipGraphDestroy(h->graph[variant]);
+    h->graph_exec[variant] = nullptr; h->graph[variant] = nullptr; h->graph_start_buf[variant] = -1;
     hipStream_t cs;
     R2S_HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     R2S_HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_steps(h, 0, h->prm.num_substeps, start_buf, cs);
+    int rc = enqueue_steps(h, 0, h->prm.num_substeps, start_buf, variant == 1, cs);
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(cs, &g);
     (void)hipStreamDestroy(cs);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     R2S_HIP_TRY(e);
-    h->graph = g;
-    R2S_HIP_TRY(hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0));
-    h->graph_start_buf = start_buf;
+    h->graph[variant] = g;
+    R2S_HIP_TRY(hipGraphInstantiate(&h->graph_exec[variant], g, nullptr, nullptr, 0));
+    h->graph_start_buf[variant] = start_buf;
+    return R2S_OK;
+}
+
+// Host view of "does any particle have candidates": the count was copied to pinned memory by the last
+// update_collision_graph; waiting on its event here costs nothing once that copy has landed.
+int resolve_cand_count(R2SPhys* h)
+{
+    if (h->cand_pending) {
+        R2S_HIP_TRY(hipEventSynchronize(h->cand_event));
+        h->n_cand = *h->h_cand_count;
+        h->cand_pending = false;
+    }
     return R2S_OK;
 }
 
@@ -696,7 +913,7 @@ int grid_sort(R2SPhys* h, hipStream_t s, const uint32_t** keys, const uint32_t**
     const float cell = h->prm.collision_dist * 5.0f;
     const float cell_inv = 1.0f / cell;
     dim3 grid((h->N + BLOCK - 1) / BLOCK, h->E);
-    hipLaunchKernelGGL(k_grid_keys, grid, dim3(BLOCK), 0, s, h->N, h->E, h->xv[h->cur], cell_inv, h->d_keys[0], h->d_ids[0]);
+    hipLaunchKernelGGL(k_grid_keys, grid, dim3(BLOCK), 0, s, h->N, h->E, h->d_inv, h->xv[h->cur], cell_inv, h->d_keys[0], h->d_ids[0]);
     rocprim::double_buffer<uint32_t> dk(h->d_keys[0], h->d_keys[1]);
     rocprim::double_buffer<uint32_t> dv(h->d_ids[0], h->d_ids[1]);
     unsigned bits = GRID_CELL_BITS;
@@ -734,14 +951,44 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     int rc = R2S_OK;
 #define TRY(x) do { rc = (x); if (rc != R2S_OK) { r2s_phys_destroy(h); return rc; } } while (0)
 
-    // ---- sliced-ELL adjacency (gather form) ----
-    std::vector<std::vector<std::pair<int, int>>> adj(N); // (neighbour, spring id) in spring order
+    // ---- Morton order of the particles (env 0's initial positions; the topology is shared by all envs) ----
+    h->h_perm.resize(N); h->h_inv.resize(N);
+    {
+        float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+        for (int i = 0; i < N; ++i)
+            for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], d->init_vertices[3 * i + k]); hi[k] = std::max(hi[k], d->init_vertices[3 * i + k]); }
+        const float ext = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), std::max(hi[2] - lo[2], 1e-9f));
+        auto spread = [](uint64_t v) { // 21 bits -> every third bit
+            v &= 0x1fffff; v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull;
+            v = (v | v << 8) & 0x100f00f00f00f00full; v = (v | v << 4) & 0x10c30c30c30c30c3ull; v = (v | v << 2) & 0x1249249249249249ull;
+            return v;
+        };
+        std::vector<std::pair<uint64_t, int>> code(N);
+        for (int i = 0; i < N; ++i) {
+            uint64_t c = 0;
+            for (int k = 0; k < 3; ++k) {
+                const double t = (d->init_vertices[3 * i + k] - lo[k]) / ext;
+                c |= spread((uint64_t)std::min(1048575.0, std::max(0.0, t * 1048575.0))) << k;
+            }
+            code[i] = {c, i};
+        }
+        std::sort(code.begin(), code.end());
+        for (int i = 0; i < N; ++i) { h->h_perm[i] = code[i].second; h->h_inv[code[i].second] = i; }
+    }
+    TRY(dev_alloc(&h->d_perm, N)); TRY(dev_alloc(&h->d_inv, N));
+    TRY(upload(h->d_perm, h->h_perm.data(), N, s)); TRY(upload(h->d_inv, h->h_inv.data(), N, s));
+
+    // ---- sliced-ELL adjacency (gather form), internal indices, neighbours sorted by index ----
+    std::vector<std::vector<std::pair<int, int>>> adj(N); // (neighbour, spring id)
     for (int sp = 0; sp < S; ++sp) {
-        const int a = h->h_springs[2 * sp], b = h->h_springs[2 * sp + 1];
+        const int a = h->h_inv[h->h_springs[2 * sp]], b = h->h_inv[h->h_springs[2 * sp + 1]];
         adj[a].push_back({b, sp});
         adj[b].push_back({a, sp});
     }
+    for (auto& l : adj) std::sort(l.begin(), l.end());
     h->n_slices = (N + SLICE - 1) / SLICE;
+    h->nb = (N + BLOCK - 1) / BLOCK;
+    h->cb = (h->nb + 7) / 8;
     std::vector<int> slice_off(h->n_slices), slice_deg(h->n_slices);
     int total = 0;
     for (int sl = 0; sl < h->n_slices; ++sl) {
@@ -751,30 +998,77 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         total += deg * SLICE;
     }
     h->ell_len = total;
+    h->h_slice_off = slice_off; h->h_slice_deg = slice_deg;
+    // halo of each block: outside neighbours by descending reference count, up to the LDS budget
+    constexpr int HALO_CAP = (64 * 1024) / 32 - BLOCK; // (BLOCK + halo) * 32 B <= 64 KiB -> two workgroups per CU
+    std::vector<int> halo_off(h->nb + 1, 0), halo_ids;
+    std::vector<int> slot_of(N, -1);
+    std::vector<std::vector<int>> halo_of_block(h->nb);
+    h->halo_max = 0;
+    for (int b = 0; b < h->nb; ++b) {
+        std::vector<std::pair<int, int>> cnt; // (-refs, id)
+        {
+            std::vector<int> refs;
+            for (int i = b * BLOCK; i < std::min(N, (b + 1) * BLOCK); ++i)
+                for (auto& nb : adj[i]) if (nb.first / BLOCK != b) refs.push_back(nb.first);
+            std::sort(refs.begin(), refs.end());
+            for (size_t a = 0; a < refs.size();) {
+                size_t e2 = a;
+                while (e2 < refs.size() && refs[e2] == refs[a]) ++e2;
+                cnt.push_back({-(int)(e2 - a), refs[a]});
+                a = e2;
+            }
+        }
+        std::sort(cnt.begin(), cnt.end());
+        if ((int)cnt.size() > HALO_CAP) cnt.resize(HALO_CAP);
+        std::vector<int>& hl = halo_of_block[b];
+        for (auto& c : cnt) hl.push_back(c.second);
+        std::sort(hl.begin(), hl.end()); // ascending ids: the staging gather walks memory forwards
+        halo_off[b + 1] = halo_off[b] + (int)hl.size();
+        halo_ids.insert(halo_ids.end(), hl.begin(), hl.end());
+        h->halo_max = std::max(h->halo_max, (int)hl.size());
+    }
     h->h_adj_spring.assign(total, -1);
     h->h_adj_nbr.assign(total, 0);
     h->h_adj_self.assign(total, 0);
-    for (int sl = 0; sl < h->n_slices; ++sl)
-        for (int ln = 0; ln < SLICE; ++ln) {
-            const int i = sl * SLICE + ln;
+    h->h_adj_loc.assign(total, 0);
+    for (int b = 0; b < h->nb; ++b) {
+        const std::vector<int>& hl = halo_of_block[b];
+        for (size_t k = 0; k < hl.size(); ++k) slot_of[hl[k]] = BLOCK + (int)k;
+        for (int i = b * BLOCK; i < std::min(h->n_slices * SLICE, (b + 1) * BLOCK); ++i) {
+            const int sl = i / SLICE, ln = i % SLICE;
             for (int n = 0; n < slice_deg[sl]; ++n) {
                 const int t = slice_off[sl] + n * SLICE + ln;
-                h->h_adj_self[t] = i < N ? i : 0;
-                if (i < N && n < (int)adj[i].size()) { h->h_adj_nbr[t] = adj[i][n].first; h->h_adj_spring[t] = adj[i][n].second; }
+                h->h_adj_self[t] = i < N ? i : b * BLOCK;
+                h->h_adj_loc[t] = h->h_adj_self[t] % BLOCK;
+                if (i < N && n < (int)adj[i].size()) {
+                    const int j = adj[i][n].first;
+                    h->h_adj_nbr[t] = j; h->h_adj_spring[t] = adj[i][n].second;
+                    h->h_adj_loc[t] = (j / BLOCK == b) ? j % BLOCK : (slot_of[j] >= 0 ? slot_of[j] : ~j);
+                }
             }
         }
+        for (size_t k = 0; k < hl.size(); ++k) slot_of[hl[k]] = -1;
+    }
     TRY(dev_alloc(&h->d_slice_off, h->n_slices)); TRY(dev_alloc(&h->d_slice_deg, h->n_slices));
-    TRY(dev_alloc(&h->d_adj_j, total)); TRY(dev_alloc(&h->d_adj_inv_rest, total)); TRY(dev_alloc(&h->d_adj_k, total));
+    TRY(dev_alloc(&h->d_adj, total)); TRY(dev_alloc(&h->d_ovf_ptr, N + 1));
+    TRY(dev_alloc(&h->d_halo_off, halo_off.size())); TRY(dev_alloc(&h->d_halo_ids, halo_ids.size()));
+    TRY(upload(h->d_halo_off, halo_off.data(), halo_off.size(), s)); TRY(upload(h->d_halo_ids, halo_ids.data(), halo_ids.size(), s));
     TRY(dev_alloc(&h->d_masses, N)); TRY(dev_alloc(&h->d_masks, N));
     TRY(upload(h->d_slice_off, slice_off.data(), slice_off.size(), s)); TRY(upload(h->d_slice_deg, slice_deg.data(), slice_deg.size(), s));
     {
         std::vector<float> zero_logy(std::max(S, 1), 0.f);
         TRY(upload_stiffness(h, S > 0 ? d->init_spring_Y : zero_logy.data(), s));
     }
-    TRY(upload(h->d_masses, d->init_masses, N, s));
     {
+        std::vector<float> m(N);
         std::vector<int> masks(N);
-        for (int i = 0; i < N; ++i) masks[i] = d->init_collision_mask ? d->init_collision_mask[i] : i;
+        for (int i = 0; i < N; ++i) {
+            const int u = h->h_perm[i];
+            m[i] = d->init_masses[u];
+            masks[i] = d->init_collision_mask ? d->init_collision_mask[u] : u;
+        }
+        TRY(upload(h->d_masses, m.data(), N, s));
         TRY(upload(h->d_masks, masks.data(), N, s));
     }
     // ---- state ----
@@ -784,11 +1078,13 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     }
     {
         std::vector<float4> pk((size_t)E * N * 2);
-        for (size_t t = 0; t < (size_t)E * N; ++t) {
-            pk[2 * t] = make_float4(d->init_vertices[3 * t], d->init_vertices[3 * t + 1], d->init_vertices[3 * t + 2], 0.f);
-            pk[2 * t + 1] = d->init_velocities ? make_float4(d->init_velocities[3 * t], d->init_velocities[3 * t + 1], d->init_velocities[3 * t + 2], 0.f)
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int e = 0; e < E; ++e)
+            for (int u = 0; u < N; ++u) {
+                const size_t src = ((size_t)e * N + u) * 3, dst = ((size_t)e * N + h->h_inv[u]) * 2;
+                pk[dst] = make_float4(d->init_vertices[src], d->init_vertices[src + 1], d->init_vertices[src + 2], 0.f);
+                pk[dst + 1] = d->init_velocities ? make_float4(d->init_velocities[src], d->init_velocities[src + 1], d->init_velocities[src + 2], 0.f)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         TRY(upload(h->xv[0], pk.data(), pk.size(), s));
     }
     h->cur = 0;
@@ -849,6 +1145,13 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     TRY(dev_alloc(&h->d_max_count, 4));
     R2S_HIP_TRY(hipMemsetAsync(h->d_max_count, 0, sizeof(int) * 4, s));
     if (h->prm.self_collision) {
+        TRY(dev_alloc(&h->d_vbc, (size_t)E * N));
+        TRY(dev_alloc(&h->d_cand_list, (size_t)E * N));
+        TRY(dev_alloc(&h->d_cand_count, 4));
+        R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int) * 4, s));
+        R2S_HIP_TRY(hipHostMalloc((void**)&h->h_cand_count, 64, hipHostMallocDefault));
+        *h->h_cand_count = 0;
+        R2S_HIP_TRY(hipEventCreateWithFlags(&h->cand_event, hipEventDisableTiming));
         h->words = (N + 31) / 32;
         TRY(dev_alloc(&h->d_coll_idx, (size_t)E * N * h->coll_cap));
         TRY(dev_alloc(&h->d_bits, (size_t)E * N * h->words));
@@ -859,7 +1162,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         TRY(r2s_phys_create_resting_case(h, stream_));
     }
     R2S_HIP_TRY(hipStreamSynchronize(s));
-    TRY(capture_graph(h, 0));
+    TRY(capture_graph(h, 0, 0));
 #undef TRY
     *out = h;
     return R2S_OK;
@@ -870,11 +1173,13 @@ void r2s_phys_destroy(R2SPhys* h)
     if (!h) return;
     (void)hipDeviceSynchronize();
     drop_graph(h);
-    void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_adj_j, h->d_adj_inv_rest, h->d_adj_k, h->d_masses, h->d_masks,
-                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp,
+    void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_adj, h->d_ovf, h->d_ovf_ptr, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
+                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp,
                     h->d_faces, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->h_cand_count) (void)hipHostFree(h->h_cand_count);
+    if (h->cand_event) (void)hipEventDestroy(h->cand_event);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -883,8 +1188,7 @@ void r2s_phys_destroy(R2SPhys* h)
 int r2s_phys_set_state(R2SPhys* h, const float* x, const float* v, r2s_stream_t stream_)
 {
     if (!h) return R2S_ERR_INVALID;
-    const int total = h->E * h->N;
-    hipLaunchKernelGGL(k_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, total, x, v, h->xv[h->cur]);
+    hipLaunchKernelGGL(k_pack, dim3((h->N + 255) / 256, h->E), dim3(256), 0, (hipStream_t)stream_, h->N, h->E, h->d_inv, x, v, h->xv[h->cur]);
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }
@@ -892,8 +1196,7 @@ int r2s_phys_set_state(R2SPhys* h, const float* x, const float* v, r2s_stream_t 
 int r2s_phys_get_state(R2SPhys* h, float* x, float* v, r2s_stream_t stream_)
 {
     if (!h) return R2S_ERR_INVALID;
-    const int total = h->E * h->N;
-    hipLaunchKernelGGL(k_unpack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, total, h->xv[h->cur], x, v);
+    hipLaunchKernelGGL(k_unpack, dim3((h->N + 255) / 256, h->E), dim3(256), 0, (hipStream_t)stream_, h->N, h->E, h->d_inv, h->xv[h->cur], x, v);
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }
@@ -908,7 +1211,7 @@ int r2s_phys_create_resting_case(R2SPhys* h, r2s_stream_t stream_)
     R2S_HIP_TRY(hipMemsetAsync(h->d_bits, 0, sizeof(uint32_t) * (size_t)h->E * h->N * h->words, s));
     const float r = h->prm.collision_dist * 5.0f;
     dim3 grid((h->N + BLOCK - 1) / BLOCK, h->E);
-    hipLaunchKernelGGL(k_build_resting, grid, dim3(BLOCK), 0, s, h->N, h->E, h->words, h->xv[h->cur], r, 1.0f / r, keys, ids, h->d_bits);
+    hipLaunchKernelGGL(k_build_resting, grid, dim3(BLOCK), 0, s, h->N, h->E, h->words, h->d_perm, h->d_inv, h->xv[h->cur], r, 1.0f / r, keys, ids, h->d_bits);
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }
@@ -923,8 +1226,13 @@ int r2s_phys_update_collision_graph(R2SPhys* h, r2s_stream_t stream_)
     R2S_HIP_TRY(hipMemsetAsync(h->d_max_count, 0, sizeof(int), s));
     const float r = h->prm.collision_dist * 5.0f;
     dim3 grid((h->N + BLOCK - 1) / BLOCK, h->E);
-    hipLaunchKernelGGL(k_candidates, grid, dim3(BLOCK), 0, s, h->N, h->E, h->words, h->coll_cap, h->xv[h->cur], h->d_masks, h->prm.collision_dist, r,
+    hipLaunchKernelGGL(k_candidates, grid, dim3(BLOCK), 0, s, h->N, h->E, h->words, h->coll_cap, h->d_inv, h->xv[h->cur], h->d_masks, h->prm.collision_dist, r,
                        1.0f / r, keys, ids, h->d_bits, h->d_coll_idx, h->d_coll_num, h->d_max_count);
+    R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_cand_list, grid, dim3(BLOCK), 0, s, h->N, h->E, h->d_coll_num, h->d_cand_list, h->d_cand_count);
+    R2S_HIP_TRY(hipMemcpyAsync(h->h_cand_count, h->d_cand_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    R2S_HIP_TRY(hipEventRecord(h->cand_event, s));
+    h->cand_pending = true;
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }
@@ -961,14 +1269,23 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         if (!h->ev0) { R2S_HIP_TRY(hipEventCreate(&h->ev0)); R2S_HIP_TRY(hipEventCreate(&h->ev1)); }
         R2S_HIP_TRY(hipEventRecord(h->ev0, s));
     }
+    int rc0 = h->prm.self_collision ? resolve_cand_count(h) : R2S_OK;
+    if (rc0) return rc0;
+    const int variant = (h->prm.self_collision && h->n_cand > 0) ? 1 : 0;
     if (use_graph) {
-        if (!h->graph_exec || h->graph_start_buf != h->cur) {
-            int rc = capture_graph(h, h->cur);
+        // variant 1 bakes a grid size derived from n_cand: re-capture if the list outgrew it
+        const bool stale = variant == 1 && h->graph_exec[1] && h->n_cand > h->graph_cand_cap;
+        if (!h->graph_exec[variant] || h->graph_start_buf[variant] != h->cur || stale) {
+            if (variant == 1) h->graph_cand_cap = std::max(h->n_cand * 2, 4096), h->n_cand_launch = h->graph_cand_cap;
+            const int keep = h->n_cand;
+            if (variant == 1) h->n_cand = h->graph_cand_cap; // size the finishing grid generously
+            int rc = capture_graph(h, variant, h->cur);
+            h->n_cand = keep;
             if (rc) return rc;
         }
-        R2S_HIP_TRY(hipGraphLaunch(h->graph_exec, s));
+        R2S_HIP_TRY(hipGraphLaunch(h->graph_exec[variant], s));
     } else {
-        int rc = enqueue_steps(h, first_substep, n, h->cur, s);
+        int rc = enqueue_steps(h, first_substep, n, h->cur, variant == 1, s);
         if (rc) return rc;
     }
     h->cur ^= (n & 1);
@@ -996,9 +1313,19 @@ int r2s_phys_mesh_maps(R2SPhys* h, int32_t* mesh_map, int32_t* face_map)
 int r2s_phys_collision_lists(R2SPhys* h, int32_t** number, int32_t** indices, int32_t* capacity)
 {
     if (!h) return R2S_ERR_INVALID;
-    if (number) *number = h->d_coll_num;
-    if (indices) *indices = h->d_coll_idx;
     if (capacity) *capacity = h->coll_cap;
+    if (!h->prm.self_collision) { if (number) *number = h->d_coll_num; if (indices) *indices = nullptr; return R2S_OK; }
+    // internal (Morton) indexing -> the caller's indexing, into side buffers (parity taps, not a hot path)
+    if (!h->d_num_user) {
+        R2S_HIP_TRY(hipMalloc((void**)&h->d_num_user, sizeof(int) * (size_t)h->E * h->N));
+        R2S_HIP_TRY(hipMalloc((void**)&h->d_idx_user, sizeof(int) * (size_t)h->E * h->N * h->coll_cap));
+    }
+    R2S_HIP_TRY(hipDeviceSynchronize());
+    hipLaunchKernelGGL(k_lists_to_user, dim3((h->N + 255) / 256, h->E), dim3(256), 0, 0, h->N, h->E, h->coll_cap, h->d_perm, h->d_coll_num,
+                       h->d_coll_idx, h->d_num_user, h->d_idx_user);
+    R2S_HIP_TRY(hipDeviceSynchronize());
+    if (number) *number = h->d_num_user;
+    if (indices) *indices = h->d_idx_user;
     return R2S_OK;
 }
 
@@ -1023,6 +1350,17 @@ int r2s_phys_set_params(R2SPhys* h, const R2SPhysParams* p, r2s_stream_t)
         return R2S_ERR_INVALID; // structural fields are fixed at construction
     h->prm = *p;
     drop_graph(h); // kernel arguments are baked into the graph; re-captured lazily by the next step
+    return R2S_OK;
+}
+
+int r2s_phys_layout_stats(R2SPhys* h, int64_t* out /* [8] */)
+{
+    if (!h || !out) return R2S_ERR_INVALID;
+    int64_t real = 0, fallback = 0;
+    for (int t = 0; t < h->ell_len; ++t)
+        if (h->h_adj_spring[t] >= 0) { ++real; if (h->h_adj_loc[t] < 0) ++fallback; }
+    out[0] = h->nb; out[1] = h->halo_max; out[2] = h->ell_len; out[3] = real; out[4] = fallback;
+    out[5] = (int64_t)(BLOCK + h->halo_max) * 32; out[6] = h->n_slices; out[7] = h->cb;
     return R2S_OK;
 }
 

@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "libr2s_hip.so")
+LIB_PATH = os.environ.get("R2S_HIP_LIB", os.path.join(_PKG_ROOT, "libr2s_hip.so"))  # override: kernel experiments only
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 

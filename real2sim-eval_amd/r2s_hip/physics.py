@@ -52,7 +52,7 @@ def _bind():
         r2s_phys_step=[vp, i32, i32, vp], r2s_phys_collision_forces=[vp, C.POINTER(vp), C.POINTER(C.c_int32)],
         r2s_phys_mesh_maps=[vp, vp, vp], r2s_phys_collision_lists=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32)],
         r2s_phys_collision_max_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_set_spring_Y=[vp, vp, vp],
-        r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
+        r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
     ).items():
         fn = getattr(L, name)
         fn.restype = i32
@@ -256,6 +256,12 @@ class PhysBatch:
         for k, v in kw.items():
             setattr(self.params, k, float(np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v, np.float32).reshape(-1)[0]))
         check(_bind().r2s_phys_set_params(self._h, C.byref(self.params), self._s()), "r2s_phys_set_params")
+
+    def layout_stats(self):
+        a = (C.c_int64 * 8)()
+        check(_bind().r2s_phys_layout_stats(self._h, a), "r2s_phys_layout_stats")
+        k = ["blocks", "halo_max", "ell_slots", "neighbour_slots", "fallback_slots", "lds_bytes", "slices", "blocks_per_xcd"]
+        return dict(zip(k, [int(v) for v in a]))
 
     def set_timing(self, on: bool):
         _bind().r2s_phys_set_timing(self._h, int(on))
