@@ -125,17 +125,11 @@ def main():
     # per-kernel time of the dominant kernel: HIP events on the launch stream around the last step's graph
     ms, k = ro.phys.last_step_ms()
     phys_ms, phys_kernels = ms, k
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        # the metric all-gather of north_star: one fixed-size record per rank (envs, steps, wall ms, instances)
-        rec = torch.tensor([ro.n_env, args.steps, elapsed * 1e3, float(ro.last_num_rendered)], device=dev, dtype=torch.float64)
-        allrec = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)
-        total_envs = int(sum(r[0].item() for r in allrec))
-    else:
-        total_envs = ro.n_env
+    # N > 1: slowest rank's time (MAX) and the metric all-gather of north_star — one fixed-size record per rank
+    from r2s_hip import dist as rdist
+    elapsed = rdist.max_over_ranks(elapsed, dev)
+    records = rdist.gather_records([ro.n_env, args.steps, elapsed * 1e3, float(ro.last_num_rendered)], dev)
+    total_envs = int(records[:, 0].sum().item())
 
     # stage timing of the raster pipeline (separate, untimed pass)
     ro.raster.set_timing(True)

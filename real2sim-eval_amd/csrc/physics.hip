@@ -644,7 +644,11 @@ __global__ void k_candidates(int N, int E, int words, int cap, const int* __rest
     const float4 q = xv[(eb + i) * 2];
     const f3 x1 = xyz(q);
     const int mask1 = masks[i];
-    const QBox b = query_box(q, radius, cell_inv);
+    // The reference visits every cell overlapping [x - 5cd, x + 5cd] and keeps j only if |xj - xi| < cd.  Such a j
+    // lies in a cell overlapping [x - cd, x + cd] (int() truncation is monotonic), and dropping the other cells
+    // keeps the relative order of the survivors: visiting the smaller box yields the identical list, ~5x cheaper.
+    (void)radius;
+    const QBox b = query_box(q, cd, cell_inv);
     const uint32_t* row = bits + (eb + i) * words;
     int cnt = 0;
     for (int z = b.zs; z <= b.ze; ++z)

@@ -1,0 +1,60 @@
+"""World-size-2 gloo test of the N>1 path of bench.py: env sharding + MAX time + all-gather of rank records."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "real2sim-eval_amd"))
+    from r2s_hip import dist as rdist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = rdist.env_shard(65, rank, world)           # uneven split on purpose
+    elapsed = 1.0 + rank                                 # rank 1 is slower
+    tmax = rdist.max_over_ranks(elapsed, "cpu")
+    rec = rdist.gather_records([hi - lo, 3, elapsed * 1e3, 7.0 + rank], "cpu")
+    q.put((rank, lo, hi, tmax, rec.tolist(), rdist.throughput(rec, tmax)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_env_shard_is_a_contiguous_partition():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "real2sim-eval_amd"))
+    from r2s_hip.dist import env_shard
+
+    for n, w in ((256, 8), (65, 2), (7, 8), (32, 1)):
+        spans = [env_shard(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    assert env_shard(256, 3, 8) == (96, 128)  # config C3: 256 envs over 8 GPUs, 32 each
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gloo_aggregation():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(2))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, t0, rec0, thr0), (r1, lo1, hi1, t1, rec1, thr1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 33, 33, 65)
+    assert t0 == t1 == 2.0                      # MAX over ranks
+    assert rec0 == rec1 and rec0[0][:2] == [33.0, 3.0] and rec0[1][:2] == [32.0, 3.0]
+    assert thr0 == thr1 == pytest.approx((33 * 3 + 32 * 3) / 2.0)
