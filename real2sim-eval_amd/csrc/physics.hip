@@ -38,7 +38,9 @@
 #include <rocprim/rocprim.hpp>
 #include "../../include/r2s_physics.h"
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #ifndef R2S_EXPERIMENT
@@ -63,14 +65,19 @@ constexpr float WIND_THRESHOLD = 0.6f; // :323
 struct PhysDev {
     int N, E, n_sub;
     // topology (shared by all envs); all particle indices are INTERNAL (Morton order)
-    int nb, cb;                // particle blocks of BLOCK, blocks per XCD chunk
+    int nb, cb;                // particle blocks of BLOCK; (block, env) work items per XCD
+    int lds_rec;               // LDS records per workgroup (BLOCK + largest halo): x records first, then v records
     const int* slice_off;      // [n_slices]
     const int* slice_deg;      // [n_slices]
-    const int4* adj;           // sliced ELL, slot-major, 16 B per slot: {LDS record of the neighbour in the owner's
-                               // block, global particle id, bits(k), bits(1/rest)}; padding / inactive / overflowed slots
-                               // point at the owner itself (zero force)
-    const int* ovf_ptr;        // [N+1] per-particle overflow neighbours that did not fit the block's halo (normally empty)
-    const int4* ovf;           // {global id, bits(k), bits(1/rest), 0}
+    // sliced ELL, slot-major, 10 B per slot in three planes (the adjacency stream is shared by every environment and
+    // is the largest L2 consumer of the kernel: 16-byte entries were measurably slower):
+    const unsigned short* adj_idx; // LDS record of the neighbour in the owner's block; padding / inactive slots point at
+                                   // the owner itself (zero force)
+    const float* adj_k;            // clamp(exp(logY), Ymin, Ymax)
+    const float* adj_ir;           // 1 / rest length
+    const int* rslice_off;     // [n_slices] second sliced ELL: neighbours NOT in the LDS window, gathered from global memory
+    const int* rslice_deg;     // [n_slices]
+    const int4* radj;          // {global particle id, bits(k), bits(1/rest), 0}; padding points at the owner
     const int* halo_off;       // [nb+1]
     const int* halo_ids;       // halo particle ids per block (LDS records BLOCK.. in this order)
     const int* perm;           // internal -> user index
@@ -237,54 +244,82 @@ __device__ MeshQ mesh_query(const PhysDev& p, int e, int step, f3 q)
 // in adjacency order instead of atomic order.  The hot loop: FMA contraction allowed, 1-ulp rsq instead of
 // sqrt + three divides (the reference's own float atomics reorder sums far more than this perturbs them).
 #pragma clang fp contract(fast)
-__device__ __forceinline__ void spring_term(float4 xj, float4 vj, f3 xi, f3 vi, float k, float inv_rest, float dashpot, float& fx,
-                                            float& fy, float& fz)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// One neighbour: (x,y) components in packed-f32 pairs (v_pk_add/mul/fma_f32), z scalar.
+__device__ __forceinline__ void spring_term(float4 xj, float4 vj, f3 xi, f3 vi, float k, float inv_rest, float dashpot, v2f& fxy,
+                                            float& fz)
 {
-    const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
-    const float d2 = dx * dx + dy * dy + dz * dz;
+    const v2f dxy = (v2f){xj.x, xj.y} - (v2f){xi.x, xi.y};
+    const float dz = xj.z - xi.z;
+    const v2f sq = dxy * dxy;
+    const float d2 = fmaf(dz, dz, sq.x + sq.y);
     const float rinv = __builtin_amdgcn_rsqf(fmaxf(d2, 1e-12f)); // 1 / max(L, 1e-6)
     const float L = d2 * rinv;
-    const float ux = dx * rinv, uy = dy * rinv, uz = dz * rinv;
-    const float v_rel = (vj.x - vi.x) * ux + (vj.y - vi.y) * uy + (vj.z - vi.z) * uz;
-    const float mag = k * (L * inv_rest - 1.0f) + dashpot * v_rel;
-    fx += ux * mag; fy += uy * mag; fz += uz * mag;
+    const v2f uxy = dxy * rinv;
+    const float uz = dz * rinv;
+    const v2f dvxy = (v2f){vj.x, vj.y} - (v2f){vi.x, vi.y};
+    const v2f pr = dvxy * uxy;
+    const float v_rel = fmaf(vj.z - vi.z, uz, pr.x + pr.y);
+    const float mag = fmaf(k, fmaf(L, inv_rest, -1.0f), dashpot * v_rel);
+    fxy += uxy * mag;
+    fz = fmaf(uz, mag, fz);
 }
 
 // Hot path: every neighbour slot is one coalesced 16-byte adjacency load + two ds_read_b128 from the workgroup's LDS
-// window (records = {x, v}); no branch in the loop, so the 4x-unrolled body keeps 4 adjacency loads and 8 LDS reads
-// in flight.  Neighbours that did not fit the halo (none for the benchmark objects) follow from a per-particle overflow
-// list with global gathers.
+// window (x records, v records); no branch in the loop.  The adjacency is software-pipelined by hand: the 4 entries of
+// group g+1 are in flight while group g is evaluated, and group 0 is issued BEFORE the staging barrier (see k_substep),
+// so only the first L2 round trip of a wave is exposed.
+struct AdjGroup {
+    int idx[R2S_UNROLL];
+    float k[R2S_UNROLL], ir[R2S_UNROLL];
+};
+__device__ __forceinline__ AdjGroup adj_load(const PhysDev& p, int base, int g)
+{
+    AdjGroup r;
+#pragma unroll
+    for (int u = 0; u < R2S_UNROLL; ++u) {
+        const int t = base + (g * R2S_UNROLL + u) * SLICE;
+        r.idx[u] = p.adj_idx[t];
+        r.k[u] = p.adj_k[t];
+        r.ir[u] = p.adj_ir[t];
+    }
+    return r;
+}
+
 __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* __restrict__ xv, const float4* lds, size_t env_base,
-                                               int i, f3 xi, f3 vi)
+                                               int i, f3 xi, f3 vi, int base, int deg, AdjGroup cur)
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) const v4f lds_f4; // explicit LDS address space -> ds_read_b128
     lds_f4* lds3 = (lds_f4*)lds;
+    lds_f4* ldv3 = lds3 + p.lds_rec;
     const int sl = i >> 6, ln = i & 63;
-    const int4* __restrict__ a = p.adj + p.slice_off[sl] + ln;
-    const int deg = p.slice_deg[sl];
-    float fx = 0.f, fy = 0.f, fz = 0.f;
+    v2f fxy = {0.f, 0.f};
+    float fz = 0.f;
+    const int ngroups = deg / R2S_UNROLL; // deg is padded to whole groups at construction
+    for (int g = 0; g < ngroups; ++g) {
+        AdjGroup nxt = cur;
+        if (g + 1 < ngroups) nxt = adj_load(p, base, g + 1);
+#pragma unroll
+        for (int u = 0; u < R2S_UNROLL; ++u) {
+            const v4f xl = lds3[cur.idx[u]], vl = ldv3[cur.idx[u]];
+            spring_term(make_float4(xl.x, xl.y, xl.z, 0.f), make_float4(vl.x, vl.y, vl.z, 0.f), xi, vi, cur.k[u], cur.ir[u], p.dashpot,
+                        fxy, fz);
+        }
+        cur = nxt;
+    }
+    // neighbours outside the LDS window: same slot-major coalesced adjacency, records gathered from global memory
+    // (the vector-memory pipe works in parallel with the LDS pipe of the loop above)
+    const int4* __restrict__ ra = p.radj + p.rslice_off[sl] + ln;
+    const int rdeg = p.rslice_deg[sl];
 #pragma unroll R2S_UNROLL
-    for (int n = 0; n < deg; ++n) {
-#if R2S_EXPERIMENT == 2 /* no adjacency loads: synthetic entries */
-        const int4 en = make_int4((i + n * 7) & 255, 0, 0x447a0000, 0x42c80000);
-#else
-        const int4 en = a[n * SLICE];
-#endif
-#if R2S_EXPERIMENT == 1 /* no LDS reads */
-        const v4f xl = {__int_as_float(en.x) , 0.1f, 0.2f, 0.f}, vl = {0.f, __int_as_float(en.y), 0.f, 0.f};
-#else
-        const v4f xl = lds3[2 * en.x], vl = lds3[2 * en.x + 1];
-#endif
-        spring_term(make_float4(xl.x, xl.y, xl.z, 0.f), make_float4(vl.x, vl.y, vl.z, 0.f), xi, vi, __int_as_float(en.z),
-                    __int_as_float(en.w), p.dashpot, fx, fy, fz);
-    }
-    for (int t = p.ovf_ptr[i], t1 = p.ovf_ptr[i + 1]; t < t1; ++t) {
-        const int4 en = p.ovf[t];
+    for (int n = 0; n < rdeg; ++n) {
+        const int4 en = ra[n * SLICE];
         const size_t g = (env_base + (size_t)en.x) * 2;
-        spring_term(xv[g], xv[g + 1], xi, vi, __int_as_float(en.y), __int_as_float(en.z), p.dashpot, fx, fy, fz);
+        spring_term(xv[g], xv[g + 1], xi, vi, __int_as_float(en.y), __int_as_float(en.z), p.dashpot, fxy, fz);
     }
-    return {fx, fy, fz};
+    return {fxy.x, fxy.y, fz};
 }
 
 #pragma clang fp contract(off)
@@ -409,36 +444,49 @@ template <bool SELF, bool MESH>
 __global__ void __launch_bounds__(BLOCK) k_substep(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out,
                                                    int step, int write_forces)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 lds[]; // (BLOCK + halo) records of 2 float4
+    extern __shared__ __attribute__((aligned(16))) float4 lds[]; // 2 * (BLOCK + halo) float4: x records, then v records
+    // work item = (particle block, environment), environment fastest; XCD c owns the contiguous item range
+    // [c * ipx, (c + 1) * ipx): equal shares for the 8 XCDs, neighbouring blocks (shared halos) on the same L2
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int e = q % p.E, bq = q / p.E;
-    const int b = xcd * p.cb + bq;
-    if (bq >= p.cb || b >= p.nb) return; // whole workgroup
+    const int item = xcd * p.cb + q;
+    if (q >= p.cb || item >= p.nb * p.E) return; // whole workgroup
+    const int b = item / p.E, e = item - b * p.E;
     const int tid = threadIdx.x;
     const int i = b * BLOCK + tid;
     const size_t eb = (size_t)e * p.N;
+    // first adjacency group of this thread: in flight while the LDS window is staged
+    const int sl0 = min(i, p.N - 1) >> 6;
+    const int adj0 = p.slice_off[sl0] + (i & 63);
+    const int deg0 = p.slice_deg[sl0];
+    AdjGroup g0;
+#pragma unroll
+    for (int u = 0; u < R2S_UNROLL; ++u) { g0.idx[u] = 0; g0.k[u] = 0.f; g0.ir[u] = 0.f; }
+    if (deg0 > 0) g0 = adj_load(p, adj0, 0);
     // stage own records (fully coalesced: 2*BLOCK consecutive float4) and the halo
     {
+        // LDS layout: x records [0, R) then v records [R, 2R), R = BLOCK + largest halo (16-byte stride per array:
+        // a ds_read_b128 of 16 random records spreads over all 16 bank quads instead of 8)
+        const int R = p.lds_rec;
         const int n_own = min(BLOCK, p.N - b * BLOCK) * 2;
         const float4* src = xv_in + (eb + (size_t)b * BLOCK) * 2;
-        if (tid < n_own) lds[tid] = src[tid];
-        if (tid + BLOCK < n_own) lds[tid + BLOCK] = src[tid + BLOCK];
+        if (tid < n_own) lds[(tid & 1) * R + (tid >> 1)] = src[tid];                             // fully coalesced
+        if (tid + BLOCK < n_own) lds[(tid & 1) * R + ((tid + BLOCK) >> 1)] = src[tid + BLOCK];
         const int h0 = p.halo_off[b], h1 = p.halo_off[b + 1];
         for (int h = h0 + tid; h < h1; h += BLOCK) {
             const size_t g = (eb + (size_t)p.halo_ids[h]) * 2;
             const int r = BLOCK + (h - h0);
-            lds[2 * r] = xv_in[g];
-            lds[2 * r + 1] = xv_in[g + 1];
+            lds[r] = xv_in[g];
+            lds[R + r] = xv_in[g + 1];
         }
     }
     __syncthreads();
     if (i >= p.N) return;
-    const f3 x0 = xyz(lds[2 * tid]);
-    const f3 v0 = xyz(lds[2 * tid + 1]);
+    const f3 x0 = xyz(lds[tid]);
+    const f3 v0 = xyz(lds[p.lds_rec + tid]);
     const float m1 = p.masses[i];
 
     // eval_springs + update_vel_from_force
-    f3 v = vel_update(p, v0, spring_force_lds(p, xv_in, lds, eb, i, x0, v0), m1);
+    f3 v = vel_update(p, v0, spring_force_lds(p, xv_in, lds, eb, i, x0, v0, adj0, deg0, g0), m1);
 
     // Self collision (object_collision, :230-268) needs the partners' post-force velocities.  Particles that have
     // contact candidates (rare; the list is rebuilt once per env step) only publish their own v_before_collision
@@ -697,14 +745,17 @@ struct R2SPhys {
     std::vector<int> h_adj_nbr;    // ELL slot -> neighbour particle (internal id)
     std::vector<int> h_adj_self;   // ELL slot -> owning particle (internal id; padding target)
     std::vector<int> h_adj_loc;    // ELL slot -> LDS record of the neighbour in the owner's block, or ~global id
-    std::vector<int> h_perm, h_inv, h_slice_off, h_slice_deg;
+    std::vector<int> h_perm, h_inv, h_slice_off, h_slice_deg, h_rslice_off, h_rslice_deg;
+    std::vector<int> h_radj_spring, h_radj_nbr, h_radj_self; // remote ELL slot -> spring / neighbour / owner
     std::vector<int> h_mesh_map, h_face_map;
     // device
     float4* xv[2] = {nullptr, nullptr};
     int cur = 0;
-    int *d_slice_off = nullptr, *d_slice_deg = nullptr, *d_ovf_ptr = nullptr;
-    int4 *d_adj = nullptr, *d_ovf = nullptr;
-    int n_ovf = 0;
+    int *d_slice_off = nullptr, *d_slice_deg = nullptr, *d_rslice_off = nullptr, *d_rslice_deg = nullptr;
+    unsigned short* d_adj_idx = nullptr;
+    float *d_adj_k = nullptr, *d_adj_ir = nullptr;
+    int4* d_radj = nullptr;
+    int rell_len = 0;
     int *d_halo_off = nullptr, *d_halo_ids = nullptr, *d_perm = nullptr, *d_inv = nullptr;
     int *d_num_user = nullptr, *d_idx_user = nullptr;
     float* d_masses = nullptr;
@@ -740,8 +791,8 @@ struct R2SPhys {
     {
         PhysDev p{};
         p.N = N; p.E = E; p.n_sub = prm.num_substeps;
-        p.nb = nb; p.cb = cb;
-        p.slice_off = d_slice_off; p.slice_deg = d_slice_deg; p.adj = d_adj; p.ovf_ptr = d_ovf_ptr; p.ovf = d_ovf;
+        p.nb = nb; p.cb = cb; p.lds_rec = BLOCK + halo_max;
+        p.slice_off = d_slice_off; p.slice_deg = d_slice_deg; p.adj_idx = d_adj_idx; p.adj_k = d_adj_k; p.adj_ir = d_adj_ir; p.rslice_off = d_rslice_off; p.rslice_deg = d_rslice_deg; p.radj = d_radj;
         p.halo_off = d_halo_off; p.halo_ids = d_halo_ids; p.perm = d_perm; p.inv = d_inv;
         p.masses = d_masses; p.masks = d_masks;
         p.dt = prm.dt; p.dashpot = prm.dashpot_damping; p.drag_factor = expf(-prm.dt * prm.drag_damping);
@@ -798,44 +849,32 @@ int upload_stiffness(R2SPhys* h, const float* log_Y, hipStream_t s)
     // Slots of inactive springs (gate exp(logY) > Ymin fails, :75) and padding slots point at the particle
     // itself with k = 0: then d = 0 and dv = 0, so neither the spring nor the dashpot term contributes.
     auto fbits = [](float f) { int i; memcpy(&i, &f, 4); return i; };
-    std::vector<int4> ell(h->ell_len);
-    std::vector<int> ovf_ptr(h->N + 1, 0);
-    std::vector<int4> ovf;
-    // ELL slots are stored slot-major per slice; walk them particle by particle so the overflow CSR is in slot order
-    for (int i = 0; i < h->n_slices * SLICE; ++i) {
-        const int sl = i / SLICE, ln = i % SLICE;
-        for (int n = 0; n < h->h_slice_deg[sl]; ++n) {
-            const int t = h->h_slice_off[sl] + n * SLICE + ln;
-            const int sp = h->h_adj_spring[t];
-            const int self = h->h_adj_self[t];
-            int4 en = make_int4(self % BLOCK, self, 0, 0);
-            if (sp >= 0 && act[sp]) {
-                const int kb = fbits(k[sp]), rb = fbits(1.0f / h->h_rest[sp]);
-                if (h->h_adj_loc[t] >= 0) en = make_int4(h->h_adj_loc[t], h->h_adj_nbr[t], kb, rb);
-                else ovf.push_back(make_int4(h->h_adj_nbr[t], kb, rb, 0));
-            }
-            ell[t] = en;
-        }
-        if (i < h->N) ovf_ptr[i + 1] = (int)ovf.size();
+    // Padding slots and slots of inactive springs (gate exp(logY) > Ymin fails, :75) point at the owner itself with
+    // k = 0: d = 0 and dv = 0, so neither the spring nor the dashpot term contributes.
+    std::vector<unsigned short> ell_idx(h->ell_len);
+    std::vector<float> ell_k(h->ell_len, 0.f), ell_ir(h->ell_len, 0.f);
+    std::vector<int4> rell(h->rell_len);
+    for (int t = 0; t < h->ell_len; ++t) {
+        const int sp = h->h_adj_spring[t], self = h->h_adj_self[t];
+        if (sp >= 0 && act[sp]) { ell_idx[t] = (unsigned short)h->h_adj_loc[t]; ell_k[t] = k[sp]; ell_ir[t] = 1.0f / h->h_rest[sp]; }
+        else ell_idx[t] = (unsigned short)(self % BLOCK);
     }
-    for (int i = 1; i <= h->N; ++i) ovf_ptr[i] = std::max(ovf_ptr[i], ovf_ptr[i - 1]);
-    if ((int)ovf.size() > h->n_ovf || !h->d_ovf) {
-        if (h->d_ovf) (void)hipFree(h->d_ovf);
-        h->d_ovf = nullptr;
-        h->n_ovf = (int)ovf.size();
-        R2S_HIP_TRY(hipMalloc((void**)&h->d_ovf, sizeof(int4) * std::max<size_t>(ovf.size(), 1)));
-        drop_graph_fwd(h); // the pointer is baked into captured kernel arguments
+    for (int t = 0; t < h->rell_len; ++t) {
+        const int sp = h->h_radj_spring[t], self = h->h_radj_self[t];
+        rell[t] = (sp >= 0 && act[sp]) ? make_int4(h->h_radj_nbr[t], fbits(k[sp]), fbits(1.0f / h->h_rest[sp]), 0) : make_int4(self, 0, 0, 0);
     }
-    int rc = upload(h->d_adj, ell.data(), ell.size(), s);
+    int rc = upload(h->d_adj_idx, ell_idx.data(), ell_idx.size(), s);
     if (rc) return rc;
-    rc = upload(h->d_ovf_ptr, ovf_ptr.data(), ovf_ptr.size(), s);
+    rc = upload(h->d_adj_k, ell_k.data(), ell_k.size(), s);
     if (rc) return rc;
-    return upload(h->d_ovf, ovf.data(), ovf.size(), s);
+    rc = upload(h->d_adj_ir, ell_ir.data(), ell_ir.size(), s);
+    if (rc) return rc;
+    return upload(h->d_radj, rell.data(), rell.size(), s);
 }
 
 int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, hipStream_t s)
 {
-    dim3 grid(8u * (unsigned)h->cb * (unsigned)h->E);
+    dim3 grid(8u * (unsigned)h->cb);
     const size_t lds = (size_t)(BLOCK + h->halo_max) * 2 * sizeof(float4);
     const bool mesh = h->nF > 0;
     const float4* in = h->xv[in_buf];
@@ -977,6 +1016,14 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             code[i] = {c, i};
         }
         std::sort(code.begin(), code.end());
+        // Inside a 256-particle block the order is free (the whole block shares one LDS window): sort by descending
+        // spring count so that the 64 particles of a slice have nearly equal degree and the sliced-ELL padding
+        // (extra adjacency bytes, LDS reads and flops for nothing) shrinks from ~15 % to a few %.
+        std::vector<int> degree(N, 0);
+        for (int sp = 0; sp < S; ++sp) { degree[h->h_springs[2 * sp]]++; degree[h->h_springs[2 * sp + 1]]++; }
+        for (int b0 = 0; b0 < N; b0 += BLOCK)
+            std::stable_sort(code.begin() + b0, code.begin() + std::min(N, b0 + BLOCK),
+                             [&](const std::pair<uint64_t, int>& a, const std::pair<uint64_t, int>& b) { return degree[a.second] > degree[b.second]; });
         for (int i = 0; i < N; ++i) { h->h_perm[i] = code[i].second; h->h_inv[code[i].second] = i; }
     }
     TRY(dev_alloc(&h->d_perm, N)); TRY(dev_alloc(&h->d_inv, N));
@@ -992,19 +1039,12 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     for (auto& l : adj) std::sort(l.begin(), l.end());
     h->n_slices = (N + SLICE - 1) / SLICE;
     h->nb = (N + BLOCK - 1) / BLOCK;
-    h->cb = (h->nb + 7) / 8;
-    std::vector<int> slice_off(h->n_slices), slice_deg(h->n_slices);
-    int total = 0;
-    for (int sl = 0; sl < h->n_slices; ++sl) {
-        int deg = 0;
-        for (int i = sl * SLICE; i < std::min(N, (sl + 1) * SLICE); ++i) deg = std::max(deg, (int)adj[i].size());
-        slice_off[sl] = total; slice_deg[sl] = deg;
-        total += deg * SLICE;
-    }
-    h->ell_len = total;
-    h->h_slice_off = slice_off; h->h_slice_deg = slice_deg;
-    // halo of each block: outside neighbours by descending reference count, up to the LDS budget
-    constexpr int HALO_CAP = (64 * 1024) / 32 - BLOCK; // (BLOCK + halo) * 32 B <= 64 KiB -> two workgroups per CU
+    h->cb = (h->nb * E + 7) / 8; // work items (block, env) per XCD
+    // LDS window of a block = its own BLOCK records + the most-referenced outside neighbours (halo) up to a budget;
+    // everything else is a "remote" neighbour gathered from global memory.  Default budget 64 KiB per workgroup
+    // (never binding for the benchmark objects: largest halo 651 records -> 29 KiB).
+    int HALO_CAP = (64 * 1024) / 32 - BLOCK;
+    if (const char* ev = getenv("R2S_HALO_CAP")) HALO_CAP = std::max(0, atoi(ev)); // tuning knob
     std::vector<int> halo_off(h->nb + 1, 0), halo_ids;
     std::vector<int> slot_of(N, -1);
     std::vector<std::vector<int>> halo_of_block(h->nb);
@@ -1032,34 +1072,92 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         halo_ids.insert(halo_ids.end(), hl.begin(), hl.end());
         h->halo_max = std::max(h->halo_max, (int)hl.size());
     }
-    h->h_adj_spring.assign(total, -1);
-    h->h_adj_nbr.assign(total, 0);
-    h->h_adj_self.assign(total, 0);
-    h->h_adj_loc.assign(total, 0);
+    // split every particle's neighbours into local (LDS window) and remote lists
+    std::vector<std::vector<std::array<int, 3>>> loc(N), rem(N); // {neighbour, spring, lds record}
     for (int b = 0; b < h->nb; ++b) {
         const std::vector<int>& hl = halo_of_block[b];
         for (size_t k = 0; k < hl.size(); ++k) slot_of[hl[k]] = BLOCK + (int)k;
-        for (int i = b * BLOCK; i < std::min(h->n_slices * SLICE, (b + 1) * BLOCK); ++i) {
-            const int sl = i / SLICE, ln = i % SLICE;
-            for (int n = 0; n < slice_deg[sl]; ++n) {
-                const int t = slice_off[sl] + n * SLICE + ln;
-                h->h_adj_self[t] = i < N ? i : b * BLOCK;
-                h->h_adj_loc[t] = h->h_adj_self[t] % BLOCK;
-                if (i < N && n < (int)adj[i].size()) {
-                    const int j = adj[i][n].first;
-                    h->h_adj_nbr[t] = j; h->h_adj_spring[t] = adj[i][n].second;
-                    h->h_adj_loc[t] = (j / BLOCK == b) ? j % BLOCK : (slot_of[j] >= 0 ? slot_of[j] : ~j);
-                }
+        for (int i = b * BLOCK; i < std::min(N, (b + 1) * BLOCK); ++i)
+            for (auto& nb : adj[i]) {
+                const int j = nb.first;
+                if (j / BLOCK == b) loc[i].push_back({j, nb.second, j % BLOCK});
+                else if (slot_of[j] >= 0) loc[i].push_back({j, nb.second, slot_of[j]});
+                else rem[i].push_back({j, nb.second, -1});
             }
-        }
         for (size_t k = 0; k < hl.size(); ++k) slot_of[hl[k]] = -1;
     }
+    auto build_ell = [&](const std::vector<std::vector<std::array<int, 3>>>& lists, std::vector<int>& off, std::vector<int>& deg,
+                         std::vector<int>& a_spring, std::vector<int>& a_nbr, std::vector<int>& a_self, std::vector<int>* a_loc) {
+        off.assign(h->n_slices, 0); deg.assign(h->n_slices, 0);
+        int total = 0;
+        for (int sl = 0; sl < h->n_slices; ++sl) {
+            int dmax = 0;
+            for (int i = sl * SLICE; i < std::min(N, (sl + 1) * SLICE); ++i) dmax = std::max(dmax, (int)lists[i].size());
+            dmax = (dmax + R2S_UNROLL - 1) / R2S_UNROLL * R2S_UNROLL; // whole unrolled groups, no remainder loop
+            off[sl] = total; deg[sl] = dmax;
+            total += dmax * SLICE;
+        }
+        a_spring.assign(total, -1); a_nbr.assign(total, 0); a_self.assign(total, 0);
+        if (a_loc) a_loc->assign(total, 0);
+        for (int sl = 0; sl < h->n_slices; ++sl)
+            for (int ln = 0; ln < SLICE; ++ln) {
+                const int i = sl * SLICE + ln;
+                const int self = i < N ? i : (i / BLOCK) * BLOCK;
+                for (int n = 0; n < deg[sl]; ++n) {
+                    const int t = off[sl] + n * SLICE + ln;
+                    a_self[t] = self;
+                    if (a_loc) (*a_loc)[t] = self % BLOCK;
+                    if (i < N && n < (int)lists[i].size()) {
+                        a_nbr[t] = lists[i][n][0]; a_spring[t] = lists[i][n][1];
+                        if (a_loc) (*a_loc)[t] = lists[i][n][2];
+                    }
+                }
+            }
+        return total;
+    };
+    // LDS bank-conflict-aware slot order.  The order of a particle's neighbours is free, so choose it per slice such
+    // that the 16 lanes a ds_read_b128 services together (MI355X lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31},
+    // +32 for the upper half) read records in 16 different bank quads (record r of the 16-byte-stride x / v arrays
+    // lives in quad r mod 16).  Greedy: slot by slot, lanes with the fewest neighbours left choose first.
+    if (!getenv("R2S_NO_BANK_ORDER")) {
+        static const int grp_of_lane16[32] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
+        for (int sl = 0; sl < h->n_slices; ++sl) {
+            const int i0 = sl * SLICE, i1 = std::min(N, (sl + 1) * SLICE);
+            std::vector<std::vector<std::array<int, 3>>> rest(loc.begin() + i0, loc.begin() + i1), out(i1 - i0);
+            int dmax = 0;
+            for (auto& l : rest) dmax = std::max(dmax, (int)l.size());
+            for (int n = 0; n < dmax; ++n) {
+                unsigned used[4] = {0, 0, 0, 0};
+                std::vector<int> order;
+                for (int ln = 0; ln < i1 - i0; ++ln) if (!rest[ln].empty()) order.push_back(ln);
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rest[a].size() < rest[b].size(); });
+                // lanes that have run out of neighbours read their own record (padding): reserve its quad first
+                for (int ln = 0; ln < i1 - i0; ++ln)
+                    if (rest[ln].empty()) used[(ln >> 5) * 2 + grp_of_lane16[ln & 31]] |= 1u << (((i0 + ln) % BLOCK) & 15);
+                for (int ln : order) {
+                    unsigned& u = used[(ln >> 5) * 2 + grp_of_lane16[ln & 31]];
+                    size_t pick = 0;
+                    for (size_t c = 0; c < rest[ln].size(); ++c)
+                        if (!(u & (1u << (rest[ln][c][2] & 15)))) { pick = c; break; }
+                    u |= 1u << (rest[ln][pick][2] & 15);
+                    out[ln].push_back(rest[ln][pick]);
+                    rest[ln].erase(rest[ln].begin() + pick);
+                }
+            }
+            for (int ln = 0; ln < i1 - i0; ++ln) loc[i0 + ln] = out[ln];
+        }
+    }
+    h->ell_len = build_ell(loc, h->h_slice_off, h->h_slice_deg, h->h_adj_spring, h->h_adj_nbr, h->h_adj_self, &h->h_adj_loc);
+    h->rell_len = build_ell(rem, h->h_rslice_off, h->h_rslice_deg, h->h_radj_spring, h->h_radj_nbr, h->h_radj_self, nullptr);
     TRY(dev_alloc(&h->d_slice_off, h->n_slices)); TRY(dev_alloc(&h->d_slice_deg, h->n_slices));
-    TRY(dev_alloc(&h->d_adj, total)); TRY(dev_alloc(&h->d_ovf_ptr, N + 1));
+    TRY(dev_alloc(&h->d_rslice_off, h->n_slices)); TRY(dev_alloc(&h->d_rslice_deg, h->n_slices));
+    TRY(dev_alloc(&h->d_adj_idx, h->ell_len)); TRY(dev_alloc(&h->d_adj_k, h->ell_len)); TRY(dev_alloc(&h->d_adj_ir, h->ell_len));
+    TRY(dev_alloc(&h->d_radj, h->rell_len));
     TRY(dev_alloc(&h->d_halo_off, halo_off.size())); TRY(dev_alloc(&h->d_halo_ids, halo_ids.size()));
     TRY(upload(h->d_halo_off, halo_off.data(), halo_off.size(), s)); TRY(upload(h->d_halo_ids, halo_ids.data(), halo_ids.size(), s));
+    TRY(upload(h->d_slice_off, h->h_slice_off.data(), h->h_slice_off.size(), s)); TRY(upload(h->d_slice_deg, h->h_slice_deg.data(), h->h_slice_deg.size(), s));
+    TRY(upload(h->d_rslice_off, h->h_rslice_off.data(), h->h_rslice_off.size(), s)); TRY(upload(h->d_rslice_deg, h->h_rslice_deg.data(), h->h_rslice_deg.size(), s));
     TRY(dev_alloc(&h->d_masses, N)); TRY(dev_alloc(&h->d_masks, N));
-    TRY(upload(h->d_slice_off, slice_off.data(), slice_off.size(), s)); TRY(upload(h->d_slice_deg, slice_deg.data(), slice_deg.size(), s));
     {
         std::vector<float> zero_logy(std::max(S, 1), 0.f);
         TRY(upload_stiffness(h, S > 0 ? d->init_spring_Y : zero_logy.data(), s));
@@ -1177,7 +1275,7 @@ void r2s_phys_destroy(R2SPhys* h)
     if (!h) return;
     (void)hipDeviceSynchronize();
     drop_graph(h);
-    void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_adj, h->d_ovf, h->d_ovf_ptr, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
+    void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
                     h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp,
                     h->d_faces, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces};
@@ -1361,9 +1459,9 @@ int r2s_phys_layout_stats(R2SPhys* h, int64_t* out /* [8] */)
 {
     if (!h || !out) return R2S_ERR_INVALID;
     int64_t real = 0, fallback = 0;
-    for (int t = 0; t < h->ell_len; ++t)
-        if (h->h_adj_spring[t] >= 0) { ++real; if (h->h_adj_loc[t] < 0) ++fallback; }
-    out[0] = h->nb; out[1] = h->halo_max; out[2] = h->ell_len; out[3] = real; out[4] = fallback;
+    for (int t = 0; t < h->ell_len; ++t) if (h->h_adj_spring[t] >= 0) ++real;
+    for (int t = 0; t < h->rell_len; ++t) if (h->h_radj_spring[t] >= 0) { ++real; ++fallback; }
+    out[0] = h->nb; out[1] = h->halo_max; out[2] = h->ell_len + h->rell_len; out[3] = real; out[4] = fallback;
     out[5] = (int64_t)(BLOCK + h->halo_max) * 32; out[6] = h->n_slices; out[7] = h->cb;
     return R2S_OK;
 }
