@@ -130,6 +130,13 @@ int64_t r2s_raster_forward_batch(
 void r2s_raster_ctx_set_timing(R2SRasterCtx* ctx, int enable);
 float r2s_raster_ctx_stage_ms(const R2SRasterCtx* ctx, int stage);
 
+/* Exact-output tile culling (off by default).  The reference emits one instance for every tile of a Gaussian's
+ * 3-sigma bounding square (duplicateWithKeys, rasterizer_impl.cu:70-111); with culling on, instances that provably
+ * cannot reach alpha >= 1/255 at any pixel of the tile are not emitted.  out_color / out_depth are unchanged (such
+ * instances are skipped per pixel at forward.cu:351 anyway); the returned instance count and the backward-only
+ * n_contrib become smaller.  Never applied by r2s_raster_forward. */
+void r2s_raster_ctx_set_tile_culling(R2SRasterCtx* ctx, int enable);
+
 /* Debug taps for parity tests: copies of the last batch call's intermediates
  * (device pointers valid until the next call on `ctx`). */
 typedef struct R2SRasterDebug {

@@ -290,10 +290,15 @@ __device__ __forceinline__ AdjGroup adj_load(const PhysDev& p, int base, int g)
 __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* __restrict__ xv, const float4* lds, size_t env_base,
                                                int i, f3 xi, f3 vi, int base, int deg, AdjGroup cur)
 {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) const v4f lds_f4; // explicit LDS address space -> ds_read_b128
-    lds_f4* lds3 = (lds_f4*)lds;
-    lds_f4* ldv3 = lds3 + p.lds_rec;
+    // LDS window planes (24 B per record, explicit LDS address space so these are ds_read_b64 / ds_read_b32):
+    //   xy[R] float2 | vxy[R] float2 | z[R] float | vz[R] float
+    typedef __attribute__((address_space(3))) const v2f lds_f2;
+    typedef __attribute__((address_space(3))) const float lds_f1;
+    const int R = p.lds_rec;
+    lds_f2* l_xy = (lds_f2*)lds;
+    lds_f2* l_vxy = l_xy + R;
+    lds_f1* l_z = (lds_f1*)(l_xy + 2 * R);
+    lds_f1* l_vz = l_z + R;
     const int sl = i >> 6, ln = i & 63;
     v2f fxy = {0.f, 0.f};
     float fz = 0.f;
@@ -303,9 +308,10 @@ __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* _
         if (g + 1 < ngroups) nxt = adj_load(p, base, g + 1);
 #pragma unroll
         for (int u = 0; u < R2S_UNROLL; ++u) {
-            const v4f xl = lds3[cur.idx[u]], vl = ldv3[cur.idx[u]];
-            spring_term(make_float4(xl.x, xl.y, xl.z, 0.f), make_float4(vl.x, vl.y, vl.z, 0.f), xi, vi, cur.k[u], cur.ir[u], p.dashpot,
-                        fxy, fz);
+            const int r = cur.idx[u];
+            const v2f xy = l_xy[r], vxy = l_vxy[r];
+            spring_term(make_float4(xy.x, xy.y, l_z[r], 0.f), make_float4(vxy.x, vxy.y, l_vz[r], 0.f), xi, vi, cur.k[u], cur.ir[u],
+                        p.dashpot, fxy, fz);
         }
         cur = nxt;
     }
@@ -444,7 +450,7 @@ template <bool SELF, bool MESH>
 __global__ void __launch_bounds__(BLOCK) k_substep(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out,
                                                    int step, int write_forces)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 lds[]; // 2 * (BLOCK + halo) float4: x records, then v records
+    extern __shared__ __attribute__((aligned(16))) float4 lds[]; // 24 B * (BLOCK + halo): planes xy | vxy | z | vz
     // work item = (particle block, environment), environment fastest; XCD c owns the contiguous item range
     // [c * ipx, (c + 1) * ipx): equal shares for the 8 XCDs, neighbouring blocks (shared halos) on the same L2
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -464,25 +470,33 @@ __global__ void __launch_bounds__(BLOCK) k_substep(const PhysDev p, const float4
     if (deg0 > 0) g0 = adj_load(p, adj0, 0);
     // stage own records (fully coalesced: 2*BLOCK consecutive float4) and the halo
     {
-        // LDS layout: x records [0, R) then v records [R, 2R), R = BLOCK + largest halo (16-byte stride per array:
-        // a ds_read_b128 of 16 random records spreads over all 16 bank quads instead of 8)
+        // LDS window: 24 B per record in four planes xy | vxy | z | vz (see spring_force_lds); R = BLOCK + largest halo
         const int R = p.lds_rec;
+        float2* w_xy = (float2*)lds;
+        float* w_z = (float*)(w_xy + 2 * R);
+        auto put = [&](int part, int r, float4 q) { w_xy[part * R + r] = make_float2(q.x, q.y); w_z[part * R + r] = q.z; };
         const int n_own = min(BLOCK, p.N - b * BLOCK) * 2;
         const float4* src = xv_in + (eb + (size_t)b * BLOCK) * 2;
-        if (tid < n_own) lds[(tid & 1) * R + (tid >> 1)] = src[tid];                             // fully coalesced
-        if (tid + BLOCK < n_own) lds[(tid & 1) * R + ((tid + BLOCK) >> 1)] = src[tid + BLOCK];
+        if (tid < n_own) put(tid & 1, tid >> 1, src[tid]);                                   // fully coalesced loads
+        if (tid + BLOCK < n_own) put(tid & 1, (tid + BLOCK) >> 1, src[tid + BLOCK]);
         const int h0 = p.halo_off[b], h1 = p.halo_off[b + 1];
         for (int h = h0 + tid; h < h1; h += BLOCK) {
             const size_t g = (eb + (size_t)p.halo_ids[h]) * 2;
             const int r = BLOCK + (h - h0);
-            lds[r] = xv_in[g];
-            lds[R + r] = xv_in[g + 1];
+            put(0, r, xv_in[g]);
+            put(1, r, xv_in[g + 1]);
         }
     }
     __syncthreads();
     if (i >= p.N) return;
-    const f3 x0 = xyz(lds[tid]);
-    const f3 v0 = xyz(lds[p.lds_rec + tid]);
+    f3 x0, v0;
+    {
+        const int R = p.lds_rec;
+        const float2* r_xy = (const float2*)lds;
+        const float* r_z = (const float*)(r_xy + 2 * R);
+        x0 = mk(r_xy[tid].x, r_xy[tid].y, r_z[tid]);
+        v0 = mk(r_xy[R + tid].x, r_xy[R + tid].y, r_z[R + tid]);
+    }
     const float m1 = p.masses[i];
 
     // eval_springs + update_vel_from_force
@@ -875,7 +889,7 @@ int upload_stiffness(R2SPhys* h, const float* log_Y, hipStream_t s)
 int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, hipStream_t s)
 {
     dim3 grid(8u * (unsigned)h->cb);
-    const size_t lds = (size_t)(BLOCK + h->halo_max) * 2 * sizeof(float4);
+    const size_t lds = ((size_t)(BLOCK + h->halo_max) * 24 + 15) / 16 * 16;
     const bool mesh = h->nF > 0;
     const float4* in = h->xv[in_buf];
     float4* out = h->xv[in_buf ^ 1];
@@ -1462,7 +1476,7 @@ int r2s_phys_layout_stats(R2SPhys* h, int64_t* out /* [8] */)
     for (int t = 0; t < h->ell_len; ++t) if (h->h_adj_spring[t] >= 0) ++real;
     for (int t = 0; t < h->rell_len; ++t) if (h->h_radj_spring[t] >= 0) { ++real; ++fallback; }
     out[0] = h->nb; out[1] = h->halo_max; out[2] = h->ell_len + h->rell_len; out[3] = real; out[4] = fallback;
-    out[5] = (int64_t)(BLOCK + h->halo_max) * 32; out[6] = h->n_slices; out[7] = h->cb;
+    out[5] = (int64_t)(BLOCK + h->halo_max) * 24; out[6] = h->n_slices; out[7] = h->cb;
     return R2S_OK;
 }
 

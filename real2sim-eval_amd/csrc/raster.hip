@@ -71,6 +71,35 @@ __device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int
     y1 = (uint32_t)min(gy, max(0, (int)((py + (float)r + (float)TILE - 1.0f) / (float)TILE)));
 }
 
+// Exact-output tile culling (optional; never used by the single-frame drop-in entry point).
+// A (Gaussian, tile) instance can only change a pixel if alpha = min(0.99, o * exp(power)) >= 1/255 somewhere in the
+// tile (forward.cu:350-352 skips it otherwise, with no side effect on C, T or the median depth).  power is minus half a
+// positive-definite quadratic in d = mean - pixel; its maximum over the tile's pixel RECTANGLE (a superset of the pixel
+// lattice) is attained at the mean if that is inside, else on one of the two rectangle edges facing the mean.  The
+// instance is dropped only if that bound is 1 % below the threshold, so float rounding can never drop a live instance.
+__device__ __forceinline__ bool tile_can_contribute(float mx, float my, float ca, float cb, float cc, float log_thresh, int tx, int ty,
+                                                    int W, int H)
+{
+    const float x_lo = (float)(tx * TILE), x_hi = (float)min(tx * TILE + TILE - 1, W - 1);
+    const float y_lo = (float)(ty * TILE), y_hi = (float)min(ty * TILE + TILE - 1, H - 1);
+    const bool in_x = mx >= x_lo && mx <= x_hi, in_y = my >= y_lo && my <= y_hi;
+    if (in_x && in_y) return true;
+    float qmin = 3.0e38f;
+    if (!in_x) { // vertical edge facing the mean: dx fixed, minimise over dy = my - y, y in [y_lo, y_hi]
+        const float dx = mx - (mx < x_lo ? x_lo : x_hi);
+        const float dy_free = -cb * dx / cc;
+        const float dy = fminf(fmaxf(dy_free, my - y_hi), my - y_lo);
+        qmin = fminf(qmin, ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy);
+    }
+    if (!in_y) {
+        const float dy = my - (my < y_lo ? y_lo : y_hi);
+        const float dx_free = -cb * dy / ca;
+        const float dx = fminf(fmaxf(dx_free, mx - x_hi), mx - x_lo);
+        qmin = fminf(qmin, ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy);
+    }
+    return !(-0.5f * qmin < log_thresh - 0.01f); // NaN-safe: anything odd keeps the instance
+}
+
 // computeColorFromSH, forward.cu:20-71.
 __device__ __forceinline__ void sh_to_rgb(int idx, int deg, int M, const float* means, const float* campos,
                                           const float* shs, float rgb[3])
@@ -117,7 +146,7 @@ __device__ __forceinline__ void sh_to_rgb(int idx, int deg, int M, const float* 
 __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__ frames, int gx, int gy, int W, int H,
                                                     float* __restrict__ depths, int* __restrict__ radii_all,
                                                     GeomRec* __restrict__ geom, uint32_t* __restrict__ tiles_touched,
-                                                    int* __restrict__ err_flag)
+                                                    int* __restrict__ err_flag, int cull)
 {
 #pragma clang fp contract(off)
     const FrameDev& fr = frames[blockIdx.y];
@@ -222,6 +251,13 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
         geom[g] = rec;
         radius_out = (int)my_radius;
         tiles = (y1 - y0) * (x1 - x0);
+        if (cull) {
+            const float lt = logf(1.0f / (255.0f * fr.opac[idx]));
+            tiles = 0;
+            for (uint32_t y = y0; y < y1; ++y)
+                for (uint32_t x = x0; x < x1; ++x) tiles += tile_can_contribute(pix, piy, ca, cb, cc, lt, (int)x, (int)y, W, H) ? 1u : 0u;
+            // a Gaussian whose every tile was culled keeps its radius (the reference reports it) but emits nothing
+        }
     } while (false);
     radii_all[g] = radius_out;
     if (fr.radii) fr.radii[idx] = radius_out;
@@ -229,11 +265,11 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
 }
 
 // duplicateWithKeys, rasterizer_impl.cu:70-111, with the tile id extended by the frame index.
-__global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ frames, int gx, int gy,
+__global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ frames, int gx, int gy, int W, int H,
                                                    const float* __restrict__ depths, const int* __restrict__ radii_all,
                                                    const GeomRec* __restrict__ geom,
                                                    const uint32_t* __restrict__ offsets, uint64_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals)
+                                                   uint32_t* __restrict__ vals, int cull)
 {
     const FrameDev& fr = frames[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -243,12 +279,15 @@ __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ 
     if (r <= 0) return;
     uint32_t off = (g == 0) ? 0u : offsets[g - 1];
     const float4 q0 = geom[g].q0;
+    const float4 q1 = geom[g].q1;
     uint32_t x0, y0, x1, y1;
     tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
     const uint32_t dbits = __float_as_uint(depths[g]);
     const uint32_t tile_base = blockIdx.y * (uint32_t)(gx * gy);
+    const float lt = cull ? logf(1.0f / (255.0f * q1.y)) : 0.f;
     for (uint32_t y = y0; y < y1; ++y)
         for (uint32_t x = x0; x < x1; ++x) {
+            if (cull && !tile_can_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, lt, (int)x, (int)y, W, H)) continue;
             const uint64_t key = ((uint64_t)(tile_base + y * (uint32_t)gx + x) << 32) | dbits;
             keys[off] = key;
             vals[off] = (uint32_t)g;
@@ -389,6 +428,7 @@ struct R2SRasterCtx {
     int frames_cap = 0;
     uint64_t* h_read = nullptr; // pinned: [0] last offset, [1] error flag
     bool timing = false;
+    int cull = 0; // exact-output tile culling of instances (batched API option)
     hipEvent_t ev[7] = {};
     bool ev_ok = false;
     float stage_ms[6] = {};
@@ -503,7 +543,7 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     if (G > 0) {
         dim3 grid((maxP + 255) / 256, F);
         hipLaunchKernelGGL(k_preprocess, grid, dim3(256), 0, stream, c->d_frames, gx, gy, W, H, depths, radii_all, geom,
-                           tiles_touched, err_flag);
+                           tiles_touched, err_flag, c->cull);
         mark(1);
         R2S_HIP_TRY(rocprim::inclusive_scan(scan_tmp, scan_bytes, tiles_touched, offsets, G, rocprim::plus<uint32_t>(), stream));
         mark(2);
@@ -538,7 +578,8 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         char* sort_tmp = cv.take<char>(sort_bytes);
 
         dim3 grid((maxP + 255) / 256, F);
-        hipLaunchKernelGGL(k_emit_keys, grid, dim3(256), 0, stream, c->d_frames, gx, gy, depths, radii_all, geom, offsets, keys_a, vals_a);
+        hipLaunchKernelGGL(k_emit_keys, grid, dim3(256), 0, stream, c->d_frames, gx, gy, W, H, depths, radii_all, geom, offsets, keys_a, vals_a,
+                           c->cull);
         mark(3);
         rocprim::double_buffer<uint64_t> dkey(keys_a, keys_b);
         rocprim::double_buffer<uint32_t> dval(vals_a, vals_b);
@@ -626,6 +667,7 @@ size_t r2s_raster_ctx_scratch_bytes(const R2SRasterCtx* c)
 }
 
 void r2s_raster_ctx_set_timing(R2SRasterCtx* c, int enable) { if (c) c->timing = enable != 0; }
+void r2s_raster_ctx_set_tile_culling(R2SRasterCtx* c, int enable) { if (c) c->cull = enable != 0; }
 float r2s_raster_ctx_stage_ms(const R2SRasterCtx* c, int stage) { return (c && stage >= 0 && stage < 6) ? c->stage_ms[stage] : -1.f; }
 void r2s_raster_ctx_set_aux(R2SRasterCtx* c, float* final_T, uint32_t* n_contrib) { if (c) { c->aux_T = final_T; c->aux_n = n_contrib; } }
 
@@ -660,6 +702,7 @@ int64_t r2s_raster_forward(r2s_alloc_fn geometry_buffer, void* geometry_user, r2
         if (!tl) return R2S_ERR_ALLOC;
     }
     tl->use_cb = true;
+    tl->cull = 0; // the drop-in entry point reproduces the reference's instance list exactly
     tl->cb.fn[0] = geometry_buffer; tl->cb.user[0] = geometry_user;
     tl->cb.fn[1] = binning_buffer; tl->cb.user[1] = binning_user;
     tl->cb.fn[2] = image_buffer; tl->cb.user[2] = image_user;

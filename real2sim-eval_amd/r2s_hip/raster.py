@@ -102,6 +102,10 @@ class RasterBatch:
     def set_timing(self, on: bool):
         _lib.lib().r2s_raster_ctx_set_timing(self._h, int(on))
 
+    def set_tile_culling(self, on: bool):
+        """Exact-output instance culling (see include/r2s_raster.h); changes the instance count, not the images."""
+        _lib.lib().r2s_raster_ctx_set_tile_culling(self._h, int(on))
+
     def stage_ms(self):
         names = ["preprocess", "scan", "emit", "sort", "ranges", "composite"]
         return {n: float(_lib.lib().r2s_raster_ctx_stage_ms(self._h, i)) for i, n in enumerate(names)}

@@ -31,7 +31,7 @@ CONFIGS = {
 
 class BatchedRollout:
     def __init__(self, config="sloth_32env", device="cuda:0", seed=0, n_env=None, num_substeps=667, views=2,
-                 self_collision=True, with_gripper=True, with_static=True):
+                 self_collision=True, with_gripper=True, with_static=True, tile_culling=True):
         shape, n_particles, n_gauss, envs, W, H = CONFIGS[config]
         self.config = config
         self.n_env = int(n_env if n_env is not None else envs)
@@ -76,6 +76,7 @@ class BatchedRollout:
         self.means[:, self.n_obj:] = t(sc["means3D"][self.n_obj:])[None]
         self.g = {k: t(v) for k, v in sc.items() if k != "means3D"}
         self.raster = RasterBatch(self.device)
+        self.raster.set_tile_culling(tile_culling)  # exact-output instance culling (include/r2s_raster.h)
         self.cams = [synth.side_camera(W, H), synth.wrist_camera(W, H, eef_pos=(c[0], c[1], top + 0.30))][:views]
         self.cam_t = [{k: (t(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()} for cam in self.cams]
         self.out_color = torch.empty(E, views, 3, H, W, dtype=torch.float32, device=self.device)
