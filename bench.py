@@ -27,6 +27,16 @@ for p in (ROOT, os.path.join(ROOT, "real2sim-eval_amd")):
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def measured_traffic(kernel, config):
+    """HBM bytes per launch from the committed PMC collection (profiles/r1_traffic.json: FETCH_SIZE x2 + WRITE_SIZE,
+    separate rocprofv3 --pmc passes, corrected per the microarch guide).  Only valid for the workload it was taken on."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        return d[kernel]["hbm_bytes_per_launch"] if config == "sloth_32env" else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(ro, budget_s=20.0):
     """Time the oracle on a bounded sample of the same workload: `n` envs stepped side by side (OpenMP over
     envs, the only parallelism the reference has) for a few substeps + one 2-view render; extrapolated to
@@ -155,12 +165,15 @@ def main():
                                    f"{ro.n_env} envs per GPU, {args.substeps} substeps + {ro.views} frames {ro.W}x{ro.H} per env step",
                        "envs_per_gpu": ro.n_env, "parallelism": f"envs sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_substep (fused spring gather + velocity + collisions + integrate)",
+                         "traffic": measured_traffic("k_substep", args.config) if (ro.n_env == 32 and args.substeps == 667) else None,
+                         "kernel": "k_substep (fused spring gather + velocity + collisions + integrate)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": t_kernel * 1e6, "launches": phys_kernels},
             "raster": {"gs_raster_mpix_per_s": frames * ro.W * ro.H / (raster_ms * 1e-3) / 1e6, "frames": frames,
                        "num_rendered": int(ro.last_num_rendered), "stage_ms": stages,
                        "composite_roofline": {"bound": "hbm", "achieved": comp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                              "frac": comp_gbs / HBM_PEAK_GBS, "algorithmic_bytes": comp_bytes}},
+                                              "frac": comp_gbs / HBM_PEAK_GBS, "algorithmic_bytes": comp_bytes,
+                                              "traffic": measured_traffic("k_composite", args.config) if ro.n_env == 32 else None,
+                                              "note": "VALU/exp-bound in practice (SURVEY.md §7): HBM fraction reported as the contract asks"}},
             "physics_ms_per_env_step": phys_ms,
         }
         if not args.no_cpu_baseline and world == 1:

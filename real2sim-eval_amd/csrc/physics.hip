@@ -50,13 +50,11 @@
 namespace {
 
 constexpr int SLICE = 64;
-#ifndef R2S_BLOCK
-#define R2S_BLOCK 256
-#endif
+
 #ifndef R2S_UNROLL
 #define R2S_UNROLL 4
 #endif
-constexpr int BLOCK = R2S_BLOCK;
+constexpr int BLOCK = 256;            // threads per workgroup (4 wavefronts)
 constexpr int GRID_DIM = 128;          // wp.HashGrid(128,128,128), spring_mass_warp.py:541
 constexpr int GRID_CELL_BITS = 21;     // 128^3 cells
 constexpr float MESH_MAX_DIST = 0.02f; // :323
@@ -65,7 +63,9 @@ constexpr float WIND_THRESHOLD = 0.6f; // :323
 struct PhysDev {
     int N, E, n_sub;
     // topology (shared by all envs); all particle indices are INTERNAL (Morton order)
-    int nb, cb;                // particle blocks of BLOCK; (block, env) work items per XCD
+    int nb, cb;                // particle blocks; (block, env group) work items per XCD
+    int eg;                    // env groups = ceil(E / EPW)
+    int plane_f4;              // float4 units between the LDS windows of two environments of a workgroup
     int lds_rec;               // LDS records per workgroup (BLOCK + largest halo): x records first, then v records
     const int* slice_off;      // [n_slices]
     const int* slice_deg;      // [n_slices]
@@ -274,12 +274,13 @@ struct AdjGroup {
     int idx[R2S_UNROLL];
     float k[R2S_UNROLL], ir[R2S_UNROLL];
 };
+template <int SL>
 __device__ __forceinline__ AdjGroup adj_load(const PhysDev& p, int base, int g)
 {
     AdjGroup r;
 #pragma unroll
     for (int u = 0; u < R2S_UNROLL; ++u) {
-        const int t = base + (g * R2S_UNROLL + u) * SLICE;
+        const int t = base + (g * R2S_UNROLL + u) * SL;
         r.idx[u] = p.adj_idx[t];
         r.k[u] = p.adj_k[t];
         r.ir[u] = p.adj_ir[t];
@@ -287,8 +288,9 @@ __device__ __forceinline__ AdjGroup adj_load(const PhysDev& p, int base, int g)
     return r;
 }
 
+template <int SL>
 __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* __restrict__ xv, const float4* lds, size_t env_base,
-                                               int i, f3 xi, f3 vi, int base, int deg, AdjGroup cur)
+                                               int i, int pl, f3 xi, f3 vi, int base, int deg, AdjGroup cur)
 {
     // LDS window planes (24 B per record, explicit LDS address space so these are ds_read_b64 / ds_read_b32):
     //   xy[R] float2 | vxy[R] float2 | z[R] float | vz[R] float
@@ -299,13 +301,13 @@ __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* _
     lds_f2* l_vxy = l_xy + R;
     lds_f1* l_z = (lds_f1*)(l_xy + 2 * R);
     lds_f1* l_vz = l_z + R;
-    const int sl = i >> 6, ln = i & 63;
+    const int sl = i / SL, ln = pl;
     v2f fxy = {0.f, 0.f};
     float fz = 0.f;
     const int ngroups = deg / R2S_UNROLL; // deg is padded to whole groups at construction
     for (int g = 0; g < ngroups; ++g) {
         AdjGroup nxt = cur;
-        if (g + 1 < ngroups) nxt = adj_load(p, base, g + 1);
+        if (g + 1 < ngroups) nxt = adj_load<SL>(p, base, g + 1);
 #pragma unroll
         for (int u = 0; u < R2S_UNROLL; ++u) {
             const int r = cur.idx[u];
@@ -321,7 +323,7 @@ __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* _
     const int rdeg = p.rslice_deg[sl];
 #pragma unroll R2S_UNROLL
     for (int n = 0; n < rdeg; ++n) {
-        const int4 en = ra[n * SLICE];
+        const int4 en = ra[n * SL];
         const size_t g = (env_base + (size_t)en.x) * 2;
         spring_term(xv[g], xv[g + 1], xi, vi, __int_as_float(en.y), __int_as_float(en.z), p.dashpot, fxy, fz);
     }
@@ -443,64 +445,72 @@ __device__ __forceinline__ void finish_particle(const PhysDev& p, int e, int i, 
 }
 
 // ---- the fused substep ------------------------------------------------------------------------------
-// One workgroup = 256 consecutive (Morton-ordered) particles of one environment.  Linear workgroup id L:
-// XCD = L % 8 (observed dispatch order; a speed assumption only), within an XCD the environment index runs
-// fastest over the XCD's contiguous chunk of particle blocks.
-template <bool SELF, bool MESH>
+// One workgroup (256 threads) = PB = 256/EPW consecutive (Morton-ordered) particles of EPW consecutive environments.
+// Inside a wavefront the 64 lanes are EPW groups of SL = 64/EPW lanes: group s works on environment eg*EPW + s, and
+// lane l of every group works on the SAME particle.  All groups therefore read the same adjacency addresses, the
+// memory pipeline fetches each line once, and the adjacency stream — shared by every environment and the largest
+// L2 consumer of this kernel — costs 1/EPW of its bytes per environment.
+// Linear workgroup id L: XCD = L % 8 (observed dispatch order; a speed assumption only); XCD c owns the contiguous
+// range [c*cb, (c+1)*cb) of (block, env group) work items, env group fastest.
+template <int EPW, bool SELF, bool MESH>
 __global__ void __launch_bounds__(BLOCK) k_substep(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out,
                                                    int step, int write_forces)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 lds[]; // 24 B * (BLOCK + halo): planes xy | vxy | z | vz
-    // work item = (particle block, environment), environment fastest; XCD c owns the contiguous item range
-    // [c * ipx, (c + 1) * ipx): equal shares for the 8 XCDs, neighbouring blocks (shared halos) on the same L2
+    constexpr int PB = BLOCK / EPW, SL = SLICE / EPW;
+    extern __shared__ __attribute__((aligned(16))) float4 lds[]; // EPW windows of 24 B * (PB + halo): planes xy | vxy | z | vz
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int item = xcd * p.cb + q;
-    if (q >= p.cb || item >= p.nb * p.E) return; // whole workgroup
-    const int b = item / p.E, e = item - b * p.E;
+    if (q >= p.cb || item >= p.nb * p.eg) return; // whole workgroup
+    const int b = item / p.eg, eg = item - b * p.eg;
     const int tid = threadIdx.x;
-    const int i = b * BLOCK + tid;
-    const size_t eb = (size_t)e * p.N;
-    // first adjacency group of this thread: in flight while the LDS window is staged
-    const int sl0 = min(i, p.N - 1) >> 6;
-    const int adj0 = p.slice_off[sl0] + (i & 63);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int sub = lane / SL, pl = lane - sub * SL;
+    const int pi = wave * SL + pl;           // particle inside the block
+    const int i = b * PB + pi;
+    const int e = eg * EPW + sub;
+    const bool valid = i < p.N && e < p.E;
+    const size_t eb = (size_t)min(e, p.E - 1) * p.N;
+    // first adjacency group of this thread: in flight while the LDS windows are staged
+    const int sl0 = min(i, p.N - 1) / SL;
+    const int adj0 = p.slice_off[sl0] + pl;
     const int deg0 = p.slice_deg[sl0];
     AdjGroup g0;
 #pragma unroll
     for (int u = 0; u < R2S_UNROLL; ++u) { g0.idx[u] = 0; g0.k[u] = 0.f; g0.ir[u] = 0.f; }
-    if (deg0 > 0) g0 = adj_load(p, adj0, 0);
-    // stage own records (fully coalesced: 2*BLOCK consecutive float4) and the halo
+    if (deg0 > 0) g0 = adj_load<SL>(p, adj0, 0);
+    const int R = p.lds_rec;
     {
-        // LDS window: 24 B per record in four planes xy | vxy | z | vz (see spring_force_lds); R = BLOCK + largest halo
-        const int R = p.lds_rec;
-        float2* w_xy = (float2*)lds;
-        float* w_z = (float*)(w_xy + 2 * R);
-        auto put = [&](int part, int r, float4 q) { w_xy[part * R + r] = make_float2(q.x, q.y); w_z[part * R + r] = q.z; };
-        const int n_own = min(BLOCK, p.N - b * BLOCK) * 2;
-        const float4* src = xv_in + (eb + (size_t)b * BLOCK) * 2;
-        if (tid < n_own) put(tid & 1, tid >> 1, src[tid]);                                   // fully coalesced loads
-        if (tid + BLOCK < n_own) put(tid & 1, (tid + BLOCK) >> 1, src[tid + BLOCK]);
-        const int h0 = p.halo_off[b], h1 = p.halo_off[b + 1];
-        for (int h = h0 + tid; h < h1; h += BLOCK) {
-            const size_t g = (eb + (size_t)p.halo_ids[h]) * 2;
-            const int r = BLOCK + (h - h0);
-            put(0, r, xv_in[g]);
-            put(1, r, xv_in[g + 1]);
+        // stage, for each of the EPW environments, the block's own records and its halo: window record r < PB is
+        // particle b*PB + r, record PB + k is halo particle k; 24 B per record in four planes xy | vxy | z | vz
+        const int h0 = p.halo_off[b], nh = p.halo_off[b + 1] - h0;
+        const int per_env = PB + nh;
+        for (int t = tid; t < per_env * EPW; t += BLOCK) {
+            const int s = t / per_env, r = t - s * per_env;
+            const int es = eg * EPW + s;
+            int particle = r < PB ? b * PB + r : p.halo_ids[h0 + r - PB];
+            if (es >= p.E || particle >= p.N) continue;
+            const size_t g = ((size_t)es * p.N + particle) * 2;
+            const float4 qx = xv_in[g], qv = xv_in[g + 1];
+            float2* w_xy = (float2*)(lds + (size_t)s * p.plane_f4);
+            float* w_z = (float*)(w_xy + 2 * R);
+            w_xy[r] = make_float2(qx.x, qx.y); w_z[r] = qx.z;
+            w_xy[R + r] = make_float2(qv.x, qv.y); w_z[R + r] = qv.z;
         }
     }
     __syncthreads();
-    if (i >= p.N) return;
+    if (!valid) return;
+    const float4* my = lds + (size_t)sub * p.plane_f4;
     f3 x0, v0;
     {
-        const int R = p.lds_rec;
-        const float2* r_xy = (const float2*)lds;
+        const float2* r_xy = (const float2*)my;
         const float* r_z = (const float*)(r_xy + 2 * R);
-        x0 = mk(r_xy[tid].x, r_xy[tid].y, r_z[tid]);
-        v0 = mk(r_xy[R + tid].x, r_xy[R + tid].y, r_z[R + tid]);
+        x0 = mk(r_xy[pi].x, r_xy[pi].y, r_z[pi]);
+        v0 = mk(r_xy[R + pi].x, r_xy[R + pi].y, r_z[R + pi]);
     }
     const float m1 = p.masses[i];
 
     // eval_springs + update_vel_from_force
-    f3 v = vel_update(p, v0, spring_force_lds(p, xv_in, lds, eb, i, x0, v0, adj0, deg0, g0), m1);
+    f3 v = vel_update(p, v0, spring_force_lds<SL>(p, xv_in, my, eb, i, pl, x0, v0, adj0, deg0, g0), m1);
 
     // Self collision (object_collision, :230-268) needs the partners' post-force velocities.  Particles that have
     // contact candidates (rare; the list is rebuilt once per env step) only publish their own v_before_collision
@@ -748,7 +758,8 @@ __global__ void k_cand_list(int N, int E, const int* __restrict__ coll_num, int2
 struct R2SPhys {
     R2SPhysParams prm{};
     int E = 0, N = 0, S = 0, n_slices = 0, ell_len = 0;
-    int nb = 0, cb = 0, halo_max = 0; // particle blocks, blocks per XCD chunk, largest halo (LDS sizing)
+    int nb = 0, cb = 0, halo_max = 0; // particle blocks, work items per XCD, largest halo (LDS sizing)
+    int epw = 1, pb = BLOCK, sl = SLICE; // environments per wavefront, particles per block, particles per ELL slice
     int coll_cap = 500;
     int words = 0;
     int n_mesh = 0, n_dyn_mesh = 0, nF = 0, nV = 0, n_dyn_pts = 0;
@@ -805,7 +816,9 @@ struct R2SPhys {
     {
         PhysDev p{};
         p.N = N; p.E = E; p.n_sub = prm.num_substeps;
-        p.nb = nb; p.cb = cb; p.lds_rec = BLOCK + halo_max;
+        p.nb = nb; p.cb = cb; p.lds_rec = pb + halo_max;
+        p.eg = (E + epw - 1) / epw;
+        p.plane_f4 = ((pb + halo_max) * 24 + 15) / 16;
         p.slice_off = d_slice_off; p.slice_deg = d_slice_deg; p.adj_idx = d_adj_idx; p.adj_k = d_adj_k; p.adj_ir = d_adj_ir; p.rslice_off = d_rslice_off; p.rslice_deg = d_rslice_deg; p.radj = d_radj;
         p.halo_off = d_halo_off; p.halo_ids = d_halo_ids; p.perm = d_perm; p.inv = d_inv;
         p.masses = d_masses; p.masks = d_masks;
@@ -871,7 +884,7 @@ int upload_stiffness(R2SPhys* h, const float* log_Y, hipStream_t s)
     for (int t = 0; t < h->ell_len; ++t) {
         const int sp = h->h_adj_spring[t], self = h->h_adj_self[t];
         if (sp >= 0 && act[sp]) { ell_idx[t] = (unsigned short)h->h_adj_loc[t]; ell_k[t] = k[sp]; ell_ir[t] = 1.0f / h->h_rest[sp]; }
-        else ell_idx[t] = (unsigned short)(self % BLOCK);
+        else ell_idx[t] = (unsigned short)(self % h->pb);
     }
     for (int t = 0; t < h->rell_len; ++t) {
         const int sp = h->h_radj_spring[t], self = h->h_radj_self[t];
@@ -886,17 +899,26 @@ int upload_stiffness(R2SPhys* h, const float* log_Y, hipStream_t s)
     return upload(h->d_radj, rell.data(), rell.size(), s);
 }
 
+template <int EPW>
+void launch_substep_epw(R2SPhys* h, const PhysDev& p, dim3 grid, size_t lds, const float4* in, float4* out, int step, int write_forces,
+                        bool with_self, bool mesh, hipStream_t s)
+{
+    if (with_self && mesh) hipLaunchKernelGGL((k_substep<EPW, true, true>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
+    else if (with_self) hipLaunchKernelGGL((k_substep<EPW, true, false>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
+    else if (mesh) hipLaunchKernelGGL((k_substep<EPW, false, true>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
+    else hipLaunchKernelGGL((k_substep<EPW, false, false>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
+}
+
 int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, hipStream_t s)
 {
     dim3 grid(8u * (unsigned)h->cb);
-    const size_t lds = ((size_t)(BLOCK + h->halo_max) * 24 + 15) / 16 * 16;
+    const size_t lds = (size_t)p.plane_f4 * 16 * h->epw;
     const bool mesh = h->nF > 0;
     const float4* in = h->xv[in_buf];
     float4* out = h->xv[in_buf ^ 1];
-    if (with_self && mesh) hipLaunchKernelGGL((k_substep<true, true>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
-    else if (with_self) hipLaunchKernelGGL((k_substep<true, false>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
-    else if (mesh) hipLaunchKernelGGL((k_substep<false, true>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
-    else hipLaunchKernelGGL((k_substep<false, false>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
+    if (h->epw == 4) launch_substep_epw<4>(h, p, grid, lds, in, out, step, write_forces, with_self, mesh, s);
+    else if (h->epw == 2) launch_substep_epw<2>(h, p, grid, lds, in, out, step, write_forces, with_self, mesh, s);
+    else launch_substep_epw<1>(h, p, grid, lds, in, out, step, write_forces, with_self, mesh, s);
     if (with_self) {
         // grid-stride over the device-side candidate list; sized for the host's view of the count
         const unsigned blocks = (unsigned)std::min(1024, std::max(1, (h->n_cand + 255) / 256));
@@ -1009,6 +1031,13 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
 #define TRY(x) do { rc = (x); if (rc != R2S_OK) { r2s_phys_destroy(h); return rc; } } while (0)
 
     // ---- Morton order of the particles (env 0's initial positions; the topology is shared by all envs) ----
+    // environments per wavefront (1, 2 or 4): splitting a wavefront over EPW environments divides the adjacency bytes per
+    // environment by EPW, but measured 28 / 30 / 32 us per substep for EPW = 1 / 2 / 4 on the 32-env benchmark (smaller
+    // blocks -> relatively larger halos), so the default is 1; kept as a knob for topologies that overflow the L2.
+    h->epw = 1;
+    if (const char* ev = getenv("R2S_EPW")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4) h->epw = v; } // tuning knob
+    h->pb = BLOCK / h->epw; h->sl = SLICE / h->epw;
+    const int PB = h->pb, SL = h->sl;
     h->h_perm.resize(N); h->h_inv.resize(N);
     {
         float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
@@ -1035,8 +1064,8 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         // (extra adjacency bytes, LDS reads and flops for nothing) shrinks from ~15 % to a few %.
         std::vector<int> degree(N, 0);
         for (int sp = 0; sp < S; ++sp) { degree[h->h_springs[2 * sp]]++; degree[h->h_springs[2 * sp + 1]]++; }
-        for (int b0 = 0; b0 < N; b0 += BLOCK)
-            std::stable_sort(code.begin() + b0, code.begin() + std::min(N, b0 + BLOCK),
+        for (int b0 = 0; b0 < N; b0 += PB)
+            std::stable_sort(code.begin() + b0, code.begin() + std::min(N, b0 + PB),
                              [&](const std::pair<uint64_t, int>& a, const std::pair<uint64_t, int>& b) { return degree[a.second] > degree[b.second]; });
         for (int i = 0; i < N; ++i) { h->h_perm[i] = code[i].second; h->h_inv[code[i].second] = i; }
     }
@@ -1051,13 +1080,13 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         adj[b].push_back({a, sp});
     }
     for (auto& l : adj) std::sort(l.begin(), l.end());
-    h->n_slices = (N + SLICE - 1) / SLICE;
-    h->nb = (N + BLOCK - 1) / BLOCK;
-    h->cb = (h->nb * E + 7) / 8; // work items (block, env) per XCD
+    h->n_slices = (N + SL - 1) / SL;
+    h->nb = (N + PB - 1) / PB;
+    h->cb = (h->nb * ((E + h->epw - 1) / h->epw) + 7) / 8; // (block, env group) work items per XCD
     // LDS window of a block = its own BLOCK records + the most-referenced outside neighbours (halo) up to a budget;
     // everything else is a "remote" neighbour gathered from global memory.  Default budget 64 KiB per workgroup
     // (never binding for the benchmark objects: largest halo 651 records -> 29 KiB).
-    int HALO_CAP = (64 * 1024) / 32 - BLOCK;
+    int HALO_CAP = (64 * 1024) / (24 * h->epw) - PB;
     if (const char* ev = getenv("R2S_HALO_CAP")) HALO_CAP = std::max(0, atoi(ev)); // tuning knob
     std::vector<int> halo_off(h->nb + 1, 0), halo_ids;
     std::vector<int> slot_of(N, -1);
@@ -1067,8 +1096,8 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         std::vector<std::pair<int, int>> cnt; // (-refs, id)
         {
             std::vector<int> refs;
-            for (int i = b * BLOCK; i < std::min(N, (b + 1) * BLOCK); ++i)
-                for (auto& nb : adj[i]) if (nb.first / BLOCK != b) refs.push_back(nb.first);
+            for (int i = b * PB; i < std::min(N, (b + 1) * PB); ++i)
+                for (auto& nb : adj[i]) if (nb.first / PB != b) refs.push_back(nb.first);
             std::sort(refs.begin(), refs.end());
             for (size_t a = 0; a < refs.size();) {
                 size_t e2 = a;
@@ -1090,11 +1119,11 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     std::vector<std::vector<std::array<int, 3>>> loc(N), rem(N); // {neighbour, spring, lds record}
     for (int b = 0; b < h->nb; ++b) {
         const std::vector<int>& hl = halo_of_block[b];
-        for (size_t k = 0; k < hl.size(); ++k) slot_of[hl[k]] = BLOCK + (int)k;
-        for (int i = b * BLOCK; i < std::min(N, (b + 1) * BLOCK); ++i)
+        for (size_t k = 0; k < hl.size(); ++k) slot_of[hl[k]] = PB + (int)k;
+        for (int i = b * PB; i < std::min(N, (b + 1) * PB); ++i)
             for (auto& nb : adj[i]) {
                 const int j = nb.first;
-                if (j / BLOCK == b) loc[i].push_back({j, nb.second, j % BLOCK});
+                if (j / PB == b) loc[i].push_back({j, nb.second, j % PB});
                 else if (slot_of[j] >= 0) loc[i].push_back({j, nb.second, slot_of[j]});
                 else rem[i].push_back({j, nb.second, -1});
             }
@@ -1106,21 +1135,21 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         int total = 0;
         for (int sl = 0; sl < h->n_slices; ++sl) {
             int dmax = 0;
-            for (int i = sl * SLICE; i < std::min(N, (sl + 1) * SLICE); ++i) dmax = std::max(dmax, (int)lists[i].size());
+            for (int i = sl * SL; i < std::min(N, (sl + 1) * SL); ++i) dmax = std::max(dmax, (int)lists[i].size());
             dmax = (dmax + R2S_UNROLL - 1) / R2S_UNROLL * R2S_UNROLL; // whole unrolled groups, no remainder loop
             off[sl] = total; deg[sl] = dmax;
-            total += dmax * SLICE;
+            total += dmax * SL;
         }
         a_spring.assign(total, -1); a_nbr.assign(total, 0); a_self.assign(total, 0);
         if (a_loc) a_loc->assign(total, 0);
         for (int sl = 0; sl < h->n_slices; ++sl)
-            for (int ln = 0; ln < SLICE; ++ln) {
-                const int i = sl * SLICE + ln;
-                const int self = i < N ? i : (i / BLOCK) * BLOCK;
+            for (int ln = 0; ln < SL; ++ln) {
+                const int i = sl * SL + ln;
+                const int self = i < N ? i : (i / PB) * PB;
                 for (int n = 0; n < deg[sl]; ++n) {
-                    const int t = off[sl] + n * SLICE + ln;
+                    const int t = off[sl] + n * SL + ln;
                     a_self[t] = self;
-                    if (a_loc) (*a_loc)[t] = self % BLOCK;
+                    if (a_loc) (*a_loc)[t] = self % PB;
                     if (i < N && n < (int)lists[i].size()) {
                         a_nbr[t] = lists[i][n][0]; a_spring[t] = lists[i][n][1];
                         if (a_loc) (*a_loc)[t] = lists[i][n][2];
@@ -1133,10 +1162,10 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     // that the 16 lanes a ds_read_b128 services together (MI355X lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31},
     // +32 for the upper half) read records in 16 different bank quads (record r of the 16-byte-stride x / v arrays
     // lives in quad r mod 16).  Greedy: slot by slot, lanes with the fewest neighbours left choose first.
-    if (!getenv("R2S_NO_BANK_ORDER")) {
+    if (h->epw == 1 && !getenv("R2S_NO_BANK_ORDER")) {
         static const int grp_of_lane16[32] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
         for (int sl = 0; sl < h->n_slices; ++sl) {
-            const int i0 = sl * SLICE, i1 = std::min(N, (sl + 1) * SLICE);
+            const int i0 = sl * SL, i1 = std::min(N, (sl + 1) * SL);
             std::vector<std::vector<std::array<int, 3>>> rest(loc.begin() + i0, loc.begin() + i1), out(i1 - i0);
             int dmax = 0;
             for (auto& l : rest) dmax = std::max(dmax, (int)l.size());
@@ -1147,7 +1176,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
                 std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rest[a].size() < rest[b].size(); });
                 // lanes that have run out of neighbours read their own record (padding): reserve its quad first
                 for (int ln = 0; ln < i1 - i0; ++ln)
-                    if (rest[ln].empty()) used[(ln >> 5) * 2 + grp_of_lane16[ln & 31]] |= 1u << (((i0 + ln) % BLOCK) & 15);
+                    if (rest[ln].empty()) used[(ln >> 5) * 2 + grp_of_lane16[ln & 31]] |= 1u << (((i0 + ln) % PB) & 15);
                 for (int ln : order) {
                     unsigned& u = used[(ln >> 5) * 2 + grp_of_lane16[ln & 31]];
                     size_t pick = 0;
@@ -1476,7 +1505,7 @@ int r2s_phys_layout_stats(R2SPhys* h, int64_t* out /* [8] */)
     for (int t = 0; t < h->ell_len; ++t) if (h->h_adj_spring[t] >= 0) ++real;
     for (int t = 0; t < h->rell_len; ++t) if (h->h_radj_spring[t] >= 0) { ++real; ++fallback; }
     out[0] = h->nb; out[1] = h->halo_max; out[2] = h->ell_len + h->rell_len; out[3] = real; out[4] = fallback;
-    out[5] = (int64_t)(BLOCK + h->halo_max) * 24; out[6] = h->n_slices; out[7] = h->cb;
+    out[5] = (int64_t)(h->pb + h->halo_max) * 24 * h->epw; out[6] = h->n_slices; out[7] = h->cb;
     return R2S_OK;
 }
 
