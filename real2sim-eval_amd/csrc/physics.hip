@@ -54,7 +54,10 @@ constexpr int SLICE = 64;
 #ifndef R2S_UNROLL
 #define R2S_UNROLL 4
 #endif
-constexpr int BLOCK = 256;            // threads per workgroup (4 wavefronts)
+#ifndef R2S_BLOCK
+#define R2S_BLOCK 256
+#endif
+constexpr int BLOCK = R2S_BLOCK;      // threads per workgroup
 constexpr int GRID_DIM = 128;          // wp.HashGrid(128,128,128), spring_mass_warp.py:541
 constexpr int GRID_CELL_BITS = 21;     // 128^3 cells
 constexpr float MESH_MAX_DIST = 0.02f; // :323
