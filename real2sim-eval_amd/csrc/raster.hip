@@ -357,8 +357,11 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
             const uint32_t id = point_list[range.x + progress];
             const GeomRec* rec = geom + id;
             const float4 a = rec->q0, b = rec->q1, c = rec->q2;
-            s_q0[tid] = a;
-            s_q1[tid] = make_float2(b.x, b.y);
+            // conic pre-scaled once per staged instance: power * log2(e) = A dx^2 + B dx dy + C dy^2 with
+            // A = -0.5 a log2e, B = -b log2e, C = -0.5 c log2e, so the pixel loop is 7 plain VALU ops + one v_exp_f32
+            constexpr float LOG2E = 1.4426950408889634f;
+            s_q0[tid] = make_float4(a.x, a.y, -0.5f * LOG2E * a.z, -LOG2E * a.w);
+            s_q1[tid] = make_float2(-0.5f * LOG2E * b.x, b.y);
             s_q2[tid] = make_float4(b.w, c.x, c.y, b.z);
         }
         __syncthreads();
@@ -368,9 +371,9 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
             const float4 a = s_q0[j];
             const float2 b = s_q1[j];
             const float dx = a.x - pfx, dy = a.y - pfy;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+            const float power = fmaf(dx, fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy); // = log2(e) * forward.cu:342's power
             if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, b.y * expf(power));
+            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
             if (alpha < 1.0f / 255.0f) continue;
             const float test_T = T * (1.f - alpha);
             if (test_T < 0.0001f) {
