@@ -77,11 +77,9 @@ __device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int
 // positive-definite quadratic in d = mean - pixel; its maximum over the tile's pixel RECTANGLE (a superset of the pixel
 // lattice) is attained at the mean if that is inside, else on one of the two rectangle edges facing the mean.  The
 // instance is dropped only if that bound is 1 % below the threshold, so float rounding can never drop a live instance.
-__device__ __forceinline__ bool tile_can_contribute(float mx, float my, float ca, float cb, float cc, float log_thresh, int tx, int ty,
-                                                    int W, int H)
+__device__ __forceinline__ bool rect_can_contribute(float mx, float my, float ca, float cb, float cc, float log_thresh, float x_lo,
+                                                    float x_hi, float y_lo, float y_hi)
 {
-    const float x_lo = (float)(tx * TILE), x_hi = (float)min(tx * TILE + TILE - 1, W - 1);
-    const float y_lo = (float)(ty * TILE), y_hi = (float)min(ty * TILE + TILE - 1, H - 1);
     const bool in_x = mx >= x_lo && mx <= x_hi, in_y = my >= y_lo && my <= y_hi;
     if (in_x && in_y) return true;
     float qmin = 3.0e38f;
@@ -98,6 +96,13 @@ __device__ __forceinline__ bool tile_can_contribute(float mx, float my, float ca
         qmin = fminf(qmin, ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy);
     }
     return !(-0.5f * qmin < log_thresh - 0.01f); // NaN-safe: anything odd keeps the instance
+}
+
+__device__ __forceinline__ bool tile_can_contribute(float mx, float my, float ca, float cb, float cc, float log_thresh, int tx, int ty,
+                                                    int W, int H)
+{
+    return rect_can_contribute(mx, my, ca, cb, cc, log_thresh, (float)(tx * TILE), (float)min(tx * TILE + TILE - 1, W - 1),
+                               (float)(ty * TILE), (float)min(ty * TILE + TILE - 1, H - 1));
 }
 
 // computeColorFromSH, forward.cu:20-71.
@@ -269,7 +274,7 @@ __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ 
                                                    const float* __restrict__ depths, const int* __restrict__ radii_all,
                                                    const GeomRec* __restrict__ geom,
                                                    const uint32_t* __restrict__ offsets, uint64_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals, int cull)
+                                                   uint32_t* __restrict__ vals, int cull, int key_shift)
 {
     const FrameDev& fr = frames[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,7 +293,7 @@ __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ 
     for (uint32_t y = y0; y < y1; ++y)
         for (uint32_t x = x0; x < x1; ++x) {
             if (cull && !tile_can_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, lt, (int)x, (int)y, W, H)) continue;
-            const uint64_t key = ((uint64_t)(tile_base + y * (uint32_t)gx + x) << 32) | dbits;
+            const uint64_t key = ((uint64_t)(tile_base + y * (uint32_t)gx + x) << key_shift) | dbits;
             keys[off] = key;
             vals[off] = (uint32_t)g;
             ++off;
@@ -296,14 +301,14 @@ __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ 
 }
 
 // identifyTileRanges, rasterizer_impl.cu:116-138.
-__global__ void __launch_bounds__(256) k_tile_ranges(uint32_t L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
+__global__ void __launch_bounds__(256) k_tile_ranges(uint32_t L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges, int key_shift)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L) return;
-    const uint32_t cur = (uint32_t)(keys[i] >> 32);
+    const uint32_t cur = (uint32_t)(keys[i] >> key_shift);
     if (i == 0) ranges[cur].x = 0;
     else {
-        const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+        const uint32_t prev = (uint32_t)(keys[i - 1] >> key_shift);
         if (cur != prev) {
             ranges[prev].y = i;
             ranges[cur].x = i;
@@ -340,19 +345,23 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
     const int n = (int)(range.y - range.x);
     const int rounds = (n + TILE_THREADS - 1) / TILE_THREADS;
 
-    __shared__ float4 s_q0[TILE_THREADS]; // px, py, conic_a, conic_b
-    __shared__ float2 s_q1[TILE_THREADS]; // conic_c, opacity
+    __shared__ float4 s_q0[TILE_THREADS]; // px, py, A, B   (conic pre-scaled, see below)
+    __shared__ float2 s_q1[TILE_THREADS]; // C, opacity
     __shared__ float4 s_q2[TILE_THREADS]; // r, g, b, depth
+    // s_live[q][w]: which of the 64 instances staged by wavefront w can reach alpha >= 1/255 somewhere in quadrant q
+    // (the same conservative bound as the tile culling, on the 8x8 pixel rectangle).  A quadrant's wavefront walks
+    // only its set bits, so an instance costs nothing in the quadrants it cannot touch.
+    __shared__ unsigned long long s_live[4][4];
 
     float T = 1.0f;
-    uint32_t contributor = 0, last_contributor = 0;
+    uint32_t last_contributor = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
     float D = 15.0f; // forward.cu:309
 
-    int todo = n;
-    for (int i = 0; i < rounds; ++i, todo -= TILE_THREADS) {
+    for (int i = 0; i < rounds; ++i) {
         if (__syncthreads_count(done) == TILE_THREADS) break;
         const int progress = i * TILE_THREADS + tid;
+        unsigned live4 = 0;
         if (progress < n) {
             const uint32_t id = point_list[range.x + progress];
             const GeomRec* rec = geom + id;
@@ -363,31 +372,49 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
             s_q0[tid] = make_float4(a.x, a.y, -0.5f * LOG2E * a.z, -LOG2E * a.w);
             s_q1[tid] = make_float2(-0.5f * LOG2E * b.x, b.y);
             s_q2[tid] = make_float4(b.w, c.x, c.y, b.z);
+            const float lt = logf(1.0f / (255.0f * b.y));
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float x_lo = (float)(tx * TILE + (qd & 1) * 8), y_lo = (float)(ty * TILE + (qd >> 1) * 8);
+                live4 |= rect_can_contribute(a.x, a.y, a.z, a.w, b.x, lt, x_lo, fminf(x_lo + 7.f, (float)(W - 1)), y_lo,
+                                             fminf(y_lo + 7.f, (float)(H - 1))) ? (1u << qd) : 0u;
+            }
+        }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64((live4 >> qd) & 1u);
+            if (lane == 0) s_live[qd][wave] = bal;
         }
         __syncthreads();
-        const int m = min(TILE_THREADS, todo);
-        for (int j = 0; !done && j < m; ++j) {
-            contributor++;
-            const float4 a = s_q0[j];
-            const float2 b = s_q1[j];
-            const float dx = a.x - pfx, dy = a.y - pfy;
-            const float power = fmaf(dx, fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy); // = log2(e) * forward.cu:342's power
-            if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T * (1.f - alpha);
-            if (test_T < 0.0001f) {
-                done = true;
-                continue;
+        const uint32_t base = (uint32_t)(i * TILE_THREADS);
+        for (int sw = 0; sw < 4; ++sw) {
+            unsigned long long bits = s_live[wave][sw]; // wave-uniform
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) break; // whole quadrant finished (forward.cu:315 per block)
+            while (bits) {
+                const int j = sw * 64 + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                if (done) continue;
+                const float4 a = s_q0[j];
+                const float2 b = s_q1[j];
+                const float dx = a.x - pfx, dy = a.y - pfy;
+                const float power = fmaf(dx, fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy); // = log2(e) * forward.cu:342's power
+                if (power > 0.0f) continue;
+                const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
+                if (alpha < 1.0f / 255.0f) continue;
+                const float test_T = T * (1.f - alpha);
+                if (test_T < 0.0001f) {
+                    done = true;
+                    continue;
+                }
+                const float4 c = s_q2[j];
+                const float w = alpha * T;
+                C0 += c.x * w;
+                C1 += c.y * w;
+                C2 += c.z * w;
+                if (T > 0.5f && test_T < 0.5f) D = c.w;
+                T = test_T;
+                last_contributor = base + (uint32_t)j + 1u; // position in the tile's list, as forward.cu:335,380
             }
-            const float4 c = s_q2[j];
-            const float w = alpha * T;
-            C0 += c.x * w;
-            C1 += c.y * w;
-            C2 += c.z * w;
-            if (T > 0.5f && test_T < 0.5f) D = c.w;
-            T = test_T;
-            last_contributor = contributor;
         }
     }
     if (inside) {
@@ -562,6 +589,10 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
 
     // ---- binning scratch (BinningState, rasterizer_impl.h:56-67) ----
     const uint32_t bits = higher_msb((uint32_t)F * (uint32_t)tiles);
+    // Kept depths exceed z_threshold; when that is >= 0 for every frame the sign bit of the depth is always clear
+    // and the tile id can start at bit 31: 48 instead of 49 key bits for 64 frames x 1200 tiles = one radix pass less.
+    int key_shift = 31;
+    for (int f = 0; f < F; ++f) if (!(frames[f].z_threshold >= 0.f)) key_shift = 32;
     uint64_t *keys_a = nullptr, *keys_b = nullptr;
     uint32_t *vals_a = nullptr, *vals_b = nullptr;
     const uint64_t* keys_sorted = nullptr;
@@ -570,7 +601,7 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         rocprim::double_buffer<uint64_t> dk((uint64_t*)nullptr, (uint64_t*)nullptr);
         rocprim::double_buffer<uint32_t> dv((uint32_t*)nullptr, (uint32_t*)nullptr);
         size_t sort_bytes = 0;
-        R2S_HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, dk, dv, (size_t)L, 0u, 32u + bits, stream));
+        R2S_HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, dk, dv, (size_t)L, 0u, (unsigned)key_shift + bits, stream));
         r2s::Carver sz(nullptr);
         sz.take<uint64_t>(L); sz.take<uint64_t>(L); sz.take<uint32_t>(L); sz.take<uint32_t>(L); sz.take<char>(sort_bytes);
         char* p = c->scratch(1, sz.bytes());
@@ -582,11 +613,11 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
 
         dim3 grid((maxP + 255) / 256, F);
         hipLaunchKernelGGL(k_emit_keys, grid, dim3(256), 0, stream, c->d_frames, gx, gy, W, H, depths, radii_all, geom, offsets, keys_a, vals_a,
-                           c->cull);
+                           c->cull, key_shift);
         mark(3);
         rocprim::double_buffer<uint64_t> dkey(keys_a, keys_b);
         rocprim::double_buffer<uint32_t> dval(vals_a, vals_b);
-        R2S_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, dkey, dval, (size_t)L, 0u, 32u + bits, stream));
+        R2S_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, dkey, dval, (size_t)L, 0u, (unsigned)key_shift + bits, stream));
         keys_sorted = dkey.current();
         vals_sorted = dval.current();
         mark(4);
@@ -595,7 +626,7 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     }
     R2S_HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)F * tiles, stream));
     if (L > 0)
-        hipLaunchKernelGGL(k_tile_ranges, dim3((L + 255) / 256), dim3(256), 0, stream, L, keys_sorted, ranges);
+        hipLaunchKernelGGL(k_tile_ranges, dim3((L + 255) / 256), dim3(256), 0, stream, L, keys_sorted, ranges, key_shift);
     mark(5);
     hipLaunchKernelGGL(k_composite, dim3((uint32_t)F * tiles), dim3(TILE_THREADS), 0, stream, c->d_frames, gx, gy, W, H, ranges,
                        vals_sorted, geom, c->aux_T, c->aux_n);
