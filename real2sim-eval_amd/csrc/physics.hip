@@ -43,10 +43,6 @@
 #include <cstdlib>
 #include <vector>
 
-#ifndef R2S_EXPERIMENT
-#define R2S_EXPERIMENT 0
-#endif
-
 namespace {
 
 constexpr int SLICE = 64;
