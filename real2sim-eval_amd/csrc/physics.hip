@@ -39,6 +39,7 @@
 #include "../../include/r2s_physics.h"
 #include <algorithm>
 #include <array>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -96,10 +97,22 @@ struct PhysDev {
     const int* cand_count;
     // meshes
     int n_mesh, n_dyn_mesh, nF, nV, n_dyn_pts;
-    const int* faces;          // [nF,3] global vertex ids
-    const int* mesh_map;       // [nF]
-    const int* face_map;       // [nF]
+    const int* faces;          // [nF,3] global vertex ids, in STORED order (large meshes: Morton-sorted clusters)
+    const int* face_orig;      // [nF] stored face -> original (caller) face id
+    const int* face_mesh;      // [nF] stored face -> mesh index
+    const int* mesh_map;       // [nF] by ORIGINAL face id
+    const int* face_map;       // [nF] by ORIGINAL face id
     const int* mesh_face_off;  // [n_mesh+1]
+    int n_cl, n_xf;            // face clusters; large dynamic meshes (one rigid transform each per env and substep)
+    const int* cl_f0;          // [n_cl] stored-face range of a cluster
+    const int* cl_f1;
+    const int* cl_mesh;        // [n_cl]
+    const float* cl_box;       // [n_cl,6] rest-frame boxes (clusters of large meshes)
+    const int* mesh_kind;      // [n_mesh] 0 small (brute force, exact winding), 1 large (clusters + pseudonormals)
+    const int* mesh_xf;        // [n_mesh] transform slot of a large dynamic mesh, else -1
+    const float* xf;           // [E,n_sub,n_xf,12]
+    const float* rest_pts;     // [nV,3] vertices at construction (= rest frame of rigid meshes)
+    const float* pnorm;        // [nF,7,3] pseudonormals of stored faces of large meshes: face, a, b, c, ab, bc, ca
     const float* mesh_pts;     // [E,nV,3] (static part is live; dynamic part = positions at t=0)
     const float* interp_pts;   // [E,n_sub,n_dyn_pts,3]
     const float* interp_center;// [E,n_sub,3]
@@ -146,50 +159,38 @@ __device__ __forceinline__ f3 vel_update(const PhysDev& p, f3 v0, f3 f0, float m
 
 // ---- mesh queries ---------------------------------------------------------------------------------
 // Closest point on triangle (a,b,c) to q as barycentrics (u of a, v of b) — Ericson, RTCD 5.1.5.
-__device__ __forceinline__ void closest_bary(f3 a, f3 b, f3 c, f3 q, float& u, float& v)
+// `region`: 0 face interior, 1/2/3 vertex a/b/c, 4/5/6 edge ab/bc/ca (selects the pseudonormal of large meshes).
+__device__ __forceinline__ void closest_bary(f3 a, f3 b, f3 c, f3 q, float& u, float& v, int& region)
 {
     const f3 ab = b - a, ac = c - a, ap = q - a;
     const float d1 = dot(ab, ap), d2 = dot(ac, ap);
-    if (d1 <= 0.f && d2 <= 0.f) { u = 1.f; v = 0.f; return; }
+    if (d1 <= 0.f && d2 <= 0.f) { u = 1.f; v = 0.f; region = 1; return; }
     const f3 bp = q - b;
     const float d3 = dot(ab, bp), d4 = dot(ac, bp);
-    if (d3 >= 0.f && d4 <= d3) { u = 0.f; v = 1.f; return; }
+    if (d3 >= 0.f && d4 <= d3) { u = 0.f; v = 1.f; region = 2; return; }
     const float vc = d1 * d4 - d3 * d2;
-    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { const float t = d1 / (d1 - d3); u = 1.f - t; v = t; return; }
+    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { const float t = d1 / (d1 - d3); u = 1.f - t; v = t; region = 4; return; }
     const f3 cp = q - c;
     const float d5 = dot(ab, cp), d6 = dot(ac, cp);
-    if (d6 >= 0.f && d5 <= d6) { u = 0.f; v = 0.f; return; }
+    if (d6 >= 0.f && d5 <= d6) { u = 0.f; v = 0.f; region = 3; return; }
     const float vb = d5 * d2 - d1 * d6;
-    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { const float w = d2 / (d2 - d6); u = 1.f - w; v = 0.f; return; }
+    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { const float w = d2 / (d2 - d6); u = 1.f - w; v = 0.f; region = 6; return; }
     const float va = d3 * d6 - d5 * d4;
     if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
         const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
-        u = 0.f; v = 1.f - w; return;
+        u = 0.f; v = 1.f - w; region = 5; return;
     }
     const float denom = 1.f / (va + vb + vc);
     const float vv = vb * denom, ww = vc * denom;
-    u = 1.f - vv - ww; v = vv;
+    u = 1.f - vv - ww; v = vv; region = 0;
 }
 
-struct MeshQ {
+struct MeshHit {
     bool result;
     float sign;
-    int face;
-    float u, v;
+    int face; // ORIGINAL (caller) face id
+    f3 pt;    // closest point, world frame
 };
-
-__device__ __forceinline__ f3 mesh_vertex(const PhysDev& p, int e, int step, int vid)
-{
-    if (vid < p.n_dyn_pts) return ld3(p.interp_pts, ((size_t)e * p.n_sub + step) * p.n_dyn_pts + vid);
-    return ld3(p.mesh_pts, (size_t)e * p.nV + vid);
-}
-
-__device__ __forceinline__ f3 mesh_eval(const PhysDev& p, int e, int step, int face, float u, float v)
-{
-    const f3 a = mesh_vertex(p, e, step, p.faces[3 * face]), b = mesh_vertex(p, e, step, p.faces[3 * face + 1]),
-             c = mesh_vertex(p, e, step, p.faces[3 * face + 2]);
-    return a * u + b * v + c * (1.f - u - v);
-}
 
 __device__ __forceinline__ float box_dist2(f3 q, const float* bb)
 {
@@ -199,27 +200,208 @@ __device__ __forceinline__ float box_dist2(f3 q, const float* bb)
     return dx * dx + dy * dy + dz * dz;
 }
 
-// wp.mesh_query_point_sign_winding_number(mesh, q, max_dist=0.02, accuracy=3.0, threshold=0.6) restated:
-// first strict-minimum closest face with squared distance < max_dist^2; sign from the exact winding number.
-// Meshes whose AABB is farther than max_dist cannot contain such a face and are skipped in the search.
-__device__ MeshQ mesh_query(const PhysDev& p, int e, int step, f3 q)
+// wavefront-wide reductions (all 64 lanes must be active)
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
-    MeshQ r = {false, 0.f, 0, 0.f, 0.f};
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, m), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), m);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float bcast(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ int bcasti(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// rigid transform of a large dynamic mesh at (env, substep): world = R * rest + t, stored row-major R[9] then t[3]
+struct Xf {
+    float r[9], t[3];
+};
+__device__ __forceinline__ f3 xf_apply(const Xf& X, f3 a)
+{
+    return mk(X.r[0] * a.x + X.r[1] * a.y + X.r[2] * a.z + X.t[0], X.r[3] * a.x + X.r[4] * a.y + X.r[5] * a.z + X.t[1],
+              X.r[6] * a.x + X.r[7] * a.y + X.r[8] * a.z + X.t[2]);
+}
+__device__ __forceinline__ f3 xf_inverse(const Xf& X, f3 w)
+{
+    const f3 d = mk(w.x - X.t[0], w.y - X.t[1], w.z - X.t[2]);
+    return mk(X.r[0] * d.x + X.r[3] * d.y + X.r[6] * d.z, X.r[1] * d.x + X.r[4] * d.y + X.r[7] * d.z, X.r[2] * d.x + X.r[5] * d.y + X.r[8] * d.z);
+}
+__device__ __forceinline__ f3 xf_rotate(const Xf& X, f3 a)
+{
+    return mk(X.r[0] * a.x + X.r[1] * a.y + X.r[2] * a.z, X.r[3] * a.x + X.r[4] * a.y + X.r[5] * a.z, X.r[6] * a.x + X.r[7] * a.y + X.r[8] * a.z);
+}
+__device__ __forceinline__ Xf xf_load(const PhysDev& p, int e, int step, int m)
+{
+    Xf X;
+    const int k = p.mesh_xf[m];
+    if (k < 0) { // static mesh or small mesh: identity
+#pragma unroll
+        for (int j = 0; j < 9; ++j) X.r[j] = (j % 4 == 0) ? 1.f : 0.f;
+        X.t[0] = X.t[1] = X.t[2] = 0.f;
+        return X;
+    }
+    const float* src = p.xf + (((size_t)e * p.n_sub + step) * p.n_xf + k) * 12;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) X.r[j] = src[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) X.t[j] = src[9 + j];
+    return X;
+}
+
+// vertex of a SMALL mesh in world frame at (env, substep): dynamic vertices follow the interpolated motion
+__device__ __forceinline__ f3 mesh_vertex(const PhysDev& p, int e, int step, int vid)
+{
+    if (vid < p.n_dyn_pts) return ld3(p.interp_pts, ((size_t)e * p.n_sub + step) * p.n_dyn_pts + vid);
+    return ld3(p.mesh_pts, (size_t)e * p.nV + vid);
+}
+
+// wp.mesh_query_point_sign_winding_number(mesh, q, max_dist=0.02, accuracy=3.0, threshold=0.6) restated, wave-cooperative.
+// Every lane of the wavefront calls this at the same point; lanes with `want` get their query answered one after the
+// other by all 64 lanes together:
+//   closest point  = lexicographic minimum of (squared distance, original face id) over every face with distance^2 <
+//                    max_dist^2 — the first strict minimum of a sequential scan.  Faces are grouped in clusters (a small
+//                    mesh = one cluster with its per-substep AABB; a large mesh = Morton-sorted runs of 64 faces with
+//                    rest-frame boxes, queried in the rest frame through the substep's rigid transform); one lane per
+//                    cluster prunes by box distance, then one lane per face of each surviving cluster.
+//   sign           = winding number > 0.6 ? -1 : +1 with the EXACT solid-angle sum when the scene is small (<= 512
+//                    faces, every mesh small), lanes striding the faces; for a large mesh (closed manifold, checked at
+//                    construction) the angle-weighted pseudonormal of the closest feature decides (Baerentzen & Aanaes),
+//                    which equals the winding-number sign for closed meshes.
+__device__ MeshHit mesh_query_wave(const PhysDev& p, int step, f3 q_lane, int e_lane, bool want)
+{
+    MeshHit out = {false, 0.f, 0, mk(0.f, 0.f, 0.f)};
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned long long pending = __builtin_amdgcn_ballot_w64(want);
+    const float MAXD2 = MESH_MAX_DIST * MESH_MAX_DIST;
+    while (pending) {
+        const int L = __builtin_ctzll(pending);
+        pending &= pending - 1;
+        const f3 q = mk(bcast(q_lane.x, L), bcast(q_lane.y, L), bcast(q_lane.z, L));
+        const int e = bcasti(e_lane, L);
+        float best = MAXD2;
+        unsigned long long bestkey = ~0ull;
+        f3 bpt = mk(0.f, 0.f, 0.f), bdl = mk(0.f, 0.f, 0.f); // closest point (world), q - p in the mesh's rest frame
+        int bstored = 0, bregion = 0;
+        for (int cb = 0; cb < p.n_cl; cb += 64) {
+            const int c = cb + lane;
+            float d2c = 3.0e38f;
+            if (c < p.n_cl) {
+                const int m = p.cl_mesh[c];
+                if (p.mesh_kind[m] == 0) {
+                    const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
+                                                       : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
+                    d2c = box_dist2(q, bb);
+                } else {
+                    const Xf X = xf_load(p, e, step, m);
+                    d2c = box_dist2(xf_inverse(X, q), p.cl_box + (size_t)c * 6);
+                }
+            }
+            unsigned long long cm = __builtin_amdgcn_ballot_w64(d2c < MAXD2 * 1.0001f + 1e-12f);
+            while (cm) {
+                const int k = __builtin_ctzll(cm);
+                cm &= cm - 1;
+                if (!(bcast(d2c, k) < best * 1.0001f + 1e-12f)) continue; // cannot beat the current best
+                const int c2 = cb + k;
+                const int f0 = p.cl_f0[c2], f1 = p.cl_f1[c2], m = p.cl_mesh[c2];
+                const bool large = p.mesh_kind[m] != 0;
+                const Xf X = xf_load(p, e, step, m);
+                const f3 qq = large ? xf_inverse(X, q) : q;
+                for (int fb = f0; fb < f1; fb += 64) {
+                    const int f = fb + lane;
+                    unsigned long long key = ~0ull;
+                    float u = 0.f, v = 0.f;
+                    int region = 0;
+                    f3 cp = mk(0.f, 0.f, 0.f);
+                    if (f < f1) {
+                        const int ia = p.faces[3 * f], ib = p.faces[3 * f + 1], ic = p.faces[3 * f + 2];
+                        const f3 a = large ? ld3(p.rest_pts, ia) : mesh_vertex(p, e, step, ia);
+                        const f3 b = large ? ld3(p.rest_pts, ib) : mesh_vertex(p, e, step, ib);
+                        const f3 c3 = large ? ld3(p.rest_pts, ic) : mesh_vertex(p, e, step, ic);
+                        closest_bary(a, b, c3, qq, u, v, region);
+                        cp = a * u + b * v + c3 * (1.f - u - v);
+                        const f3 d = cp - qq;
+                        const float d2 = dot(d, d);
+                        if (d2 < MAXD2) key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)p.face_orig[f];
+                    }
+                    const unsigned long long mn = wave_min_u64(key);
+                    if (mn < bestkey) {
+                        bestkey = mn;
+                        best = __uint_as_float((unsigned)(mn >> 32));
+                        const int w = __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == mn));
+                        const f3 cpw = mk(bcast(cp.x, w), bcast(cp.y, w), bcast(cp.z, w));
+                        bdl = qq - cpw;
+                        bpt = large ? xf_apply(X, cpw) : cpw;
+                        bstored = fb + w;
+                        bregion = bcasti(region, w);
+                    }
+                }
+            }
+        }
+        const bool found = bestkey != ~0ull;
+        float sign = 1.f;
+        if (found) {
+            const int bm = p.face_mesh[bstored];
+            if (p.mesh_kind[bm] != 0) {
+                const f3 n = ld3(p.pnorm, (size_t)bstored * 7 + bregion); // rest frame, like bdl
+                sign = dot(bdl, n) < 0.f ? -1.f : 1.f;
+            } else {
+                // exact winding number over the faces of every SMALL mesh (all faces when the scene has no large mesh)
+                float ws = 0.f;
+                for (int f = lane; f < p.nF; f += 64) {
+                    if (p.mesh_kind[p.face_mesh[f]] != 0) continue;
+                    const f3 a = mesh_vertex(p, e, step, p.faces[3 * f]) - q, b = mesh_vertex(p, e, step, p.faces[3 * f + 1]) - q,
+                             c3 = mesh_vertex(p, e, step, p.faces[3 * f + 2]) - q;
+                    const float la = len(a), lb = len(b), lc = len(c3);
+                    const float det = dot(a, cross(b, c3));
+                    const float den = la * lb * lc + dot(a, b) * lc + dot(b, c3) * la + dot(c3, a) * lb;
+                    ws += 2.f * atan2f(det, den);
+                }
+                const float wn = wave_sum(ws) / (float)(4.0 * 3.14159265358979323846);
+                sign = wn > WIND_THRESHOLD ? -1.f : 1.f;
+            }
+        }
+        if (lane == L) {
+            out.result = found;
+            out.sign = sign;
+            out.face = (int)(unsigned)(bestkey & 0xffffffffull);
+            out.pt = bpt;
+        }
+    }
+    return out;
+}
+
+// Per-lane version of the same query for scenes whose meshes are all small (gripper fingers, box obstacles): plain
+// loops over the faces of the meshes whose AABB is within max_dist, exact winding number over all faces.  It keeps the
+// fused substep kernel at 60 VGPRs (the cooperative version needs 94, one occupancy step lower), so kernels are
+// instantiated for both and the handle picks by scene.
+__device__ MeshHit mesh_query_lane(const PhysDev& p, int e, int step, f3 q, bool want)
+{
+    MeshHit r = {false, 0.f, 0, mk(0.f, 0.f, 0.f)};
+    if (!want) return r;
     float best = MESH_MAX_DIST * MESH_MAX_DIST;
     const float cull = best * 1.0001f + 1e-12f;
     for (int m = 0; m < p.n_mesh; ++m) {
         const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
                                            : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
         if (box_dist2(q, bb) > cull) continue;
-        for (int f = p.mesh_face_off[m]; f < p.mesh_face_off[m + 1]; ++f) {
+        for (int f = p.mesh_face_off[m]; f < p.mesh_face_off[m + 1]; ++f) { // stored order == original order for small meshes
             const f3 a = mesh_vertex(p, e, step, p.faces[3 * f]), b = mesh_vertex(p, e, step, p.faces[3 * f + 1]),
                      c = mesh_vertex(p, e, step, p.faces[3 * f + 2]);
             float u, v;
-            closest_bary(a, b, c, q, u, v);
+            int region;
+            closest_bary(a, b, c, q, u, v, region);
             const f3 cp = a * u + b * v + c * (1.f - u - v);
             const f3 d = cp - q;
             const float d2 = dot(d, d);
-            if (d2 < best) { best = d2; r.result = true; r.face = f; r.u = u; r.v = v; }
+            if (d2 < best) { best = d2; r.result = true; r.face = f; r.pt = cp; }
         }
     }
     if (!r.result) return r;
@@ -331,11 +513,13 @@ __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* _
 
 #pragma clang fp contract(off)
 
-// ---- everything after the velocity update for ONE particle: mesh collision, ground, store -------------------
-// (shared by the fused substep and the self-collision finishing kernel)
-template <bool MESH>
-__device__ __forceinline__ void finish_particle(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v,
-                                                float4* __restrict__ xv_out)
+// ---- everything after the velocity update: mesh collision, ground, store ------------------------------------
+// Called by EVERY lane of a wavefront at the same point (the mesh queries inside are wave-cooperative); `fin` says
+// whether this lane has a particle to finish.  Shared by the fused substep and the self-collision finishing kernel.
+// MESH: 0 no meshes, 1 small meshes only (per-lane queries), 2 a large mesh is present (wave-cooperative queries)
+template <int MESH>
+__device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v, bool fin,
+                                            float4* __restrict__ xv_out)
 {
     f3 x = x0;
     // mesh_collision, :295-421 — advances x by v*dt for EVERY particle (:321, :420)
@@ -348,26 +532,33 @@ __device__ __forceinline__ void finish_particle(const PhysDev& p, int e, int i, 
         // outside the mesh (winding number 0 < 0.6, sign +1) and its distance to the mesh is at least its distance
         // to the AABB: if that is >= the margin for every mesh, nothing can happen and the query is skipped.
         bool need = false;
-        for (int m = 0; m < p.n_mesh; ++m) {
-            const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
-                                               : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
-            const float mg = (m < p.n_dyn_mesh && !p.use_pusher) ? 0.005f : 0.001f;
-            need = need || box_dist2(next_x, bb) < mg * mg * 1.0001f;
+        if (fin) {
+            for (int m = 0; m < p.n_mesh; ++m) {
+                const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
+                                                   : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
+                const float mg = (m < p.n_dyn_mesh && !p.use_pusher) ? 0.005f : 0.001f;
+                need = need || box_dist2(next_x, bb) < mg * mg * 1.0001f;
+            }
         }
-        MeshQ q = {false, 0.f, 0, 0.f, 0.f};
-        if (need) q = mesh_query(p, e, step, next_x);
+        MeshHit q = MESH == 2 ? mesh_query_wave(p, step, next_x, e, need) // wave-cooperative, convergent call site 1
+                              : mesh_query_lane(p, e, step, next_x, need);
+        // per-lane response; lanes that must re-query (gripper branch, :394-408) park their state and meet again below
+        bool requery = false;
+        f3 normal = mk(0.f, 0.f, 0.f), v_normal = mk(0.f, 0.f, 0.f), v_normal_new = mk(0.f, 0.f, 0.f);
+        float margin = 0.f;
+        bool hit = false;
         if (q.result) {
             int is_gripper;
             const int mm = p.mesh_map[q.face];
             if (!p.use_pusher) is_gripper = mm == 0 ? 1 : (mm == 1 ? 2 : 0);
             else is_gripper = mm >= 0 ? 1 : 0;
-            f3 pt = mesh_eval(p, e, step, q.face, q.u, q.v);
-            f3 delta = next_x - pt;
+            f3 delta = next_x - q.pt;
             float dist = len(delta) * q.sign;
-            const float margin = (is_gripper >= 1 && !p.use_pusher) ? 0.005f : 0.001f;
+            margin = (is_gripper >= 1 && !p.use_pusher) ? 0.005f : 0.001f;
             float err = dist - margin;
             if (err < 0.f) {
-                f3 normal = normalize0(delta) * q.sign;
+                hit = true;
+                normal = normalize0(delta) * q.sign;
                 f3 rdv = mk(0.f, 0.f, 0.f);
                 float ce, cf;
                 if (is_gripper >= 1) {
@@ -380,45 +571,49 @@ __device__ __forceinline__ void finish_particle(const PhysDev& p, int e, int i, 
                 } else {
                     ce = p.ce; cf = p.cf;
                 }
-                const f3 v_normal = normal * dot(vin, normal);
+                v_normal = normal * dot(vin, normal);
                 const f3 v_tao = vin - v_normal;
                 const float vnl = len(v_normal);
                 const float vtl = fmaxf(len(v_tao), 1e-6f);
-                const f3 v_normal_new = v_normal * (-ce);
+                v_normal_new = v_normal * (-ce);
                 const float a = fmaxf(0.f, 1.f - cf * (1.f + ce) * vnl / vtl);
                 next_v = v_normal_new + v_tao * a;
                 if (is_gripper >= 1) {
                     next_v = next_v + rdv;
                     next_x = x0 + next_v * p.dt;
-                    q = mesh_query(p, e, step, next_x); // the reference rebinds `query` (:397)
-                    if (q.result) {
-                        pt = mesh_eval(p, e, step, q.face, q.u, q.v);
-                        delta = next_x - pt;
-                        dist = len(delta) * q.sign;
-                        err = dist - margin;
-                        if (err < 0.f) {
-                            normal = normalize0(delta) * q.sign;
-                            next_x = next_x - normal * err;
-                        }
-                    }
+                    requery = true; // the reference rebinds `query` (:397)
                 } else {
                     next_x = next_x - normal * err;
                 }
-                if (write_forces) {
-                    const f3 fo = (v_normal_new - v_normal) / p.dt;
-                    float* cf3 = p.coll_forces + ((size_t)e * p.nF + p.face_map[q.face]) * 3;
-                    atomicAdd(cf3, fo.x);
-                    atomicAdd(cf3 + 1, fo.y);
-                    atomicAdd(cf3 + 2, fo.z);
+            }
+        }
+        const MeshHit q2 = MESH == 2 ? mesh_query_wave(p, step, next_x, e, requery) // convergent call site 2
+                                     : mesh_query_lane(p, e, step, next_x, requery);
+        if (requery) {
+            if (q2.result) {
+                const f3 delta = next_x - q2.pt;
+                const float dist = len(delta) * q2.sign;
+                const float err = dist - margin;
+                if (err < 0.f) {
+                    normal = normalize0(delta) * q2.sign;
+                    next_x = next_x - normal * err;
                 }
             }
+            q = q2; // face of the LAST query (0 if the re-query missed)
+        }
+        if (hit && write_forces) {
+            const f3 fo = (v_normal_new - v_normal) / p.dt;
+            float* cf3 = p.coll_forces + ((size_t)e * p.nF + p.face_map[q.face]) * 3;
+            atomicAdd(cf3, fo.x);
+            atomicAdd(cf3 + 1, fo.y);
+            atomicAdd(cf3 + 2, fo.z);
         }
         x = next_x;
         v = next_v;
     }
 
     // integrate_ground_collision, :424-474
-    {
+    if (fin) {
         const f3 normal = mk(0.f, 0.f, 1.f) * p.rf;
         const float x_z = x.z, v_z = v.z;
         const float next_x_z = (x_z + v_z * p.dt) * p.rf;
@@ -451,7 +646,7 @@ __device__ __forceinline__ void finish_particle(const PhysDev& p, int e, int i, 
 // L2 consumer of this kernel — costs 1/EPW of its bytes per environment.
 // Linear workgroup id L: XCD = L % 8 (observed dispatch order; a speed assumption only); XCD c owns the contiguous
 // range [c*cb, (c+1)*cb) of (block, env group) work items, env group fastest.
-template <int EPW, bool SELF, bool MESH>
+template <int EPW, bool SELF, int MESH>
 __global__ void __launch_bounds__(BLOCK) k_substep(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out,
                                                    int step, int write_forces)
 {
@@ -497,7 +692,8 @@ __global__ void __launch_bounds__(BLOCK) k_substep(const PhysDev p, const float4
         }
     }
     __syncthreads();
-    if (!valid) return;
+    // no early exit: lanes without a particle stay in the wavefront (the mesh queries at the end are wave-cooperative)
+    // and simply compute on clamped indices without storing anything
     const float4* my = lds + (size_t)sub * p.plane_f4;
     f3 x0, v0;
     {
@@ -506,64 +702,71 @@ __global__ void __launch_bounds__(BLOCK) k_substep(const PhysDev p, const float4
         x0 = mk(r_xy[pi].x, r_xy[pi].y, r_z[pi]);
         v0 = mk(r_xy[R + pi].x, r_xy[R + pi].y, r_z[R + pi]);
     }
-    const float m1 = p.masses[i];
+    const int ic = min(i, p.N - 1);
+    const float m1 = p.masses[ic];
 
     // eval_springs + update_vel_from_force
-    f3 v = vel_update(p, v0, spring_force_lds<SL>(p, xv_in, my, eb, i, pl, x0, v0, adj0, deg0, g0), m1);
+    f3 v = vel_update(p, v0, spring_force_lds<SL>(p, xv_in, my, eb, ic, pl, x0, v0, adj0, deg0, g0), m1);
 
     // Self collision (object_collision, :230-268) needs the partners' post-force velocities.  Particles that have
     // contact candidates (rare; the list is rebuilt once per env step) only publish their own v_before_collision
     // here and are finished by k_self_finish, which reads the partners' published values; everyone else is done.
+    bool fin = valid;
     if (SELF) {
-        if (p.coll_num[eb + i] > 0) {
+        if (valid && p.coll_num[eb + i] > 0) {
             p.vbc[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
-            return;
+            fin = false; // finished by k_self_finish
         }
     }
-    finish_particle<MESH>(p, e, i, eb, step, write_forces, x0, v, xv_out);
+    finish_wave<MESH>(p, min(e, p.E - 1), i, eb, step, write_forces, x0, v, fin, xv_out);
 }
 
 // object_collision + loop (:132-193, :230-268) for the particles on the candidate list, then the rest of the substep.
-template <bool MESH>
+template <int MESH>
 __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
                                                      int write_forces)
 {
     const int n = *p.cand_count;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-        const int2 ei = p.cand_list[t];
+    // wave-uniform trip count: every lane of a wavefront reaches the cooperative mesh queries of finish_wave together
+    for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const int t = base + (int)threadIdx.x;
+        const bool act = t < n;
+        const int2 ei = p.cand_list[act ? t : 0];
         const int e = ei.x, i = ei.y;
         const size_t eb = (size_t)e * p.N;
         const f3 x0 = xyz(xv_in[(eb + i) * 2]);
         f3 v = xyz(p.vbc[eb + i]);
-        const float m1 = p.masses[i];
-        const int mask1 = p.masks[i];
-        const int cnt = p.coll_num[eb + i];
-        float valid = 0.f;
-        f3 Jsum = mk(0.f, 0.f, 0.f);
-        for (int k = 0; k < cnt; ++k) {
-            const int j = p.coll_idx[(eb + i) * (size_t)p.coll_cap + k];
-            const f3 x2 = xyz(xv_in[(eb + j) * 2]);
-            const f3 v2 = xyz(p.vbc[eb + j]); // j lists i too (the candidate relation is symmetric), so it published
-            const float m2 = p.masses[j];
-            const f3 dis = x2 - x0;
-            const float dis_len = len(dis);
-            const f3 rv = v2 - v;
-            if (mask1 != p.masks[j] && dis_len < p.cd && dot(dis, rv) < -1e-4f) {
-                valid += 1.f;
-                const f3 nrm = dis / fmaxf(dis_len, 1e-6f);
-                const f3 v_rel_n = nrm * dot(rv, nrm);
-                const float inv = 1.f / m1 + 1.f / m2;
-                const f3 impulse_n = (v_rel_n * (-(1.f + p.cse))) / inv;
-                const float vnl = len(v_rel_n);
-                const f3 v_rel_t = rv - v_rel_n;
-                const float vtl = fmaxf(len(v_rel_t), 1e-6f);
-                const float a = fmaxf(0.f, 1.f - p.csf * (1.f + p.cse) * vnl / vtl);
-                const f3 impulse_t = (v_rel_t * (a - 1.f)) / inv;
-                Jsum = Jsum + (impulse_n + impulse_t);
+        if (act) {
+            const float m1 = p.masses[i];
+            const int mask1 = p.masks[i];
+            const int cnt = p.coll_num[eb + i];
+            float valid = 0.f;
+            f3 Jsum = mk(0.f, 0.f, 0.f);
+            for (int k = 0; k < cnt; ++k) {
+                const int j = p.coll_idx[(eb + i) * (size_t)p.coll_cap + k];
+                const f3 x2 = xyz(xv_in[(eb + j) * 2]);
+                const f3 v2 = xyz(p.vbc[eb + j]); // j lists i too (the candidate relation is symmetric), so it published
+                const float m2 = p.masses[j];
+                const f3 dis = x2 - x0;
+                const float dis_len = len(dis);
+                const f3 rv = v2 - v;
+                if (mask1 != p.masks[j] && dis_len < p.cd && dot(dis, rv) < -1e-4f) {
+                    valid += 1.f;
+                    const f3 nrm = dis / fmaxf(dis_len, 1e-6f);
+                    const f3 v_rel_n = nrm * dot(rv, nrm);
+                    const float inv = 1.f / m1 + 1.f / m2;
+                    const f3 impulse_n = (v_rel_n * (-(1.f + p.cse))) / inv;
+                    const float vnl = len(v_rel_n);
+                    const f3 v_rel_t = rv - v_rel_n;
+                    const float vtl = fmaxf(len(v_rel_t), 1e-6f);
+                    const float a = fmaxf(0.f, 1.f - p.csf * (1.f + p.cse) * vnl / vtl);
+                    const f3 impulse_t = (v_rel_t * (a - 1.f)) / inv;
+                    Jsum = Jsum + (impulse_n + impulse_t);
+                }
             }
+            if (valid > 0.f) v = v - (Jsum / valid) / m1;
         }
-        if (valid > 0.f) v = v - (Jsum / valid) / m1;
-        finish_particle<MESH>(p, e, i, eb, step, write_forces, x0, v, xv_out);
+        finish_wave<MESH>(p, e, i, eb, step, write_forces, x0, v, act, xv_out);
     }
 }
 
@@ -601,11 +804,12 @@ __global__ void k_lists_to_user(int N, int E, int cap, const int* __restrict__ p
 
 // ---- mesh AABBs per (env, substep, dynamic mesh) and per (env, static mesh) ----------------------------
 __global__ void k_mesh_aabb_dyn(int E, int n_sub, int n_dyn_mesh, int n_dyn_pts, const int* __restrict__ mesh_vert_off,
-                                const float* __restrict__ interp, float* __restrict__ aabb)
+                                const int* __restrict__ mesh_kind, const float* __restrict__ interp, float* __restrict__ aabb)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= E * n_sub * n_dyn_mesh) return;
     const int m = t % n_dyn_mesh;
+    if (mesh_kind[m] != 0) return; // large rigid meshes: box from the transformed rest box (k_mesh_xf)
     const size_t es = t / n_dyn_mesh;
     float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
     for (int vtx = mesh_vert_off[m]; vtx < mesh_vert_off[m + 1]; ++vtx) {
@@ -628,6 +832,58 @@ __global__ void k_mesh_aabb_static(int E, int n_static, int n_dyn_mesh, int nV, 
     }
     float* o = aabb + (size_t)t * 6;
     for (int k = 0; k < 3; ++k) { o[k] = lo[k]; o[3 + k] = hi[k]; }
+}
+
+// Rigid transform of every large dynamic mesh at every (env, substep), recovered from three reference vertices of the
+// interpolated motion (rest frame = vertex positions at construction): orthonormal frames on both sides, R = Fcur Frest^T,
+// t = c0 - R r0.  Also the mesh's world AABB (the 8 transformed corners of its rest box: a superset, which keeps the
+// early-out conservative) and a rigidity check on a sample of vertices (max deviation -> rigid_err, float bits).
+__global__ void k_mesh_xf(int E, int n_sub, int n_dyn_mesh, int n_dyn_pts, int n_xf, const int* __restrict__ xf_mesh,
+                          const int* __restrict__ xf_ref, const int* __restrict__ mesh_vert_off, const float* __restrict__ rest,
+                          const float* __restrict__ rest_box, const float* __restrict__ interp, float* __restrict__ xf,
+                          float* __restrict__ aabb_dyn, unsigned* __restrict__ rigid_err)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * n_sub * n_xf) return;
+    const int k = t % n_xf;
+    const size_t es = t / n_xf;
+    const int m = xf_mesh[k];
+    const float* cur = interp + es * n_dyn_pts * 3;
+    auto frame = [](f3 p0, f3 p1, f3 p2, f3& e1, f3& e2, f3& e3) {
+        e1 = normalize0(p1 - p0);
+        const f3 w = p2 - p0;
+        e2 = normalize0(w - e1 * dot(w, e1));
+        e3 = cross(e1, e2);
+    };
+    const int i0 = xf_ref[3 * k], i1 = xf_ref[3 * k + 1], i2 = xf_ref[3 * k + 2];
+    f3 a1, a2, a3, b1, b2, b3;
+    frame(ld3(rest, i0), ld3(rest, i1), ld3(rest, i2), a1, a2, a3);
+    frame(ld3(cur, i0), ld3(cur, i1), ld3(cur, i2), b1, b2, b3);
+    Xf X;
+    // R = b1 a1^T + b2 a2^T + b3 a3^T
+    X.r[0] = b1.x * a1.x + b2.x * a2.x + b3.x * a3.x; X.r[1] = b1.x * a1.y + b2.x * a2.y + b3.x * a3.y; X.r[2] = b1.x * a1.z + b2.x * a2.z + b3.x * a3.z;
+    X.r[3] = b1.y * a1.x + b2.y * a2.x + b3.y * a3.x; X.r[4] = b1.y * a1.y + b2.y * a2.y + b3.y * a3.y; X.r[5] = b1.y * a1.z + b2.y * a2.z + b3.y * a3.z;
+    X.r[6] = b1.z * a1.x + b2.z * a2.x + b3.z * a3.x; X.r[7] = b1.z * a1.y + b2.z * a2.y + b3.z * a3.y; X.r[8] = b1.z * a1.z + b2.z * a2.z + b3.z * a3.z;
+    const f3 r0 = ld3(rest, i0), c0 = ld3(cur, i0);
+    const f3 rr = xf_rotate(X, r0);
+    X.t[0] = c0.x - rr.x; X.t[1] = c0.y - rr.y; X.t[2] = c0.z - rr.z;
+    float* o = xf + (size_t)t * 12;
+    for (int j = 0; j < 9; ++j) o[j] = X.r[j];
+    for (int j = 0; j < 3; ++j) o[9 + j] = X.t[j];
+    const float* rb = rest_box + (size_t)k * 6;
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+    for (int c = 0; c < 8; ++c) {
+        const f3 w = xf_apply(X, mk(rb[(c & 1) ? 3 : 0], rb[(c & 2) ? 4 : 1], rb[(c & 4) ? 5 : 2]));
+        lo[0] = fminf(lo[0], w.x); hi[0] = fmaxf(hi[0], w.x); lo[1] = fminf(lo[1], w.y); hi[1] = fmaxf(hi[1], w.y);
+        lo[2] = fminf(lo[2], w.z); hi[2] = fmaxf(hi[2], w.z);
+    }
+    float* bb = aabb_dyn + (es * n_dyn_mesh + m) * 6;
+    for (int j = 0; j < 3; ++j) { bb[j] = lo[j] - 1e-6f; bb[3 + j] = hi[j] + 1e-6f; }
+    const int v0 = mesh_vert_off[m], v1 = mesh_vert_off[m + 1];
+    const int stride = max(1, (v1 - v0) / 48);
+    float worst = 0.f;
+    for (int v = v0; v < v1; v += stride) worst = fmaxf(worst, len(xf_apply(X, ld3(rest, v)) - ld3(cur, v)));
+    atomicMax(rigid_err, __float_as_uint(worst));
 }
 
 // ---- warp-style hash grid -----------------------------------------------------------------------------
@@ -797,6 +1053,14 @@ struct R2SPhys {
     char* d_sort_tmp = nullptr;
     size_t sort_bytes = 0;
     int *d_faces = nullptr, *d_mesh_map = nullptr, *d_face_map = nullptr, *d_mesh_face_off = nullptr, *d_mesh_vert_off = nullptr;
+    int *d_face_orig = nullptr, *d_face_mesh = nullptr, *d_cl_f0 = nullptr, *d_cl_f1 = nullptr, *d_cl_mesh = nullptr, *d_mesh_kind = nullptr,
+        *d_mesh_xf = nullptr, *d_xf_mesh = nullptr, *d_xf_ref = nullptr;
+    float *d_cl_box = nullptr, *d_xf = nullptr, *d_rest_pts = nullptr, *d_pnorm = nullptr, *d_xf_rest_box = nullptr;
+    unsigned* d_rigid_err = nullptr;
+    unsigned* h_rigid_err = nullptr; // pinned
+    bool rigid_pending = false;
+    int n_cl = 0, n_xf = 0;
+    bool any_large = false; // some mesh has more than 256 faces -> cluster hierarchy + wave-cooperative queries
     float *d_mesh_pts = nullptr, *d_interp = nullptr, *d_center = nullptr, *d_dyn_vel = nullptr, *d_dyn_omega = nullptr;
     float *d_aabb_dyn = nullptr, *d_aabb_static = nullptr, *d_coll_forces = nullptr;
     // graph
@@ -832,6 +1096,9 @@ struct R2SPhys {
         p.vbc = d_vbc; p.cand_list = d_cand_list; p.cand_count = d_cand_count;
         p.n_mesh = n_mesh; p.n_dyn_mesh = n_dyn_mesh; p.nF = nF; p.nV = nV; p.n_dyn_pts = n_dyn_pts;
         p.faces = d_faces; p.mesh_map = d_mesh_map; p.face_map = d_face_map; p.mesh_face_off = d_mesh_face_off;
+        p.face_orig = d_face_orig; p.face_mesh = d_face_mesh; p.n_cl = n_cl; p.n_xf = n_xf; p.cl_f0 = d_cl_f0; p.cl_f1 = d_cl_f1;
+        p.cl_mesh = d_cl_mesh; p.cl_box = d_cl_box; p.mesh_kind = d_mesh_kind; p.mesh_xf = d_mesh_xf; p.xf = d_xf; p.rest_pts = d_rest_pts;
+        p.pnorm = d_pnorm;
         p.mesh_pts = d_mesh_pts; p.interp_pts = d_interp; p.interp_center = d_center; p.dyn_vel = d_dyn_vel; p.dyn_omega = d_dyn_omega;
         p.aabb_dyn = d_aabb_dyn; p.aabb_static = d_aabb_static; p.coll_forces = d_coll_forces;
         return p;
@@ -900,19 +1167,19 @@ int upload_stiffness(R2SPhys* h, const float* log_Y, hipStream_t s)
 
 template <int EPW>
 void launch_substep_epw(R2SPhys* h, const PhysDev& p, dim3 grid, size_t lds, const float4* in, float4* out, int step, int write_forces,
-                        bool with_self, bool mesh, hipStream_t s)
+                        bool with_self, int mesh, hipStream_t s)
 {
-    if (with_self && mesh) hipLaunchKernelGGL((k_substep<EPW, true, true>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
-    else if (with_self) hipLaunchKernelGGL((k_substep<EPW, true, false>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
-    else if (mesh) hipLaunchKernelGGL((k_substep<EPW, false, true>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
-    else hipLaunchKernelGGL((k_substep<EPW, false, false>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces);
+#define R2S_LAUNCH(SELF, MESH) hipLaunchKernelGGL((k_substep<EPW, SELF, MESH>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces)
+    if (with_self) { if (mesh == 2) R2S_LAUNCH(true, 2); else if (mesh == 1) R2S_LAUNCH(true, 1); else R2S_LAUNCH(true, 0); }
+    else { if (mesh == 2) R2S_LAUNCH(false, 2); else if (mesh == 1) R2S_LAUNCH(false, 1); else R2S_LAUNCH(false, 0); }
+#undef R2S_LAUNCH
 }
 
 int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, hipStream_t s)
 {
     dim3 grid(8u * (unsigned)h->cb);
     const size_t lds = (size_t)p.plane_f4 * 16 * h->epw;
-    const bool mesh = h->nF > 0;
+    const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
     const float4* in = h->xv[in_buf];
     float4* out = h->xv[in_buf ^ 1];
     if (h->epw == 4) launch_substep_epw<4>(h, p, grid, lds, in, out, step, write_forces, with_self, mesh, s);
@@ -921,8 +1188,9 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
     if (with_self) {
         // grid-stride over the device-side candidate list; sized for the host's view of the count
         const unsigned blocks = (unsigned)std::min(1024, std::max(1, (h->n_cand + 255) / 256));
-        if (mesh) hipLaunchKernelGGL((k_self_finish<true>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
-        else hipLaunchKernelGGL((k_self_finish<false>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
+        if (mesh == 2) hipLaunchKernelGGL((k_self_finish<2>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
+        else if (mesh == 1) hipLaunchKernelGGL((k_self_finish<1>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
+        else hipLaunchKernelGGL((k_self_finish<0>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
     }
     return R2S_OK;
 }
@@ -983,6 +1251,20 @@ int resolve_cand_count(R2SPhys* h)
         h->n_cand = *h->h_cand_count;
         h->cand_pending = false;
     }
+    return R2S_OK;
+}
+
+// Per-substep rigid transforms (+ world boxes, + rigidity check) of the large dynamic meshes from the current interpolation.
+int update_mesh_transforms(R2SPhys* h, hipStream_t s)
+{
+    if (h->n_xf == 0) return R2S_OK;
+    const int tot = h->E * h->prm.num_substeps * h->n_xf;
+    R2S_HIP_TRY(hipMemsetAsync(h->d_rigid_err, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_mesh_xf, dim3((tot + 255) / 256), dim3(256), 0, s, h->E, h->prm.num_substeps, h->n_dyn_mesh, h->n_dyn_pts, h->n_xf, h->d_xf_mesh,
+                       h->d_xf_ref, h->d_mesh_vert_off, h->d_rest_pts, h->d_xf_rest_box, h->d_interp, h->d_xf, h->d_aabb_dyn, h->d_rigid_err);
+    R2S_HIP_TRY(hipMemcpyAsync(h->h_rigid_err, h->d_rigid_err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    h->rigid_pending = true;
+    R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }
 
@@ -1216,6 +1498,131 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
                 h->h_mesh_map[f] = m < h->n_dyn_mesh ? m : -(m - h->n_dyn_mesh) - 1;
                 h->h_face_map[f] = f;
             }
+        // ---- mesh query acceleration (the role of wp.Mesh's BVH, :673/:899) ----
+        // small mesh (<= LARGE_FACES faces): one cluster, brute force; large mesh: faces Morton-sorted by centroid and cut
+        // into clusters of 64 with rest-frame boxes; must be a closed manifold (sign by pseudonormal) and, if dynamic,
+        // move rigidly (the per-substep transform is recovered from three reference vertices).
+        constexpr int LARGE_FACES = 256, CL = 64;
+        std::vector<int> mesh_kind(h->n_mesh, 0), mesh_xf(h->n_mesh, -1), xf_mesh, xf_ref;
+        std::vector<float> xf_rest_box;
+        std::vector<int> stored(3 * (size_t)h->nF), face_orig(h->nF), face_mesh(h->nF), cl_f0, cl_f1, cl_mesh;
+        std::vector<float> cl_box, pnorm(21 * (size_t)h->nF, 0.f);
+        const float* V = d->mesh_vertices;
+        auto vtx = [&](int gv, int k) { return (double)V[3 * (size_t)gv + k]; };
+        for (int m = 0; m < h->n_mesh; ++m) {
+            const int f0 = foff[m], nf = foff[m + 1] - foff[m];
+            std::vector<int> order(nf);
+            for (int k = 0; k < nf; ++k) order[k] = f0 + k;
+            if (nf > LARGE_FACES) {
+                mesh_kind[m] = 1;
+                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                for (int v = voff[m]; v < voff[m + 1]; ++v) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], vtx(v, k)); hi[k] = std::max(hi[k], vtx(v, k)); }
+                const double ext = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-12});
+                auto spread = [](uint64_t v) { v &= 0x1fffff; v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull;
+                                               v = (v | v << 8) & 0x100f00f00f00f00full; v = (v | v << 4) & 0x10c30c30c30c30c3ull; v = (v | v << 2) & 0x1249249249249249ull; return v; };
+                std::vector<std::pair<uint64_t, int>> code(nf);
+                for (int k = 0; k < nf; ++k) {
+                    uint64_t c = 0;
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const double cen = (vtx(faces[3 * (f0 + k)], ax) + vtx(faces[3 * (f0 + k) + 1], ax) + vtx(faces[3 * (f0 + k) + 2], ax)) / 3.0;
+                        c |= spread((uint64_t)std::min(1048575.0, std::max(0.0, (cen - lo[ax]) / ext * 1048575.0))) << ax;
+                    }
+                    code[k] = {c, f0 + k};
+                }
+                std::sort(code.begin(), code.end());
+                for (int k = 0; k < nf; ++k) order[k] = code[k].second;
+                // closed-manifold check + pseudonormals (Baerentzen & Aanaes 2005), in the rest frame
+                std::vector<std::array<double, 3>> fn(nf);
+                std::vector<std::array<double, 3>> vn(voff[m + 1] - voff[m], {0, 0, 0});
+                std::vector<std::array<long long, 3>> edges; // (min v, max v, +-(face+1))
+                auto sub3 = [&](int a, int b, double* o) { for (int k = 0; k < 3; ++k) o[k] = vtx(a, k) - vtx(b, k); };
+                for (int k = 0; k < nf; ++k) {
+                    const int ia = faces[3 * (f0 + k)], ib = faces[3 * (f0 + k) + 1], ic = faces[3 * (f0 + k) + 2];
+                    double ab[3], ac[3]; sub3(ib, ia, ab); sub3(ic, ia, ac);
+                    double n[3] = {ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0]};
+                    const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                    for (int q = 0; q < 3; ++q) fn[k][q] = l > 0 ? n[q] / l : 0.0;
+                    const int tri[3] = {ia, ib, ic};
+                    for (int c = 0; c < 3; ++c) {
+                        const int p0 = tri[c], p1 = tri[(c + 1) % 3], p2 = tri[(c + 2) % 3];
+                        double e1[3], e2[3]; sub3(p1, p0, e1); sub3(p2, p0, e2);
+                        const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+                        const double cs = (l1 > 0 && l2 > 0) ? (e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2]) / (l1 * l2) : 1.0;
+                        const double ang = std::acos(std::min(1.0, std::max(-1.0, cs)));
+                        for (int q = 0; q < 3; ++q) vn[p0 - voff[m]][q] += ang * fn[k][q];
+                        edges.push_back({std::min(p0, p1), std::max(p0, p1), p0 < p1 ? (long long)(k + 1) : -(long long)(k + 1)});
+                    }
+                }
+                std::sort(edges.begin(), edges.end());
+                bool manifold = edges.size() % 2 == 0;
+                for (size_t q = 0; manifold && q + 1 < edges.size(); q += 2)
+                    manifold = edges[q][0] == edges[q + 1][0] && edges[q][1] == edges[q + 1][1] && (edges[q][2] < 0) != (edges[q + 1][2] < 0) &&
+                               (q + 2 >= edges.size() || edges[q + 2][0] != edges[q][0] || edges[q + 2][1] != edges[q][1]);
+                if (!manifold) {
+                    r2s::set_last_error_msg("collision meshes with more than 256 faces must be closed manifolds (sign by pseudonormal)");
+                    r2s_phys_destroy(h);
+                    return R2S_ERR_INVALID;
+                }
+                auto edge_normal = [&](int p0, int p1, double* o) {
+                    std::array<long long, 3> key = {std::min(p0, p1), std::max(p0, p1), LLONG_MIN};
+                    auto it = std::lower_bound(edges.begin(), edges.end(), key);
+                    for (int q = 0; q < 3; ++q) o[q] = 0;
+                    for (int r = 0; r < 2; ++r, ++it) { const int ff = (int)std::llabs((*it)[2]) - 1; for (int q = 0; q < 3; ++q) o[q] += fn[ff][q]; }
+                };
+                for (int k = 0; k < nf; ++k) {
+                    const int of = order[k], kk = of - f0;            // original face, index inside the mesh
+                    const size_t st = (size_t)(f0 + k) * 21;          // stored slot
+                    const int tri[3] = {faces[3 * of], faces[3 * of + 1], faces[3 * of + 2]};
+                    for (int q = 0; q < 3; ++q) pnorm[st + q] = (float)fn[kk][q];
+                    for (int c = 0; c < 3; ++c) for (int q = 0; q < 3; ++q) pnorm[st + 3 * (1 + c) + q] = (float)vn[tri[c] - voff[m]][q];
+                    for (int c = 0; c < 3; ++c) { double en[3]; edge_normal(tri[c], tri[(c + 1) % 3], en); for (int q = 0; q < 3; ++q) pnorm[st + 3 * (4 + c) + q] = (float)en[q]; }
+                }
+                if (m < h->n_dyn_mesh) { // reference vertices of the rigid transform: first, farthest from it, max triangle area
+                    const int i0 = voff[m];
+                    int i1 = i0, i2 = i0; double bd = -1, ba = -1;
+                    for (int v = voff[m]; v < voff[m + 1]; ++v) { double dd[3]; sub3(v, i0, dd); const double l = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]; if (l > bd) { bd = l; i1 = v; } }
+                    for (int v = voff[m]; v < voff[m + 1]; ++v) {
+                        double a1[3], a2[3]; sub3(i1, i0, a1); sub3(v, i0, a2);
+                        const double cx = a1[1] * a2[2] - a1[2] * a2[1], cy = a1[2] * a2[0] - a1[0] * a2[2], cz = a1[0] * a2[1] - a1[1] * a2[0];
+                        const double ar = cx * cx + cy * cy + cz * cz; if (ar > ba) { ba = ar; i2 = v; }
+                    }
+                    mesh_xf[m] = (int)xf_mesh.size();
+                    xf_mesh.push_back(m); xf_ref.push_back(i0); xf_ref.push_back(i1); xf_ref.push_back(i2);
+                    for (int k = 0; k < 3; ++k) xf_rest_box.push_back((float)lo[k]);
+                    for (int k = 0; k < 3; ++k) xf_rest_box.push_back((float)hi[k]);
+                }
+            }
+            for (int k = 0; k < nf; ++k) {
+                const int of = order[k], st = f0 + k;
+                for (int q = 0; q < 3; ++q) stored[3 * st + q] = faces[3 * of + q];
+                face_orig[st] = of; face_mesh[st] = m;
+            }
+            const int step = mesh_kind[m] ? CL : std::max(nf, 1);
+            for (int k = 0; k < nf; k += step) {
+                cl_f0.push_back(f0 + k); cl_f1.push_back(f0 + std::min(nf, k + step)); cl_mesh.push_back(m);
+                float bb[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
+                for (int st = f0 + k; st < f0 + std::min(nf, k + step); ++st)
+                    for (int c = 0; c < 3; ++c) for (int q = 0; q < 3; ++q) { const float x = V[3 * (size_t)stored[3 * st + c] + q]; bb[q] = std::min(bb[q], x); bb[3 + q] = std::max(bb[3 + q], x); }
+                for (int q = 0; q < 6; ++q) cl_box.push_back(bb[q]);
+            }
+        }
+        h->n_cl = (int)cl_f0.size(); h->n_xf = (int)xf_mesh.size();
+        for (int m = 0; m < h->n_mesh; ++m) h->any_large = h->any_large || mesh_kind[m] != 0;
+        TRY(dev_alloc(&h->d_face_orig, h->nF)); TRY(dev_alloc(&h->d_face_mesh, h->nF)); TRY(dev_alloc(&h->d_cl_f0, h->n_cl)); TRY(dev_alloc(&h->d_cl_f1, h->n_cl));
+        TRY(dev_alloc(&h->d_cl_mesh, h->n_cl)); TRY(dev_alloc(&h->d_cl_box, cl_box.size())); TRY(dev_alloc(&h->d_mesh_kind, h->n_mesh)); TRY(dev_alloc(&h->d_mesh_xf, h->n_mesh));
+        TRY(dev_alloc(&h->d_rest_pts, 3 * (size_t)h->nV)); TRY(dev_alloc(&h->d_pnorm, pnorm.size()));
+        TRY(dev_alloc(&h->d_xf_mesh, xf_mesh.size())); TRY(dev_alloc(&h->d_xf_ref, xf_ref.size())); TRY(dev_alloc(&h->d_xf_rest_box, xf_rest_box.size()));
+        TRY(dev_alloc(&h->d_xf, (size_t)E * n_sub * std::max(1, h->n_xf) * 12)); TRY(dev_alloc(&h->d_rigid_err, 4));
+        R2S_HIP_TRY(hipMemsetAsync(h->d_rigid_err, 0, 16, s));
+        R2S_HIP_TRY(hipHostMalloc((void**)&h->h_rigid_err, 64, hipHostMallocDefault));
+        *h->h_rigid_err = 0;
+        TRY(upload(h->d_face_orig, face_orig.data(), face_orig.size(), s)); TRY(upload(h->d_face_mesh, face_mesh.data(), face_mesh.size(), s));
+        TRY(upload(h->d_cl_f0, cl_f0.data(), cl_f0.size(), s)); TRY(upload(h->d_cl_f1, cl_f1.data(), cl_f1.size(), s)); TRY(upload(h->d_cl_mesh, cl_mesh.data(), cl_mesh.size(), s));
+        TRY(upload(h->d_cl_box, cl_box.data(), cl_box.size(), s)); TRY(upload(h->d_mesh_kind, mesh_kind.data(), mesh_kind.size(), s));
+        TRY(upload(h->d_mesh_xf, mesh_xf.data(), mesh_xf.size(), s)); TRY(upload(h->d_rest_pts, d->mesh_vertices, 3 * (size_t)h->nV, s));
+        TRY(upload(h->d_pnorm, pnorm.data(), pnorm.size(), s)); TRY(upload(h->d_xf_mesh, xf_mesh.data(), xf_mesh.size(), s));
+        TRY(upload(h->d_xf_ref, xf_ref.data(), xf_ref.size(), s)); TRY(upload(h->d_xf_rest_box, xf_rest_box.data(), xf_rest_box.size(), s));
+        faces = stored; // the device face table is in stored (cluster) order
         TRY(dev_alloc(&h->d_faces, faces.size())); TRY(dev_alloc(&h->d_mesh_map, h->nF)); TRY(dev_alloc(&h->d_face_map, h->nF));
         TRY(dev_alloc(&h->d_mesh_face_off, h->n_mesh + 1)); TRY(dev_alloc(&h->d_mesh_vert_off, h->n_mesh + 1));
         TRY(upload(h->d_faces, faces.data(), faces.size(), s)); TRY(upload(h->d_mesh_map, h->h_mesh_map.data(), h->nF, s));
@@ -1243,7 +1650,9 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         R2S_HIP_TRY(hipMemsetAsync(h->d_coll_forces, 0, sizeof(float) * 3 * (size_t)E * h->nF, s));
         if (h->n_dyn_mesh > 0) {
             const int tot = E * n_sub * h->n_dyn_mesh;
-            hipLaunchKernelGGL(k_mesh_aabb_dyn, dim3((tot + 255) / 256), dim3(256), 0, s, E, n_sub, h->n_dyn_mesh, h->n_dyn_pts, h->d_mesh_vert_off, h->d_interp, h->d_aabb_dyn);
+            hipLaunchKernelGGL(k_mesh_aabb_dyn, dim3((tot + 255) / 256), dim3(256), 0, s, E, n_sub, h->n_dyn_mesh, h->n_dyn_pts, h->d_mesh_vert_off, h->d_mesh_kind,
+                               h->d_interp, h->d_aabb_dyn);
+            TRY(update_mesh_transforms(h, s));
         }
         if (h->n_mesh > h->n_dyn_mesh) {
             const int ns = h->n_mesh - h->n_dyn_mesh, tot = E * ns;
@@ -1287,10 +1696,12 @@ void r2s_phys_destroy(R2SPhys* h)
     drop_graph(h);
     void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
                     h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp,
-                    h->d_faces, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
+                    h->d_faces, h->d_face_orig, h->d_face_mesh, h->d_cl_f0, h->d_cl_f1, h->d_cl_mesh, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
+                    h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_cand_count) (void)hipHostFree(h->h_cand_count);
+    if (h->h_rigid_err) (void)hipHostFree(h->h_rigid_err);
     if (h->cand_event) (void)hipEventDestroy(h->cand_event);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1363,7 +1774,10 @@ int r2s_phys_set_mesh_interactive(R2SPhys* h, const float* interp_points, const 
     R2S_HIP_TRY(hipMemcpyAsync(h->d_dyn_omega, dynamic_omega, sizeof(float) * 3 * (size_t)E, hipMemcpyDeviceToDevice, s));
     if (h->n_dyn_mesh > 0) {
         const int tot = E * n_sub * h->n_dyn_mesh;
-        hipLaunchKernelGGL(k_mesh_aabb_dyn, dim3((tot + 255) / 256), dim3(256), 0, s, E, n_sub, h->n_dyn_mesh, h->n_dyn_pts, h->d_mesh_vert_off, h->d_interp, h->d_aabb_dyn);
+        hipLaunchKernelGGL(k_mesh_aabb_dyn, dim3((tot + 255) / 256), dim3(256), 0, s, E, n_sub, h->n_dyn_mesh, h->n_dyn_pts, h->d_mesh_vert_off, h->d_mesh_kind,
+                           h->d_interp, h->d_aabb_dyn);
+        int rc = update_mesh_transforms(h, s);
+        if (rc) return rc;
     }
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
@@ -1383,6 +1797,15 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     }
     int rc0 = h->prm.self_collision ? resolve_cand_count(h) : R2S_OK;
     if (rc0) return rc0;
+    if (h->rigid_pending) { // large dynamic meshes must move rigidly: the check ran with the last set_mesh_interactive
+        R2S_HIP_TRY(hipStreamSynchronize(s));
+        h->rigid_pending = false;
+        float worst; memcpy(&worst, h->h_rigid_err, 4);
+        if (!(worst < 1e-4f)) {
+            r2s::set_last_error_msg("a dynamic collision mesh with more than 256 faces does not move rigidly (unsupported)");
+            return R2S_ERR_INVALID;
+        }
+    }
     const int variant = (h->prm.self_collision && h->n_cand > 0) ? 1 : 0;
     if (use_graph) {
         // variant 1 bakes a grid size derived from n_cand: re-capture if the list outgrew it

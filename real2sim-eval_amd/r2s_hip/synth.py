@@ -154,6 +154,30 @@ def box_mesh(center, size):
     return v, f
 
 
+def cylinder_mesh(center, radius=0.005, length=0.2, n_seg=64, n_rings=190, axis=2):
+    """Closed, outward-facing cylinder: the stand-in for the pusher collision mesh
+    (assets/robots/xarm/xarm_pusher/meshes/pusher_20cm.stl: 25 368 faces; the defaults give 24 448)."""
+    th = np.linspace(0, 2 * np.pi, n_seg, endpoint=False)
+    zs = np.linspace(-length / 2, length / 2, n_rings + 1)
+    ring = np.stack([radius * np.cos(th), radius * np.sin(th)], 1)
+    v = [np.concatenate([ring, np.full((n_seg, 1), z)], 1) for z in zs]
+    v = np.concatenate(v + [np.array([[0, 0, zs[0]], [0, 0, zs[-1]]])]).astype(np.float64)
+    f = []
+    for r in range(n_rings):
+        for k in range(n_seg):
+            a, b = r * n_seg + k, r * n_seg + (k + 1) % n_seg
+            c, d_ = a + n_seg, b + n_seg
+            f += [[a, b, d_], [a, d_, c]]
+    bot, top = len(v) - 2, len(v) - 1
+    for k in range(n_seg):
+        f.append([bot, (k + 1) % n_seg, k])
+        f.append([top, n_rings * n_seg + k, n_rings * n_seg + (k + 1) % n_seg])
+    if axis != 2:
+        perm = {0: [2, 0, 1], 1: [1, 2, 0]}[axis]
+        v = v[:, perm]
+    return (v + np.asarray(center, np.float64)).astype(np.float32), np.array(f, np.int32)
+
+
 def finger_mesh(center, size=(0.02, 0.01, 0.05), n_faces=44):
     """A closed box re-tessellated to ``n_faces`` triangles (the real finger collision meshes have 44,
     assets/robots/xarm/xarm7_with_gripper_collision.urdf:425,519): the two large side faces are split

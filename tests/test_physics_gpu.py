@@ -193,3 +193,34 @@ def test_drop_in_surface_smoke():
     assert sim.wp_state.wp_x.shape == (len(ob["points"]), 3)
     assert np.abs(sim.wp_state.wp_x.cpu().numpy() - o.x).max() < ATOL
     assert (sim.wp_state.wp_x - x_before).abs().max() > 0
+
+
+def test_pusher_25k_face_mesh_cluster_query_vs_oracle():
+    """configs[3] ingredient: a ~25k-face closed pusher mesh (cluster hierarchy + rigid transform + pseudonormal sign on
+    the GPU) against the oracle's brute-force closest point + exact winding number."""
+    import torch
+    from r2s_hip import synth
+    from util_physics import rigid_motion
+
+    n_sub = 16
+    ob = make_object("T", 2229, seed=9)
+    c = ob["points"].mean(0); top = ob["points"][:, 2].max()
+    x_lo = ob["points"][:, 0].min()
+    # vertical pusher rod just outside the block's -x face, sweeping into it at 1.5 m/s while yawing slowly
+    rod = synth.cylinder_mesh((x_lo - 0.0052, c[1] + 0.03, top * 0.5 + 0.02), radius=0.005, length=0.2)
+    assert len(rod[1]) > 20000
+    interp, centers, dv, om = rigid_motion(rod, n_sub, 5e-5, vel=(2.0, 0.0, 0.0), omega=(0.0, 0.0, 3.0))
+    kw = dict(dynamic_meshes=[rod], self_collision=False, use_pusher=True, collide_eef_fric=0.2)
+    o = oracle_env(ob, num_substeps=n_sub, **kw)
+    h = hip_env(ob, num_substeps=n_sub, **kw)
+    o.set_mesh_interactive(interp, centers, dv, om)
+    h.set_mesh_interactive(torch.from_numpy(interp)[None].cuda(), torch.from_numpy(centers)[None].cuda(),
+                           torch.from_numpy(dv)[None].cuda(), torch.from_numpy(om)[None].cuda())
+    o.step(); h.step()
+    x = h.x[0].cpu().numpy()
+    moved = np.abs(o.x - ob["points"]).max()
+    assert np.abs(o.collision_forces).max() > 0, "the rod must touch the block in this scenario"
+    assert np.abs(x - o.x).max() < 1e-5, (np.abs(x - o.x).max(), moved)
+    f = h.collision_forces()[0].cpu().numpy()
+    tot_o, tot_h = o.collision_forces.sum(0), f.sum(0)
+    assert np.allclose(tot_h, tot_o, rtol=2e-3, atol=np.abs(tot_o).max() * 2e-3), (tot_o, tot_h)

@@ -84,3 +84,25 @@ def gripper_motion(fingers, n_sub, dt, vel=(0.0, 0.0, -0.4), omega=(0.0, 0.0, 0.
     dyn_vel = np.stack([vel * 0.5 + np.array([0, closing * 0.5, 0]), vel * 0.5 - np.array([0, closing * 0.5, 0])])
     dyn_omega = -np.asarray(omega, np.float64)[None] * 0.5
     return interp.astype(np.float32), centers.astype(np.float32), dyn_vel.astype(np.float32), dyn_omega.astype(np.float32)
+
+
+def rigid_motion(mesh, n_sub, dt, vel=(0.1, 0.0, 0.0), omega=(0.0, 0.0, 0.0)):
+    """One rigid dynamic mesh (the pusher) over one env step in the reference's parametrisation (phystwin.py:462-510):
+    per-substep vertices, centre, dynamic_velocity [1,3] (= half the eef velocity), dynamic_omega [1,3] (= -half the rate)."""
+    pts0 = np.asarray(mesh[0], np.float64)
+    c0 = pts0.mean(0)
+    vel, omega = np.asarray(vel, np.float64), np.asarray(omega, np.float64)
+    interp = np.empty((n_sub, len(pts0), 3))
+    centers = np.empty((n_sub, 3))
+    for s in range(n_sub):
+        t = (s + 1) * dt
+        ang = np.linalg.norm(omega) * t
+        if ang > 0:
+            k = omega / np.linalg.norm(omega)
+            K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+            R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        else:
+            R = np.eye(3)
+        centers[s] = c0 + vel * t
+        interp[s] = (pts0 - c0) @ R.T + centers[s]
+    return interp.astype(np.float32), centers.astype(np.float32), (vel * 0.5)[None].astype(np.float32), (-omega * 0.5)[None].astype(np.float32)
