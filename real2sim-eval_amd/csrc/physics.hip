@@ -110,6 +110,7 @@ struct PhysDev {
     const float* cl_box;       // [n_cl,6] rest-frame boxes (clusters of large meshes)
     const int* mesh_kind;      // [n_mesh] 0 small (brute force, exact winding), 1 large (clusters + pseudonormals)
     const int* mesh_xf;        // [n_mesh] transform slot of a large dynamic mesh, else -1
+    const int* xf_mesh;        // [n_xf] mesh of a transform slot
     const float* xf;           // [E,n_sub,n_xf,12]
     const float* rest_pts;     // [nV,3] vertices at construction (= rest frame of rigid meshes)
     const float* pnorm;        // [nF,7,3] pseudonormals of stored faces of large meshes: face, a, b, c, ab, bc, ca
@@ -290,21 +291,39 @@ __device__ MeshHit mesh_query_wave(const PhysDev& p, int step, f3 q_lane, int e_
         unsigned long long bestkey = ~0ull;
         f3 bpt = mk(0.f, 0.f, 0.f), bdl = mk(0.f, 0.f, 0.f); // closest point (world), q - p in the mesh's rest frame
         int bstored = 0, bregion = 0;
-        for (int cb = 0; cb < p.n_cl; cb += 64) {
-            const int c = cb + lane;
-            float d2c = 3.0e38f;
-            if (c < p.n_cl) {
-                const int m = p.cl_mesh[c];
-                if (p.mesh_kind[m] == 0) {
-                    const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
-                                                       : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
-                    d2c = box_dist2(q, bb);
-                } else {
-                    const Xf X = xf_load(p, e, step, m);
-                    d2c = box_dist2(xf_inverse(X, q), p.cl_box + (size_t)c * 6);
-                }
+        // the query point in the rest frame of each large dynamic mesh, once per query (at most two such meshes are
+        // kept in registers; further ones are transformed per cluster)
+        f3 q_rest0 = q, q_rest1 = q;
+        if (p.n_xf > 0) q_rest0 = xf_inverse(xf_load(p, e, step, p.xf_mesh[0]), q);
+        if (p.n_xf > 1) q_rest1 = xf_inverse(xf_load(p, e, step, p.xf_mesh[1]), q);
+        auto cluster_d2 = [&](int c) -> float {
+            if (c >= p.n_cl) return 3.0e38f;
+            const int m = p.cl_mesh[c];
+            if (p.mesh_kind[m] == 0) {
+                const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
+                                                   : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
+                return box_dist2(q, bb);
             }
-            unsigned long long cm = __builtin_amdgcn_ballot_w64(d2c < MAXD2 * 1.0001f + 1e-12f);
+            const int k = p.mesh_xf[m];
+            const f3 qr = k < 0 ? q : (k == 0 ? q_rest0 : (k == 1 ? q_rest1 : xf_inverse(xf_load(p, e, step, m), q)));
+            return box_dist2(qr, p.cl_box + (size_t)c * 6);
+        };
+        // pass 0 visits only the cluster whose box is nearest (so `best` is tight before anything else is looked at);
+        // pass 1 visits every other cluster whose box is still closer than `best` — typically two or three
+        unsigned long long nearest = ~0ull;
+        for (int cb = 0; cb < p.n_cl; cb += 64) {
+            const float d2c = cluster_d2(cb + lane);
+            const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2c) << 32) | (unsigned)(cb + lane);
+            nearest = k2 < nearest ? k2 : nearest;
+        }
+        nearest = wave_min_u64(nearest);
+        const int first = (int)(unsigned)(nearest & 0xffffffffull);
+        for (int pass = 0; pass < 2; ++pass)
+        for (int cb = pass == 0 ? (first & ~63) : 0; cb < (pass == 0 ? (first & ~63) + 64 : p.n_cl); cb += 64) {
+            const int c = cb + lane;
+            const float d2c = cluster_d2(c);
+            unsigned long long cm = __builtin_amdgcn_ballot_w64(pass == 0 ? (c == first && d2c < MAXD2 * 1.0001f + 1e-12f)
+                                                                          : (c != first && d2c < best * 1.0001f + 1e-12f));
             while (cm) {
                 const int k = __builtin_ctzll(cm);
                 cm &= cm - 1;
@@ -1097,7 +1116,7 @@ struct R2SPhys {
         p.n_mesh = n_mesh; p.n_dyn_mesh = n_dyn_mesh; p.nF = nF; p.nV = nV; p.n_dyn_pts = n_dyn_pts;
         p.faces = d_faces; p.mesh_map = d_mesh_map; p.face_map = d_face_map; p.mesh_face_off = d_mesh_face_off;
         p.face_orig = d_face_orig; p.face_mesh = d_face_mesh; p.n_cl = n_cl; p.n_xf = n_xf; p.cl_f0 = d_cl_f0; p.cl_f1 = d_cl_f1;
-        p.cl_mesh = d_cl_mesh; p.cl_box = d_cl_box; p.mesh_kind = d_mesh_kind; p.mesh_xf = d_mesh_xf; p.xf = d_xf; p.rest_pts = d_rest_pts;
+        p.cl_mesh = d_cl_mesh; p.cl_box = d_cl_box; p.mesh_kind = d_mesh_kind; p.mesh_xf = d_mesh_xf; p.xf_mesh = d_xf_mesh; p.xf = d_xf; p.rest_pts = d_rest_pts;
         p.pnorm = d_pnorm;
         p.mesh_pts = d_mesh_pts; p.interp_pts = d_interp; p.interp_center = d_center; p.dyn_vel = d_dyn_vel; p.dyn_omega = d_dyn_omega;
         p.aabb_dyn = d_aabb_dyn; p.aabb_static = d_aabb_static; p.coll_forces = d_coll_forces;

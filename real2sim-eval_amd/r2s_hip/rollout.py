@@ -25,6 +25,7 @@ CONFIGS = {
     "rope_1env": ("rope", 8000, 40000, 1, 640, 480),
     "sloth_32env": ("sloth", 15000, 80000, 32, 640, 480),
     "T_32env": ("T", 2229, 40000, 32, 640, 480),
+    "T_pusher_32env": ("T", 2229, 40000, 32, 640, 480),   # configs[3] per GPU: T block pushed by the ~25k-face pusher rod
     "tiny": ("rope", 600, 3000, 2, 160, 120),
 }
 
@@ -53,14 +54,20 @@ class BatchedRollout:
         c = pts.mean(0)
         top = pts[:, 2].max()
         dyn, sta = [], []
-        if with_gripper:
+        self.use_pusher = "pusher" in config
+        if with_gripper and self.use_pusher:
+            # vertical pusher rod next to the block's -x face (assets/.../pusher_20cm.stl has 25 368 faces)
+            self.fingers = [synth.cylinder_mesh((pts[:, 0].min() - 0.02, c[1], 0.12), radius=0.005, length=0.2)]
+            dyn = self.fingers
+        elif with_gripper:
             self.fingers = [synth.finger_mesh((c[0], c[1] - 0.03, top + 0.04)), synth.finger_mesh((c[0], c[1] + 0.03, top + 0.04))]
             dyn = self.fingers
         if with_static:
             sta = [synth.box_mesh((c[0] + 0.25, c[1] + 0.2, 0.135), (0.2, 0.13, 0.27))]
         self.phys = PhysBatch(init_vertices=x0, init_springs=ob["springs"], init_rest_lengths=ob["rest"],
                               init_masses=np.ones(self.N, np.float32), init_spring_Y=ob["log_Y"], num_substeps=num_substeps,
-                              self_collision=self_collision, dynamic_meshes=dyn, static_meshes=sta, device=self.device)
+                              self_collision=self_collision, dynamic_meshes=dyn, static_meshes=sta, use_pusher=self.use_pusher,
+                              collide_eef_fric=0.2 if self.use_pusher else 1.0, device=self.device)
         self.with_gripper = with_gripper
         # Gaussians: object splats ride on particles, table splats are static
         sc = synth.gaussian_scene(n_gauss, seed, object_points=pts)
@@ -107,6 +114,8 @@ class BatchedRollout:
     def _gripper_velocity(self, step):
         w = 2 * np.pi * 0.25
         tt = step / 30.0
+        if self.use_pusher:  # push along +x at 5 cm/s with a slow lateral weave
+            return np.array([0.05, 0.02 * np.cos(w * tt), 0.0], np.float32)
         return np.array([0.05 * w * np.cos(w * tt) * 0.6, 0.05 * w * np.cos(2 * w * tt + 0.5) * 0.6, -0.01 * np.sin(w * tt)], np.float32)
 
     def _set_gripper(self, step):
@@ -117,7 +126,7 @@ class BatchedRollout:
         interp = base[None] + vel[None, None] * self.ts[:, None, None]               # [n, M, 3]
         centers = (self.finger_center0 + disp)[None] + vel[None] * self.ts[:, None]   # [n, 3]
         self._disp = disp + vel * (n * self.dt)
-        dv = torch.stack([vel * 0.5, vel * 0.5])                                       # phystwin.py:439
+        dv = (vel * 0.5)[None] if self.use_pusher else torch.stack([vel * 0.5, vel * 0.5])  # phystwin.py:439, :498
         om = torch.zeros(1, 3, device=self.device)
         self.phys.set_mesh_interactive(interp[None].expand(E, -1, -1, -1), centers[None].expand(E, -1, -1),
                                        dv[None].expand(E, -1, -1), om[None].expand(E, -1, -1))
