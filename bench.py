@@ -149,6 +149,14 @@ def main():
     ro.raster.set_timing(False)
     frames = ro.n_env * ro.views
     raster_ms = sum(stages.values())
+    # skinning (row f1): torch events are valid here, the kernels run on torch's current stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ro._update_means()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    skin_ms = e0.elapsed_time(e1) / 5
 
     if rank == 0:
         value = total_envs * args.steps / elapsed
@@ -174,7 +182,7 @@ def main():
                                               "frac": comp_gbs / HBM_PEAK_GBS, "algorithmic_bytes": comp_bytes,
                                               "traffic": measured_traffic("k_composite", args.config) if ro.n_env == 32 else None,
                                               "note": "VALU/exp-bound in practice (SURVEY.md §7): HBM fraction reported as the contract asks"}},
-            "physics_ms_per_env_step": phys_ms,
+            "physics_ms_per_env_step": phys_ms, "skinning_ms_per_env_step": skin_ms,
         }
         if not args.no_cpu_baseline and world == 1:
             try:

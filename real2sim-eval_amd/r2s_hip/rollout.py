@@ -6,7 +6,7 @@ One env step =
     update_collision_graph                       (once per env step, phystwin.py:365-366)
     set_mesh_interactive(gripper motion)         (phystwin.py:455-460)
     num_substeps fused physics substeps          (the captured graph, phystwin.py:515-519)
-    Gaussians follow their particles             (stand-in for LBS skinning, a "next" row: rigid attach)
+    Gaussians follow their particles             (LBS skinning, incremental: gs_renderer.py:717-747 -> r2s_skin_*)
     2 rasterised frames per env (side + wrist)   (env.py:55-56)
 
 Synthetic inputs only: there is no network for the real PhysTwin / Scaniverse assets.
@@ -19,6 +19,7 @@ import torch
 from . import synth
 from .physics import PhysBatch
 from .raster import RasterBatch
+from .skinning import Skinning, knn_relations, knn_weights
 
 CONFIGS = {
     # name: (object shape, particles, gaussians per env, envs, W, H)  — BASELINE.json configs[1..3]
@@ -74,13 +75,17 @@ class BatchedRollout:
         self.P = len(sc["means3D"])
         n_tab = int(n_gauss * 0.35)
         self.n_obj = self.P - n_tab
-        rgen = np.random.default_rng(seed + 104729)  # same stream synth.gaussian_scene used for `pick`
-        pick = rgen.integers(0, len(pts), self.n_obj)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)  # noqa: E731
-        self.pick = t(pick.astype(np.int64))
-        self.offset = t(sc["means3D"][: self.n_obj] - pts[pick])
+        # LBS topology, once per scene (gs_renderer.py:195-211): 8-NN among bones (= particles), 16 nearest bones per Gaussian
+        obj0 = sc["means3D"][: self.n_obj]
+        w, wi = knn_weights(pts, obj0, min(16, self.N))
+        self.skin = Skinning(knn_relations(pts, min(8, self.N - 1)), w, wi, device=self.device)
         self.means = torch.empty(E, self.P, 3, dtype=torch.float32, device=self.device)
+        self.means[:, : self.n_obj] = t(obj0)[None] + t(self.env_shift)[:, None]
         self.means[:, self.n_obj:] = t(sc["means3D"][self.n_obj:])[None]
+        self.obj_xyz = self.means[:, : self.n_obj].contiguous()   # skinned object Gaussians of the last rendered state
+        self.obj_tmp = torch.empty_like(self.obj_xyz)
+        self.bones = self.phys.x.clone()                          # particle positions the Gaussians currently correspond to
         self.g = {k: t(v) for k, v in sc.items() if k != "means3D"}
         self.raster = RasterBatch(self.device)
         self.raster.set_tile_culling(tile_culling)  # exact-output instance culling (include/r2s_raster.h)
@@ -132,7 +137,13 @@ class BatchedRollout:
                                        dv[None].expand(E, -1, -1), om[None].expand(E, -1, -1))
 
     def _update_means(self):
-        self.means[:, : self.n_obj] = self.phys.x[:, self.pick] + self.offset[None]
+        """Incremental skinning as update_rendervar does it: bones = particles at the last render, motions = what they
+        moved since, applied to the last skinned Gaussian positions (gs_renderer.py:738-747, :762-769, :1096)."""
+        x = self.phys.x
+        self.skin.interpolate_motions(self.bones, x - self.bones, self.obj_xyz, out=self.obj_tmp)
+        self.obj_xyz, self.obj_tmp = self.obj_tmp, self.obj_xyz
+        self.bones.copy_(x)
+        self.means[:, : self.n_obj] = self.obj_xyz
 
     # ---- one batched env step -----------------------------------------------------------------------------------
     def physics_step(self):

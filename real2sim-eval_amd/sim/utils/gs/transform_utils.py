@@ -21,3 +21,37 @@ def setup_camera(w, h, k, w2c, near=0.01, far=100.0, bg=[0, 0, 0], z_threshold=0
         bg=torch.tensor(bg, dtype=torch.float32, device=device), scale_modifier=1.0, viewmatrix=w2c.to(device),
         projmatrix=full_proj.to(device), sh_degree=sh_degree, campos=cam_center.to(device), prefiltered=False,
         z_threshold=z_threshold)
+
+
+# ---- linear-blend skinning (row f1 of SURVEY.md §8f) --------------------------------------------------------------
+_SKIN_CACHE = {}
+
+
+def interpolate_motions(bones, motions, relations, xyz, rot=None, quat=None, weights=None, weights_indices=None, device='cuda',
+                        step='n/a'):
+    """Drop-in for the reference's ``interpolate_motions`` (sim/utils/gs/transform_utils.py:58-212) as the simulator calls
+    it (gs_renderer.py:738-747): returns ``(xyz_transformed, rot, weights)``.  The per-bone Kabsch fit and the blend run
+    as two HIP kernels (r2s_skin_interpolate_motions).  ``quat`` (rotating the Gaussians, never used by the simulator)
+    is not implemented."""
+    from r2s_hip.skinning import Skinning
+
+    if quat is not None:
+        raise NotImplementedError("interpolate_motions(quat=...) is outside the hot path: the simulator passes quat=None")
+    if weights is None:  # sparsified weights over the 5 nearest bones, reference :166-174
+        dist = torch.norm(xyz[:, None] - bones, dim=-1)
+        _, indices = torch.topk(dist, 5, dim=-1, largest=False)
+        dist = torch.norm(bones[indices] - xyz[:, None], dim=-1)
+        weights = 1 / (dist + 1e-6)
+        weights = weights / weights.sum(dim=-1, keepdim=True)
+        weights_indices = indices
+    assert weights_indices is not None
+    assert weights_indices.shape[0] == weights.shape[0] == xyz.shape[0]
+    assert weights_indices.shape[1] == weights.shape[1]
+    rel_t = relations if isinstance(relations, torch.Tensor) else torch.as_tensor(relations)
+    key = (rel_t.data_ptr(), tuple(rel_t.shape), weights.data_ptr(), tuple(weights.shape), weights_indices.data_ptr(), str(xyz.device))
+    sk = _SKIN_CACHE.get(key)
+    if sk is None:
+        if len(_SKIN_CACHE) > 8:
+            _SKIN_CACHE.clear()
+        sk = _SKIN_CACHE[key] = Skinning(rel_t, weights, weights_indices, n_bones=bones.shape[0], device=xyz.device)
+    return sk.interpolate_motions(bones, motions, xyz), rot, weights

@@ -11,7 +11,7 @@ LIB = os.path.join(ROOT, "real2sim-eval_amd", "libr2s_hip.so")
 
 def _declared():
     names = []
-    for h in ("r2s_raster.h", "r2s_physics.h"):
+    for h in ("r2s_raster.h", "r2s_physics.h", "r2s_skinning.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names += re.findall(r"\b(r2s_[a-z0-9_]+)\s*\(", src)
@@ -58,6 +58,11 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert L.r2s_phys_create(ctypes.byref(d), ctypes.byref(h), None) == -1  # R2S_ERR_INVALID: n_env == 0
     assert L.r2s_phys_step(None, 0, 0, None) == -1
     assert _lib.lib().r2s_raster_forward_batch(None, None, 0, None, 0, 64, 64, None, None) == -1
+    from r2s_hip import skinning
+
+    S = skinning._bind()
+    assert S.r2s_skin_create(0, 8, None, 0, 16, None, None, ctypes.byref(h), None) == -1
+    assert S.r2s_skin_interpolate_motions(None, 1, None, None, None, None, None) == -1
 
 
 def test_product_package_never_imports_the_oracle():
