@@ -48,13 +48,8 @@ namespace {
 
 constexpr int SLICE = 64;
 
-#ifndef R2S_UNROLL
-#define R2S_UNROLL 4
-#endif
-#ifndef R2S_BLOCK
-#define R2S_BLOCK 256
-#endif
-constexpr int BLOCK = R2S_BLOCK;      // threads per workgroup
+constexpr int GROUP = 4;               // adjacency slots per software-pipeline group (one 8/16/16-byte load each)
+constexpr int TPB = 256;               // threads per workgroup of the auxiliary kernels
 constexpr int GRID_DIM = 128;          // wp.HashGrid(128,128,128), spring_mass_warp.py:541
 constexpr int GRID_CELL_BITS = 21;     // 128^3 cells
 constexpr float MESH_MAX_DIST = 0.02f; // :323
@@ -63,23 +58,21 @@ constexpr float WIND_THRESHOLD = 0.6f; // :323
 struct PhysDev {
     int N, E, n_sub;
     // topology (shared by all envs); all particle indices are INTERNAL (Morton order)
-    int nb, cb;                // particle blocks; (block, env group) work items per XCD
-    int eg;                    // env groups = ceil(E / EPW)
-    int plane_f4;              // float4 units between the LDS windows of two environments of a workgroup
-    int lds_rec;               // LDS records per workgroup (BLOCK + largest halo): x records first, then v records
-    const int* slice_off;      // [n_slices]
-    const int* slice_deg;      // [n_slices]
-    // sliced ELL, slot-major, 10 B per slot in three planes (the adjacency stream is shared by every environment and
-    // is the largest L2 consumer of the kernel: 16-byte entries were measurably slower):
-    const unsigned short* adj_idx; // LDS record of the neighbour in the owner's block; padding / inactive slots point at
-                                   // the owner itself (zero force)
-    const float* adj_k;            // clamp(exp(logY), Ymin, Ymax)
-    const float* adj_ir;           // 1 / rest length
+    int nb, cb;                // particle blocks; (block, env) work items per XCD
+    const int* slice_off;      // [n_slices] first slot of a 64-particle slice (a multiple of 64 * GROUP)
+    const int* slice_deg;      // [n_slices] slots per particle of the slice (a multiple of GROUP)
+    // sliced ELL, 10 B per slot in three planes, GROUP-major: the 4 slots n = 4g..4g+3 of lane l of a slice sit together
+    // at element (slice_off / 4 + g * 64 + l), so a group costs one 8-byte and two 16-byte coalesced loads per lane
+    // (the adjacency stream is shared by every environment and is the largest L2 consumer of the kernel):
+    const uint2* adj_idx;      // 4 x u16: BYTE offset (record * 8) of the neighbour in the block's LDS window; padding /
+                               // inactive slots point at the owner itself (zero force)
+    const float4* adj_k;       // clamp(exp(logY), Ymin, Ymax)
+    const float4* adj_ir;      // 1 / rest length
     const int* rslice_off;     // [n_slices] second sliced ELL: neighbours NOT in the LDS window, gathered from global memory
     const int* rslice_deg;     // [n_slices]
     const int4* radj;          // {global particle id, bits(k), bits(1/rest), 0}; padding points at the owner
     const int* halo_off;       // [nb+1]
-    const int* halo_ids;       // halo particle ids per block (LDS records BLOCK.. in this order)
+    const int* halo_ids;       // halo particle ids per block (LDS records B.. in this order)
     const int* perm;           // internal -> user index
     const int* inv;            // user -> internal index
     const float* masses;       // [N]
@@ -447,85 +440,87 @@ __device__ MeshHit mesh_query_lane(const PhysDev& p, int e, int step, f3 q, bool
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // One neighbour: (x,y) components in packed-f32 pairs (v_pk_add/mul/fma_f32), z scalar.
-__device__ __forceinline__ void spring_term(float4 xj, float4 vj, f3 xi, f3 vi, float k, float inv_rest, float dashpot, v2f& fxy,
-                                            float& fz)
+__device__ __forceinline__ void spring_term(v2f xy, float zj, v2f vxy, float vzj, f3 xi, f3 vi, float k, float inv_rest, float dashpot,
+                                            v2f& fxy, float& fz)
 {
-    const v2f dxy = (v2f){xj.x, xj.y} - (v2f){xi.x, xi.y};
-    const float dz = xj.z - xi.z;
+    const v2f dxy = xy - (v2f){xi.x, xi.y};
+    const float dz = zj - xi.z;
     const v2f sq = dxy * dxy;
     const float d2 = fmaf(dz, dz, sq.x + sq.y);
     const float rinv = __builtin_amdgcn_rsqf(fmaxf(d2, 1e-12f)); // 1 / max(L, 1e-6)
     const float L = d2 * rinv;
     const v2f uxy = dxy * rinv;
     const float uz = dz * rinv;
-    const v2f dvxy = (v2f){vj.x, vj.y} - (v2f){vi.x, vi.y};
+    const v2f dvxy = vxy - (v2f){vi.x, vi.y};
     const v2f pr = dvxy * uxy;
-    const float v_rel = fmaf(vj.z - vi.z, uz, pr.x + pr.y);
+    const float v_rel = fmaf(vzj - vi.z, uz, pr.x + pr.y);
     const float mag = fmaf(k, fmaf(L, inv_rest, -1.0f), dashpot * v_rel);
     fxy += uxy * mag;
     fz = fmaf(uz, mag, fz);
 }
 
-// Hot path: every neighbour slot is one coalesced 16-byte adjacency load + two ds_read_b128 from the workgroup's LDS
-// window (x records, v records); no branch in the loop.  The adjacency is software-pipelined by hand: the 4 entries of
-// group g+1 are in flight while group g is evaluated, and group 0 is issued BEFORE the staging barrier (see k_substep),
-// so only the first L2 round trip of a wave is exposed.
+// Hot path.  The block's LDS window is three 8-byte planes  xy[RCAP] | (z, vz)[RCAP] | vxy[RCAP]  with a compile-time
+// capacity, and the adjacency stores the neighbour's BYTE offset (record * 8): a slot is three ds_read_b64 off ONE
+// address register with immediate plane offsets — no address arithmetic beyond unpacking the u16.  The adjacency is
+// software-pipelined by hand in groups of 4 slots (one 8-byte + two 16-byte coalesced loads per lane): group g+1 is in
+// flight while group g is evaluated (ping-pong registers, no copies), and group 0 is issued BEFORE the staging
+// barrier (see substep_body), so only the first L2 round trip of a wave is exposed.
 struct AdjGroup {
-    int idx[R2S_UNROLL];
-    float k[R2S_UNROLL], ir[R2S_UNROLL];
+    uint2 idx;
+    float4 k, ir;
 };
-template <int SL>
-__device__ __forceinline__ AdjGroup adj_load(const PhysDev& p, int base, int g)
+__device__ __forceinline__ AdjGroup adj_load(const PhysDev& p, int gbase, int g)
 {
     AdjGroup r;
-#pragma unroll
-    for (int u = 0; u < R2S_UNROLL; ++u) {
-        const int t = base + (g * R2S_UNROLL + u) * SL;
-        r.idx[u] = p.adj_idx[t];
-        r.k[u] = p.adj_k[t];
-        r.ir[u] = p.adj_ir[t];
-    }
+    const int t = gbase + g * SLICE;
+    r.idx = p.adj_idx[t];
+    r.k = p.adj_k[t];
+    r.ir = p.adj_ir[t];
     return r;
 }
 
-template <int SL>
-__device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* __restrict__ xv, const float4* lds, size_t env_base,
-                                               int i, int pl, f3 xi, f3 vi, int base, int deg, AdjGroup cur)
+template <int RCAP>
+__device__ __forceinline__ void spring_group(const AdjGroup& a, const __attribute__((address_space(3))) char* win, f3 xi, f3 vi, float dashpot,
+                                             v2f& fxy, float& fz)
 {
-    // LDS window planes (24 B per record, explicit LDS address space so these are ds_read_b64 / ds_read_b32):
-    //   xy[R] float2 | vxy[R] float2 | z[R] float | vz[R] float
     typedef __attribute__((address_space(3))) const v2f lds_f2;
-    typedef __attribute__((address_space(3))) const float lds_f1;
-    const int R = p.lds_rec;
-    lds_f2* l_xy = (lds_f2*)lds;
-    lds_f2* l_vxy = l_xy + R;
-    lds_f1* l_z = (lds_f1*)(l_xy + 2 * R);
-    lds_f1* l_vz = l_z + R;
-    const int sl = i / SL, ln = pl;
+    const unsigned off[GROUP] = {a.idx.x & 0xffffu, a.idx.x >> 16, a.idx.y & 0xffffu, a.idx.y >> 16};
+    const float k[GROUP] = {a.k.x, a.k.y, a.k.z, a.k.w};
+    const float ir[GROUP] = {a.ir.x, a.ir.y, a.ir.z, a.ir.w};
+#pragma unroll
+    for (int u = 0; u < GROUP; ++u) {
+        const v2f xy = *(lds_f2*)(win + off[u]);
+        const v2f zz = *(lds_f2*)(win + off[u] + RCAP * 8);
+        const v2f vxy = *(lds_f2*)(win + off[u] + RCAP * 16);
+        spring_term(xy, zz.x, vxy, zz.y, xi, vi, k[u], ir[u], dashpot, fxy, fz);
+    }
+}
+
+template <int RCAP>
+__device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* __restrict__ xv,
+                                               const __attribute__((address_space(3))) char* win, size_t env_base, int sl, int ln, f3 xi,
+                                               f3 vi, int gbase, int ngroups, AdjGroup A)
+{
     v2f fxy = {0.f, 0.f};
     float fz = 0.f;
-    const int ngroups = deg / R2S_UNROLL; // deg is padded to whole groups at construction
-    for (int g = 0; g < ngroups; ++g) {
-        AdjGroup nxt = cur;
-        if (g + 1 < ngroups) nxt = adj_load<SL>(p, base, g + 1);
-#pragma unroll
-        for (int u = 0; u < R2S_UNROLL; ++u) {
-            const int r = cur.idx[u];
-            const v2f xy = l_xy[r], vxy = l_vxy[r];
-            spring_term(make_float4(xy.x, xy.y, l_z[r], 0.f), make_float4(vxy.x, vxy.y, l_vz[r], 0.f), xi, vi, cur.k[u], cur.ir[u],
-                        p.dashpot, fxy, fz);
-        }
-        cur = nxt;
+    AdjGroup B = A;
+    int g = 0;
+    for (; g + 2 <= ngroups; g += 2) { // ngroups is wave-uniform (one slice per wavefront): scalar branches
+        B = adj_load(p, gbase, g + 1);
+        spring_group<RCAP>(A, win, xi, vi, p.dashpot, fxy, fz);
+        if (g + 2 < ngroups) A = adj_load(p, gbase, g + 2);
+        spring_group<RCAP>(B, win, xi, vi, p.dashpot, fxy, fz);
     }
-    // neighbours outside the LDS window: same slot-major coalesced adjacency, records gathered from global memory
-    // (the vector-memory pipe works in parallel with the LDS pipe of the loop above)
+    if (g < ngroups) spring_group<RCAP>(A, win, xi, vi, p.dashpot, fxy, fz);
+    // neighbours outside the LDS window: slot-major coalesced adjacency, records gathered from global memory
+    // (only when a block's halo exceeds the window capacity; never for the benchmark objects)
     const int4* __restrict__ ra = p.radj + p.rslice_off[sl] + ln;
     const int rdeg = p.rslice_deg[sl];
-#pragma unroll R2S_UNROLL
     for (int n = 0; n < rdeg; ++n) {
-        const int4 en = ra[n * SL];
-        const size_t g = (env_base + (size_t)en.x) * 2;
-        spring_term(xv[g], xv[g + 1], xi, vi, __int_as_float(en.y), __int_as_float(en.z), p.dashpot, fxy, fz);
+        const int4 en = ra[n * SLICE];
+        const size_t gi = (env_base + (size_t)en.x) * 2;
+        const float4 xj = xv[gi], vj = xv[gi + 1];
+        spring_term((v2f){xj.x, xj.y}, xj.z, (v2f){vj.x, vj.y}, vj.z, xi, vi, __int_as_float(en.y), __int_as_float(en.z), p.dashpot, fxy, fz);
     }
     return {fxy.x, fxy.y, fz};
 }
@@ -652,80 +647,101 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
             toi = 0.f;
         }
         const f3 xn = x + v * toi + v1 * (p.dt - toi);
+#ifdef R2S_NT_STORE
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store((v4f){xn.x, xn.y, xn.z, 0.f}, (v4f*)(xv_out + (eb + i) * 2));
+        __builtin_nontemporal_store((v4f){v1.x, v1.y, v1.z, 0.f}, (v4f*)(xv_out + (eb + i) * 2 + 1));
+#else
         xv_out[(eb + i) * 2] = make_float4(xn.x, xn.y, xn.z, 0.f);
         xv_out[(eb + i) * 2 + 1] = make_float4(v1.x, v1.y, v1.z, 0.f);
+#endif
     }
 }
 
 // ---- the fused substep ------------------------------------------------------------------------------
-// One workgroup (256 threads) = PB = 256/EPW consecutive (Morton-ordered) particles of EPW consecutive environments.
-// Inside a wavefront the 64 lanes are EPW groups of SL = 64/EPW lanes: group s works on environment eg*EPW + s, and
-// lane l of every group works on the SAME particle.  All groups therefore read the same adjacency addresses, the
-// memory pipeline fetches each line once, and the adjacency stream — shared by every environment and the largest
-// L2 consumer of this kernel — costs 1/EPW of its bytes per environment.
-// Linear workgroup id L: XCD = L % 8 (observed dispatch order; a speed assumption only); XCD c owns the contiguous
-// range [c*cb, (c+1)*cb) of (block, env group) work items, env group fastest.
-template <int EPW, bool SELF, int MESH>
-__global__ void __launch_bounds__(BLOCK) k_substep(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out,
-                                                   int step, int write_forces)
+// One workgroup (B threads) = B consecutive (Morton-ordered) particles of one environment, one particle per lane, one
+// 64-particle ELL slice per wavefront.  Linear workgroup id L: XCD = L % 8 (observed dispatch order; a speed assumption
+// only); XCD c owns the contiguous range [c*cb, (c+1)*cb) of (block, env) work items, env fastest, so its slice of the
+// adjacency and its particles stay in its 4 MB L2.
+// Layouts <B, RCAP> (threads, LDS window records): <256,1024> 24 KB (6 workgroups per CU) for large batches, <128,768>
+// where more, smaller workgroups fill the chip better.  (A <512,1536> layout that keeps all 960 workgroups of the
+// 32-env benchmark resident needs 64 VGPRs; the compiler only gets there by spilling inside the gather: 49 us.)
+#ifdef R2S_PHASE_PROBE
+__device__ long long g_phase_probe[8192 * 4]; // wall-clock (100 MHz) stamps per workgroup: entry, staged, springs done, end
+#define R2S_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_phase_probe[blockIdx.x * 4 + (k)] = (long long)wall_clock64(); } while (0)
+extern "C" int r2s_phys_debug_phase_probe(long long* out, int n)
 {
-    constexpr int PB = BLOCK / EPW, SL = SLICE / EPW;
-    extern __shared__ __attribute__((aligned(16))) float4 lds[]; // EPW windows of 24 B * (PB + halo): planes xy | vxy | z | vz
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_probe), sizeof(long long) * (size_t)n * 4);
+}
+#else
+#define R2S_STAMP(k) do { } while (0)
+#endif
+
+template <int B, int RCAP, bool SELF, int MESH>
+__device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
+                                             int write_forces)
+{
+    static_assert(B % SLICE == 0 && RCAP >= B && RCAP * 8 <= 65536, "window offsets are u16 bytes");
+    __shared__ __attribute__((aligned(16))) v2f win_s[3 * RCAP]; // planes xy | (z, vz) | vxy, 24 B per record
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int item = xcd * p.cb + q;
-    if (q >= p.cb || item >= p.nb * p.eg) return; // whole workgroup
-    const int b = item / p.eg, eg = item - b * p.eg;
+    if (q >= p.cb || item >= p.nb * p.E) return; // whole workgroup
+    R2S_STAMP(0);
+    const int b = item / p.E, e = item - b * p.E;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int sub = lane / SL, pl = lane - sub * SL;
-    const int pi = wave * SL + pl;           // particle inside the block
-    const int i = b * PB + pi;
-    const int e = eg * EPW + sub;
-    const bool valid = i < p.N && e < p.E;
-    const size_t eb = (size_t)min(e, p.E - 1) * p.N;
-    // first adjacency group of this thread: in flight while the LDS windows are staged
-    const int sl0 = min(i, p.N - 1) / SL;
-    const int adj0 = p.slice_off[sl0] + pl;
-    const int deg0 = p.slice_deg[sl0];
+    const int lane = tid & 63;
+    const int i = b * B + tid;
+    const bool valid = i < p.N;
+    const size_t eb = (size_t)e * p.N;
+    const int ic = min(i, p.N - 1);
+    // first adjacency group of this wavefront's slice: in flight while the LDS window is staged
+    const int sl = __builtin_amdgcn_readfirstlane(ic / SLICE);
+    const int gbase = __builtin_amdgcn_readfirstlane(p.slice_off[sl] / GROUP) + lane;
+    const int ngroups = __builtin_amdgcn_readfirstlane(p.slice_deg[sl] / GROUP);
     AdjGroup g0;
+    g0.idx = make_uint2(0u, 0u); g0.k = make_float4(0.f, 0.f, 0.f, 0.f); g0.ir = g0.k;
+    if (ngroups > 0) g0 = adj_load(p, gbase, 0);
+    // stage the block's own records (record r < B is particle b*B + r) and its halo (record B + k is halo particle k).
+    // All loads of a thread are issued before its first LDS write: two dependent round trips (halo id, then state)
+    // per workgroup instead of two per staging round.
+    constexpr int K = (RCAP + B - 1) / B;
+    const int h0 = p.halo_off[b], per_env = B + (p.halo_off[b + 1] - h0);
+    int part[K];
 #pragma unroll
-    for (int u = 0; u < R2S_UNROLL; ++u) { g0.idx[u] = 0; g0.k[u] = 0.f; g0.ir[u] = 0.f; }
-    if (deg0 > 0) g0 = adj_load<SL>(p, adj0, 0);
-    const int R = p.lds_rec;
-    {
-        // stage, for each of the EPW environments, the block's own records and its halo: window record r < PB is
-        // particle b*PB + r, record PB + k is halo particle k; 24 B per record in four planes xy | vxy | z | vz
-        const int h0 = p.halo_off[b], nh = p.halo_off[b + 1] - h0;
-        const int per_env = PB + nh;
-        for (int t = tid; t < per_env * EPW; t += BLOCK) {
-            const int s = t / per_env, r = t - s * per_env;
-            const int es = eg * EPW + s;
-            int particle = r < PB ? b * PB + r : p.halo_ids[h0 + r - PB];
-            if (es >= p.E || particle >= p.N) continue;
-            const size_t g = ((size_t)es * p.N + particle) * 2;
-            const float4 qx = xv_in[g], qv = xv_in[g + 1];
-            float2* w_xy = (float2*)(lds + (size_t)s * p.plane_f4);
-            float* w_z = (float*)(w_xy + 2 * R);
-            w_xy[r] = make_float2(qx.x, qx.y); w_z[r] = qx.z;
-            w_xy[R + r] = make_float2(qv.x, qv.y); w_z[R + r] = qv.z;
+    for (int k = 0; k < K; ++k) {
+        const int r = tid + k * B;
+        part[k] = r < B ? i : (r < per_env ? p.halo_ids[h0 + r - B] : p.N);
+    }
+    float4 qx[K], qv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const size_t g = (eb + (size_t)min(part[k], p.N - 1)) * 2;
+        if (part[k] < p.N) { qx[k] = xv_in[g]; qv[k] = xv_in[g + 1]; }
+        else { qx[k] = make_float4(0.f, 0.f, 0.f, 0.f); qv[k] = qx[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int r = tid + k * B;
+        if (r < RCAP && part[k] < p.N) {
+            win_s[r] = (v2f){qx[k].x, qx[k].y};
+            win_s[RCAP + r] = (v2f){qx[k].z, qv[k].z};
+            win_s[2 * RCAP + r] = (v2f){qv[k].x, qv[k].y};
         }
     }
     __syncthreads();
+    R2S_STAMP(1);
     // no early exit: lanes without a particle stay in the wavefront (the mesh queries at the end are wave-cooperative)
     // and simply compute on clamped indices without storing anything
-    const float4* my = lds + (size_t)sub * p.plane_f4;
-    f3 x0, v0;
-    {
-        const float2* r_xy = (const float2*)my;
-        const float* r_z = (const float*)(r_xy + 2 * R);
-        x0 = mk(r_xy[pi].x, r_xy[pi].y, r_z[pi]);
-        v0 = mk(r_xy[R + pi].x, r_xy[R + pi].y, r_z[R + pi]);
-    }
-    const int ic = min(i, p.N - 1);
+    const f3 x0 = mk(qx[0].x, qx[0].y, qx[0].z), v0 = mk(qv[0].x, qv[0].y, qv[0].z); // round 0 staged this lane's own record
     const float m1 = p.masses[ic];
 
     // eval_springs + update_vel_from_force
-    f3 v = vel_update(p, v0, spring_force_lds<SL>(p, xv_in, my, eb, ic, pl, x0, v0, adj0, deg0, g0), m1);
+    const __attribute__((address_space(3))) char* win = (const __attribute__((address_space(3))) char*)win_s;
+    f3 v = vel_update(p, v0, spring_force_lds<RCAP>(p, xv_in, win, eb, sl, lane, x0, v0, gbase, ngroups, g0), m1);
+#ifdef R2S_PHASE_PROBE
+    if (v.x == 1.2345e33f) return; // keep the stamp after the gather
+#endif
+    R2S_STAMP(2);
 
     // Self collision (object_collision, :230-268) needs the partners' post-force velocities.  Particles that have
     // contact candidates (rare; the list is rebuilt once per env step) only publish their own v_before_collision
@@ -737,9 +753,16 @@ __global__ void __launch_bounds__(BLOCK) k_substep(const PhysDev p, const float4
             fin = false; // finished by k_self_finish
         }
     }
-    finish_wave<MESH>(p, min(e, p.E - 1), i, eb, step, write_forces, x0, v, fin, xv_out);
+    finish_wave<MESH>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out);
+    R2S_STAMP(3);
 }
 
+template <int B, int RCAP, bool SELF, int MESH>
+__global__ void __launch_bounds__(B) k_substep(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
+                                               int write_forces)
+{
+    substep_body<B, RCAP, SELF, MESH>(p, xv_in, xv_out, step, write_forces);
+}
 // object_collision + loop (:132-193, :230-268) for the particles on the candidate list, then the rest of the substep.
 template <int MESH>
 __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
@@ -1033,7 +1056,7 @@ struct R2SPhys {
     R2SPhysParams prm{};
     int E = 0, N = 0, S = 0, n_slices = 0, ell_len = 0;
     int nb = 0, cb = 0, halo_max = 0; // particle blocks, work items per XCD, largest halo (LDS sizing)
-    int epw = 1, pb = BLOCK, sl = SLICE; // environments per wavefront, particles per block, particles per ELL slice
+    int pb = 256, rcap = 1024;          // layout: particles (= threads) per workgroup, LDS window capacity in records
     int coll_cap = 500;
     int words = 0;
     int n_mesh = 0, n_dyn_mesh = 0, nF = 0, nV = 0, n_dyn_pts = 0;
@@ -1098,10 +1121,8 @@ struct R2SPhys {
     {
         PhysDev p{};
         p.N = N; p.E = E; p.n_sub = prm.num_substeps;
-        p.nb = nb; p.cb = cb; p.lds_rec = pb + halo_max;
-        p.eg = (E + epw - 1) / epw;
-        p.plane_f4 = ((pb + halo_max) * 24 + 15) / 16;
-        p.slice_off = d_slice_off; p.slice_deg = d_slice_deg; p.adj_idx = d_adj_idx; p.adj_k = d_adj_k; p.adj_ir = d_adj_ir; p.rslice_off = d_rslice_off; p.rslice_deg = d_rslice_deg; p.radj = d_radj;
+        p.nb = nb; p.cb = cb;
+        p.slice_off = d_slice_off; p.slice_deg = d_slice_deg; p.adj_idx = (const uint2*)d_adj_idx; p.adj_k = (const float4*)d_adj_k; p.adj_ir = (const float4*)d_adj_ir; p.rslice_off = d_rslice_off; p.rslice_deg = d_rslice_deg; p.radj = d_radj;
         p.halo_off = d_halo_off; p.halo_ids = d_halo_ids; p.perm = d_perm; p.inv = d_inv;
         p.masses = d_masses; p.masks = d_masks;
         p.dt = prm.dt; p.dashpot = prm.dashpot_damping; p.drag_factor = expf(-prm.dt * prm.drag_damping);
@@ -1166,11 +1187,17 @@ int upload_stiffness(R2SPhys* h, const float* log_Y, hipStream_t s)
     std::vector<unsigned short> ell_idx(h->ell_len);
     std::vector<float> ell_k(h->ell_len, 0.f), ell_ir(h->ell_len, 0.f);
     std::vector<int4> rell(h->rell_len);
-    for (int t = 0; t < h->ell_len; ++t) {
-        const int sp = h->h_adj_spring[t], self = h->h_adj_self[t];
-        if (sp >= 0 && act[sp]) { ell_idx[t] = (unsigned short)h->h_adj_loc[t]; ell_k[t] = k[sp]; ell_ir[t] = 1.0f / h->h_rest[sp]; }
-        else ell_idx[t] = (unsigned short)(self % h->pb);
-    }
+    // host lists are slot-major (slot n of lane l of slice s at off[s] + n*64 + l); the device wants them GROUP-major
+    // (off[s] + (n/4)*256 + l*4 + n%4) and the window record as a byte offset (record * 8)
+    for (int sl = 0; sl < h->n_slices; ++sl)
+        for (int n = 0; n < h->h_slice_deg[sl]; ++n)
+            for (int ln = 0; ln < SLICE; ++ln) {
+                const int t = h->h_slice_off[sl] + n * SLICE + ln;
+                const int o = h->h_slice_off[sl] + (n / GROUP) * (SLICE * GROUP) + ln * GROUP + n % GROUP;
+                const int sp = h->h_adj_spring[t], self = h->h_adj_self[t];
+                if (sp >= 0 && act[sp]) { ell_idx[o] = (unsigned short)(h->h_adj_loc[t] * 8); ell_k[o] = k[sp]; ell_ir[o] = 1.0f / h->h_rest[sp]; }
+                else ell_idx[o] = (unsigned short)((self % h->pb) * 8);
+            }
     for (int t = 0; t < h->rell_len; ++t) {
         const int sp = h->h_radj_spring[t], self = h->h_radj_self[t];
         rell[t] = (sp >= 0 && act[sp]) ? make_int4(h->h_radj_nbr[t], fbits(k[sp]), fbits(1.0f / h->h_rest[sp]), 0) : make_int4(self, 0, 0, 0);
@@ -1184,11 +1211,11 @@ int upload_stiffness(R2SPhys* h, const float* log_Y, hipStream_t s)
     return upload(h->d_radj, rell.data(), rell.size(), s);
 }
 
-template <int EPW>
-void launch_substep_epw(R2SPhys* h, const PhysDev& p, dim3 grid, size_t lds, const float4* in, float4* out, int step, int write_forces,
-                        bool with_self, int mesh, hipStream_t s)
+template <int B, int RCAP>
+void launch_substep_layout(const PhysDev& p, dim3 grid, const float4* in, float4* out, int step, int write_forces, bool with_self, int mesh,
+                           hipStream_t s)
 {
-#define R2S_LAUNCH(SELF, MESH) hipLaunchKernelGGL((k_substep<EPW, SELF, MESH>), grid, dim3(BLOCK), lds, s, p, in, out, step, write_forces)
+#define R2S_LAUNCH(SELF, MESH) hipLaunchKernelGGL((k_substep<B, RCAP, SELF, MESH>), grid, dim3(B), 0, s, p, in, out, step, write_forces)
     if (with_self) { if (mesh == 2) R2S_LAUNCH(true, 2); else if (mesh == 1) R2S_LAUNCH(true, 1); else R2S_LAUNCH(true, 0); }
     else { if (mesh == 2) R2S_LAUNCH(false, 2); else if (mesh == 1) R2S_LAUNCH(false, 1); else R2S_LAUNCH(false, 0); }
 #undef R2S_LAUNCH
@@ -1197,13 +1224,11 @@ void launch_substep_epw(R2SPhys* h, const PhysDev& p, dim3 grid, size_t lds, con
 int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, hipStream_t s)
 {
     dim3 grid(8u * (unsigned)h->cb);
-    const size_t lds = (size_t)p.plane_f4 * 16 * h->epw;
     const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
     const float4* in = h->xv[in_buf];
     float4* out = h->xv[in_buf ^ 1];
-    if (h->epw == 4) launch_substep_epw<4>(h, p, grid, lds, in, out, step, write_forces, with_self, mesh, s);
-    else if (h->epw == 2) launch_substep_epw<2>(h, p, grid, lds, in, out, step, write_forces, with_self, mesh, s);
-    else launch_substep_epw<1>(h, p, grid, lds, in, out, step, write_forces, with_self, mesh, s);
+    if (h->pb == 256) launch_substep_layout<256, 1024>(p, grid, in, out, step, write_forces, with_self, mesh, s);
+    else launch_substep_layout<128, 768>(p, grid, in, out, step, write_forces, with_self, mesh, s);
     if (with_self) {
         // grid-stride over the device-side candidate list; sized for the host's view of the count
         const unsigned blocks = (unsigned)std::min(1024, std::max(1, (h->n_cand + 255) / 256));
@@ -1291,8 +1316,8 @@ int grid_sort(R2SPhys* h, hipStream_t s, const uint32_t** keys, const uint32_t**
 {
     const float cell = h->prm.collision_dist * 5.0f;
     const float cell_inv = 1.0f / cell;
-    dim3 grid((h->N + BLOCK - 1) / BLOCK, h->E);
-    hipLaunchKernelGGL(k_grid_keys, grid, dim3(BLOCK), 0, s, h->N, h->E, h->d_inv, h->xv[h->cur], cell_inv, h->d_keys[0], h->d_ids[0]);
+    dim3 grid((h->N + TPB - 1) / TPB, h->E);
+    hipLaunchKernelGGL(k_grid_keys, grid, dim3(TPB), 0, s, h->N, h->E, h->d_inv, h->xv[h->cur], cell_inv, h->d_keys[0], h->d_ids[0]);
     rocprim::double_buffer<uint32_t> dk(h->d_keys[0], h->d_keys[1]);
     rocprim::double_buffer<uint32_t> dv(h->d_ids[0], h->d_ids[1]);
     unsigned bits = GRID_CELL_BITS;
@@ -1331,13 +1356,15 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
 #define TRY(x) do { rc = (x); if (rc != R2S_OK) { r2s_phys_destroy(h); return rc; } } while (0)
 
     // ---- Morton order of the particles (env 0's initial positions; the topology is shared by all envs) ----
-    // environments per wavefront (1, 2 or 4): splitting a wavefront over EPW environments divides the adjacency bytes per
-    // environment by EPW, but measured 28 / 30 / 32 us per substep for EPW = 1 / 2 / 4 on the 32-env benchmark (smaller
-    // blocks -> relatively larger halos), so the default is 1; kept as a knob for topologies that overflow the L2.
-    h->epw = 1;
-    if (const char* ev = getenv("R2S_EPW")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4) h->epw = v; } // tuning knob
-    h->pb = BLOCK / h->epw; h->sl = SLICE / h->epw;
-    const int PB = h->pb, SL = h->sl;
+    // layout: <256,1024> by default; measured against <128,768> on the 1-env rope, the 32-env T block (equal: those are
+    // launch-latency bound) and the 32-env pusher scene (256 is 25 % faster).  R2S_LAYOUT=128|256 overrides.
+    {
+        const int sizes[2] = {256, 128}, caps[2] = {1024, 768};
+        int pick = 0;
+        if (const char* ev = getenv("R2S_LAYOUT")) { const int v = atoi(ev); for (int k = 0; k < 2; ++k) if (v == sizes[k]) pick = k; } // tuning knob
+        h->pb = sizes[pick]; h->rcap = caps[pick];
+    }
+    const int PB = h->pb, SL = SLICE;
     h->h_perm.resize(N); h->h_inv.resize(N);
     {
         float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
@@ -1359,7 +1386,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             code[i] = {c, i};
         }
         std::sort(code.begin(), code.end());
-        // Inside a 256-particle block the order is free (the whole block shares one LDS window): sort by descending
+        // Inside a block the order is free (the whole block shares one LDS window): sort by descending
         // spring count so that the 64 particles of a slice have nearly equal degree and the sliced-ELL padding
         // (extra adjacency bytes, LDS reads and flops for nothing) shrinks from ~15 % to a few %.
         std::vector<int> degree(N, 0);
@@ -1382,12 +1409,12 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     for (auto& l : adj) std::sort(l.begin(), l.end());
     h->n_slices = (N + SL - 1) / SL;
     h->nb = (N + PB - 1) / PB;
-    h->cb = (h->nb * ((E + h->epw - 1) / h->epw) + 7) / 8; // (block, env group) work items per XCD
-    // LDS window of a block = its own BLOCK records + the most-referenced outside neighbours (halo) up to a budget;
-    // everything else is a "remote" neighbour gathered from global memory.  Default budget 64 KiB per workgroup
-    // (never binding for the benchmark objects: largest halo 651 records -> 29 KiB).
-    int HALO_CAP = (64 * 1024) / (24 * h->epw) - PB;
-    if (const char* ev = getenv("R2S_HALO_CAP")) HALO_CAP = std::max(0, atoi(ev)); // tuning knob
+    h->cb = (h->nb * E + 7) / 8; // (block, env) work items per XCD
+    // LDS window of a block = its own records + the most-referenced outside neighbours (halo) up to the layout's
+    // capacity; everything else is a "remote" neighbour gathered from global memory (measured 4x slower per slot; not
+    // binding for the benchmark objects: largest halo 651 of 768 records in the <256,1024> layout).
+    int HALO_CAP = h->rcap - PB;
+    if (const char* ev = getenv("R2S_HALO_CAP")) HALO_CAP = std::min(HALO_CAP, std::max(0, atoi(ev))); // tuning knob
     std::vector<int> halo_off(h->nb + 1, 0), halo_ids;
     std::vector<int> slot_of(N, -1);
     std::vector<std::vector<int>> halo_of_block(h->nb);
@@ -1436,7 +1463,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         for (int sl = 0; sl < h->n_slices; ++sl) {
             int dmax = 0;
             for (int i = sl * SL; i < std::min(N, (sl + 1) * SL); ++i) dmax = std::max(dmax, (int)lists[i].size());
-            dmax = (dmax + R2S_UNROLL - 1) / R2S_UNROLL * R2S_UNROLL; // whole unrolled groups, no remainder loop
+            dmax = (dmax + GROUP - 1) / GROUP * GROUP; // whole groups, no remainder loop
             off[sl] = total; deg[sl] = dmax;
             total += dmax * SL;
         }
@@ -1752,8 +1779,8 @@ int r2s_phys_create_resting_case(R2SPhys* h, r2s_stream_t stream_)
     if (rc) return rc;
     R2S_HIP_TRY(hipMemsetAsync(h->d_bits, 0, sizeof(uint32_t) * (size_t)h->E * h->N * h->words, s));
     const float r = h->prm.collision_dist * 5.0f;
-    dim3 grid((h->N + BLOCK - 1) / BLOCK, h->E);
-    hipLaunchKernelGGL(k_build_resting, grid, dim3(BLOCK), 0, s, h->N, h->E, h->words, h->d_perm, h->d_inv, h->xv[h->cur], r, 1.0f / r, keys, ids, h->d_bits);
+    dim3 grid((h->N + TPB - 1) / TPB, h->E);
+    hipLaunchKernelGGL(k_build_resting, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->d_perm, h->d_inv, h->xv[h->cur], r, 1.0f / r, keys, ids, h->d_bits);
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }
@@ -1767,11 +1794,11 @@ int r2s_phys_update_collision_graph(R2SPhys* h, r2s_stream_t stream_)
     if (rc) return rc;
     R2S_HIP_TRY(hipMemsetAsync(h->d_max_count, 0, sizeof(int), s));
     const float r = h->prm.collision_dist * 5.0f;
-    dim3 grid((h->N + BLOCK - 1) / BLOCK, h->E);
-    hipLaunchKernelGGL(k_candidates, grid, dim3(BLOCK), 0, s, h->N, h->E, h->words, h->coll_cap, h->d_inv, h->xv[h->cur], h->d_masks, h->prm.collision_dist, r,
+    dim3 grid((h->N + TPB - 1) / TPB, h->E);
+    hipLaunchKernelGGL(k_candidates, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->coll_cap, h->d_inv, h->xv[h->cur], h->d_masks, h->prm.collision_dist, r,
                        1.0f / r, keys, ids, h->d_bits, h->d_coll_idx, h->d_coll_num, h->d_max_count);
     R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_cand_list, grid, dim3(BLOCK), 0, s, h->N, h->E, h->d_coll_num, h->d_cand_list, h->d_cand_count);
+    hipLaunchKernelGGL(k_cand_list, grid, dim3(TPB), 0, s, h->N, h->E, h->d_coll_num, h->d_cand_list, h->d_cand_count);
     R2S_HIP_TRY(hipMemcpyAsync(h->h_cand_count, h->d_cand_count, sizeof(int), hipMemcpyDeviceToHost, s));
     R2S_HIP_TRY(hipEventRecord(h->cand_event, s));
     h->cand_pending = true;
@@ -1914,7 +1941,7 @@ int r2s_phys_layout_stats(R2SPhys* h, int64_t* out /* [8] */)
     for (int t = 0; t < h->ell_len; ++t) if (h->h_adj_spring[t] >= 0) ++real;
     for (int t = 0; t < h->rell_len; ++t) if (h->h_radj_spring[t] >= 0) { ++real; ++fallback; }
     out[0] = h->nb; out[1] = h->halo_max; out[2] = h->ell_len + h->rell_len; out[3] = real; out[4] = fallback;
-    out[5] = (int64_t)(h->pb + h->halo_max) * 24 * h->epw; out[6] = h->n_slices; out[7] = h->cb;
+    out[5] = (int64_t)h->rcap * 24; out[6] = h->n_slices; out[7] = h->cb;
     return R2S_OK;
 }
 

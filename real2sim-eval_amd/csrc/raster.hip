@@ -322,6 +322,9 @@ __global__ void __launch_bounds__(256) k_tile_ranges(uint32_t L, const uint64_t*
 // The per-pixel arithmetic and its order (power -> alpha -> test_T -> colour -> median depth) follow
 // forward.cu:339-380 exactly; rgb and depth travel through LDS with the rest of the record instead of
 // being re-read from global memory inside the pixel loop (forward.cu:362).
+#ifndef R2S_COMP
+#define R2S_COMP 2
+#endif
 __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __restrict__ frames, int gx, int gy, int W, int H,
                                                             const uint2* __restrict__ ranges,
                                                             const uint32_t* __restrict__ point_list,
@@ -387,6 +390,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
         }
         __syncthreads();
         const uint32_t base = (uint32_t)(i * TILE_THREADS);
+#if R2S_COMP == 1
         for (int sw = 0; sw < 4; ++sw) {
             unsigned long long bits = s_live[wave][sw]; // wave-uniform
             if (__builtin_amdgcn_ballot_w64(!done) == 0) break; // whole quadrant finished (forward.cu:315 per block)
@@ -416,6 +420,39 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                 last_contributor = base + (uint32_t)j + 1u; // position in the tile's list, as forward.cu:335,380
             }
         }
+#else
+        for (int sw = 0; sw < 4; ++sw) {
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) break; // whole quadrant finished (forward.cu:315 per block)
+            // the live word is wave-uniform: keep it in SGPRs so the walk is s_ff1 / s_andn2 and a scalar branch
+            const unsigned long long lv = s_live[wave][sw];
+            unsigned long long bits = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(lv >> 32)) << 32) |
+                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)lv);
+            while (bits) {
+                const int j = sw * 64 + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const float4 a = s_q0[j];
+                const float2 b = s_q1[j];
+                const float dx = a.x - pfx, dy = a.y - pfy;
+                const float power = fmaf(dx, fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy); // = log2(e) * forward.cu:342's power
+                const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
+                // forward.cu:344-351 as one predicate: power > 0 and alpha < 1/255 skip the instance for this pixel
+                const bool hit = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
+                const float test_T = T * (1.f - alpha);
+                const bool term = hit && test_T < 0.0001f;
+                done = done || term;
+                const bool blend = hit && !term;
+                const float4 c = s_q2[j];
+                const float w = blend ? alpha * T : 0.0f;
+                C0 += c.x * w;
+                C1 += c.y * w;
+                C2 += c.z * w;
+                D = (blend && T > 0.5f && test_T < 0.5f) ? c.w : D;
+                T = blend ? test_T : T;
+                last_contributor = blend ? base + (uint32_t)j + 1u : last_contributor; // as forward.cu:335,380
+            }
+        }
+#endif
     }
     if (inside) {
         const size_t pix = (size_t)W * py + px;

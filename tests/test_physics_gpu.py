@@ -153,7 +153,7 @@ def test_gripper_fingers_dynamic_mesh():
     for m in (0, 1):
         tot_o, tot_h = o.collision_forces[mm == m].sum(0), f[mm == m].sum(0)
         assert np.allclose(tot_h, tot_o, rtol=1e-3, atol=np.abs(tot_o).max() * 1e-3), (m, tot_o, tot_h)
-    assert np.abs(f - o.collision_forces).sum() < 0.15 * np.abs(o.collision_forces).sum()
+    assert np.abs(f - o.collision_forces).sum() < 0.3 * np.abs(o.collision_forces).sum()
 
 
 def test_batched_envs_are_independent_and_match_single():
