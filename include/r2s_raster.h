@@ -146,8 +146,8 @@ typedef struct R2SRasterDebug {
     const int32_t* radii;         /* [total_gaussians] */
     const float* geom;            /* [total_gaussians, 12]: x,y,conic_a,conic_b | conic_c,opacity,depth,r | g,b,0,0 */
     const uint32_t* tiles_touched;/* [total_gaussians] */
-    const uint32_t* point_offsets;/* [total_gaussians] inclusive scan */
-    const uint64_t* keys_sorted;  /* [num_rendered] */
+    const uint32_t* point_offsets;/* [total_gaussians] inclusive scan, Gaussians in (frame, depth) order */
+    const uint32_t* keys_sorted;  /* [num_rendered] frame-extended tile id of every sorted instance */
     const uint32_t* point_list;   /* [num_rendered] (global Gaussian index = frame base + idx) */
     const uint32_t* ranges;       /* [n_frames*tiles, 2] */
 } R2SRasterDebug;

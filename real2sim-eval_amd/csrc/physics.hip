@@ -1040,6 +1040,64 @@ __global__ void k_candidates(int N, int E, int words, int cap, const int* __rest
     if (cnt > 0) atomicMax(max_count, cnt);
 }
 
+// Direct cell table for the per-env-step candidate rebuild.  tab[(env << 21) | cell] = [first, last+1) in the sorted key
+// array; all-zero between calls (k_cell_mark fills the occupied cells, k_cell_clear wipes exactly those again), so a
+// lookup is one load instead of two 14-step binary searches.  xs[k] = position and INTERNAL index of the k-th sorted
+// particle, so a cell's points stream as consecutive 16-byte records instead of three dependent gathers each.
+__global__ void k_cell_mark(int N, int E, const int* __restrict__ inv, const float4* __restrict__ xv, const uint32_t* __restrict__ keys,
+                            const uint32_t* __restrict__ ids, int2* __restrict__ tab, float4* __restrict__ xs)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    if (k >= N) return;
+    const size_t g = (size_t)e * N + k;
+    const uint32_t key = keys[g];
+    if (k == 0 || keys[g - 1] != key) tab[key].x = (int)g;
+    if (k == N - 1 || keys[g + 1] != key) tab[key].y = (int)g + 1;
+    const int j = inv[ids[g]];
+    const float4 q = xv[((size_t)e * N + j) * 2];
+    xs[g] = make_float4(q.x, q.y, q.z, __int_as_float(j));
+}
+__global__ void k_cell_clear(int N, int E, const uint32_t* __restrict__ keys, int2* __restrict__ tab)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    tab[keys[(size_t)blockIdx.y * N + k]] = make_int2(0, 0);
+}
+// update_potential_collision with the table: identical candidate order (cells x-fastest, sorted order inside a cell)
+__global__ void k_candidates_tab(int N, int E, int words, int cap, const float4* __restrict__ xv, const int* __restrict__ masks, float cd,
+                                 float cell_inv, const int2* __restrict__ tab, const float4* __restrict__ xs, const uint32_t* __restrict__ bits,
+                                 int* __restrict__ coll_idx, int* __restrict__ coll_num, int* __restrict__ max_count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    if (i >= N) return;
+    const size_t eb = (size_t)e * N;
+    const float4 q = xv[(eb + i) * 2];
+    const f3 x1 = xyz(q);
+    const int mask1 = masks[i];
+    const QBox b = query_box(q, cd, cell_inv);
+    const uint32_t* row = bits + (eb + i) * words;
+    int cnt = 0;
+    for (int z = b.zs; z <= b.ze; ++z)
+        for (int y = b.ys; y <= b.ye; ++y)
+            for (int x = b.xs; x <= b.xe; ++x) {
+                const int2 st = tab[((uint32_t)e << GRID_CELL_BITS) | (uint32_t)grid_cell(x, y, z)];
+                for (int k = st.x; k < st.y; ++k) {
+                    const float4 c = xs[k];
+                    const int j = __float_as_int(c.w);
+                    if (j == i) continue;
+                    if (!(len(xyz(c) - x1) < cd)) continue;
+                    if (row[j >> 5] & (1u << (j & 31))) continue; // resting pair (stored symmetrically)
+                    if (mask1 == masks[j]) continue;
+                    if (cnt < cap) coll_idx[(eb + i) * (size_t)cap + cnt] = j;
+                    cnt++;
+                }
+            }
+    coll_num[eb + i] = min(cnt, cap);
+    if (cnt > 0) atomicMax(max_count, cnt);
+}
+
 // compact (env, particle) list of the particles that have candidates (order irrelevant: each is independent)
 __global__ void k_cand_list(int N, int E, const int* __restrict__ coll_num, int2* __restrict__ list, int* __restrict__ count)
 {
@@ -1092,6 +1150,8 @@ struct R2SPhys {
     int n_cand = 0;              // particles with candidates after the last update (host view)
     int graph_cand_cap = 0, n_cand_launch = 0;
     uint32_t *d_bits = nullptr, *d_keys[2] = {nullptr, nullptr}, *d_ids[2] = {nullptr, nullptr};
+    int2* d_cell_tab = nullptr;  // [E << 21] direct cell table (null when it would exceed 4 GiB: binary search instead)
+    float4* d_cell_xs = nullptr; // [E,N] sorted positions + internal index
     char* d_sort_tmp = nullptr;
     size_t sort_bytes = 0;
     int *d_faces = nullptr, *d_mesh_map = nullptr, *d_face_map = nullptr, *d_mesh_face_off = nullptr, *d_mesh_vert_off = nullptr;
@@ -1726,6 +1786,11 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         rocprim::double_buffer<uint32_t> dk((uint32_t*)nullptr, (uint32_t*)nullptr), dv((uint32_t*)nullptr, (uint32_t*)nullptr);
         R2S_HIP_TRY(rocprim::radix_sort_pairs(nullptr, h->sort_bytes, dk, dv, (size_t)E * N, 0u, 32u, s));
         TRY(dev_alloc(&h->d_sort_tmp, h->sort_bytes));
+        if (E <= 256) { // 16 MiB per environment
+            TRY(dev_alloc(&h->d_cell_tab, (size_t)E << GRID_CELL_BITS));
+            R2S_HIP_TRY(hipMemsetAsync(h->d_cell_tab, 0, sizeof(int2) * ((size_t)E << GRID_CELL_BITS), s));
+            TRY(dev_alloc(&h->d_cell_xs, (size_t)E * N));
+        }
         TRY(r2s_phys_create_resting_case(h, stream_));
     }
     R2S_HIP_TRY(hipStreamSynchronize(s));
@@ -1741,7 +1806,7 @@ void r2s_phys_destroy(R2SPhys* h)
     (void)hipDeviceSynchronize();
     drop_graph(h);
     void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
-                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp,
+                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
                     h->d_faces, h->d_face_orig, h->d_face_mesh, h->d_cl_f0, h->d_cl_f1, h->d_cl_mesh, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
                     h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces};
@@ -1795,8 +1860,15 @@ int r2s_phys_update_collision_graph(R2SPhys* h, r2s_stream_t stream_)
     R2S_HIP_TRY(hipMemsetAsync(h->d_max_count, 0, sizeof(int), s));
     const float r = h->prm.collision_dist * 5.0f;
     dim3 grid((h->N + TPB - 1) / TPB, h->E);
-    hipLaunchKernelGGL(k_candidates, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->coll_cap, h->d_inv, h->xv[h->cur], h->d_masks, h->prm.collision_dist, r,
-                       1.0f / r, keys, ids, h->d_bits, h->d_coll_idx, h->d_coll_num, h->d_max_count);
+    if (h->d_cell_tab) {
+        hipLaunchKernelGGL(k_cell_mark, grid, dim3(TPB), 0, s, h->N, h->E, h->d_inv, h->xv[h->cur], keys, ids, h->d_cell_tab, h->d_cell_xs);
+        hipLaunchKernelGGL(k_candidates_tab, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->coll_cap, h->xv[h->cur], h->d_masks, h->prm.collision_dist,
+                           1.0f / r, h->d_cell_tab, h->d_cell_xs, h->d_bits, h->d_coll_idx, h->d_coll_num, h->d_max_count);
+        hipLaunchKernelGGL(k_cell_clear, grid, dim3(TPB), 0, s, h->N, h->E, keys, h->d_cell_tab);
+    } else {
+        hipLaunchKernelGGL(k_candidates, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->coll_cap, h->d_inv, h->xv[h->cur], h->d_masks, h->prm.collision_dist, r,
+                           1.0f / r, keys, ids, h->d_bits, h->d_coll_idx, h->d_coll_num, h->d_max_count);
+    }
     R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_cand_list, grid, dim3(TPB), 0, s, h->N, h->E, h->d_coll_num, h->d_cand_list, h->d_cand_count);
     R2S_HIP_TRY(hipMemcpyAsync(h->h_cand_count, h->d_cand_count, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -173,7 +173,7 @@ class RasterBatch:
             depths=view(d.depths, G, torch.float32), radii=view(d.radii, G, torch.int32),
             geom=view(d.geom, G * 12, torch.float32).reshape(G, 12),
             tiles_touched=view(d.tiles_touched, G, torch.int32), point_offsets=view(d.point_offsets, G, torch.int32),
-            keys_sorted=view(d.keys_sorted, L, torch.int64), point_list=view(d.point_list, L, torch.int32),
+            keys_sorted=view(d.keys_sorted, L, torch.int32), point_list=view(d.point_list, L, torch.int32),
         )
 
 
