@@ -462,56 +462,46 @@ __device__ __forceinline__ void spring_term(v2f xy, float zj, v2f vxy, float vzj
 // Hot path.  The block's LDS window is three 8-byte planes  xy[RCAP] | (z, vz)[RCAP] | vxy[RCAP]  with a compile-time
 // capacity, and the adjacency stores the neighbour's BYTE offset (record * 8): a slot is three ds_read_b64 off ONE
 // address register with immediate plane offsets — no address arithmetic beyond unpacking the u16.  The adjacency is
-// software-pipelined by hand in groups of 4 slots (one 8-byte + two 16-byte coalesced loads per lane): group g+1 is in
-// flight while group g is evaluated (ping-pong registers, no copies), and group 0 is issued BEFORE the staging
-// barrier (see substep_body), so only the first L2 round trip of a wave is exposed.
-struct AdjGroup {
-    uint2 idx;
-    float4 k, ir;
-};
-__device__ __forceinline__ AdjGroup adj_load(const PhysDev& p, int gbase, int g)
-{
-    AdjGroup r;
-    const int t = gbase + g * SLICE;
-    r.idx = p.adj_idx[t];
-    r.k = p.adj_k[t];
-    r.ir = p.adj_ir[t];
-    return r;
-}
-
+// read in groups of 4 slots (one 8-byte + two 16-byte coalesced loads per lane); the index word of group g+1 is in
+// flight while group g is evaluated (ping-pong registers, no copies) and that of group 0 is issued BEFORE the staging
+// barrier (see substep_body).
+// Register budget: only the 8-byte index word of group g+1 is prefetched while group g is evaluated; the stiffness and
+// rest-length words (32 B per lane) of a group are loaded when the group starts — their latency hides behind the other
+// wavefronts of the SIMD and the group's own LDS gathers.  That keeps the gather at <= 64 VGPRs = 8 wavefronts per SIMD.
 template <int RCAP>
-__device__ __forceinline__ void spring_group(const AdjGroup& a, const __attribute__((address_space(3))) char* win, f3 xi, f3 vi, float dashpot,
-                                             v2f& fxy, float& fz)
+__device__ __forceinline__ void spring_group(const PhysDev& p, int t, uint2 idx, const __attribute__((address_space(3))) char* win, f3 xi,
+                                             f3 vi, v2f& fxy, float& fz)
 {
     typedef __attribute__((address_space(3))) const v2f lds_f2;
-    const unsigned off[GROUP] = {a.idx.x & 0xffffu, a.idx.x >> 16, a.idx.y & 0xffffu, a.idx.y >> 16};
-    const float k[GROUP] = {a.k.x, a.k.y, a.k.z, a.k.w};
-    const float ir[GROUP] = {a.ir.x, a.ir.y, a.ir.z, a.ir.w};
+    const float4 kk = p.adj_k[t], rr = p.adj_ir[t];
+    const unsigned off[GROUP] = {idx.x & 0xffffu, idx.x >> 16, idx.y & 0xffffu, idx.y >> 16};
+    const float k[GROUP] = {kk.x, kk.y, kk.z, kk.w};
+    const float ir[GROUP] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
     for (int u = 0; u < GROUP; ++u) {
         const v2f xy = *(lds_f2*)(win + off[u]);
         const v2f zz = *(lds_f2*)(win + off[u] + RCAP * 8);
         const v2f vxy = *(lds_f2*)(win + off[u] + RCAP * 16);
-        spring_term(xy, zz.x, vxy, zz.y, xi, vi, k[u], ir[u], dashpot, fxy, fz);
+        spring_term(xy, zz.x, vxy, zz.y, xi, vi, k[u], ir[u], p.dashpot, fxy, fz);
     }
 }
 
 template <int RCAP>
 __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* __restrict__ xv,
                                                const __attribute__((address_space(3))) char* win, size_t env_base, int sl, int ln, f3 xi,
-                                               f3 vi, int gbase, int ngroups, AdjGroup A)
+                                               f3 vi, int gbase, int ngroups, uint2 idx0)
 {
     v2f fxy = {0.f, 0.f};
     float fz = 0.f;
-    AdjGroup B = A;
+    uint2 a = idx0, b = idx0;
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) { // ngroups is wave-uniform (one slice per wavefront): scalar branches
-        B = adj_load(p, gbase, g + 1);
-        spring_group<RCAP>(A, win, xi, vi, p.dashpot, fxy, fz);
-        if (g + 2 < ngroups) A = adj_load(p, gbase, g + 2);
-        spring_group<RCAP>(B, win, xi, vi, p.dashpot, fxy, fz);
+        b = p.adj_idx[gbase + (g + 1) * SLICE];
+        spring_group<RCAP>(p, gbase + g * SLICE, a, win, xi, vi, fxy, fz);
+        if (g + 2 < ngroups) a = p.adj_idx[gbase + (g + 2) * SLICE];
+        spring_group<RCAP>(p, gbase + (g + 1) * SLICE, b, win, xi, vi, fxy, fz);
     }
-    if (g < ngroups) spring_group<RCAP>(A, win, xi, vi, p.dashpot, fxy, fz);
+    if (g < ngroups) spring_group<RCAP>(p, gbase + g * SLICE, a, win, xi, vi, fxy, fz);
     // neighbours outside the LDS window: slot-major coalesced adjacency, records gathered from global memory
     // (only when a block's halo exceeds the window capacity; never for the benchmark objects)
     const int4* __restrict__ ra = p.radj + p.rslice_off[sl] + ln;
@@ -664,8 +654,10 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
 // only); XCD c owns the contiguous range [c*cb, (c+1)*cb) of (block, env) work items, env fastest, so its slice of the
 // adjacency and its particles stay in its 4 MB L2.
 // Layouts <B, RCAP> (threads, LDS window records): <256,1024> 24 KB (6 workgroups per CU) for large batches, <128,768>
-// where more, smaller workgroups fill the chip better.  (A <512,1536> layout that keeps all 960 workgroups of the
-// 32-env benchmark resident needs 64 VGPRs; the compiler only gets there by spilling inside the gather: 49 us.)
+// where more, smaller workgroups fill the chip better.  (A <512,1536> layout held to 64 VGPRs / 80 SGPRs keeps all 960
+// workgroups of the 32-env benchmark resident at once; measured 26.0 vs 25.5 us — the kernel is bound by per-CU VALU
+// throughput in the gather, not by residency; lowering residency with LDS padding is slower: 26.3 / 26.5 / 27.3 / 28.5 us
+// for 6 / 5 / 4 / 3 workgroups per CU.)
 #ifdef R2S_PHASE_PROBE
 __device__ long long g_phase_probe[8192 * 4]; // wall-clock (100 MHz) stamps per workgroup: entry, staged, springs done, end
 #define R2S_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_phase_probe[blockIdx.x * 4 + (k)] = (long long)wall_clock64(); } while (0)
@@ -698,9 +690,8 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __r
     const int sl = __builtin_amdgcn_readfirstlane(ic / SLICE);
     const int gbase = __builtin_amdgcn_readfirstlane(p.slice_off[sl] / GROUP) + lane;
     const int ngroups = __builtin_amdgcn_readfirstlane(p.slice_deg[sl] / GROUP);
-    AdjGroup g0;
-    g0.idx = make_uint2(0u, 0u); g0.k = make_float4(0.f, 0.f, 0.f, 0.f); g0.ir = g0.k;
-    if (ngroups > 0) g0 = adj_load(p, gbase, 0);
+    uint2 g0 = make_uint2(0u, 0u);
+    if (ngroups > 0) g0 = p.adj_idx[gbase];
     // stage the block's own records (record r < B is particle b*B + r) and its halo (record B + k is halo particle k).
     // All loads of a thread are issued before its first LDS write: two dependent round trips (halo id, then state)
     // per workgroup instead of two per staging round.
