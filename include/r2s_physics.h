@@ -98,6 +98,31 @@ int r2s_phys_set_mesh_interactive(R2SPhys* h, const float* interp_points, const 
                                   const float* dynamic_velocity, const float* dynamic_omega,
                                   r2s_stream_t stream);
 
+/* On-device gripper / pusher kinematics + grasp state machine: the caller side of the stepper,
+ * SpringMassDynamicsModule.step (sim/physics/phystwin.py:362-513), for all environments at once.  Replaces the
+ * host-built [num_substeps, n_dynamic_points, 3] tensor of set_mesh_interactive (~100 MB per environment step for
+ * the pusher) and the blocking collision_forces.numpy() read of the grasp test (:383-389).
+ *
+ * r2s_phys_set_eef_table: the knots of eef_pts_func = scipy interp1d(arange(n_knots) / (n_knots - 1), eef_pts_list)
+ *   (robot_pc_transformations.py:190, :225; 101 knots) as HOST float64 [n_knots, n_dynamic_points, 3], init_eef_xyz
+ *   (HOST [3], gs_renderer.py:513-517) and cfg.physics.grasp_force_threshold.  Resets the per-environment state
+ *   (current_openness = None, grasped = False).
+ * r2s_phys_set_eef_motion: DEVICE pointers eef_xyz [n_env,3], eef_vel [n_env,3], eef_rot [n_env,3,3], eef_rot_vel [n_env,3],
+ *   gripper_openness [n_env] (first gripper of each environment; ignored for the pusher).  Runs the openness / grasp
+ *   state machine (:391-408) on the collision forces of the previous step, then fills the stepper's interpolated
+ *   vertices, centres, dynamic velocities and omega exactly as set_mesh_interactive would have received them.  For a
+ *   rigid mesh with more than 256 faces only the vertices the stepper reads are evaluated.
+ * r2s_phys_eef_state: device pointers to current_openness (float64 [n_env]) and grasped (int32 [n_env]).
+ * r2s_phys_mesh_motion: device pointers to the stepper's current motion inputs (interp_points [n_env, num_substeps,
+ *   n_dynamic_points, 3], interp_center [n_env, num_substeps, 3], dynamic_velocity [n_env, 2, 3], dynamic_omega [n_env, 3]). */
+int r2s_phys_set_eef_table(R2SPhys* h, int32_t n_knots, const double* eef_pts, const float* init_eef_xyz,
+                           float grasp_force_threshold, r2s_stream_t stream);
+int r2s_phys_set_eef_motion(R2SPhys* h, const float* eef_xyz, const float* eef_vel, const float* eef_rot,
+                            const float* eef_rot_vel, const float* gripper_openness, r2s_stream_t stream);
+int r2s_phys_eef_state(R2SPhys* h, double** current_openness, int32_t** grasped);
+int r2s_phys_mesh_motion(R2SPhys* h, float** interp_points, float** interp_center, float** dynamic_velocity,
+                         float** dynamic_omega);
+
 /* step (:823-943) / wp.capture_launch(graph) (phystwin.py:515-519).  n_substeps <= 0 or
  * == params.num_substeps replays the captured graph; any other count runs substeps
  * [first_substep, first_substep + n_substeps) eagerly (they index the interpolated mesh motion). */

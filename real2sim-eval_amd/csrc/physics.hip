@@ -919,6 +919,167 @@ __global__ void k_mesh_xf(int E, int n_sub, int n_dyn_mesh, int n_dyn_pts, int n
     atomicMax(rigid_err, __float_as_uint(worst));
 }
 
+// ---- on-device gripper / pusher kinematics + grasp state machine ----------------------------------------------
+// What SpringMassDynamicsModule.step computes on the host before it calls set_mesh_interactive (phystwin.py:362-513),
+// for every environment at once and without the D2H read of collision_forces.  float32 where the reference uses float32
+// torch ops (same operation order, no FMA contraction), float64 for the host-side python / scipy part (openness state
+// machine, interp1d of the finger vertices).
+struct EefIn {
+    const float* xyz;      // [E,3]   eef_xyz (first gripper)
+    const float* vel;      // [E,3]   eef_vel
+    const float* rot;      // [E,3,3] eef_rot
+    const float* rot_vel;  // [E,3]   eef_rot_vel (axis-angle rate)
+    const float* open;     // [E]     gripper_openness
+};
+
+// scipy.interpolate.interp1d(kind='linear') over x = arange(K) / (K-1.0), evaluated like scipy's _call_linear:
+// hi = clip(searchsorted(x, x_new, 'left'), 1, K-1), slope = (y_hi - y_lo) / (x_hi - x_lo), y = slope * (x_new - x_lo) + y_lo.
+__device__ __forceinline__ void eef_knot(double x_new, int K, int& lo, double& x_lo, double& inv_dx_num, double& x_hi)
+{
+    const double den = (double)(K - 1);
+    int a = 0, b = K; // first index with x[i] >= x_new
+    while (a < b) { const int m = (a + b) >> 1; if ((double)m / den < x_new) a = m + 1; else b = m; }
+    const int hi = min(max(a, 1), K - 1);
+    lo = hi - 1;
+    x_lo = (double)lo / den; x_hi = (double)hi / den;
+    inv_dx_num = x_hi - x_lo;
+}
+
+// One workgroup per environment: state machine (thread 0), then the per-vertex quantities that do not depend on the
+// substep — relative_eef_pts at the substep-0 end (rel0), eef_pts_delta (delta) — and the finger closing velocities.
+__global__ void __launch_bounds__(256) k_eef_prepare(int E, int M, int K, int use_pusher, const double* __restrict__ table, float ix, float iy,
+                                                     float iz, float thr, int f_left, int f_right, int nF,
+                                                     const float* __restrict__ coll_forces, EefIn in, double* __restrict__ cur_open,
+                                                     int* __restrict__ grasped, int* __restrict__ has_state, float* __restrict__ rel0,
+                                                     float* __restrict__ delta, float* __restrict__ dyn_vel, float* __restrict__ dyn_omega,
+                                                     float two_dt_n)
+{
+    const int e = blockIdx.x, tid = threadIdx.x;
+    __shared__ double s_open[2];
+    __shared__ float s_red[2][3][256 / 64];
+    if (tid == 0) {
+        double now, before;
+        if (use_pusher) {
+            now = before = 1.0; cur_open[e] = 1.0; // phystwin.py:464, :474-477
+        } else {
+            double openness = (double)in.open[e]; // gripper_openness.item()
+            double cur = has_state[e] ? cur_open[e] : openness; // :371-372
+            int g = grasped[e];
+            const float* F = coll_forces + (size_t)e * nF * 3;
+            float n2[2];
+            for (int side = 0; side < 2; ++side) { // :380-389: faces 18, 19, 1 of each finger, float32 sums and norm
+                const float* f0 = F + (size_t)((side ? f_right : f_left) + 18) * 3;
+                const float* f1 = F + (size_t)((side ? f_right : f_left) + 19) * 3;
+                const float* f2 = F + (size_t)((side ? f_right : f_left) + 1) * 3;
+                const float x = (f0[0] + f1[0]) + f2[0], y = (f0[1] + f1[1]) + f2[1], z = (f0[2] + f1[2]) + f2[2];
+                n2[side] = sqrtf((x * x + y * y) + z * z);
+            }
+            before = cur;
+            if (n2[0] < 100.f && n2[1] < 100.f) g = 0; // :393-394
+            if (openness < cur) {                       // :395-405
+                if (n2[0] > thr && n2[1] > thr) { openness = cur; g = 1; }
+                else if (g) { cur = fmax(openness, cur - 0.05); openness = cur; }
+                else cur = openness;
+            } else cur = openness;
+            cur_open[e] = cur; grasped[e] = g; has_state[e] = 1;
+            now = fmin(fmax(openness, 0.0), 1.0); before = fmin(fmax(before, 0.0), 1.0); // np.clip, :411, :419
+        }
+        s_open[0] = now; s_open[1] = before;
+    }
+    __syncthreads();
+    int lo_n, lo_b; double xl_n, dx_n, xh_n, xl_b, dx_b, xh_b;
+    eef_knot(s_open[0], K, lo_n, xl_n, dx_n, xh_n);
+    eef_knot(s_open[1], K, lo_b, xl_b, dx_b, xh_b);
+    const float* R = in.rot + (size_t)e * 9;
+    float accL[3] = {0.f, 0.f, 0.f}, accR[3] = {0.f, 0.f, 0.f};
+    const int half = M / 2;
+    for (int v = tid; v < M; v += 256) {
+        float pn[3], pb[3];
+        for (int c = 0; c < 3; ++c) {
+            const double yl = table[((size_t)lo_n * M + v) * 3 + c], yh = table[((size_t)(lo_n + 1) * M + v) * 3 + c];
+            pn[c] = (float)(((yh - yl) / dx_n) * (s_open[0] - xl_n) + yl);
+            const double zl = table[((size_t)lo_b * M + v) * 3 + c], zh = table[((size_t)(lo_b + 1) * M + v) * 3 + c];
+            pb[c] = (float)(((zh - zl) / dx_b) * (s_open[1] - xl_b) + zl);
+        }
+        float d[3] = {pn[0] - pb[0], -(pn[1] - pb[1]), -(pn[2] - pb[2])};              // :422-424 (flip y, z)
+        float r[3] = {pb[0] - ix, -(pb[1] - iy), -(pb[2] - iz)};                          // :425-427
+        float* o = rel0 + ((size_t)e * M + v) * 3; o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
+        float* q = delta + ((size_t)e * M + v) * 3; q[0] = d[0]; q[1] = d[1]; q[2] = d[2];
+        if (!use_pusher) { // closing velocity: (delta @ eef_rot[0]^T) / (2 dt n), :446-447
+            const float c0 = ((d[0] * R[0] + d[1] * R[1]) + d[2] * R[2]) / two_dt_n;
+            const float c1 = ((d[0] * R[3] + d[1] * R[4]) + d[2] * R[5]) / two_dt_n;
+            const float c2 = ((d[0] * R[6] + d[1] * R[7]) + d[2] * R[8]) / two_dt_n;
+            float* a = v < half ? accL : accR;
+            a[0] += c0; a[1] += c1; a[2] += c2;
+        }
+    }
+    // block sums of the two halves (the reference takes torch means; summation order differs in the last bits)
+    for (int side = 0; side < 2; ++side)
+        for (int c = 0; c < 3; ++c) {
+            float x = side ? accR[c] : accL[c];
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+            if ((tid & 63) == 0) s_red[side][c][tid >> 6] = x;
+        }
+    __syncthreads();
+    if (tid < 3) {
+        const float ev = in.vel[(size_t)e * 3 + tid] * 0.5f; // :443
+        if (use_pusher) {
+            dyn_vel[(size_t)e * 6 + tid] = ev; dyn_vel[(size_t)e * 6 + 3 + tid] = 0.f;
+        } else {
+            const float sl = (s_red[0][tid][0] + s_red[0][tid][1]) + (s_red[0][tid][2] + s_red[0][tid][3]);
+            const float sr = (s_red[1][tid][0] + s_red[1][tid][1]) + (s_red[1][tid][2] + s_red[1][tid][3]);
+            dyn_vel[(size_t)e * 6 + tid] = ev + sl / (float)max(half, 1);          // :448-454
+            dyn_vel[(size_t)e * 6 + 3 + tid] = ev + sr / (float)max(M - half, 1);
+        }
+        dyn_omega[(size_t)e * 3 + tid] = -in.rot_vel[(size_t)e * 3 + tid] * 0.5f; // :457
+    }
+}
+
+// kornia.geometry.conversions.axis_angle_to_rotation_matrix (third-party, not under the reference tree; restated from
+// its published source): Rodrigues with w = aa / (theta + 1e-6) where theta^2 > 1e-6, first-order matrix otherwise.
+__device__ __forceinline__ void eef_aa_to_matrix(float ax, float ay, float az, float* r)
+{
+    const float theta2 = (ax * ax + ay * ay) + az * az;
+    if (theta2 > 1e-6f) {
+        const float theta = sqrtf(theta2);
+        const float wx = ax / (theta + 1e-6f), wy = ay / (theta + 1e-6f), wz = az / (theta + 1e-6f);
+        const float c = cosf(theta), sn = sinf(theta), k = 1.0f - c;
+        r[0] = c + wx * wx * k;        r[1] = wx * wy * k - wz * sn; r[2] = wy * sn + wx * wz * k;
+        r[3] = wz * sn + wx * wy * k;  r[4] = c + wy * wy * k;       r[5] = -wx * sn + wy * wz * k;
+        r[6] = -wy * sn + wx * wz * k; r[7] = wx * sn + wy * wz * k; r[8] = c + wz * wz * k;
+    } else {
+        r[0] = 1.f; r[1] = -az; r[2] = ay; r[3] = az; r[4] = 1.f; r[5] = -ax; r[6] = -ay; r[7] = ax; r[8] = 1.f;
+    }
+}
+
+// interpolated_dynamic_points / interpolated_center for every (env, substep) and every vertex the stepper reads
+// (all vertices of small meshes; for large rigid meshes only the three reference vertices and the rigidity sample).
+__global__ void __launch_bounds__(256) k_eef_points(int E, int n_sub, int M, int n_need, const int* __restrict__ need, EefIn in,
+                                                    const float* __restrict__ rel0, const float* __restrict__ delta, float dt, float dt_n,
+                                                    float* __restrict__ interp, float* __restrict__ center)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y, e = blockIdx.z;
+    if (k >= n_need) return;
+    const int v = need[k];
+    const float dts = (float)(s + 1) * dt;                                   // linspace(1, n, n) * dt, :374
+    const float* X = in.xyz + (size_t)e * 3; const float* V = in.vel + (size_t)e * 3; const float* W = in.rot_vel + (size_t)e * 3;
+    const float* R = in.rot + (size_t)e * 9;
+    const float nx = X[0] + V[0] * dts, ny = X[1] + V[1] * dts, nz = X[2] + V[2] * dts;   // eef_xyz_next, :376
+    float D[9];
+    eef_aa_to_matrix(W[0] * dts, W[1] * dts, W[2] * dts, D);               // :377-378
+    float Rn[9];                                                             // eef_rot_next = D^T @ eef_rot, :379
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = (D[0 * 3 + i] * R[0 * 3 + j] + D[1 * 3 + i] * R[1 * 3 + j]) + D[2 * 3 + i] * R[2 * 3 + j];
+    const float* r0 = rel0 + ((size_t)e * M + v) * 3; const float* d = delta + ((size_t)e * M + v) * 3;
+    const float rx = r0[0] + (d[0] / dt_n) * dts, ry = r0[1] + (d[1] / dt_n) * dts, rz = r0[2] + (d[2] / dt_n) * dts; // :429
+    float* o = interp + (((size_t)e * n_sub + s) * M + v) * 3;             // xyz_next + rel @ Rn^T, :432
+    o[0] = nx + ((rx * Rn[0] + ry * Rn[1]) + rz * Rn[2]);
+    o[1] = ny + ((rx * Rn[3] + ry * Rn[4]) + rz * Rn[5]);
+    o[2] = nz + ((rx * Rn[6] + ry * Rn[7]) + rz * Rn[8]);
+    if (k == 0) { float* c = center + ((size_t)e * n_sub + s) * 3; c[0] = nx; c[1] = ny; c[2] = nz; } // :436
+}
+
 // ---- warp-style hash grid -----------------------------------------------------------------------------
 __device__ __forceinline__ int grid_cell(int x, int y, int z)
 {
@@ -1154,6 +1315,11 @@ struct R2SPhys {
     bool rigid_pending = false;
     int n_cl = 0, n_xf = 0;
     bool any_large = false; // some mesh has more than 256 faces -> cluster hierarchy + wave-cooperative queries
+    // on-device eef kinematics (r2s_phys_set_eef_table / r2s_phys_set_eef_motion)
+    std::vector<int> h_mesh_kind, h_voff, h_foff, h_xf_mesh, h_xf_ref;
+    double* d_eef_table = nullptr; int eef_knots = 0; float eef_init[3] = {0.f, 0.f, 0.f}; float eef_thr = 0.f;
+    double* d_eef_open = nullptr; int *d_eef_grasped = nullptr, *d_eef_has = nullptr, *d_eef_need = nullptr; int eef_n_need = 0;
+    float *d_eef_rel0 = nullptr, *d_eef_delta = nullptr;
     float *d_mesh_pts = nullptr, *d_interp = nullptr, *d_center = nullptr, *d_dyn_vel = nullptr, *d_dyn_omega = nullptr;
     float *d_aabb_dyn = nullptr, *d_aabb_static = nullptr, *d_coll_forces = nullptr;
     // graph
@@ -1704,6 +1870,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             }
         }
         h->n_cl = (int)cl_f0.size(); h->n_xf = (int)xf_mesh.size();
+        h->h_mesh_kind = mesh_kind; h->h_voff = voff; h->h_foff = foff; h->h_xf_mesh = xf_mesh; h->h_xf_ref = xf_ref;
         for (int m = 0; m < h->n_mesh; ++m) h->any_large = h->any_large || mesh_kind[m] != 0;
         TRY(dev_alloc(&h->d_face_orig, h->nF)); TRY(dev_alloc(&h->d_face_mesh, h->nF)); TRY(dev_alloc(&h->d_cl_f0, h->n_cl)); TRY(dev_alloc(&h->d_cl_f1, h->n_cl));
         TRY(dev_alloc(&h->d_cl_mesh, h->n_cl)); TRY(dev_alloc(&h->d_cl_box, cl_box.size())); TRY(dev_alloc(&h->d_mesh_kind, h->n_mesh)); TRY(dev_alloc(&h->d_mesh_xf, h->n_mesh));
@@ -1800,7 +1967,8 @@ void r2s_phys_destroy(R2SPhys* h)
                     h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
                     h->d_faces, h->d_face_orig, h->d_face_mesh, h->d_cl_f0, h->d_cl_f1, h->d_cl_mesh, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
                     h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
-                    h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces};
+                    h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
+                    h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_cand_count) (void)hipHostFree(h->h_cand_count);
     if (h->h_rigid_err) (void)hipHostFree(h->h_rigid_err);
@@ -1889,6 +2057,87 @@ int r2s_phys_set_mesh_interactive(R2SPhys* h, const float* interp_points, const 
         if (rc) return rc;
     }
     R2S_HIP_TRY(hipGetLastError());
+    return R2S_OK;
+}
+
+int r2s_phys_set_eef_table(R2SPhys* h, int32_t n_knots, const double* eef_pts, const float* init_eef_xyz, float grasp_force_threshold,
+                           r2s_stream_t stream_)
+{
+    if (!h || h->n_dyn_mesh == 0 || n_knots < 2 || !eef_pts || !init_eef_xyz) return R2S_ERR_INVALID;
+    if (!h->prm.use_pusher && (h->n_dyn_mesh < 2 || h->h_foff[1] - h->h_foff[0] < 20 || h->h_foff[2] - h->h_foff[1] < 20))
+        return R2S_ERR_INVALID; // the grasp test reads faces 1, 18, 19 of the two finger meshes (phystwin.py:386-387)
+    hipStream_t s = (hipStream_t)stream_;
+    const int E = h->E, M = h->n_dyn_pts;
+    if (h->d_eef_table) { (void)hipFree(h->d_eef_table); h->d_eef_table = nullptr; }
+    int rc = dev_alloc(&h->d_eef_table, (size_t)n_knots * M * 3);
+    if (rc) return rc;
+    R2S_HIP_TRY(hipMemcpyAsync(h->d_eef_table, eef_pts, sizeof(double) * (size_t)n_knots * M * 3, hipMemcpyHostToDevice, s));
+    h->eef_knots = n_knots; h->eef_thr = grasp_force_threshold;
+    for (int k = 0; k < 3; ++k) h->eef_init[k] = init_eef_xyz[k];
+    if (!h->d_eef_open) {
+        if ((rc = dev_alloc(&h->d_eef_open, E)) || (rc = dev_alloc(&h->d_eef_grasped, E)) || (rc = dev_alloc(&h->d_eef_has, E)) ||
+            (rc = dev_alloc(&h->d_eef_rel0, (size_t)E * M * 3)) || (rc = dev_alloc(&h->d_eef_delta, (size_t)E * M * 3)))
+            return rc;
+        // vertices the stepper reads: everything of a small mesh; reference + rigidity-sample vertices of a large one (k_mesh_xf)
+        std::vector<int> need;
+        for (int m = 0; m < h->n_dyn_mesh; ++m) {
+            const int v0 = h->h_voff[m], v1 = h->h_voff[m + 1];
+            if (h->h_mesh_kind[m] == 0) { for (int v = v0; v < v1; ++v) need.push_back(v); continue; }
+            const int stride = std::max(1, (v1 - v0) / 48);
+            for (int v = v0; v < v1; v += stride) need.push_back(v);
+            for (size_t k = 0; k < h->h_xf_mesh.size(); ++k)
+                if (h->h_xf_mesh[k] == m) for (int j = 0; j < 3; ++j) need.push_back(h->h_xf_ref[3 * k + j]);
+        }
+        std::sort(need.begin(), need.end()); need.erase(std::unique(need.begin(), need.end()), need.end());
+        h->eef_n_need = (int)need.size();
+        if ((rc = dev_alloc(&h->d_eef_need, need.size())) || (rc = upload(h->d_eef_need, need.data(), need.size(), s))) return rc;
+    }
+    R2S_HIP_TRY(hipMemsetAsync(h->d_eef_open, 0, sizeof(double) * E, s));
+    R2S_HIP_TRY(hipMemsetAsync(h->d_eef_grasped, 0, sizeof(int) * E, s));
+    R2S_HIP_TRY(hipMemsetAsync(h->d_eef_has, 0, sizeof(int) * E, s));
+    R2S_HIP_TRY(hipStreamSynchronize(s)); // eef_pts is a host buffer of the caller
+    return R2S_OK;
+}
+
+int r2s_phys_set_eef_motion(R2SPhys* h, const float* eef_xyz, const float* eef_vel, const float* eef_rot, const float* eef_rot_vel,
+                            const float* gripper_openness, r2s_stream_t stream_)
+{
+    if (!h || !h->d_eef_table || !eef_xyz || !eef_vel || !eef_rot || !eef_rot_vel || (!h->prm.use_pusher && !gripper_openness)) return R2S_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream_;
+    const int E = h->E, n_sub = h->prm.num_substeps, M = h->n_dyn_pts;
+    EefIn in{eef_xyz, eef_vel, eef_rot, eef_rot_vel, gripper_openness};
+    const float dt = h->prm.dt;
+    const float dt_n = (float)((double)h->prm.dt * n_sub), two_dt_n = (float)(2.0 * (double)h->prm.dt * n_sub);
+    const int f_left = h->h_foff[0], f_right = h->n_dyn_mesh > 1 ? h->h_foff[1] : h->h_foff[0];
+    hipLaunchKernelGGL(k_eef_prepare, dim3(E), dim3(256), 0, s, E, M, h->eef_knots, (int)h->prm.use_pusher, h->d_eef_table, h->eef_init[0], h->eef_init[1],
+                       h->eef_init[2], h->eef_thr, f_left, f_right, h->nF, h->d_coll_forces, in, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_rel0,
+                       h->d_eef_delta, h->d_dyn_vel, h->d_dyn_omega, two_dt_n);
+    hipLaunchKernelGGL(k_eef_points, dim3((h->eef_n_need + 255) / 256, n_sub, E), dim3(256), 0, s, E, n_sub, M, h->eef_n_need, h->d_eef_need, in, h->d_eef_rel0,
+                       h->d_eef_delta, dt, dt_n, h->d_interp, h->d_center);
+    const int tot = E * n_sub * h->n_dyn_mesh;
+    hipLaunchKernelGGL(k_mesh_aabb_dyn, dim3((tot + 255) / 256), dim3(256), 0, s, E, n_sub, h->n_dyn_mesh, h->n_dyn_pts, h->d_mesh_vert_off, h->d_mesh_kind,
+                       h->d_interp, h->d_aabb_dyn);
+    int rc = update_mesh_transforms(h, s);
+    if (rc) return rc;
+    R2S_HIP_TRY(hipGetLastError());
+    return R2S_OK;
+}
+
+int r2s_phys_eef_state(R2SPhys* h, double** current_openness, int32_t** grasped)
+{
+    if (!h || !h->d_eef_open) return R2S_ERR_INVALID;
+    if (current_openness) *current_openness = h->d_eef_open;
+    if (grasped) *grasped = h->d_eef_grasped;
+    return R2S_OK;
+}
+
+int r2s_phys_mesh_motion(R2SPhys* h, float** interp_points, float** interp_center, float** dynamic_velocity, float** dynamic_omega)
+{
+    if (!h || h->n_dyn_mesh == 0) return R2S_ERR_INVALID;
+    if (interp_points) *interp_points = h->d_interp;
+    if (interp_center) *interp_center = h->d_center;
+    if (dynamic_velocity) *dynamic_velocity = h->d_dyn_vel;
+    if (dynamic_omega) *dynamic_omega = h->d_dyn_omega;
     return R2S_OK;
 }
 

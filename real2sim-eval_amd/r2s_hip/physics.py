@@ -52,6 +52,8 @@ def _bind():
         r2s_phys_step=[vp, i32, i32, vp], r2s_phys_collision_forces=[vp, C.POINTER(vp), C.POINTER(C.c_int32)],
         r2s_phys_mesh_maps=[vp, vp, vp], r2s_phys_collision_lists=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32)],
         r2s_phys_collision_max_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_set_spring_Y=[vp, vp, vp],
+        r2s_phys_set_eef_table=[vp, C.c_int32, vp, vp, C.c_float, vp], r2s_phys_set_eef_motion=[vp, vp, vp, vp, vp, vp, vp],
+        r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
         r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
     ).items():
         fn = getattr(L, name)
@@ -208,6 +210,60 @@ class PhysBatch:
             check(_bind().r2s_phys_set_mesh_interactive(self._h, ip.data_ptr(), ic.data_ptr(), dv.data_ptr(), om.data_ptr(), self._s()),
                   "r2s_phys_set_mesh_interactive")
         self._keep_mesh = (ip, ic, dv, om)
+
+    # -- on-device gripper / pusher kinematics (the caller side of the stepper, phystwin.py:362-513) ----------------
+    def set_eef_table(self, eef_pts_list, init_eef_xyz, grasp_force_threshold: float):
+        """``eef_pts_list``: the knots of the reference's ``eef_pts_func`` (scipy interp1d over arange(K)/(K-1)),
+        [K, n_dynamic_points, 3]; ``init_eef_xyz`` [3].  Resets current_openness / grasped of every environment."""
+        tab = np.ascontiguousarray(np.asarray(eef_pts_list, np.float64))
+        assert tab.ndim == 3 and tab.shape[1] == self.n_dyn_pts and tab.shape[2] == 3, tab.shape
+        init = np.ascontiguousarray(np.asarray(init_eef_xyz, np.float32).reshape(-1)[:3])
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_set_eef_table(self._h, int(tab.shape[0]), tab.ctypes.data, init.ctypes.data, float(grasp_force_threshold), self._s()),
+                  "r2s_phys_set_eef_table")
+
+    def set_eef_motion(self, eef_xyz, eef_vel, eef_rot, eef_rot_vel, gripper_openness=None):
+        """Per-environment inputs of ``SpringMassDynamicsModule.step``: eef_xyz/eef_vel/eef_rot_vel [n_env,3], eef_rot
+        [n_env,3,3], gripper_openness [n_env] (device tensors).  Everything downstream happens on the device."""
+        E = self.n_env
+        t = lambda a, shape: a.to(self.device, torch.float32).contiguous().reshape(shape)  # noqa: E731
+        x, v, r, w = t(eef_xyz, (E, 3)), t(eef_vel, (E, 3)), t(eef_rot, (E, 3, 3)), t(eef_rot_vel, (E, 3))
+        o = t(gripper_openness, (E,)) if gripper_openness is not None else None
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_set_eef_motion(self._h, x.data_ptr(), v.data_ptr(), r.data_ptr(), w.data_ptr(),
+                                                  o.data_ptr() if o is not None else None, self._s()), "r2s_phys_set_eef_motion")
+        self._keep_eef = (x, v, r, w, o)
+
+    def eef_state(self):
+        """(current_openness float64 [n_env], grasped int32 [n_env]) copies."""
+        from .raster import _memcpy_d2d
+
+        po, pg = C.c_void_p(), C.c_void_p()
+        check(_bind().r2s_phys_eef_state(self._h, C.byref(po), C.byref(pg)), "r2s_phys_eef_state")
+        o = torch.empty(self.n_env, dtype=torch.float64, device=self.device)
+        g = torch.empty(self.n_env, dtype=torch.int32, device=self.device)
+        _memcpy_d2d(o.data_ptr(), po.value, o.numel() * 8, self.device)
+        _memcpy_d2d(g.data_ptr(), pg.value, g.numel() * 4, self.device)
+        return o.cpu(), g.cpu()
+
+    def mesh_motion(self, points: bool = True):
+        """Copies of the stepper's current motion inputs: interp_points [n_env, n_sub, n_dyn_pts, 3] (optional),
+        interp_center [n_env, n_sub, 3], dynamic_velocity [n_env, 2, 3], dynamic_omega [n_env, 3]."""
+        from .raster import _memcpy_d2d
+
+        p = [C.c_void_p() for _ in range(4)]
+        check(_bind().r2s_phys_mesh_motion(self._h, *[C.byref(q) for q in p]), "r2s_phys_mesh_motion")
+        E, n = self.n_env, self.num_substeps
+        shapes = [(E, n, self.n_dyn_pts, 3), (E, n, 3), (E, 2, 3), (E, 3)]
+        out = []
+        for k, (q, sh) in enumerate(zip(p, shapes)):
+            if k == 0 and not points:
+                out.append(None)
+                continue
+            t = torch.empty(*sh, dtype=torch.float32, device=self.device)
+            _memcpy_d2d(t.data_ptr(), q.value, t.numel() * 4, self.device)
+            out.append(t)
+        return out
 
     def step(self, n_substeps: int = 0, first_substep: int = 0, sync_state: bool = True):
         with torch.cuda.device(self.device):

@@ -4,7 +4,7 @@ gs_renderer.py:924-1000), for ``n_env`` environments of one GPU at once.
 
 One env step =
     update_collision_graph                       (once per env step, phystwin.py:365-366)
-    set_mesh_interactive(gripper motion)         (phystwin.py:455-460)
+    gripper / pusher kinematics + grasp logic    (on device: r2s_phys_set_eef_motion; phystwin.py:367-513)
     num_substeps fused physics substeps          (the captured graph, phystwin.py:515-519)
     Gaussians follow their particles             (LBS skinning, incremental: gs_renderer.py:717-747 -> r2s_skin_*)
     2 rasterised frames per env (side + wrist)   (env.py:55-56)
@@ -56,13 +56,23 @@ class BatchedRollout:
         top = pts[:, 2].max()
         dyn, sta = [], []
         self.use_pusher = "pusher" in config
+        self.eef_table = None
         if with_gripper and self.use_pusher:
             # vertical pusher rod next to the block's -x face (assets/.../pusher_20cm.stl has 25 368 faces)
-            self.fingers = [synth.cylinder_mesh((pts[:, 0].min() - 0.02, c[1], 0.12), radius=0.005, length=0.2)]
-            dyn = self.fingers
+            self.eef_init = np.array([0.3, 0.0, 0.4], np.float32)
+            rod_v, rod_f = synth.cylinder_mesh((0.0, 0.0, -0.1), radius=0.005, length=0.2)
+            rel = rod_v.astype(np.float64)
+            rel[:, 1] *= -1
+            rel[:, 2] *= -1
+            self.eef_table = np.repeat((self.eef_init.astype(np.float64) + rel)[None], 2, axis=0)   # rigid: two equal knots
+            self.eef0 = np.array([pts[:, 0].min() - 0.02, c[1], 0.2], np.float32)
+            dyn = [(synth.eef_world_points(self.eef_table[-1], self.eef_init, self.eef0), rod_f)]
         elif with_gripper:
-            self.fingers = [synth.finger_mesh((c[0], c[1] - 0.03, top + 0.04)), synth.finger_mesh((c[0], c[1] + 0.03, top + 0.04))]
-            dyn = self.fingers
+            self.eef_table, self.eef_init, fl, fr = synth.gripper_eef_table()
+            self.eef0 = np.array([c[0], c[1], top + 0.1], np.float32)
+            w0 = synth.eef_world_points(self.eef_table[-1], self.eef_init, self.eef0)
+            dyn = [(w0[: len(w0) // 2], fl), (w0[len(w0) // 2:], fr)]
+        self.fingers = dyn
         if with_static:
             sta = [synth.box_mesh((c[0] + 0.25, c[1] + 0.2, 0.135), (0.2, 0.13, 0.27))]
         self.phys = PhysBatch(init_vertices=x0, init_springs=ob["springs"], init_rest_lengths=ob["rest"],
@@ -107,16 +117,18 @@ class BatchedRollout:
         if with_gripper:
             self._init_gripper_motion()
 
-    # ---- gripper motion: fixed Lissajous path at <= 0.1 m/s, rigid, computed on device ------------------------
+    # ---- end-effector trace: fixed Lissajous path at <= 0.1 m/s; the gripper closes at step 100 and opens at 300 ------
+    # (SURVEY.md §8d).  Only the eef pose / rates / commanded opening are produced here — what BaseEnv hands to
+    # SpringMassDynamicsModule.step (phystwin.py:362); finger vertices, grasp logic and per-substep motion are on device.
     def _init_gripper_motion(self):
-        pts0 = np.concatenate([v for v, _ in self.fingers]).astype(np.float32)
+        E = self.n_env
+        self.phys.set_eef_table(self.eef_table, self.eef_init, 2000.0)   # cfg/physics/default.yaml grasp_force_threshold
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)  # noqa: E731
-        self.finger_pts0 = t(pts0)
-        self.finger_center0 = t(pts0.mean(0))
-        n = self.num_substeps
-        self.ts = (torch.arange(1, n + 1, device=self.device, dtype=torch.float32) * self.dt)
+        self.eef_xyz = t(np.repeat(self.eef0[None], E, 0) + self.env_shift)
+        self.eef_rot = torch.eye(3, device=self.device).repeat(E, 1, 1)
+        self.eef_rot_vel = torch.zeros(E, 3, device=self.device)
 
-    def _gripper_velocity(self, step):
+    def _eef_velocity(self, step):
         w = 2 * np.pi * 0.25
         tt = step / 30.0
         if self.use_pusher:  # push along +x at 5 cm/s with a slow lateral weave
@@ -124,17 +136,12 @@ class BatchedRollout:
         return np.array([0.05 * w * np.cos(w * tt) * 0.6, 0.05 * w * np.cos(2 * w * tt + 0.5) * 0.6, -0.01 * np.sin(w * tt)], np.float32)
 
     def _set_gripper(self, step):
-        E, n = self.n_env, self.num_substeps
-        vel = torch.from_numpy(self._gripper_velocity(step)).to(self.device)
-        disp = getattr(self, "_disp", torch.zeros(3, device=self.device))
-        base = self.finger_pts0 + disp
-        interp = base[None] + vel[None, None] * self.ts[:, None, None]               # [n, M, 3]
-        centers = (self.finger_center0 + disp)[None] + vel[None] * self.ts[:, None]   # [n, 3]
-        self._disp = disp + vel * (n * self.dt)
-        dv = (vel * 0.5)[None] if self.use_pusher else torch.stack([vel * 0.5, vel * 0.5])  # phystwin.py:439, :498
-        om = torch.zeros(1, 3, device=self.device)
-        self.phys.set_mesh_interactive(interp[None].expand(E, -1, -1, -1), centers[None].expand(E, -1, -1),
-                                       dv[None].expand(E, -1, -1), om[None].expand(E, -1, -1))
+        E = self.n_env
+        vel = torch.from_numpy(self._eef_velocity(step)).to(self.device)[None].expand(E, 3).contiguous()
+        cmd = 0.3 if 100 <= step < 300 else 1.0
+        openness = torch.full((E,), cmd, dtype=torch.float32, device=self.device)
+        self.phys.set_eef_motion(self.eef_xyz, vel, self.eef_rot, self.eef_rot_vel, None if self.use_pusher else openness)
+        self.eef_xyz = self.eef_xyz + vel * (self.num_substeps * self.dt)
 
     def _update_means(self):
         """Incremental skinning as update_rendervar does it: bones = particles at the last render, motions = what they

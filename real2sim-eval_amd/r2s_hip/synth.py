@@ -225,3 +225,32 @@ def gaussian_scene(n_gaussians: int, seed: int, object_points: np.ndarray | None
     opac = (1.0 / (1.0 + np.exp(-rng.normal(2.0, 2.0, (P, 1))))).astype(np.float32)
     shs = rng.normal(0, 1, (P, sh_coeffs, 3)).astype(np.float32)
     return dict(means3D=means, scales=scales, rotations=q.astype(np.float32), opacities=opac, shs=shs)
+
+
+def gripper_eef_table(n_knots=101, init_eef_xyz=(0.37, 0.05, 0.35), gap_closed=0.012, gap_open=0.085, finger_size=(0.02, 0.01, 0.05), drop=0.06):
+    """Synthetic stand-in for ``get_eef_pts_xarm_gripper`` (robot_pc_transformations.py:158-192): the vertices of the two
+    finger collision meshes at ``n_knots`` gripper openings in the frame the reference samples them in, i.e. such that
+    ``flip_yz(eef_pts - init_eef_xyz)`` is the finger geometry relative to the end effector.  Returns
+    (eef_pts_list float64 [n_knots, M, 3], init_eef_xyz float32 [3], faces_left, faces_right)."""
+    init = np.asarray(init_eef_xyz, np.float64)
+    tab, fl, fr = [], None, None
+    for k in range(n_knots):
+        o = k / (n_knots - 1.0)
+        half = 0.5 * (gap_closed + o * (gap_open - gap_closed)) + 0.5 * finger_size[1]
+        vl, fl = finger_mesh((0.0, -half, -drop), finger_size)
+        vr, fr = finger_mesh((0.0, +half, -drop), finger_size)
+        rel = np.concatenate([vl, vr]).astype(np.float64)
+        rel[:, 1] *= -1
+        rel[:, 2] *= -1
+        tab.append(init + rel)
+    return np.asarray(tab), init.astype(np.float32), fl, fr
+
+
+def eef_world_points(eef_pts, init_eef_xyz, eef_xyz, eef_rot=None):
+    """World vertices of the dynamic meshes for an end effector at ``eef_xyz`` with rotation ``eef_rot``
+    (phystwin.py:425-432 at zero elapsed time)."""
+    rel = np.asarray(eef_pts, np.float64) - np.asarray(init_eef_xyz, np.float64)
+    rel[:, 1] *= -1
+    rel[:, 2] *= -1
+    R = np.eye(3) if eef_rot is None else np.asarray(eef_rot, np.float64)
+    return (np.asarray(eef_xyz, np.float64) + rel @ R.T).astype(np.float32)
