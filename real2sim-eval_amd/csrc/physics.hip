@@ -1458,13 +1458,24 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
 
 // Enqueue substeps [first, first+n) starting from buffer `start_buf`; the final state is left in buffer
 // start_buf ^ (n & 1).
+// A captured hipMemsetAsync node zeroes on the first replay only with this runtime (later replays fill the buffer with
+// stale host words — caught by a multi-step force test), so the accumulator is cleared by a kernel node instead.
+__global__ void k_zero_f32(float* __restrict__ p, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
 int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, hipStream_t s)
 {
     const PhysDev p = h->dev();
     int buf = start_buf;
     for (int k = 0; k < n; ++k) {
         const int last = (k == n - 1);
-        if (last && h->nF > 0) R2S_HIP_TRY(hipMemsetAsync(h->d_coll_forces, 0, sizeof(float) * 3 * (size_t)h->E * h->nF, s));
+        if (last && h->nF > 0) {
+            const size_t cnt = 3 * (size_t)h->E * h->nF;
+            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->d_coll_forces, cnt);
+        }
         int rc = launch_substep(h, p, buf, first + k, last, with_self, s);
         if (rc) return rc;
         buf ^= 1;

@@ -156,6 +156,39 @@ def test_gripper_fingers_dynamic_mesh():
     assert np.abs(f - o.collision_forces).sum() < 0.3 * np.abs(o.collision_forces).sum()
 
 
+def test_collision_forces_are_cleared_on_every_replay_of_the_step():
+    """collision_forces holds the LAST substep's forces of the LAST step (the reference zeroes the accumulator in every
+    substep): a second step without contact must read all zeros.  Regression for a captured memset that only cleared on
+    the first replay."""
+    import torch
+    from r2s_hip import synth
+
+    n_sub = 60
+    ob = make_object("sloth", 500, seed=6)
+    c = ob["points"].mean(0)
+    top = ob["points"][:, 2].max()
+    fl = synth.finger_mesh((c[0], c[1] - 0.02, top + 0.03))
+    fr = synth.finger_mesh((c[0], c[1] + 0.02, top + 0.03))
+    kw = dict(dynamic_meshes=[fl, fr], self_collision=False)
+    o = oracle_env(ob, num_substeps=n_sub, **kw)
+    h = hip_env(ob, num_substeps=n_sub, **kw)
+    t = lambda a: torch.from_numpy(a)[None].cuda()  # noqa: E731
+    seen = []
+    for vel in ((0.0, 0.0, -12.0), (0.0, 0.0, 0.0), (0.0, 0.0, 40.0), (0.0, 0.0, 0.0)):
+        interp, centers, dv, om = gripper_motion([fl, fr], n_sub, 5e-5, vel=vel, closing=0.0)
+        fl = (interp[-1][: len(fl[0])], fl[1]); fr = (interp[-1][len(fl[0]):], fr[1])
+        o.set_mesh_interactive(interp, centers, dv, om)
+        h.set_mesh_interactive(t(interp), t(centers), t(dv), t(om))
+        o.step(); h.step()
+        f = h.collision_forces()[0].cpu().numpy()
+        seen.append(float(np.abs(o.collision_forces).max()))
+        if seen[-1] == 0.0:
+            assert np.abs(f).max() == 0.0
+        else:
+            assert np.allclose(f.sum(0), o.collision_forces.sum(0), rtol=1e-3, atol=np.abs(o.collision_forces).max() * 1e-3)
+    assert max(seen[:2]) > 0 and seen[-1] == 0.0, seen
+
+
 def test_batched_envs_are_independent_and_match_single():
     ob = make_object("rope", 500, seed=7, lift=0.1)
     import torch
