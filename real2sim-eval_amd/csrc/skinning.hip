@@ -11,6 +11,7 @@
 
 #include "r2s_common.h"
 #include "../../include/r2s_skinning.h"
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -120,21 +121,25 @@ __global__ void __launch_bounds__(256) k_bone_fit(int N, int k_rel, const int* _
 }
 
 // xyz' = sum_j w_j (R_bj (x - b_j) + m_j + b_j), transform_utils.py:178-189, in the reference's order of operations
-__global__ void __launch_bounds__(256) k_skin(int N, int P, int k_wgt, const float* __restrict__ weights, const int* __restrict__ widx,
-                                              const BoneRec* __restrict__ rec, const int* __restrict__ ident_flag,
+// Thread t works on point order[t]: the points are walked sorted by their first bone, so that neighbouring lanes (and
+// neighbouring workgroups) gather the same few 64-byte bone records — caller order has no locality (2.2 GB fetched per
+// call on the benchmark scene before, for 0.25 GB of algorithmic traffic).  weights / widx are stored [k][t] (coalesced).
+__global__ void __launch_bounds__(256) k_skin(int N, int P, int k_wgt, const int* __restrict__ order, const float* __restrict__ weights,
+                                              const int* __restrict__ widx, const BoneRec* __restrict__ rec, const int* __restrict__ ident_flag,
                                               const float* __restrict__ xyz, float* __restrict__ out)
 {
 #pragma clang fp contract(off)
-    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
-    if (pt >= P) return;
+    if (t >= P) return;
+    const int pt = order[t];
     const size_t ep = ((size_t)e * P + pt) * 3;
     const float x = xyz[ep], y = xyz[ep + 1], z = xyz[ep + 2];
     const bool ident = ident_flag[e] != 0;
     float ax = 0.f, ay = 0.f, az = 0.f;
     for (int k = 0; k < k_wgt; ++k) {
-        const int j = widx[(size_t)pt * k_wgt + k];
-        const float w = weights[(size_t)pt * k_wgt + k];
+        const int j = widx[(size_t)k * P + t];
+        const float w = weights[(size_t)k * P + t];
         const float4* q = reinterpret_cast<const float4*>(rec + (size_t)e * N + j);
         const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3]; // r0..r3 | r4..r7 | r8 b0 b1 b2 | m0 m1 m2 pad
         const float dx = x - q2.y, dy = y - q2.z, dz = z - q2.w;
@@ -155,7 +160,7 @@ __global__ void __launch_bounds__(256) k_skin(int N, int P, int k_wgt, const flo
 
 struct R2SSkin {
     int N = 0, k_rel = 0, P = 0, k_wgt = 0;
-    int *d_rel = nullptr, *d_widx = nullptr, *d_flag = nullptr;
+    int *d_rel = nullptr, *d_widx = nullptr, *d_flag = nullptr, *d_order = nullptr;
     float* d_w = nullptr;
     BoneRec* d_rec = nullptr;
     float* d_rot = nullptr; // debug copy
@@ -180,9 +185,20 @@ int r2s_skin_create(int32_t n_bones, int32_t k_rel, const int32_t* relations, in
     if (hipMalloc((void**)&h->d_widx, sizeof(int) * std::max<size_t>((size_t)n_points * k_wgt, 1)) != hipSuccess) return fail(R2S_ERR_ALLOC);
     if (hipMalloc((void**)&h->d_w, sizeof(float) * std::max<size_t>((size_t)n_points * k_wgt, 1)) != hipSuccess) return fail(R2S_ERR_ALLOC);
     R2S_HIP_TRY(hipMemcpyAsync(h->d_rel, relations, sizeof(int) * (size_t)n_bones * k_rel, hipMemcpyHostToDevice, s));
+    std::vector<int> order(n_points), widx_t((size_t)n_points * k_wgt);
+    std::vector<float> w_t((size_t)n_points * k_wgt);
     if (n_points > 0) {
-        R2S_HIP_TRY(hipMemcpyAsync(h->d_widx, weights_indices, sizeof(int) * (size_t)n_points * k_wgt, hipMemcpyHostToDevice, s));
-        R2S_HIP_TRY(hipMemcpyAsync(h->d_w, weights, sizeof(float) * (size_t)n_points * k_wgt, hipMemcpyHostToDevice, s));
+        if (hipMalloc((void**)&h->d_order, sizeof(int) * (size_t)n_points) != hipSuccess) return fail(R2S_ERR_ALLOC);
+        for (int i = 0; i < n_points; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weights_indices[(size_t)a * k_wgt] < weights_indices[(size_t)b * k_wgt]; });
+        for (int t = 0; t < n_points; ++t)
+            for (int k = 0; k < k_wgt; ++k) {
+                widx_t[(size_t)k * n_points + t] = weights_indices[(size_t)order[t] * k_wgt + k];
+                w_t[(size_t)k * n_points + t] = weights[(size_t)order[t] * k_wgt + k];
+            }
+        R2S_HIP_TRY(hipMemcpyAsync(h->d_order, order.data(), sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, s));
+        R2S_HIP_TRY(hipMemcpyAsync(h->d_widx, widx_t.data(), sizeof(int) * (size_t)n_points * k_wgt, hipMemcpyHostToDevice, s));
+        R2S_HIP_TRY(hipMemcpyAsync(h->d_w, w_t.data(), sizeof(float) * (size_t)n_points * k_wgt, hipMemcpyHostToDevice, s));
     }
     R2S_HIP_TRY(hipStreamSynchronize(s));
     *out = h;
@@ -193,7 +209,7 @@ void r2s_skin_destroy(R2SSkin* h)
 {
     if (!h) return;
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {h->d_rel, h->d_widx, h->d_w, h->d_flag, h->d_rec, h->d_rot};
+    void* ptrs[] = {h->d_rel, h->d_widx, h->d_w, h->d_flag, h->d_rec, h->d_rot, h->d_order};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
 }
@@ -215,7 +231,7 @@ int r2s_skin_interpolate_motions(R2SSkin* h, int32_t n_env, const float* bones, 
     R2S_HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int) * (size_t)n_env, s));
     hipLaunchKernelGGL(k_bone_fit, dim3((h->N + 255) / 256, n_env), dim3(256), 0, s, h->N, h->k_rel, h->d_rel, bones, motions, h->d_rec, h->d_flag);
     if (h->P > 0)
-        hipLaunchKernelGGL(k_skin, dim3((h->P + 255) / 256, n_env), dim3(256), 0, s, h->N, h->P, h->k_wgt, h->d_w, h->d_widx, h->d_rec, h->d_flag, xyz,
+        hipLaunchKernelGGL(k_skin, dim3((h->P + 255) / 256, n_env), dim3(256), 0, s, h->N, h->P, h->k_wgt, h->d_order, h->d_w, h->d_widx, h->d_rec, h->d_flag, xyz,
                            xyz_out);
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
