@@ -138,7 +138,8 @@ def main():
     # N > 1: slowest rank's time (MAX) and the metric all-gather of north_star — one fixed-size record per rank
     from r2s_hip import dist as rdist
     elapsed = rdist.max_over_ranks(elapsed, dev)
-    records = rdist.gather_records([ro.n_env, args.steps, elapsed * 1e3, float(ro.last_num_rendered)], dev)
+    n_success = int(ro.success_flags().sum().item())  # device-side task predicate (row f4); outside the timed region
+    records = rdist.gather_records([ro.n_env, args.steps, elapsed * 1e3, float(ro.last_num_rendered), float(n_success)], dev)
     total_envs = int(records[:, 0].sum().item())
 
     # stage timing of the raster pipeline (separate, untimed pass)
@@ -183,6 +184,9 @@ def main():
                                               "traffic": measured_traffic("k_composite", args.config) if ro.n_env == 32 else None,
                                               "note": "VALU/exp-bound in practice (SURVEY.md §7): HBM fraction reported as the contract asks"}},
             "physics_ms_per_env_step": phys_ms, "skinning_ms_per_env_step": skin_ms,
+            "task_success": {"envs_satisfying_predicate": int(records[:, 4].sum().item()), "of": total_envs,
+                             "note": "frame-level success predicate of the scene's task evaluated on the device after the last step "
+                                     "(synthetic action trace: not a policy result)"},
         }
         if not args.no_cpu_baseline and world == 1:
             try:

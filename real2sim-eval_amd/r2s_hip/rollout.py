@@ -44,6 +44,7 @@ class BatchedRollout:
         E = self.n_env
         ob = synth.phystwin_object(shape, n_particles, seed)
         self.ob = ob
+        self.ob_shape = shape
         pts = ob["points"]
         self.N, self.S = len(pts), len(ob["springs"])
         # per-env pose: grid randomisation stand-in — planar shifts of a few cm (cfg/gs/*.yaml patterns)
@@ -80,6 +81,9 @@ class BatchedRollout:
                               self_collision=self_collision, dynamic_meshes=dyn, static_meshes=sta, use_pusher=self.use_pusher,
                               collide_eef_fric=0.2 if self.use_pusher else 1.0, device=self.device)
         self.with_gripper = with_gripper
+        self._springs_dev = torch.from_numpy(np.ascontiguousarray(ob["springs"], np.int32)).to(self.device)
+        self._target_dev = torch.from_numpy(np.ascontiguousarray(pts + np.array([0.10, 0.0, 0.0], np.float32))).to(self.device)  # push-T goal: 10 cm along +x
+        self._box = (np.array([c[0] + 0.25, c[1] + 0.2, 0.135]), 0.5 * np.array([0.2, 0.13, 0.27]))
         # Gaussians: object splats ride on particles, table splats are static
         sc = synth.gaussian_scene(n_gauss, seed, object_points=pts)
         self.P = len(sc["means3D"])
@@ -170,6 +174,20 @@ class BatchedRollout:
         out = self.render()
         self.t += 1
         return out
+
+    # ---- task success of the current state, on the device (calculate_success_{rope,sloth,T}.py) -----------------------
+    def success_flags(self):
+        """bool [n_env]: the frame-level predicate of the scene's task, evaluated on the device-resident particle state."""
+        from . import metrics
+
+        x = self.phys.x
+        if self.ob_shape == "rope":
+            return metrics.rope_routed(x, self._springs_dev)
+        if self.ob_shape == "T":
+            return metrics.pusht_success(x, self._target_dev)
+        # sloth: >= 3050 of ~15k particles (the same fraction here) inside the box obstacle's OBB scaled by 1.05
+        c, half = self._box
+        return metrics.points_in_obb(x, c, np.eye(3), 1.05 * half) >= int(round(3050 / 15000 * self.N))
 
     # ---- accounting (SURVEY.md §8d) -------------------------------------------------------------------------------
     def physics_algorithmic_bytes_per_substep(self):

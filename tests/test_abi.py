@@ -11,7 +11,7 @@ LIB = os.path.join(ROOT, "real2sim-eval_amd", "libr2s_hip.so")
 
 def _declared():
     names = []
-    for h in ("r2s_raster.h", "r2s_physics.h", "r2s_skinning.h"):
+    for h in ("r2s_raster.h", "r2s_physics.h", "r2s_skinning.h", "r2s_metrics.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names += re.findall(r"\b(r2s_[a-z0-9_]+)\s*\(", src)
@@ -63,6 +63,12 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     S = skinning._bind()
     assert S.r2s_skin_create(0, 8, None, 0, 16, None, None, ctypes.byref(h), None) == -1
     assert S.r2s_skin_interpolate_motions(None, 1, None, None, None, None, None) == -1
+    from r2s_hip import metrics
+
+    M = metrics._bind()
+    assert M.r2s_metric_mse(0, 10, None, None, None, None) == -1
+    assert M.r2s_metric_plane_crossings(1, 10, None, 5, None, None, None, 1e-12, None, None) == -1
+    assert physics._bind().r2s_phys_set_eef_motion(None, None, None, None, None, None, None) == -1
 
 
 def test_product_package_never_imports_the_oracle():
