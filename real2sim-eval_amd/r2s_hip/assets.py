@@ -1,0 +1,188 @@
+"""Asset formats either side of the hot paths: the INRIA / Scaniverse Gaussian-splat PLY that
+``GSProcessor.load / save`` read and write (sim/utils/gs/gs_processor.py:59-171) and the PhysTwin case directory that
+``SpringMassDynamicsModule.__init__`` loads (sim/physics/phystwin.py:231-298).  Host code; the PLY codec is a
+self-contained numpy reader / writer of the binary_little_endian (and ascii) vertex element — the reference uses the
+``plyfile`` package, which this image does not have."""
+from __future__ import annotations
+
+import glob
+import os
+import pickle as pkl
+
+import numpy as np
+
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2",
+              "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+GS_FIELDS = (["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(45)] + ["opacity", "scale_0", "scale_1", "scale_2",
+             "rot_0", "rot_1", "rot_2", "rot_3"])   # property order GSProcessor.save writes (gs_processor.py:157-167)
+
+
+def read_ply_vertices(path) -> np.ndarray:
+    """The ``vertex`` element of a PLY file as a numpy structured array (scalar properties only)."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, elements, cur = None, [], None
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: unterminated PLY header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok or tok[0] in ("comment", "obj_info"):
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                cur = dict(name=tok[1], count=int(tok[2]), props=[])
+                elements.append(cur)
+            elif tok[0] == "property":
+                if tok[1] == "list":
+                    cur["props"].append(("list", tok[2], tok[3], tok[4]))
+                else:
+                    cur["props"].append((tok[2], _PLY_TYPES[tok[1]]))
+            elif tok[0] == "end_header":
+                break
+        if fmt not in ("binary_little_endian", "binary_big_endian", "ascii"):
+            raise ValueError(f"{path}: unsupported PLY format {fmt}")
+        for el in elements:
+            if any(p[0] == "list" for p in el["props"]):
+                if el["name"] == "vertex":
+                    raise ValueError(f"{path}: list properties in the vertex element are not supported")
+                break  # a list element before the vertices would need a walk; splat files put the vertices first
+            order = "<" if fmt != "binary_big_endian" else ">"
+            dt = np.dtype([(n, order + t) for n, t in el["props"]])
+            if fmt == "ascii":
+                rows = [f.readline().split() for _ in range(el["count"])]
+                arr = np.zeros(el["count"], dtype=dt)
+                for k, (n, _) in enumerate(el["props"]):
+                    arr[n] = np.array([r[k] for r in rows], dtype=np.float64).astype(dt[n])
+            else:
+                arr = np.frombuffer(f.read(dt.itemsize * el["count"]), dtype=dt, count=el["count"])
+            if el["name"] == "vertex":
+                return arr
+    raise ValueError(f"{path}: no vertex element")
+
+
+def write_ply_vertices(path, vertex: np.ndarray):
+    """binary_little_endian PLY with one ``vertex`` element, header laid out like plyfile writes it."""
+    names = {"f4": "float", "f8": "double", "u1": "uchar", "i1": "char", "i2": "short", "u2": "ushort", "i4": "int", "u4": "uint"}
+    v = np.ascontiguousarray(vertex.astype(vertex.dtype.newbyteorder("<")))
+    head = ["ply", "format binary_little_endian 1.0", f"element vertex {len(v)}"]
+    head += [f"property {names[v.dtype[n].str[1:]]} {n}" for n in v.dtype.names]
+    head.append("end_header")
+    with open(path, "wb") as f:
+        f.write(("\n".join(head) + "\n").encode("ascii"))
+        f.write(v.tobytes())
+
+
+def load_gaussians_ply(path, rot_x_minus90=False):
+    """``GSProcessor.load`` (gs_processor.py:59-100): dict of numpy float32 arrays means3D [n,3], sh_colors [n,48],
+    log_scales [n,3], unnorm_rotations [n,4] (w,x,y,z), logit_opacities [n,1]."""
+    v = read_ply_vertices(path)
+    col = lambda n: np.asarray(v[n], np.float32)  # noqa: E731
+    pts = np.stack([col("x"), col("y"), col("z")], -1)
+    sh = np.stack([col("f_dc_0"), col("f_dc_1"), col("f_dc_2")] + [col(f"f_rest_{i}") for i in range(45)], -1)
+    quats = np.stack([col(f"rot_{i}") for i in range(4)], -1)
+    if rot_x_minus90:  # make z the up axis (:88-92)
+        Rm = np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+        pts = np.dot(Rm, pts.T).T.astype(np.float32)
+        q0 = rot_mat_to_quat(Rm)
+        quats = np.stack([quat_mult(q0, q) for q in quats]).astype(np.float32) if len(quats) else quats
+    return dict(means3D=pts, sh_colors=sh, log_scales=np.stack([col(f"scale_{i}") for i in range(3)], -1), unnorm_rotations=quats,
+                logit_opacities=col("opacity")[:, None])
+
+
+def save_gaussians_ply(params, path):
+    """``GSProcessor.save`` (gs_processor.py:139-171)."""
+    n = len(params["means3D"])
+    colors = np.asarray(params["sh_colors"], np.float32).reshape(n, -1)
+    fields = ["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(colors.shape[1] - 3)] + GS_FIELDS[-8:]
+    out = np.zeros(n, dtype=[(f, "<f4") for f in fields])
+    data = np.concatenate([np.asarray(params["means3D"], np.float32), colors, np.asarray(params["logit_opacities"], np.float32).reshape(n, 1),
+                           np.asarray(params["log_scales"], np.float32), np.asarray(params["unnorm_rotations"], np.float32)], axis=1)
+    for k, f in enumerate(fields):
+        out[f] = data[:, k]
+    write_ply_vertices(path, out)
+
+
+def quat_mult(q1, q2):
+    """Hamilton product, (w, x, y, z)."""
+    w1, x1, y1, z1 = q1
+    w2, x2, y2, z2 = q2
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                     w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], np.float32)
+
+
+def rot_mat_to_quat(R):
+    """Rotation matrix -> unit quaternion (w, x, y, z), w >= 0 branch-stable form."""
+    R = np.asarray(R, np.float64)
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = np.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        q = [(R[2, 1] - R[1, 2]) / s, 0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s]
+    elif R[1, 1] > R[2, 2]:
+        s = np.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        q = [(R[0, 2] - R[2, 0]) / s, (R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s]
+    else:
+        s = np.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        q = [(R[1, 0] - R[0, 1]) / s, (R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s]
+    return np.asarray(q, np.float32)
+
+
+def render_inputs_from_params(params, use_shs=False):
+    """What GSRenderer hands to the rasteriser from loaded params (gs_renderer.py:897-917): normalised rotations,
+    exp(log_scales), sigmoid(logit_opacities), shs [n,1,3] (DC only) or [n,16,3]."""
+    q = np.asarray(params["unnorm_rotations"], np.float32)
+    q = q / np.maximum(np.linalg.norm(q, axis=-1, keepdims=True), 1e-12)
+    sh = np.asarray(params["sh_colors"], np.float32)
+    shs = (np.concatenate([sh[:, :3][:, None], sh[:, 3:].reshape(len(sh), 3, -1).transpose(0, 2, 1)], axis=1) if use_shs else sh[:, None, :3])
+    return dict(means3D=np.asarray(params["means3D"], np.float32), rotations=q.astype(np.float32), scales=np.exp(np.asarray(params["log_scales"], np.float32)),
+                opacities=(1.0 / (1.0 + np.exp(-np.asarray(params["logit_opacities"], np.float32)))).astype(np.float32), shs=np.ascontiguousarray(shs, np.float32))
+
+
+# ---- PhysTwin case directory ------------------------------------------------------------------------------------------
+_RENAMES = {"global_spring_Y": "init_spring_Y", "collide_object_elas": "collide_self_elas", "collide_object_fric": "collide_self_fric"}
+
+
+def load_phystwin_case(data_path, zeroth_order_ckpt_path, first_order_ckpt_path, case_name, init_pose=None, object_radius=0.02,
+                       object_max_neighbours=30):
+    """What SpringMassDynamicsModule.__init__ reads (phystwin.py:231-298):
+      {data_path}/{case}/final_data.pkl              object_points [T,N,3], surface_points, interior_points
+      {zeroth}/{case}/optimal_params.pkl             scalar physics parameters (renamed like :251-255)
+      {first}/{case}/train/best_*.pth                spring_Y (log stiffness), collide_*, num_object_springs
+    Returns dict(points float32 [n,3] (aligned by init_pose), springs int32 [S,2], rest float32 [S], spring_Y float32 [S],
+    collide_elas/fric, collide_self_elas/fric (float), params dict).  Springs are rebuilt with the reference's
+    procedure (hybrid radius / k-nearest search, de-duplicated, rest > 1e-4) and must number num_object_springs."""
+    import torch
+
+    from .synth import build_springs
+
+    with open(os.path.join(data_path, case_name, "final_data.pkl"), "rb") as f:
+        data = pkl.load(f)
+    object_pts = np.concatenate([np.asarray(data["object_points"])[0], np.asarray(data["surface_points"]), np.asarray(data["interior_points"])], axis=0)
+    pose = np.eye(4) if init_pose is None else np.asarray(init_pose, np.float64)
+    aligned = object_pts @ pose[:3, :3].T + pose[:3, 3]
+    with open(os.path.join(zeroth_order_ckpt_path, case_name, "optimal_params.pkl"), "rb") as f:
+        optimal = dict(pkl.load(f))
+    params = {_RENAMES.get(k, k): (v.item() if hasattr(v, "item") else v) for k, v in optimal.items()}
+    springs, _ = build_springs(object_pts, object_radius, object_max_neighbours)
+    keep = np.linalg.norm(aligned[springs[:, 0]] - aligned[springs[:, 1]], axis=1) > 1e-4
+    springs = springs[keep]
+    p32 = aligned.astype(np.float32)
+    rest = np.linalg.norm(p32[springs[:, 0]] - p32[springs[:, 1]], axis=1).astype(np.float32)
+    best = sorted(glob.glob(os.path.join(first_order_ckpt_path, case_name, "train", "best_*.pth")))
+    if not best:
+        raise FileNotFoundError(f"no best_*.pth under {first_order_ckpt_path}/{case_name}/train")
+    ck = torch.load(best[0], map_location="cpu", weights_only=False)
+    n_obj = int(ck["num_object_springs"])
+    if len(springs) != n_obj:
+        raise ValueError(f"{case_name}: rebuilt {len(springs)} springs, checkpoint has {n_obj} object springs")
+    sc = lambda k: float(np.asarray(ck[k].detach().cpu() if hasattr(ck[k], "detach") else ck[k]).reshape(-1)[0])  # noqa: E731
+    sy = ck["spring_Y"]
+    sy = (sy.detach().cpu().numpy() if hasattr(sy, "detach") else np.asarray(sy)).astype(np.float32)[:n_obj]
+    return dict(points=p32, springs=springs.astype(np.int32), rest=rest, spring_Y=sy, collide_elas=sc("collide_elas"), collide_fric=sc("collide_fric"),
+                collide_self_elas=sc("collide_object_elas"), collide_self_fric=sc("collide_object_fric"), params=params)

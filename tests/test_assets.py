@@ -1,0 +1,90 @@
+"""Asset formats (row f3): Gaussian-splat PLY codec and the PhysTwin case loader, exercised on synthetic files laid out
+like the reference's (gs_processor.py:59-171 property names and order; phystwin.py:231-298 file names and keys)."""
+import os
+import pickle as pkl
+
+import numpy as np
+
+from r2s_hip import assets, synth
+
+
+def _params(n=257, seed=0):
+    r = np.random.default_rng(seed)
+    return dict(means3D=r.normal(size=(n, 3)).astype(np.float32), sh_colors=r.normal(size=(n, 48)).astype(np.float32),
+                log_scales=r.normal(-5, 0.5, (n, 3)).astype(np.float32), unnorm_rotations=r.normal(size=(n, 4)).astype(np.float32),
+                logit_opacities=r.normal(size=(n, 1)).astype(np.float32))
+
+
+def test_ply_header_and_payload_are_the_inria_layout(tmp_path):
+    p = _params(3)
+    path = tmp_path / "g.ply"
+    assets.save_gaussians_ply(p, path)
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode().split("\n")
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 3"]
+    props = [l.split()[-1] for l in lines[3:] if l.startswith("property float ")]
+    assert props == assets.GS_FIELDS and len(props) == 59
+    rec = np.frombuffer(body, "<f4").reshape(3, 59)
+    assert np.array_equal(rec[:, :3], p["means3D"]) and np.array_equal(rec[:, 3:51], p["sh_colors"])
+    assert np.array_equal(rec[:, 51:52], p["logit_opacities"]) and np.array_equal(rec[:, 52:55], p["log_scales"]) and np.array_equal(rec[:, 55:], p["unnorm_rotations"])
+
+
+def test_ply_round_trip_binary_and_ascii_and_extra_properties(tmp_path):
+    p = _params()
+    path = tmp_path / "g.ply"
+    assets.save_gaussians_ply(p, path)
+    q = assets.load_gaussians_ply(path)
+    for k in p:
+        assert np.array_equal(p[k], q[k]), k
+    # Scaniverse-style file: extra normals, shuffled property order, ascii
+    names = ["x", "y", "z", "nx", "ny", "nz"] + assets.GS_FIELDS[3:][::-1]
+    with open(tmp_path / "a.ply", "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment made by a test\nelement vertex 2\n" + "".join(f"property float {n}\n" for n in names) + "end_header\n")
+        flat = {n: None for n in names}
+        for i in range(2):
+            vals = dict(zip(assets.GS_FIELDS, np.concatenate([p["means3D"][i], p["sh_colors"][i], p["logit_opacities"][i], p["log_scales"][i], p["unnorm_rotations"][i]])))
+            vals.update(nx=0.0, ny=0.0, nz=1.0)
+            f.write(" ".join(repr(float(vals[n])) for n in names) + "\n")
+    a = assets.load_gaussians_ply(tmp_path / "a.ply")
+    for k in p:
+        assert np.array_equal(p[k][:2], a[k]), k
+
+
+def test_rot_x_minus90_makes_z_up_and_render_inputs_are_activated(tmp_path):
+    p = _params(5)
+    p["unnorm_rotations"] = np.tile(np.array([[1.0, 0, 0, 0]], np.float32), (5, 1))
+    assets.save_gaussians_ply(p, tmp_path / "g.ply")
+    q = assets.load_gaussians_ply(tmp_path / "g.ply", rot_x_minus90=True)
+    assert np.allclose(q["means3D"], np.stack([p["means3D"][:, 0], -p["means3D"][:, 2], p["means3D"][:, 1]], -1))
+    Rq = q["unnorm_rotations"][0]
+    assert np.allclose(Rq, assets.rot_mat_to_quat(np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]])), atol=1e-6) and abs(np.linalg.norm(Rq) - 1) < 1e-6
+    r = assets.render_inputs_from_params(q)
+    assert r["shs"].shape == (5, 1, 3) and np.allclose(np.linalg.norm(r["rotations"], axis=1), 1, atol=1e-6)
+    assert np.allclose(r["scales"], np.exp(q["log_scales"])) and ((r["opacities"] > 0) & (r["opacities"] < 1)).all()
+    assert assets.render_inputs_from_params(q, use_shs=True)["shs"].shape == (5, 16, 3)
+
+
+def test_phystwin_case_directory_round_trip(tmp_path):
+    import torch
+
+    ob = synth.phystwin_object("rope", 400, 3)
+    pts = ob["points"].astype(np.float64)
+    n0 = 250
+    case = "demo_case"
+    for d in ("data", "zeroth", "first"):
+        os.makedirs(tmp_path / d / case / ("train" if d == "first" else ""), exist_ok=True)
+    with open(tmp_path / "data" / case / "final_data.pkl", "wb") as f:
+        pkl.dump(dict(object_points=pts[None, :n0], object_colors=np.zeros((1, n0, 3)), surface_points=pts[n0:330], interior_points=pts[330:]), f)
+    with open(tmp_path / "zeroth" / case / "optimal_params.pkl", "wb") as f:
+        pkl.dump(dict(global_spring_Y=3000.0, collide_object_elas=0.4, collide_object_fric=0.2, drag_damping=3.0), f)
+    springs, rest = synth.build_springs(pts)
+    torch.save(dict(spring_Y=torch.cat([torch.from_numpy(ob["log_Y"]), torch.zeros(17)]), collide_elas=torch.tensor([0.5]), collide_fric=torch.tensor([0.3]),
+                    collide_object_elas=torch.tensor([0.6]), collide_object_fric=torch.tensor([0.1]), num_object_springs=len(springs)),
+               tmp_path / "first" / case / "train" / "best_12.pth")
+    pose = np.eye(4); pose[:3, 3] = (0.1, -0.2, 0.05)
+    out = assets.load_phystwin_case(tmp_path / "data", tmp_path / "zeroth", tmp_path / "first", case, init_pose=pose)
+    assert np.allclose(out["points"], (pts + pose[:3, 3]).astype(np.float32)) and np.array_equal(out["springs"], springs)
+    assert np.allclose(out["rest"], rest, atol=1e-6) and np.array_equal(out["spring_Y"], ob["log_Y"])        # control springs dropped
+    assert out["params"]["init_spring_Y"] == 3000.0 and out["params"]["collide_self_elas"] == 0.4 and "global_spring_Y" not in out["params"]
+    assert (out["collide_elas"], out["collide_fric"]) == (0.5, 0.30000001192092896) and out["collide_self_fric"] == 0.10000000149011612
