@@ -163,6 +163,7 @@ def main():
         value = total_envs * args.steps / elapsed
         t_kernel = phys_ms * 1e-3 / max(phys_kernels, 1)
         alg_bytes = ro.physics_algorithmic_bytes_per_substep()
+        chains = ro.phys.layout_stats()["chains"]
         achieved = alg_bytes / t_kernel / 1e9
         comp_bytes = ro.composite_algorithmic_bytes()
         comp_gbs = comp_bytes / (stages["composite"] * 1e-3) / 1e9 if stages["composite"] > 0 else 0.0
@@ -176,7 +177,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic("k_substep", args.config) if (ro.n_env == 32 and args.substeps == 667) else None,
                          "kernel": "k_substep (fused spring gather + velocity + collisions + integrate)",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": t_kernel * 1e6, "launches": phys_kernels},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": t_kernel * 1e6, "launches": phys_kernels,
+                         "concurrent_chains": chains,
+                         "note": f"one 'launch' = one batched substep of all {ro.n_env} envs; it is issued as {chains} concurrent kernels over disjoint "
+                                 "env ranges, so rocprofv3's per-kernel durations overlap in time (sum > wall clock); avg_launch_us is the HIP-event "
+                                 "time of the 667-substep graph / 667.  profiles/ holds the trace for R2S_CHAINS=1 as well, where both agree"},
             "raster": {"gs_raster_mpix_per_s": frames * ro.W * ro.H / (raster_ms * 1e-3) / 1e6, "frames": frames,
                        "num_rendered": int(ro.last_num_rendered), "stage_ms": stages,
                        "composite_roofline": {"bound": "hbm", "achieved": comp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -146,7 +146,7 @@ int r2s_phys_set_params(R2SPhys* h, const R2SPhysParams* params, r2s_stream_t st
 
 /* Layout report (DESIGN.md / bench.py): out[0] particle blocks, [1] largest halo (records), [2] ELL slots incl.
  * padding, [3] real neighbour slots (= 2 * active springs), [4] slots served by the global fallback instead of LDS,
- * [5] LDS bytes per workgroup, [6] slices, [7] blocks per XCD chunk. */
+ * [5] LDS bytes per workgroup, [6] concurrent kernel chains of the captured env step, [7] work items per XCD chunk. */
 int r2s_phys_layout_stats(R2SPhys* h, int64_t* out);
 
 /* Measurement hook for bench.py: HIP-event time (ms) of the last r2s_phys_step on its stream and

@@ -59,6 +59,7 @@ struct PhysDev {
     int N, E, n_sub;
     // topology (shared by all envs); all particle indices are INTERNAL (Morton order)
     int nb, cb;                // particle blocks; (block, env) work items per XCD
+    int e0, ne;                // environments [e0, e0 + ne) handled by this launch (an env-step may run as parallel chains)
     const int* slice_off;      // [n_slices] first slot of a 64-particle slice (a multiple of 64 * GROUP)
     const int* slice_deg;      // [n_slices] slots per particle of the slice (a multiple of GROUP)
     // sliced ELL, 10 B per slot in three planes, GROUP-major: the 4 slots n = 4g..4g+3 of lane l of a slice sit together
@@ -677,9 +678,9 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __r
     __shared__ __attribute__((aligned(16))) v2f win_s[3 * RCAP]; // planes xy | (z, vz) | vxy, 24 B per record
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int item = xcd * p.cb + q;
-    if (q >= p.cb || item >= p.nb * p.E) return; // whole workgroup
+    if (q >= p.cb || item >= p.nb * p.ne) return; // whole workgroup
     R2S_STAMP(0);
-    const int b = item / p.E, e = item - b * p.E;
+    const int b = item / p.ne, e = p.e0 + (item - b * p.ne);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int i = b * B + tid;
@@ -763,8 +764,8 @@ __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const floa
     // wave-uniform trip count: every lane of a wavefront reaches the cooperative mesh queries of finish_wave together
     for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
         const int t = base + (int)threadIdx.x;
-        const bool act = t < n;
-        const int2 ei = p.cand_list[act ? t : 0];
+        const int2 ei = p.cand_list[t < n ? t : 0];
+        const bool act = t < n && ei.x >= p.e0 && ei.x < p.e0 + p.ne; // this chain's environments only
         const int e = ei.x, i = ei.y;
         const size_t eb = (size_t)e * p.N;
         const f3 x0 = xyz(xv_in[(eb + i) * 2]);
@@ -1301,6 +1302,12 @@ struct R2SPhys {
     bool cand_pending = false;
     int n_cand = 0;              // particles with candidates after the last update (host view)
     int graph_cand_cap = 0, n_cand_launch = 0;
+    int chains() const // parallel kernel chains of the captured env step (measured: 23.5 / 21.3 / 22.4 / 23.2 us per substep for 1 / 2 / 3 / 4)
+    {
+        int c = E >= 8 ? 2 : 1;
+        if (const char* ev = getenv("R2S_CHAINS")) c = std::max(1, std::min(atoi(ev), std::min(E, 8))); // tuning knob
+        return c;
+    }
     uint32_t *d_bits = nullptr, *d_keys[2] = {nullptr, nullptr}, *d_ids[2] = {nullptr, nullptr};
     int2* d_cell_tab = nullptr;  // [E << 21] direct cell table (null when it would exceed 4 GiB: binary search instead)
     float4* d_cell_xs = nullptr; // [E,N] sorted positions + internal index
@@ -1325,9 +1332,10 @@ struct R2SPhys {
     // graph
     // two captured variants of the num_substeps step: [0] no particle has candidates (one kernel per substep),
     // [1] some do (fused kernel + self-collision finishing kernel per substep)
-    hipGraph_t graph[2] = {nullptr, nullptr};
-    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
-    int graph_start_buf[2] = {-1, -1};
+    // slot = variant * 2 + start buffer: with an odd substep count (667) the state buffer flips every env step, so both
+    // parities are kept instead of re-capturing 667 nodes per step
+    hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1338,7 +1346,7 @@ struct R2SPhys {
     {
         PhysDev p{};
         p.N = N; p.E = E; p.n_sub = prm.num_substeps;
-        p.nb = nb; p.cb = cb;
+        p.nb = nb; p.cb = cb; p.e0 = 0; p.ne = E;
         p.slice_off = d_slice_off; p.slice_deg = d_slice_deg; p.adj_idx = (const uint2*)d_adj_idx; p.adj_k = (const float4*)d_adj_k; p.adj_ir = (const float4*)d_adj_ir; p.rslice_off = d_rslice_off; p.rslice_deg = d_rslice_deg; p.radj = d_radj;
         p.halo_off = d_halo_off; p.halo_ids = d_halo_ids; p.perm = d_perm; p.inv = d_inv;
         p.masses = d_masses; p.masks = d_masks;
@@ -1440,7 +1448,7 @@ void launch_substep_layout(const PhysDev& p, dim3 grid, const float4* in, float4
 
 int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, hipStream_t s)
 {
-    dim3 grid(8u * (unsigned)h->cb);
+    dim3 grid(8u * (unsigned)p.cb);
     const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
     const float4* in = h->xv[in_buf];
     float4* out = h->xv[in_buf ^ 1];
@@ -1466,15 +1474,17 @@ __global__ void k_zero_f32(float* __restrict__ p, size_t n)
     if (i < n) p[i] = 0.f;
 }
 
-int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, hipStream_t s)
+int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, hipStream_t s, int e0 = 0, int ne = -1, bool zero_forces = true)
 {
-    const PhysDev p = h->dev();
+    PhysDev p = h->dev();
+    if (ne < 0) ne = h->E;
+    p.e0 = e0; p.ne = ne; p.cb = (h->nb * ne + 7) / 8;
     int buf = start_buf;
     for (int k = 0; k < n; ++k) {
         const int last = (k == n - 1);
-        if (last && h->nF > 0) {
-            const size_t cnt = 3 * (size_t)h->E * h->nF;
-            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->d_coll_forces, cnt);
+        if (last && h->nF > 0 && zero_forces) { // this chain's slice of the accumulator
+            const size_t cnt = 3 * (size_t)ne * h->nF;
+            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->d_coll_forces + 3 * (size_t)e0 * h->nF, cnt);
         }
         int rc = launch_substep(h, p, buf, first + k, last, with_self, s);
         if (rc) return rc;
@@ -1485,10 +1495,10 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
 
 void drop_graph(R2SPhys* h)
 {
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < 4; ++v) {
         if (h->graph_exec[v]) (void)hipGraphExecDestroy(h->graph_exec[v]);
         if (h->graph[v]) (void)hipGraphDestroy(h->graph[v]);
-        h->graph_exec[v] = nullptr; h->graph[v] = nullptr; h->graph_start_buf[v] = -1;
+        h->graph_exec[v] = nullptr; h->graph[v] = nullptr;
     }
 }
 
@@ -1496,21 +1506,52 @@ void drop_graph_fwd(R2SPhys* h) { drop_graph(h); }
 
 int capture_graph(R2SPhys* h, int variant, int start_buf)
 {
-    if (h->graph_exec[variant]) (void)hipGraphExecDestroy(h->graph_exec[variant]);
-    if (h->graph[variant]) (void)hipGraphDestroy(h->graph[variant]);
-    h->graph_exec[variant] = nullptr; h->graph[variant] = nullptr; h->graph_start_buf[variant] = -1;
+    const int slot = variant * 2 + (start_buf & 1);
+    if (h->graph_exec[slot]) (void)hipGraphExecDestroy(h->graph_exec[slot]);
+    if (h->graph[slot]) (void)hipGraphDestroy(h->graph[slot]);
+    h->graph_exec[slot] = nullptr; h->graph[slot] = nullptr;
     hipStream_t cs;
     R2S_HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     R2S_HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_steps(h, 0, h->prm.num_substeps, start_buf, variant == 1, cs);
+    // Environments are independent, so the env step is captured as `chains` parallel kernel chains over disjoint
+    // environment ranges: while one chain's workgroups stage their windows (memory phase, VALU idle) or sit in the launch
+    // gap between two substeps, another chain's are in the gather (VALU phase).
+    const int chains = h->chains();
+    int rc = R2S_OK;
+    std::vector<hipStream_t> side;
+    std::vector<hipEvent_t> evs;
+    hipEvent_t fork = nullptr;
+    if (chains > 1) {
+        R2S_HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        R2S_HIP_TRY(hipEventRecord(fork, cs));
+    }
+    for (int c = 0; c < chains && rc == R2S_OK; ++c) {
+        const int e0 = (int)((int64_t)h->E * c / chains), e1 = (int)((int64_t)h->E * (c + 1) / chains);
+        hipStream_t st = cs;
+        if (c > 0) {
+            R2S_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            side.push_back(st);
+            R2S_HIP_TRY(hipStreamWaitEvent(st, fork, 0));
+        }
+        rc = enqueue_steps(h, 0, h->prm.num_substeps, start_buf, variant == 1, st, e0, e1 - e0);
+        if (c > 0 && rc == R2S_OK) {
+            hipEvent_t j;
+            R2S_HIP_TRY(hipEventCreateWithFlags(&j, hipEventDisableTiming));
+            evs.push_back(j);
+            R2S_HIP_TRY(hipEventRecord(j, st));
+            R2S_HIP_TRY(hipStreamWaitEvent(cs, j, 0));
+        }
+    }
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(cs, &g);
+    for (hipStream_t st : side) (void)hipStreamDestroy(st);
+    for (hipEvent_t j : evs) (void)hipEventDestroy(j);
+    if (fork) (void)hipEventDestroy(fork);
     (void)hipStreamDestroy(cs);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     R2S_HIP_TRY(e);
-    h->graph[variant] = g;
-    R2S_HIP_TRY(hipGraphInstantiate(&h->graph_exec[variant], g, nullptr, nullptr, 0));
-    h->graph_start_buf[variant] = start_buf;
+    h->graph[slot] = g;
+    R2S_HIP_TRY(hipGraphInstantiate(&h->graph_exec[slot], g, nullptr, nullptr, 0));
     return R2S_OK;
 }
 
@@ -2178,8 +2219,12 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     const int variant = (h->prm.self_collision && h->n_cand > 0) ? 1 : 0;
     if (use_graph) {
         // variant 1 bakes a grid size derived from n_cand: re-capture if the list outgrew it
-        const bool stale = variant == 1 && h->graph_exec[1] && h->n_cand > h->graph_cand_cap;
-        if (!h->graph_exec[variant] || h->graph_start_buf[variant] != h->cur || stale) {
+        const int slot = variant * 2 + (h->cur & 1);
+        const bool stale = variant == 1 && h->n_cand > h->graph_cand_cap;
+        if (stale) { // both parities of the self-collision variant bake the old grid size
+            for (int k = 2; k < 4; ++k) if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); (void)hipGraphDestroy(h->graph[k]); h->graph_exec[k] = nullptr; h->graph[k] = nullptr; }
+        }
+        if (!h->graph_exec[slot]) {
             if (variant == 1) h->graph_cand_cap = std::max(h->n_cand * 2, 4096), h->n_cand_launch = h->graph_cand_cap;
             const int keep = h->n_cand;
             if (variant == 1) h->n_cand = h->graph_cand_cap; // size the finishing grid generously
@@ -2187,7 +2232,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
             h->n_cand = keep;
             if (rc) return rc;
         }
-        R2S_HIP_TRY(hipGraphLaunch(h->graph_exec[variant], s));
+        R2S_HIP_TRY(hipGraphLaunch(h->graph_exec[slot], s));
     } else {
         int rc = enqueue_steps(h, first_substep, n, h->cur, variant == 1, s);
         if (rc) return rc;
@@ -2264,7 +2309,7 @@ int r2s_phys_layout_stats(R2SPhys* h, int64_t* out /* [8] */)
     for (int t = 0; t < h->ell_len; ++t) if (h->h_adj_spring[t] >= 0) ++real;
     for (int t = 0; t < h->rell_len; ++t) if (h->h_radj_spring[t] >= 0) { ++real; ++fallback; }
     out[0] = h->nb; out[1] = h->halo_max; out[2] = h->ell_len + h->rell_len; out[3] = real; out[4] = fallback;
-    out[5] = (int64_t)h->rcap * 24; out[6] = h->n_slices; out[7] = h->cb;
+    out[5] = (int64_t)h->rcap * 24; out[6] = h->chains(); out[7] = h->cb;
     return R2S_OK;
 }
 

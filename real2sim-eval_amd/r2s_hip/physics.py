@@ -316,7 +316,7 @@ class PhysBatch:
     def layout_stats(self):
         a = (C.c_int64 * 8)()
         check(_bind().r2s_phys_layout_stats(self._h, a), "r2s_phys_layout_stats")
-        k = ["blocks", "halo_max", "ell_slots", "neighbour_slots", "fallback_slots", "lds_bytes", "slices", "blocks_per_xcd"]
+        k = ["blocks", "halo_max", "ell_slots", "neighbour_slots", "fallback_slots", "lds_bytes", "chains", "blocks_per_xcd"]
         return dict(zip(k, [int(v) for v in a]))
 
     def set_timing(self, on: bool):
