@@ -345,6 +345,15 @@ __global__ void __launch_bounds__(256) k_tile_ranges(uint32_t L, const uint32_t*
 #ifndef R2S_COMP
 #define R2S_COMP 2
 #endif
+#ifdef R2S_COMP_STATS // instrumented build (scratch/comp_stats.py): lane efficiency of the compositor
+__device__ unsigned long long g_comp_stats[4]; // wave iterations, hit lanes, iterations without a hit, lanes still alive
+extern "C" int r2s_raster_debug_comp_stats(unsigned long long* out, int reset)
+{
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_comp_stats), 32);
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_comp_stats), z, 32); }
+    return rc;
+}
+#endif
 __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __restrict__ frames, int gx, int gy, int W, int H,
                                                             const uint2* __restrict__ ranges,
                                                             const uint32_t* __restrict__ point_list,
@@ -457,6 +466,13 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                 const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
                 // forward.cu:344-351 as one predicate: power > 0 and alpha < 1/255 skip the instance for this pixel
                 const bool hit = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+#ifdef R2S_COMP_STATS
+                {
+                    const unsigned long long hb = __builtin_amdgcn_ballot_w64(hit), ab = __builtin_amdgcn_ballot_w64(!done);
+                    if (lane == 0) { atomicAdd(&g_comp_stats[0], 1ull); atomicAdd(&g_comp_stats[1], (unsigned long long)__builtin_popcountll(hb));
+                                     atomicAdd(&g_comp_stats[2], hb == 0 ? 1ull : 0ull); atomicAdd(&g_comp_stats[3], (unsigned long long)__builtin_popcountll(ab)); }
+                }
+#endif
                 if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
                 const float test_T = T * (1.f - alpha);
                 const bool term = hit && test_T < 0.0001f;
