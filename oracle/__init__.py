@@ -5,9 +5,14 @@ rasteriser forward pass and PhysTwin spring-mass stepper.  Only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
 package; nothing under ``real2sim-eval_amd/`` does.
 
-PARITY UNPINNED: the reference has no tests or golden vectors and can be neither built
-nor imported in the authoring container.  The restatement is pinned by
-the builder-authored known-answer tests in ``tests/test_*_kat.py``.
+PARITY: the reference has no tests or golden vectors and can be neither built nor
+imported as a whole in the authoring container.
+ * rasteriser kernels: PARITY UNPINNED (CUDA C++ + GLM, unbuildable here) — builder-authored
+   known-answer tests (``tests/test_raster_oracle_kat.py``); the camera builder is pinned
+   (``tests/golden/camera_side_848x480.json``, made by the reference's own setup_camera);
+ * physics stepper: arithmetic kernels pinned by fixtures made by executing the reference's
+   kernel bodies through a float32 shim (``tests/golden/physics_kernels.npz``); warp's HashGrid
+   traversal and mesh query: PARITY UNPINNED (restated, ``tests/test_physics_oracle_kat.py``).
 """
 from __future__ import annotations
 

@@ -4,6 +4,8 @@
 Tolerance (BASELINE.json north_star): particle positions within 1e-5 abs.  The reference sums spring forces
 with float atomics in a non-deterministic order; the HIP path sums in adjacency order and the oracle in
 spring order, so agreement is to rounding, not bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -257,3 +259,38 @@ def test_pusher_25k_face_mesh_cluster_query_vs_oracle():
     f = h.collision_forces()[0].cpu().numpy()
     tot_o, tot_h = o.collision_forces.sum(0), f.sum(0)
     assert np.allclose(tot_h, tot_o, rtol=2e-3, atol=np.abs(tot_o).max() * 2e-3), (tot_o, tot_h)
+
+
+def test_hip_stepper_matches_fixtures_from_the_reference_kernel_bodies():
+    """tests/golden/physics_kernels.npz was produced by executing the reference's own kernel source (make_physics_golden.py):
+    the HIP stepper reproduces the springs / gate / ground trajectory (A) and the finger + static-box contact trajectory with
+    per-face forces (C)."""
+    import torch
+
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "physics_kernels.npz"))
+    obA = dict(points=G["A_x0"], springs=G["A_springs"], rest=G["A_rest"], log_Y=G["A_logY"], v0=G["A_v0"])
+    n = len(G["A_x_traj"])
+    h = hip_env(obA, num_substeps=n, self_collision=False, spring_Y_min=float(G["A_Ymin"]))
+    for k in range(n):
+        h.step(1, k)
+        assert np.abs(h.x[0].cpu().numpy() - G["A_x_traj"][k]).max() < 2e-6, k
+        assert np.abs(h.v[0].cpu().numpy() - G["A_v_traj"][k]).max() < 2e-4, k
+    n_dyn = int(G["C_n_dyn"])
+    verts, faces, mm = G["C_verts"], G["C_faces"], G["C_mesh_map"]
+    nl, nr = int((mm == 0).sum()), int((mm == 1).sum())
+    vl = int(faces[:nl].max()) + 1
+    dyn = [(verts[:vl], faces[:nl]), (verts[vl:n_dyn], faces[nl:nl + nr] - vl)]
+    sta = [(verts[n_dyn:], faces[nl + nr:] - n_dyn)]
+    obC = dict(points=G["C_x0"], springs=G["C_springs"], rest=G["C_rest"], log_Y=G["C_logY"], v0=G["C_v0"])
+    n = len(G["C_x_traj"])
+    h = hip_env(obC, num_substeps=n, self_collision=False, dynamic_meshes=dyn, static_meshes=sta, collide_eef_elas=0.5, collide_eef_fric=1.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None].cuda()  # noqa: E731
+    h.set_mesh_interactive(t(G["C_interp"]), t(G["C_centers"]), t(G["C_dyn_vel"]), t(G["C_dyn_omega"]))
+    for k in range(n):
+        h.step(1, k)
+        assert np.abs(h.x[0].cpu().numpy() - G["C_x_traj"][k]).max() < 2e-6, k
+        assert np.abs(h.v[0].cpu().numpy() - G["C_v_traj"][k]).max() < 2e-3, k
+    # forces of the last substep: per-finger / per-mesh totals (the per-face split has genuine ties, see above)
+    f, ref = h.collision_forces()[0].cpu().numpy(), G["C_forces_traj"][-1]
+    for m in (0, 1, -1):
+        assert np.allclose(f[mm == m].sum(0), ref[mm == m].sum(0), rtol=2e-3, atol=1e-3 * max(1.0, np.abs(ref).max())), m
