@@ -86,7 +86,11 @@ struct PhysDev {
     const int* coll_num;       // [E,N]
     const int* coll_idx;       // [E,N,cap]
     int coll_cap;
-    float4* vbc;               // [E,N] v_before_collision published by particles that have candidates
+    float4* vbc;               // [E,N] v_before_collision published by particles that have candidates; also the velocity of
+                               // particles whose large-mesh query is deferred to k_mesh_finish
+    int2* mesh_list;           // (env, particle) of the particles deferred in this substep (one list per chain, reused)
+    int* mesh_cnt;             // [n_sub] entries of mesh_list per substep (zeroed once per env step)
+    int mesh_cap, mesh_defer;  // defer = 1: needy particles go to the list; 0: they are only counted and queried in place
     const int2* cand_list;     // (env, particle) of every particle with candidates
     const int* cand_count;
     // meshes
@@ -107,6 +111,8 @@ struct PhysDev {
     const int* xf_mesh;        // [n_xf] mesh of a transform slot
     const float* xf;           // [E,n_sub,n_xf,12]
     const float* rest_pts;     // [nV,3] vertices at construction (= rest frame of rigid meshes)
+    const float* tri_rest;     // [nF,9] rest-frame corners of every stored face (one load instead of index -> vertex)
+    const int4* cl_info;       // [n_cl] {mesh, kind, transform slot of the mesh (-1 none), 0}: one load instead of three dependent ones
     const float* pnorm;        // [nF,7,3] pseudonormals of stored faces of large meshes: face, a, b, c, ab, bc, ca
     const float* mesh_pts;     // [E,nV,3] (static part is live; dynamic part = positions at t=0)
     const float* interp_pts;   // [E,n_sub,n_dyn_pts,3]
@@ -292,13 +298,14 @@ __device__ MeshHit mesh_query_wave(const PhysDev& p, int step, f3 q_lane, int e_
         if (p.n_xf > 1) q_rest1 = xf_inverse(xf_load(p, e, step, p.xf_mesh[1]), q);
         auto cluster_d2 = [&](int c) -> float {
             if (c >= p.n_cl) return 3.0e38f;
-            const int m = p.cl_mesh[c];
-            if (p.mesh_kind[m] == 0) {
+            const int4 ci = p.cl_info[c];
+            const int m = ci.x;
+            if (ci.y == 0) {
                 const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
                                                    : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
                 return box_dist2(q, bb);
             }
-            const int k = p.mesh_xf[m];
+            const int k = ci.z;
             const f3 qr = k < 0 ? q : (k == 0 ? q_rest0 : (k == 1 ? q_rest1 : xf_inverse(xf_load(p, e, step, m), q)));
             return box_dist2(qr, p.cl_box + (size_t)c * 6);
         };
@@ -334,10 +341,14 @@ __device__ MeshHit mesh_query_wave(const PhysDev& p, int step, f3 q_lane, int e_
                     int region = 0;
                     f3 cp = mk(0.f, 0.f, 0.f);
                     if (f < f1) {
-                        const int ia = p.faces[3 * f], ib = p.faces[3 * f + 1], ic = p.faces[3 * f + 2];
-                        const f3 a = large ? ld3(p.rest_pts, ia) : mesh_vertex(p, e, step, ia);
-                        const f3 b = large ? ld3(p.rest_pts, ib) : mesh_vertex(p, e, step, ib);
-                        const f3 c3 = large ? ld3(p.rest_pts, ic) : mesh_vertex(p, e, step, ic);
+                        f3 a, b, c3;
+                        if (large) {
+                            const float* t9 = p.tri_rest + (size_t)f * 9;
+                            a = mk(t9[0], t9[1], t9[2]); b = mk(t9[3], t9[4], t9[5]); c3 = mk(t9[6], t9[7], t9[8]);
+                        } else {
+                            const int ia = p.faces[3 * f], ib = p.faces[3 * f + 1], ic = p.faces[3 * f + 2];
+                            a = mesh_vertex(p, e, step, ia); b = mesh_vertex(p, e, step, ib); c3 = mesh_vertex(p, e, step, ic);
+                        }
                         closest_bary(a, b, c3, qq, u, v, region);
                         cp = a * u + b * v + c3 * (1.f - u - v);
                         const f3 d = cp - qq;
@@ -522,7 +533,11 @@ __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* _
 // Called by EVERY lane of a wavefront at the same point (the mesh queries inside are wave-cooperative); `fin` says
 // whether this lane has a particle to finish.  Shared by the fused substep and the self-collision finishing kernel.
 // MESH: 0 no meshes, 1 small meshes only (per-lane queries), 2 a large mesh is present (wave-cooperative queries)
-template <int MESH>
+// MAIN + p.mesh_defer (large-mesh scenes, main kernel only): a particle that needs a mesh query is not queried here — a wave-cooperative
+// query costs ~5 us of dependent round trips and the particles that need one sit next to each other, so one wavefront
+// would run dozens back to back while the rest of the chip waits.  It publishes its velocity, appends itself to the
+// substep's list and is finished by k_mesh_finish, one WAVEFRONT per particle, all of them in flight at once.
+template <int MESH, bool MAIN = false>
 __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v, bool fin,
                                             float4* __restrict__ xv_out)
 {
@@ -543,6 +558,19 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
                                                    : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
                 const float mg = (m < p.n_dyn_mesh && !p.use_pusher) ? 0.005f : 0.001f;
                 need = need || box_dist2(next_x, bb) < mg * mg * 1.0001f;
+            }
+        }
+        if (MAIN) { // main kernel of a large-mesh scene: count the particles that need a query (the host picks next step's
+                    // graph from the total) and, in deferring mode, hand them to k_mesh_finish
+            if (need) {
+                const int slot = atomicAdd(p.mesh_cnt + step, 1);
+                if (p.mesh_defer && slot < p.mesh_cap) {
+                    p.vbc[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
+                    p.mesh_list[slot] = make_int2(e, i);
+                    fin = false; // finished by k_mesh_finish
+                    need = false;
+                }
+                // list full (never with the sizing below): fall through to the in-place query
             }
         }
         MeshHit q = MESH == 2 ? mesh_query_wave(p, step, next_x, e, need) // wave-cooperative, convergent call site 1
@@ -745,7 +773,7 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __r
             fin = false; // finished by k_self_finish
         }
     }
-    finish_wave<MESH>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out);
+    finish_wave<MESH, MESH == 2>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out);
     R2S_STAMP(3);
 }
 
@@ -802,6 +830,31 @@ __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const floa
         }
         finish_wave<MESH>(p, e, i, eb, step, write_forces, x0, v, act, xv_out);
     }
+}
+
+// The particles the main kernel deferred (large-mesh scenes): one wavefront per particle — lane 0 carries it through
+// finish_wave, the other 63 lanes only lend their hands to the cooperative queries.
+__global__ void __launch_bounds__(256) k_mesh_finish(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
+                                                     int write_forces)
+{
+    const int n = min(p.mesh_cnt[step], p.mesh_cap);
+    const int lane = (int)(threadIdx.x & 63), wpb = (int)(blockDim.x >> 6);
+    for (int t = blockIdx.x * wpb + (int)(threadIdx.x >> 6); t < n; t += gridDim.x * wpb) {
+        const int2 ei = p.mesh_list[t];
+        const int e = ei.x, i = ei.y;
+        const size_t eb = (size_t)e * p.N;
+        const f3 x0 = xyz(xv_in[(eb + i) * 2]);
+        const f3 v = xyz(p.vbc[eb + i]);
+        finish_wave<2, false>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out);
+    }
+}
+
+__global__ void k_sum_i32(const int* __restrict__ a, int n, int* __restrict__ out)
+{
+    int s = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += a[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
 // ---- state pack / unpack: caller order [env][user index][3]  <->  internal [env][Morton index]{x,v} -------
@@ -1335,6 +1388,9 @@ struct R2SPhys {
     int* d_masks = nullptr;
     int *d_coll_num = nullptr, *d_coll_idx = nullptr, *d_max_count = nullptr;
     float4* d_vbc = nullptr;
+    int2* d_mesh_list = nullptr; int* d_mesh_cnt = nullptr; int mesh_cap = 0; // deferred large-mesh queries: [chains][cap], [chains][n_sub]
+    int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false;
+    int mesh_defer = 0; // this env step's graph flavour: 1 = needy particles are finished by k_mesh_finish (contact likely), 0 = in place
     int2* d_cand_list = nullptr;
     int* d_cand_count = nullptr;
     int* h_cand_count = nullptr; // pinned; filled asynchronously by update_collision_graph
@@ -1356,7 +1412,8 @@ struct R2SPhys {
     int *d_faces = nullptr, *d_mesh_map = nullptr, *d_face_map = nullptr, *d_mesh_face_off = nullptr, *d_mesh_vert_off = nullptr;
     int *d_face_orig = nullptr, *d_face_mesh = nullptr, *d_cl_f0 = nullptr, *d_cl_f1 = nullptr, *d_cl_mesh = nullptr, *d_mesh_kind = nullptr,
         *d_mesh_xf = nullptr, *d_xf_mesh = nullptr, *d_xf_ref = nullptr;
-    float *d_cl_box = nullptr, *d_xf = nullptr, *d_rest_pts = nullptr, *d_pnorm = nullptr, *d_xf_rest_box = nullptr;
+    float *d_cl_box = nullptr, *d_xf = nullptr, *d_rest_pts = nullptr, *d_pnorm = nullptr, *d_xf_rest_box = nullptr, *d_tri_rest = nullptr;
+    int4* d_cl_info = nullptr;
     unsigned* d_rigid_err = nullptr;
     unsigned* h_rigid_err = nullptr; // pinned
     bool rigid_pending = false;
@@ -1372,10 +1429,10 @@ struct R2SPhys {
     // graph
     // two captured variants of the num_substeps step: [0] no particle has candidates (one kernel per substep),
     // [1] some do (fused kernel + self-collision finishing kernel per substep)
-    // slot = variant * 2 + start buffer: with an odd substep count (667) the state buffer flips every env step, so both
+    // slot = defer * 4 + variant * 2 + start buffer: with an odd substep count (667) the state buffer flips every env step, so both
     // parities are kept instead of re-capturing 667 nodes per step
-    hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipGraph_t graph[8] = {};
+    hipGraphExec_t graph_exec[8] = {};
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1399,11 +1456,12 @@ struct R2SPhys {
         p.self_collision = prm.self_collision; p.use_pusher = prm.use_pusher;
         p.coll_num = d_coll_num; p.coll_idx = d_coll_idx; p.coll_cap = coll_cap;
         p.vbc = d_vbc; p.cand_list = d_cand_list; p.cand_count = d_cand_count;
+        p.mesh_list = d_mesh_list; p.mesh_cnt = d_mesh_cnt; p.mesh_cap = mesh_cap; p.mesh_defer = mesh_defer;
         p.n_mesh = n_mesh; p.n_dyn_mesh = n_dyn_mesh; p.nF = nF; p.nV = nV; p.n_dyn_pts = n_dyn_pts;
         p.faces = d_faces; p.mesh_map = d_mesh_map; p.face_map = d_face_map; p.mesh_face_off = d_mesh_face_off;
         p.face_orig = d_face_orig; p.face_mesh = d_face_mesh; p.n_cl = n_cl; p.n_xf = n_xf; p.cl_f0 = d_cl_f0; p.cl_f1 = d_cl_f1;
         p.cl_mesh = d_cl_mesh; p.cl_box = d_cl_box; p.mesh_kind = d_mesh_kind; p.mesh_xf = d_mesh_xf; p.xf_mesh = d_xf_mesh; p.xf = d_xf; p.rest_pts = d_rest_pts;
-        p.pnorm = d_pnorm;
+        p.pnorm = d_pnorm; p.tri_rest = d_tri_rest; p.cl_info = d_cl_info;
         p.mesh_pts = d_mesh_pts; p.interp_pts = d_interp; p.interp_center = d_center; p.dyn_vel = d_dyn_vel; p.dyn_omega = d_dyn_omega;
         p.aabb_dyn = d_aabb_dyn; p.aabb_static = d_aabb_static; p.coll_forces = d_coll_forces;
         return p;
@@ -1501,6 +1559,7 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
         else if (mesh == 1) hipLaunchKernelGGL((k_self_finish<1>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
         else hipLaunchKernelGGL((k_self_finish<0>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
     }
+    if (mesh == 2 && p.mesh_defer) hipLaunchKernelGGL(k_mesh_finish, dim3(512), dim3(256), 0, s, p, in, out, step, write_forces); // 2048 wavefronts, grid-stride
     return R2S_OK;
 }
 
@@ -1514,11 +1573,17 @@ __global__ void k_zero_f32(float* __restrict__ p, size_t n)
     if (i < n) p[i] = 0.f;
 }
 
-int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, hipStream_t s, int e0 = 0, int ne = -1, bool zero_forces = true)
+int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, hipStream_t s, int e0 = 0, int ne = -1, bool zero_forces = true, int chain_id = 0)
 {
     PhysDev p = h->dev();
     if (ne < 0) ne = h->E;
     p.e0 = e0; p.ne = ne; p.cb = (h->nb * ne + 7) / 8;
+    const int chain = chain_id;
+    if (h->any_large) { // this chain's slice of the deferred-query list and counters
+        p.mesh_list = h->d_mesh_list + (size_t)chain * h->mesh_cap;
+        p.mesh_cnt = h->d_mesh_cnt + (size_t)chain * h->prm.num_substeps;
+        hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((h->prm.num_substeps + 255) / 256)), dim3(256), 0, s, (float*)p.mesh_cnt, (size_t)h->prm.num_substeps);
+    }
     int buf = start_buf;
     for (int k = 0; k < n; ++k) {
         const int last = (k == n - 1);
@@ -1535,7 +1600,7 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
 
 void drop_graph(R2SPhys* h)
 {
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 8; ++v) {
         if (h->graph_exec[v]) (void)hipGraphExecDestroy(h->graph_exec[v]);
         if (h->graph[v]) (void)hipGraphDestroy(h->graph[v]);
         h->graph_exec[v] = nullptr; h->graph[v] = nullptr;
@@ -1546,7 +1611,7 @@ void drop_graph_fwd(R2SPhys* h) { drop_graph(h); }
 
 int capture_graph(R2SPhys* h, int variant, int start_buf)
 {
-    const int slot = variant * 2 + (start_buf & 1);
+    const int slot = h->mesh_defer * 4 + variant * 2 + (start_buf & 1);
     if (h->graph_exec[slot]) (void)hipGraphExecDestroy(h->graph_exec[slot]);
     if (h->graph[slot]) (void)hipGraphDestroy(h->graph[slot]);
     h->graph_exec[slot] = nullptr; h->graph[slot] = nullptr;
@@ -1573,7 +1638,7 @@ int capture_graph(R2SPhys* h, int variant, int start_buf)
             side.push_back(st);
             R2S_HIP_TRY(hipStreamWaitEvent(st, fork, 0));
         }
-        rc = enqueue_steps(h, 0, h->prm.num_substeps, start_buf, variant == 1, st, e0, e1 - e0);
+        rc = enqueue_steps(h, 0, h->prm.num_substeps, start_buf, variant == 1, st, e0, e1 - e0, true, c);
         if (c > 0 && rc == R2S_OK) {
             hipEvent_t j;
             R2S_HIP_TRY(hipEventCreateWithFlags(&j, hipEventDisableTiming));
@@ -1978,6 +2043,16 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         TRY(upload(h->d_cl_box, cl_box.data(), cl_box.size(), s)); TRY(upload(h->d_mesh_kind, mesh_kind.data(), mesh_kind.size(), s));
         TRY(upload(h->d_mesh_xf, mesh_xf.data(), mesh_xf.size(), s)); TRY(upload(h->d_rest_pts, d->mesh_vertices, 3 * (size_t)h->nV, s));
         TRY(upload(h->d_pnorm, pnorm.data(), pnorm.size(), s)); TRY(upload(h->d_xf_mesh, xf_mesh.data(), xf_mesh.size(), s));
+        {
+            std::vector<float> tri(9 * (size_t)h->nF);
+            for (int f = 0; f < h->nF; ++f)
+                for (int c = 0; c < 3; ++c)
+                    for (int k = 0; k < 3; ++k) tri[(size_t)f * 9 + c * 3 + k] = d->mesh_vertices[3 * (size_t)stored[3 * f + c] + k];
+            std::vector<int4> info(h->n_cl);
+            for (int c = 0; c < h->n_cl; ++c) info[c] = make_int4(cl_mesh[c], mesh_kind[cl_mesh[c]], mesh_xf[cl_mesh[c]], 0);
+            TRY(dev_alloc(&h->d_tri_rest, tri.size())); TRY(upload(h->d_tri_rest, tri.data(), tri.size(), s));
+            TRY(dev_alloc(&h->d_cl_info, info.size())); TRY(upload(h->d_cl_info, info.data(), info.size(), s));
+        }
         TRY(upload(h->d_xf_ref, xf_ref.data(), xf_ref.size(), s)); TRY(upload(h->d_xf_rest_box, xf_rest_box.data(), xf_rest_box.size(), s));
         faces = stored; // the device face table is in stored (cluster) order
         TRY(dev_alloc(&h->d_faces, faces.size())); TRY(dev_alloc(&h->d_mesh_map, h->nF)); TRY(dev_alloc(&h->d_face_map, h->nF));
@@ -2022,6 +2097,17 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     R2S_HIP_TRY(hipMemsetAsync(h->d_coll_num, 0, sizeof(int) * (size_t)E * N, s));
     TRY(dev_alloc(&h->d_max_count, 4));
     R2S_HIP_TRY(hipMemsetAsync(h->d_max_count, 0, sizeof(int) * 4, s));
+    if (h->any_large) { // deferred large-mesh queries
+        h->mesh_cap = std::max(4096, E * std::min(N, 2048));
+        TRY(dev_alloc(&h->d_mesh_list, (size_t)8 * h->mesh_cap));
+        TRY(dev_alloc(&h->d_mesh_cnt, (size_t)8 * h->prm.num_substeps));
+        TRY(dev_alloc(&h->d_mesh_total, 4));
+        R2S_HIP_TRY(hipHostMalloc((void**)&h->h_mesh_total, 64, hipHostMallocDefault));
+        *h->h_mesh_total = 0;
+        R2S_HIP_TRY(hipEventCreateWithFlags(&h->mesh_event, hipEventDisableTiming));
+        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_cnt, 0, sizeof(int) * 8 * (size_t)h->prm.num_substeps, s));
+        if (!h->prm.self_collision) TRY(dev_alloc(&h->d_vbc, (size_t)E * N));
+    }
     if (h->prm.self_collision) {
         TRY(dev_alloc(&h->d_vbc, (size_t)E * N));
         TRY(dev_alloc(&h->d_cand_list, (size_t)E * N));
@@ -2057,13 +2143,15 @@ void r2s_phys_destroy(R2SPhys* h)
     (void)hipDeviceSynchronize();
     drop_graph(h);
     void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
-                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
+                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_mesh_list, h->d_mesh_cnt, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
                     h->d_faces, h->d_face_orig, h->d_face_mesh, h->d_cl_f0, h->d_cl_f1, h->d_cl_mesh, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
-                    h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
+                    h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
                     h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_cand_count) (void)hipHostFree(h->h_cand_count);
+    if (h->h_mesh_total) (void)hipHostFree(h->h_mesh_total);
+    if (h->mesh_event) (void)hipEventDestroy(h->mesh_event);
     if (h->h_rigid_err) (void)hipHostFree(h->h_rigid_err);
     if (h->cand_event) (void)hipEventDestroy(h->cand_event);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -2259,12 +2347,16 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         }
     }
     const int variant = (h->prm.self_collision && h->n_cand > 0) ? 1 : 0;
+    if (h->any_large) { // large-mesh scenes: defer the queries when the last finished step saw particles near a mesh
+        if (h->mesh_pending && hipEventQuery(h->mesh_event) == hipSuccess) h->mesh_pending = false;
+        if (!h->mesh_pending) h->mesh_defer = *h->h_mesh_total > 0 ? 1 : 0; // an unfinished count keeps the previous flavour
+    }
     if (use_graph) {
         // variant 1 bakes a grid size derived from n_cand: re-capture if the list outgrew it
-        const int slot = variant * 2 + (h->cur & 1);
+        const int slot = h->mesh_defer * 4 + variant * 2 + (h->cur & 1);
         const bool stale = variant == 1 && h->n_cand > h->graph_cand_cap;
-        if (stale) { // both parities of the self-collision variant bake the old grid size
-            for (int k = 2; k < 4; ++k) if (h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); (void)hipGraphDestroy(h->graph[k]); h->graph_exec[k] = nullptr; h->graph[k] = nullptr; }
+        if (stale) { // every captured self-collision flavour bakes the old grid size
+            for (int k = 0; k < 8; ++k) if ((k & 2) && h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); (void)hipGraphDestroy(h->graph[k]); h->graph_exec[k] = nullptr; h->graph[k] = nullptr; }
         }
         if (!h->graph_exec[slot]) {
             if (variant == 1) h->graph_cand_cap = std::max(h->n_cand * 2, 4096), h->n_cand_launch = h->graph_cand_cap;
@@ -2280,6 +2372,13 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         if (rc) return rc;
     }
     h->cur ^= (n & 1);
+    if (h->any_large && !h->mesh_pending) { // how many queries this step needed -> pinned memory, read at a later step without waiting
+        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(256), 0, s, h->d_mesh_cnt, 8 * h->prm.num_substeps, h->d_mesh_total);
+        R2S_HIP_TRY(hipMemcpyAsync(h->h_mesh_total, h->d_mesh_total, sizeof(int), hipMemcpyDeviceToHost, s));
+        R2S_HIP_TRY(hipEventRecord(h->mesh_event, s));
+        h->mesh_pending = true;
+    }
     if (h->timing) { R2S_HIP_TRY(hipEventRecord(h->ev1, s)); h->ev_pending = true; h->last_kernels = n; }
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
