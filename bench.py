@@ -150,6 +150,15 @@ def main():
     ro.raster.set_timing(False)
     frames = ro.n_env * ro.views
     raster_ms = sum(stages.values())
+    # realised scene statistics: visible Gaussians, instances, tile list lengths
+    dbg = ro.raster.debug()
+    tiles = ((ro.W + 15) // 16) * ((ro.H + 15) // 16)
+    from r2s_hip.raster import _memcpy_d2d
+    rng_t = torch.empty(frames * tiles, 2, dtype=torch.int32, device=dev)
+    _memcpy_d2d(rng_t.data_ptr(), dbg["ranges_ptr"], rng_t.numel() * 4, dev)
+    lens = (rng_t[:, 1] - rng_t[:, 0]).float()
+    scene = {"gaussians_per_frame": ro.P, "visible_fraction": float((dbg["radii"] > 0).float().mean()), "instances": int(dbg["num_rendered"]),
+             "tile_list_mean": float(lens.mean()), "tile_list_max": int(lens.max())}
     # skinning (row f1): torch events are valid here, the kernels run on torch's current stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -183,7 +192,7 @@ def main():
                                  "env ranges, so rocprofv3's per-kernel durations overlap in time (sum > wall clock); avg_launch_us is the HIP-event "
                                  "time of the 667-substep graph / 667.  profiles/ holds the trace for R2S_CHAINS=1 as well, where both agree"},
             "raster": {"gs_raster_mpix_per_s": frames * ro.W * ro.H / (raster_ms * 1e-3) / 1e6, "frames": frames,
-                       "num_rendered": int(ro.last_num_rendered), "stage_ms": stages,
+                       "num_rendered": int(ro.last_num_rendered), "stage_ms": stages, "scene": scene,
                        "composite_roofline": {"bound": "hbm", "achieved": comp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": comp_gbs / HBM_PEAK_GBS, "algorithmic_bytes": comp_bytes,
                                               "traffic": measured_traffic("k_composite", args.config) if ro.n_env == 32 else None,

@@ -174,6 +174,7 @@ class RasterBatch:
             geom=view(d.geom, G * 12, torch.float32).reshape(G, 12),
             tiles_touched=view(d.tiles_touched, G, torch.int32), point_offsets=view(d.point_offsets, G, torch.int32),
             keys_sorted=view(d.keys_sorted, L, torch.int32), point_list=view(d.point_list, L, torch.int32),
+            ranges_ptr=d.ranges,
         )
 
 
