@@ -107,6 +107,28 @@ def test_self_collision_two_blobs():
     assert o.v[len(o.v) // 2:, 0].mean() > -2.9
 
 
+def test_self_collision_with_concurrent_chains_and_odd_substeps():
+    """9 environments (the env step then runs as 2 concurrent kernel chains over env ranges 0-3 / 4-8), an odd substep
+    count (the state buffer flips parity every step, exercising both cached graphs) and live self-collision contacts
+    (fused kernel + k_self_finish per chain): every environment must reproduce the single-environment oracle."""
+    ob = two_blobs(seed=1, gap=0.06, speed=3.0)
+    n_sub = 201
+    kw = dict(num_substeps=n_sub, collide_self_fric=0.3)
+    o = oracle_env(ob, **kw)
+    h = hip_env(ob, n_env=9, **kw)
+    assert h.layout_stats()["chains"] == 2
+    tot = 0
+    for _ in range(4):
+        o.update_collision_graph(); h.update_collision_graph()
+        tot += int(o.coll_num.sum())
+        o.step(); h.step()
+    assert tot > 0, "scenario must produce contacts"
+    x = h.x.cpu().numpy()
+    for e in range(9):
+        assert np.abs(x[e] - o.x).max() < 5e-5, e
+    assert np.abs(x - x[0:1]).max() < 1e-6
+
+
 def test_static_box_mesh_collision():
     from r2s_hip import synth
 
