@@ -2350,6 +2350,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     if (h->any_large) { // large-mesh scenes: defer the queries when the last finished step saw particles near a mesh
         if (h->mesh_pending && hipEventQuery(h->mesh_event) == hipSuccess) h->mesh_pending = false;
         if (!h->mesh_pending) h->mesh_defer = *h->h_mesh_total > 0 ? 1 : 0; // an unfinished count keeps the previous flavour
+        if (const char* ev = getenv("R2S_MESH_DEFER")) h->mesh_defer = atoi(ev) != 0; // test / tuning knob: force a flavour
     }
     if (use_graph) {
         // variant 1 bakes a grid size derived from n_cand: re-capture if the list outgrew it

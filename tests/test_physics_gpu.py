@@ -252,10 +252,14 @@ def test_drop_in_surface_smoke():
     assert (sim.wp_state.wp_x - x_before).abs().max() > 0
 
 
-def test_pusher_25k_face_mesh_cluster_query_vs_oracle():
+@pytest.mark.parametrize("defer", ["0", "1"], ids=["queries in place", "queries deferred to k_mesh_finish"])
+def test_pusher_25k_face_mesh_cluster_query_vs_oracle(defer, monkeypatch):
     """configs[3] ingredient: a ~25k-face closed pusher mesh (cluster hierarchy + rigid transform + pseudonormal sign on
-    the GPU) against the oracle's brute-force closest point + exact winding number."""
+    the GPU) against the oracle's brute-force closest point + exact winding number — with the queries done inside the
+    fused kernel and with the flavour used while in contact (one wavefront per touching particle)."""
     import torch
+
+    monkeypatch.setenv("R2S_MESH_DEFER", defer)
     from r2s_hip import synth
     from util_physics import rigid_motion
 
