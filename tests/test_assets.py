@@ -88,3 +88,33 @@ def test_phystwin_case_directory_round_trip(tmp_path):
     assert np.allclose(out["rest"], rest, atol=1e-6) and np.array_equal(out["spring_Y"], ob["log_Y"])        # control springs dropped
     assert out["params"]["init_spring_Y"] == 3000.0 and out["params"]["collide_self_elas"] == 0.4 and "global_spring_Y" not in out["params"]
     assert (out["collide_elas"], out["collide_fric"]) == (0.5, 0.30000001192092896) and out["collide_self_fric"] == 0.10000000149011612
+
+
+def test_gs_processor_drop_in_round_trip_and_edits(tmp_path):
+    import torch
+    from scipy.spatial.transform import Rotation
+    from sim.utils.gs.gs_processor import GSProcessor
+
+    gp = GSProcessor()
+    p = {k: torch.from_numpy(v) for k, v in _params(40, 3).items()}
+    gp.save(p, tmp_path / "a.ply")
+    q = gp.load(tmp_path / "a.ply")
+    for k in p:
+        assert torch.equal(p[k], q[k]), k
+    # rotate: points and splat orientations turn together (compare rotation matrices: q and -q are the same rotation)
+    Rm = Rotation.from_euler("xyz", [0.3, -0.2, 0.9]).as_matrix().astype(np.float32)
+    r = gp.rotate(q, Rm)
+    assert torch.allclose(r["means3D"], q["means3D"] @ torch.from_numpy(Rm).T, atol=1e-6)
+    qn = torch.nn.functional.normalize(q["unnorm_rotations"], dim=-1).numpy().astype(np.float64)
+    want = Rm.astype(np.float64)[None] @ Rotation.from_quat(qn[:, [1, 2, 3, 0]]).as_matrix()
+    got = Rotation.from_quat(r["unnorm_rotations"].numpy().astype(np.float64)[:, [1, 2, 3, 0]]).as_matrix()
+    assert np.abs(got - want).max() < 1e-5
+    s = gp.scale({k: v.clone() for k, v in q.items()}, 2.0)
+    assert torch.allclose(s["means3D"], 2 * q["means3D"]) and torch.allclose(s["log_scales"], q["log_scales"] + np.log(2.0), atol=1e-6)
+    t = gp.translate({k: v.clone() for k, v in q.items()}, [0.1, 0.0, -0.2])
+    assert torch.allclose(t["means3D"] - q["means3D"], torch.tensor([0.1, 0.0, -0.2]).expand(40, 3), atol=1e-6)
+    c = gp.crop(q, [[-0.5, 0.5], [-10, 10], [-10, 10]])
+    inside = (q["means3D"][:, 0].abs() <= 0.5)
+    assert len(c["means3D"]) == int(inside.sum()) and len(gp.crop(q, [[-0.5, 0.5], [-10, 10], [-10, 10]], invert=True)["means3D"]) == 40 - int(inside.sum())
+    m = gp.merge([c, gp.apply_mask(q, ~inside)])
+    assert len(m["means3D"]) == 40 and m["sh_colors"].shape == (40, 48)
