@@ -1,5 +1,5 @@
 import sys, os, ctypes as C
-R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0]=[os.path.join(R,'real2sim-eval_amd'),R]
+R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0]=[os.path.join(R,'real2sim-eval_amd'),R]
 import torch, numpy as np
 from r2s_hip.rollout import BatchedRollout
 from r2s_hip import _lib
