@@ -186,3 +186,48 @@ def load_phystwin_case(data_path, zeroth_order_ckpt_path, first_order_ckpt_path,
     sy = (sy.detach().cpu().numpy() if hasattr(sy, "detach") else np.asarray(sy)).astype(np.float32)[:n_obj]
     return dict(points=p32, springs=springs.astype(np.int32), rest=rest, spring_Y=sy, collide_elas=sc("collide_elas"), collide_fric=sc("collide_fric"),
                 collide_self_elas=sc("collide_object_elas"), collide_self_fric=sc("collide_object_fric"), params=params)
+
+
+# ---- scene colour correction of the SH coefficients (gs_renderer.py:656-699) -----------------------------------------------
+C0 = 0.28209479177387814
+
+
+def sh_colors_to_shs(sh_colors):
+    """(n, 48) file layout (3 DC, then 45 rest grouped per channel) -> (n, 16, 3) coefficient-major (gs_renderer.py:650-654)."""
+    sh = np.asarray(sh_colors)
+    n = sh.shape[0]
+    return np.concatenate([sh[:, :3][:, None], sh[:, 3:].reshape(n, 3, -1).transpose((0, 2, 1))], axis=1)
+
+
+def color_correct_shs(shs, color_A, color_b):
+    """The scene's colour calibration applied to SH coefficients so that the RENDERED colour c = C0 * sh0 + 0.5 becomes
+    A c + b (``color_A`` 3x3) or A2 c^2 + A1 c + b (``color_A`` 3x6 = [A2 | A1], DC band only for the square term), bands
+    >= 1 transformed by the linear part.  shs: (n, K, 3) with K = (deg + 1)^2."""
+    shs = np.asarray(shs)
+    A = np.array(color_A, dtype=np.float32).reshape(3, -1)
+    b = np.array(color_b, dtype=np.float32).reshape(3)
+    deg = int(np.sqrt(shs.shape[1]) - 1)
+    out = []
+    if A.shape[1] == 3:
+        for si in range(deg + 1):
+            band = shs[:, si ** 2:(si + 1) ** 2, :]
+            if si == 0:
+                off = np.ones(3) * 0.5
+                bias = (1.0 / C0) * (off.reshape(1, 3) @ A.T + b - off)
+                out.append((np.squeeze(band, axis=1) @ A.T + bias)[:, None])
+            else:
+                out.append(band @ A.T)
+    elif A.shape[1] == 6:
+        A_2, A_1 = A[:, :3], A[:, 3:]
+        for si in range(deg + 1):
+            band = shs[:, si ** 2:(si + 1) ** 2, :]
+            if si == 0:
+                flat = np.squeeze(band, axis=1)
+                o1, o2 = np.ones(3) * 0.5, np.ones(3) * 0.25
+                bias = (1.0 / C0) * (o2.reshape(1, 3) @ A_2.T + o1.reshape(1, 3) @ A_1.T + b - o1)
+                out.append((flat @ A_1.T + (flat + C0 * flat ** 2) @ A_2.T + bias)[:, None])
+            else:
+                out.append(band @ A_1.T)
+    else:
+        raise ValueError("color_A must have 9 (linear) or 18 (quadratic) entries")
+    return np.concatenate(out, axis=1)

@@ -118,3 +118,18 @@ def test_gs_processor_drop_in_round_trip_and_edits(tmp_path):
     assert len(c["means3D"]) == int(inside.sum()) and len(gp.crop(q, [[-0.5, 0.5], [-10, 10], [-10, 10]], invert=True)["means3D"]) == 40 - int(inside.sum())
     m = gp.merge([c, gp.apply_mask(q, ~inside)])
     assert len(m["means3D"]) == 40 and m["sh_colors"].shape == (40, 48)
+
+
+def test_sh_colour_correction_acts_on_the_rendered_colour():
+    r = np.random.default_rng(1)
+    sh48 = r.normal(0, 0.5, (50, 48)).astype(np.float32)
+    shs = assets.sh_colors_to_shs(sh48)
+    assert shs.shape == (50, 16, 3) and np.array_equal(shs[:, 0], sh48[:, :3]) and np.array_equal(shs[:, 1:, 0], sh48[:, 3:18])
+    rgb = assets.C0 * shs[:, 0] + 0.5
+    A = np.array([[1.1, 0.05, 0.0], [0.02, 0.9, 0.03], [0.0, 0.1, 1.2]], np.float32); b = np.array([0.01, -0.02, 0.03], np.float32)
+    lin = assets.color_correct_shs(shs, A.reshape(-1), b)
+    assert np.allclose(assets.C0 * lin[:, 0] + 0.5, rgb @ A.T + b, atol=1e-5) and np.allclose(lin[:, 1:], shs[:, 1:] @ A.T, atol=1e-6)
+    assert np.allclose(assets.color_correct_shs(shs, np.eye(3).reshape(-1), np.zeros(3)), shs, atol=1e-6)
+    A2 = 0.1 * r.normal(size=(3, 3)).astype(np.float32)
+    quad = assets.color_correct_shs(shs[:, :1], np.concatenate([A2, A], axis=1).reshape(-1), b)
+    assert np.allclose(assets.C0 * quad[:, 0] + 0.5, (rgb ** 2) @ A2.T + rgb @ A.T + b, atol=1e-5)
