@@ -27,6 +27,7 @@ CONFIGS = {
     "sloth_32env": ("sloth", 15000, 80000, 32, 640, 480),
     "T_32env": ("T", 2229, 40000, 32, 640, 480),
     "T_pusher_32env": ("T", 2229, 40000, 32, 640, 480),   # configs[3] per GPU: T block pushed by the ~25k-face pusher rod
+    "sloth_multicam_8env": ("sloth", 15000, 140000, 8, 1280, 720),   # configs[4] per GPU: 4 views, +60k robot-link Gaussians
     "tiny": ("rope", 600, 3000, 2, 160, 120),
 }
 
@@ -37,6 +38,8 @@ class BatchedRollout:
         shape, n_particles, n_gauss, envs, W, H = CONFIGS[config]
         self.config = config
         self.n_env = int(n_env if n_env is not None else envs)
+        if "multicam" in config:
+            views = 4
         self.W, self.H, self.views = W, H, views
         self.device = torch.device(device)
         self.num_substeps = int(num_substeps)
@@ -103,7 +106,8 @@ class BatchedRollout:
         self.g = {k: t(v) for k, v in sc.items() if k != "means3D"}
         self.raster = RasterBatch(self.device)
         self.raster.set_tile_culling(tile_culling)  # exact-output instance culling (include/r2s_raster.h)
-        self.cams = [synth.side_camera(W, H), synth.wrist_camera(W, H, eef_pos=(c[0], c[1], top + 0.30))][:views]
+        self.cams = [synth.side_camera(W, H), synth.wrist_camera(W, H, eef_pos=(c[0], c[1], top + 0.30)),
+                     synth.orbit_camera(W, H, 60.0, target=c), synth.orbit_camera(W, H, -110.0, target=c)][:views]
         self.cam_t = [{k: (t(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()} for cam in self.cams]
         self.out_color = torch.empty(E, views, 3, H, W, dtype=torch.float32, device=self.device)
         self.out_depth = torch.empty(E, views, 1, H, W, dtype=torch.float32, device=self.device)

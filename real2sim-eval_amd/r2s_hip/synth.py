@@ -54,6 +54,20 @@ def side_camera(W, H, **kw):
     return camera_settings(scaled_K(SIDE_K, W, H), np.linalg.inv(SIDE_C2W), W, H, **kw)
 
 
+def orbit_camera(W, H, azimuth_deg, target=OBJECT_CENTER, distance=0.9, elevation_deg=35.0, **kw):
+    """An extra fixed view looking at ``target`` (the custom cameras of configs[4], gs_renderer.py:145 set_camera_custom):
+    OpenCV convention (x right, y down, z forward), side-camera intrinsics."""
+    az, el = np.deg2rad(azimuth_deg), np.deg2rad(elevation_deg)
+    eye = np.asarray(target, np.float64) + distance * np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+    fwd = np.asarray(target, np.float64) - eye
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, np.array([0.0, 0.0, 1.0])); right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    c2w = np.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, eye
+    return camera_settings(scaled_K(SIDE_K, W, H), np.linalg.inv(c2w), W, H, **kw)
+
+
 def wrist_camera(W, H, eef_pos=(0.37, 0.05, 0.35), **kw):
     """Wrist camera attached to an end effector pointing straight down at ``eef_pos``
     (w2c = eef2c . inv(eef2base), sim/renderer/gs_renderer.py:967-985)."""
