@@ -1398,9 +1398,12 @@ struct R2SPhys {
     bool cand_pending = false;
     int n_cand = 0;              // particles with candidates after the last update (host view)
     int graph_cand_cap = 0, n_cand_launch = 0;
-    int chains() const // parallel kernel chains of the captured env step (measured: 23.5 / 21.3 / 22.4 / 23.2 us per substep for 1 / 2 / 3 / 4)
+    int chains() const // parallel kernel chains of the captured env step
     {
-        int c = E >= 8 ? 2 : 1;
+        // two chains pay once a single kernel would not fit the chip in one go (6 workgroups per CU): 32 sloth envs = 1888
+        // workgroups: 23.5 / 21.3 / 22.4 / 23.2 us per substep for 1 / 2 / 3 / 4 chains; smaller batches lose (16 sloth envs
+        // 15.1 vs 16.8 us, 8 envs 10.7 vs 12.5 us, 32 T-block envs 10.3 vs 11.1 us for 1 vs 2 chains)
+        int c = (int64_t)nb * E >= 1536 ? 2 : 1;
         if (const char* ev = getenv("R2S_CHAINS")) c = std::max(1, std::min(atoi(ev), std::min(E, 8))); // tuning knob
         return c;
     }

@@ -107,10 +107,11 @@ def test_self_collision_two_blobs():
     assert o.v[len(o.v) // 2:, 0].mean() > -2.9
 
 
-def test_self_collision_with_concurrent_chains_and_odd_substeps():
+def test_self_collision_with_concurrent_chains_and_odd_substeps(monkeypatch):
     """9 environments (the env step then runs as 2 concurrent kernel chains over env ranges 0-3 / 4-8), an odd substep
     count (the state buffer flips parity every step, exercising both cached graphs) and live self-collision contacts
     (fused kernel + k_self_finish per chain): every environment must reproduce the single-environment oracle."""
+    monkeypatch.setenv("R2S_CHAINS", "2")  # small batches default to one chain
     ob = two_blobs(seed=1, gap=0.06, speed=3.0)
     n_sub = 201
     kw = dict(num_substeps=n_sub, collide_self_fric=0.3)
