@@ -142,6 +142,20 @@ def main():
     records = rdist.gather_records([ro.n_env, args.steps, elapsed * 1e3, float(ro.last_num_rendered), float(n_success)], dev)
     total_envs = int(records[:, 0].sum().item())
 
+    # cross-check for the roofline (untimed): the same env step captured as ONE kernel per batched substep, so that the
+    # HIP-event time / 667 is a per-kernel duration that rocprofv3's per-kernel average can be compared with directly
+    single_us = None
+    if ro.phys.layout_stats()["chains"] > 1:
+        os.environ["R2S_CHAINS"] = "1"
+        ro.phys.set_params()          # drops the captured graphs; the next steps re-capture with one chain
+        for _ in range(3):
+            ro.physics_step()
+        torch.cuda.synchronize(dev)
+        ms1, k1 = ro.phys.last_step_ms()
+        single_us = ms1 / max(k1, 1) * 1e3
+        del os.environ["R2S_CHAINS"]
+        ro.phys.set_params()
+
     # stage timing of the raster pipeline (separate, untimed pass)
     ro.raster.set_timing(True)
     ro.render()
@@ -188,6 +202,10 @@ def main():
                          "kernel": "k_substep (fused spring gather + velocity + collisions + integrate)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": t_kernel * 1e6, "launches": phys_kernels,
                          "concurrent_chains": chains,
+                         "single_chain_check": None if single_us is None else {
+                             "avg_launch_us": single_us, "achieved": alg_bytes / (single_us * 1e-6) / 1e9, "frac": alg_bytes / (single_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "note": "same step with R2S_CHAINS=1 (one kernel per batched substep, measured after the timed region): compare with "
+                                     "profiles/r1_bench_kernel_stats_chains1.md"},
                          "note": f"one 'launch' = one batched substep of all {ro.n_env} envs; it is issued as {chains} concurrent kernels over disjoint "
                                  "env ranges, so rocprofv3's per-kernel durations overlap in time (sum > wall clock); avg_launch_us is the HIP-event "
                                  "time of the 667-substep graph / 667.  profiles/ holds the trace for R2S_CHAINS=1 as well, where both agree"},
