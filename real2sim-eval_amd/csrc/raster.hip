@@ -337,6 +337,18 @@ __global__ void __launch_bounds__(256) k_tile_ranges(uint32_t L, const uint32_t*
     if (i == L - 1) ranges[cur].y = L;
 }
 
+// Workgroup order of the compositor: tiles sorted by the length of their instance list, longest first.  On the benchmark
+// scene 5 % of the tiles (the object region) hold 85 % of the instances; started in tile order, the deep tiles of the last
+// frames run alone at the end of the kernel (1.26 ms); started first, the short ones fill the gaps (0.97 ms).
+__global__ void __launch_bounds__(256) k_tile_len_keys(uint32_t n, const uint2* __restrict__ ranges, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 r = ranges[i];
+    keys[i] = 16383u - min(r.y - r.x, 16383u); // 14 bits are plenty to order the long lists; ties do not matter
+    vals[i] = i;
+}
+
 // renderCUDA, forward.cu:262-394.  One workgroup per 16x16 tile; wavefront w owns the 8x8 quadrant
 // (w&1, w>>1) so that a whole-wave skip (all 64 pixels fail the alpha test) is likely for small splats.
 // The per-pixel arithmetic and its order (power -> alpha -> test_T -> colour -> median depth) follow
@@ -358,11 +370,12 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                                                             const uint2* __restrict__ ranges,
                                                             const uint32_t* __restrict__ point_list,
                                                             const GeomRec* __restrict__ geom, float* __restrict__ aux_T,
-                                                            uint32_t* __restrict__ aux_n)
+                                                            uint32_t* __restrict__ aux_n, const uint32_t* __restrict__ tile_order)
 {
     const int tiles = gx * gy;
-    const int f = blockIdx.x / tiles;
-    const int t = blockIdx.x - f * tiles;
+    const uint32_t ft = tile_order ? tile_order[blockIdx.x] : blockIdx.x; // longest instance lists first
+    const int f = (int)(ft / (uint32_t)tiles);
+    const int t = (int)ft - f * tiles;
     const int ty = t / gx, tx = t - ty * gx;
     const FrameDev& fr = frames[f];
     const int tid = threadIdx.x;
@@ -373,7 +386,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
     const float pfx = (float)px, pfy = (float)py;
     bool done = !inside;
 
-    const uint2 range = ranges[blockIdx.x];
+    const uint2 range = ranges[ft];
     const int n = (int)(range.y - range.x);
     const int rounds = (n + TILE_THREADS - 1) / TILE_THREADS;
 
@@ -661,13 +674,21 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     }
     // ---- image scratch (ImageState: ranges; accum_alpha / n_contrib are backward-only) ----
     uint2* ranges;
+    uint32_t *tl_keys[2], *tl_vals[2];
+    char* tl_tmp;
+    size_t tl_bytes = 0;
+    const size_t FT = (size_t)F * tiles;
     {
+        rocprim::double_buffer<uint32_t> dk((uint32_t*)nullptr, (uint32_t*)nullptr), dv((uint32_t*)nullptr, (uint32_t*)nullptr);
+        R2S_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tl_bytes, dk, dv, FT, 0u, 14u, stream));
         r2s::Carver sz(nullptr);
-        sz.take<uint2>((size_t)F * tiles);
+        sz.take<uint2>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>(FT); sz.take<char>(tl_bytes);
         char* p = c->scratch(2, sz.bytes());
         if (!p) return R2S_ERR_ALLOC;
         r2s::Carver cv(p);
-        ranges = cv.take<uint2>((size_t)F * tiles);
+        ranges = cv.take<uint2>(FT);
+        tl_keys[0] = cv.take<uint32_t>(FT); tl_keys[1] = cv.take<uint32_t>(FT); tl_vals[0] = cv.take<uint32_t>(FT); tl_vals[1] = cv.take<uint32_t>(FT);
+        tl_tmp = cv.take<char>(tl_bytes);
     }
 
     R2S_HIP_TRY(hipMemcpyAsync(c->d_frames, c->h_frames, sizeof(FrameDev) * F, hipMemcpyHostToDevice, stream));
@@ -737,9 +758,16 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     R2S_HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)F * tiles, stream));
     if (L > 0)
         hipLaunchKernelGGL(k_tile_ranges, dim3((L + 255) / 256), dim3(256), 0, stream, L, keys_sorted, ranges);
+    const uint32_t* tile_order = nullptr;
+    if (L > 0 && FT >= 4096 && !getenv("R2S_NO_TILE_ORDER")) { // big batches: start the deepest tiles first (knob: A/B measurement)
+        hipLaunchKernelGGL(k_tile_len_keys, dim3((unsigned)((FT + 255) / 256)), dim3(256), 0, stream, (uint32_t)FT, ranges, tl_keys[0], tl_vals[0]);
+        rocprim::double_buffer<uint32_t> dk(tl_keys[0], tl_keys[1]), dv(tl_vals[0], tl_vals[1]);
+        R2S_HIP_TRY(rocprim::radix_sort_pairs(tl_tmp, tl_bytes, dk, dv, FT, 0u, 14u, stream));
+        tile_order = dv.current();
+    }
     mark(5);
     hipLaunchKernelGGL(k_composite, dim3((uint32_t)F * tiles), dim3(TILE_THREADS), 0, stream, c->d_frames, gx, gy, W, H, ranges,
-                       vals_sorted, geom, c->aux_T, c->aux_n);
+                       vals_sorted, geom, c->aux_T, c->aux_n, tile_order);
     mark(6);
     R2S_HIP_TRY(hipGetLastError());
 
