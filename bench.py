@@ -1,14 +1,19 @@
 #!/usr/bin/env python
 """bench.py — env-steps/s (physics + render) of the batched rollout on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: re-launches itself as N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one batched env step of the hot path over `envs` environments per GPU: collision-candidate rebuild,
-667 fused physics substeps, and 2 rasterised 640x480 frames per environment (SURVEY.md §8d Metric 1), on
-synthetic inputs of BASELINE.json configs[2] (sloth PhysTwin ~15k particles / ~80k Gaussians, 32 envs per GPU).
-Inputs are resident in HBM before the timed region.  Envs shard across GPUs with no data-path collective
-(weak scaling); the only collective is the final all-gather of per-rank result records.
+A "step" is one batched env step of the hot path over `envs` environments per GPU: collision-candidate rebuild, gripper
+kinematics + grasp logic, 667 fused physics substeps, skinning, and 2 rasterised 640x480 frames per environment
+(SURVEY.md §8d Metric 1), on synthetic inputs of BASELINE.json configs[2] (sloth PhysTwin ~15k particles / ~80k Gaussians,
+32 envs per GPU).  Inputs are resident in HBM before the timed region.  Envs shard across GPUs with no data-path
+collective (weak scaling); the only collective is the final all-gather of per-rank result records.
+
+The timed window is a SCHEDULE, not a best case: the first half of the K steps is free motion (the open gripper comes down
+over the toy's raised arms, nothing touches), at step W + K//2 the fingers close — finger contact, the arms pressed
+together (live self-collision candidates, k_self_finish in the graph), grasp detection — and the toy is lifted.  `value`
+is the mean over the whole window; `phases` splits it.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the fused physics substep) and `cpu_baseline`
 (the oracle — a CPU restatement of the reference algorithm, kind "port" — on a bounded sample).
@@ -25,14 +30,16 @@ for p in (ROOT, os.path.join(ROOT, "real2sim-eval_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_FILE = os.path.join("profiles", "r2_pmc_summary.json")
 
 
-def measured_traffic(kernel, config):
-    """HBM bytes per launch from the committed PMC collection (profiles/r1_traffic.json: FETCH_SIZE x2 + WRITE_SIZE,
-    separate rocprofv3 --pmc passes, corrected per the microarch guide).  Only valid for the workload it was taken on."""
+def pmc_summary(kernel, config):
+    """Counter-derived figures of `kernel` from the committed rocprofv3 --pmc passes over THIS workload (profiles/, produced
+    by tools/profiling/refresh_profiles.sh; FETCH_SIZE x2 + WRITE_SIZE per the microarchitecture guide).  They are NOT
+    measured in this run — the JSON says so next to every number taken from here."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-        return d[kernel]["hbm_bytes_per_launch"] if config == "sloth_32env" else None
+        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
+        return d[config][kernel]
     except Exception:
         return None
 
@@ -41,7 +48,6 @@ def cpu_baseline(ro, budget_s=20.0):
     """Time the oracle on a bounded sample of the same workload: `n` envs stepped side by side (OpenMP over
     envs, the only parallelism the reference has) for a few substeps + one 2-view render; extrapolated to
     env-steps/s.  Returns the cpu_baseline object."""
-    import numpy as np
     import oracle
 
     cores = len(os.sched_getaffinity(0))
@@ -86,24 +92,70 @@ def cpu_baseline(ro, budget_s=20.0):
     }
 
 
+class StubRollout:
+    """CPU stand-in for BatchedRollout: the launcher / barrier / MAX / all-gather / JSON path of this file without a GPU
+    (tests/test_distributed_gloo.py drives `bench.py --stub --gpus 2` through the same self-launch as the real bench)."""
+
+    def __init__(self, n_env, rank):
+        self.n_env, self.rank, self.t = n_env, rank, 0
+
+    def step(self):
+        time.sleep(0.002 * (1 + self.rank))
+        self.t += 1
+
+
+def run_stub(args, rank, world):
+    import torch
+    import torch.distributed as dist
+    from r2s_hip import dist as rdist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ro = StubRollout(args.envs or 4, rank)
+    for _ in range(args.warmup):
+        ro.step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ro.step()
+    if world > 1:
+        dist.barrier()
+    elapsed = rdist.max_over_ranks(time.perf_counter() - t0, "cpu")
+    records = rdist.gather_records([ro.n_env, args.steps, elapsed * 1e3, float(rank), 0.0], "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "stub env-steps/s", "value": rdist.throughput(records, elapsed), "unit": "env-steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "data": "stub", "ranks_seen": int(records.shape[0]), "envs_total": int(records[:, 0].sum().item())}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="sloth_32env")
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default: the config's)")
     ap.add_argument("--substeps", type=int, default=667)
+    ap.add_argument("--schedule", default=None, help="grasp | lissajous (default: the scene's; see r2s_hip/rollout.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--stub", action="store_true", help="CPU stand-in workload over gloo (launcher test)")
     args = ap.parse_args()
+
+    from r2s_hip import dist as rdist
+
+    # --gpus N from a plain process: start N ranks (one per GPU) and exit with their code; a rank checks WORLD_SIZE == N
+    rank, local_rank, world = rdist.resolve_world(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    if args.stub:
+        return run_stub(args, rank, world)
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
@@ -114,8 +166,8 @@ def main():
 
     from r2s_hip.rollout import BatchedRollout
 
-    ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps)
-    ro.phys.set_timing(True)
+    close_at = args.warmup + args.steps // 2   # the timed window is half free motion, half contact (grasp schedule / pusher)
+    ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=close_at)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -126,17 +178,16 @@ def main():
     for _ in range(args.warmup):
         ro.step()
     barrier()
-    phys_ms, phys_kernels = 0.0, 0
+    # per-step stamps on the launch stream (torch's current stream is the one every kernel of the step is enqueued on):
+    # step boundaries + the physics graph alone.  Contact counters are logged on the device, read after the window.
+    ro.start_log(args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ro.step()
     barrier()
     elapsed = time.perf_counter() - t0
-    # per-kernel time of the dominant kernel: HIP events on the launch stream around the last step's graph
-    ms, k = ro.phys.last_step_ms()
-    phys_ms, phys_kernels = ms, k
+    log = ro.read_log()
     # N > 1: slowest rank's time (MAX) and the metric all-gather of north_star — one fixed-size record per rank
-    from r2s_hip import dist as rdist
     elapsed = rdist.max_over_ranks(elapsed, dev)
     n_success = int(ro.success_flags().sum().item())  # device-side task predicate (row f4); outside the timed region
     records = rdist.gather_records([ro.n_env, args.steps, elapsed * 1e3, float(ro.last_num_rendered), float(n_success)], dev)
@@ -145,16 +196,16 @@ def main():
     # cross-check for the roofline (untimed): the same env step captured as ONE kernel per batched substep, so that the
     # HIP-event time / 667 is a per-kernel duration that rocprofv3's per-kernel average can be compared with directly
     single_us = None
+    ro.phys.set_timing(True)
     if ro.phys.layout_stats()["chains"] > 1:
-        os.environ["R2S_CHAINS"] = "1"
-        ro.phys.set_params()          # drops the captured graphs; the next steps re-capture with one chain
+        ro.phys.set_tuning(chains=1)          # drops the captured graphs; the next steps re-capture with one chain
         for _ in range(3):
             ro.physics_step()
         torch.cuda.synchronize(dev)
         ms1, k1 = ro.phys.last_step_ms()
         single_us = ms1 / max(k1, 1) * 1e3
-        del os.environ["R2S_CHAINS"]
-        ro.phys.set_params()
+        ro.phys.set_tuning(chains=0)
+    ro.phys.set_timing(False)
 
     # stage timing of the raster pipeline (separate, untimed pass)
     ro.raster.set_timing(True)
@@ -184,37 +235,70 @@ def main():
 
     if rank == 0:
         value = total_envs * args.steps / elapsed
-        t_kernel = phys_ms * 1e-3 / max(phys_kernels, 1)
+        n_sub = args.substeps
+        phys_ms = sum(log["phys_ms"]) / args.steps                 # mean physics graph time per env step over the timed window
+        t_kernel = phys_ms * 1e-3 / n_sub
         alg_bytes = ro.physics_algorithmic_bytes_per_substep()
         chains = ro.phys.layout_stats()["chains"]
         achieved = alg_bytes / t_kernel / 1e9
         comp_bytes = ro.composite_algorithmic_bytes()
         comp_gbs = comp_bytes / (stages["composite"] * 1e-3) / 1e9 if stages["composite"] > 0 else 0.0
+
+        def phase(sel):
+            idx = [i for i in range(args.steps) if sel(i)]
+            if not idx:
+                return None
+            return {"steps": len(idx), "ms_per_step": sum(log["step_ms"][i] for i in idx) / len(idx),
+                    "physics_ms_per_step": sum(log["phys_ms"][i] for i in idx) / len(idx),
+                    "substep_us": sum(log["phys_ms"][i] for i in idx) / len(idx) / n_sub * 1e3,
+                    "self_collision_candidates": int(max(log["candidates"][i] for i in idx)),
+                    "mesh_contacts": int(max(log["mesh_hits"][i] for i in idx)),
+                    "grasped_envs": int(max(log["grasped"][i] for i in idx)),
+                    "kernel_flavours": sorted({log["flavour"][i] for i in idx})}
+
+        first_contact = ro.close_at - args.warmup  # index in the timed window of the step in which the fingers close / rod arrives
+        pmc_sub, pmc_comp = pmc_summary("k_substep", args.config), pmc_summary("k_composite", args.config)
+        src = f"{PMC_FILE} (rocprofv3 --pmc passes of this workload, committed; NOT measured in this run)"
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_sub["hbm_bytes_per_launch"] if pmc_sub and ro.n_env == 32 and n_sub == 667 else None,
+                "traffic_source": src if pmc_sub else None,
+                "hbm_actual_frac": (pmc_sub["hbm_bytes_per_launch"] / t_kernel / 1e9 / HBM_PEAK_GBS) if pmc_sub and ro.n_env == 32 and n_sub == 667 else None,
+                "valu_busy_frac": pmc_sub.get("valu_busy_frac") if pmc_sub else None,
+                "kernel": "k_substep (fused spring gather + velocity + collisions + integrate)",
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": t_kernel * 1e6, "launches": n_sub * args.steps,
+                "concurrent_chains": chains,
+                "single_chain_check": None if single_us is None else {
+                    "avg_launch_us": single_us, "achieved": alg_bytes / (single_us * 1e-6) / 1e9, "frac": alg_bytes / (single_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "note": "same step with one kernel per batched substep (r2s_phys_set_tuning chains=1, measured after the timed region, "
+                            "in the contact state the window ended in): a per-kernel duration, comparable with profiles/r2_bench_kernel_stats_chains1.md"},
+                "note": f"frac is the SURVEY.md §8d contract figure: algorithmic bytes (16 S + 48 N per env) / avg launch time / 8 TB/s, averaged over "
+                        f"the whole timed window (free + contact).  The topology (16 S) is shared by the {ro.n_env} envs and stays in L2, so the bytes that "
+                        "reach HBM are hbm_actual_frac of peak; valu_busy_frac = SQ_ACTIVE_INST_VALU share of the kernel span: the kernel is "
+                        f"VALU-issue / latency bound, not HBM bound.  One 'launch' = one batched substep of all {ro.n_env} envs, issued as {chains} concurrent "
+                        "kernels over disjoint env ranges (per-kernel durations overlap); avg_launch_us = HIP-event time of the 667-substep graph / 667"}
         out = {
             "metric": "sim env-steps/sec (phys+render) per node at 32 envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {ro.N} particles / {ro.S} springs / {ro.P} Gaussians per env, "
-                                   f"{ro.n_env} envs per GPU, {args.substeps} substeps + {ro.views} frames {ro.W}x{ro.H} per env step",
+                                   f"{ro.n_env} envs per GPU, {args.substeps} substeps + {ro.views} frames {ro.W}x{ro.H} per env step; "
+                                   f"action trace '{ro.schedule}': free motion, contact from timed step {first_contact}",
                        "envs_per_gpu": ro.n_env, "parallelism": f"envs sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("k_substep", args.config) if (ro.n_env == 32 and args.substeps == 667) else None,
-                         "kernel": "k_substep (fused spring gather + velocity + collisions + integrate)",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": t_kernel * 1e6, "launches": phys_kernels,
-                         "concurrent_chains": chains,
-                         "single_chain_check": None if single_us is None else {
-                             "avg_launch_us": single_us, "achieved": alg_bytes / (single_us * 1e-6) / 1e9, "frac": alg_bytes / (single_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                             "note": "same step with R2S_CHAINS=1 (one kernel per batched substep, measured after the timed region): compare with "
-                                     "profiles/r1_bench_kernel_stats_chains1.md"},
-                         "note": f"one 'launch' = one batched substep of all {ro.n_env} envs; it is issued as {chains} concurrent kernels over disjoint "
-                                 "env ranges, so rocprofv3's per-kernel durations overlap in time (sum > wall clock); avg_launch_us is the HIP-event "
-                                 "time of the 667-substep graph / 667.  profiles/ holds the trace for R2S_CHAINS=1 as well, where both agree"},
+            "phases": {"free": phase(lambda i: i < first_contact), "contact": phase(lambda i: i >= first_contact),
+                       "note": "free = the end effector moves, nothing touches; contact = fingers closed on the toy's arms / rod against the block "
+                               "(mesh_contacts = particles inside a collision margin in the last substep, self_collision_candidates = particles "
+                               "with live candidates, maxima over the phase's steps)"},
+            "roofline": roof,
             "raster": {"gs_raster_mpix_per_s": frames * ro.W * ro.H / (raster_ms * 1e-3) / 1e6, "frames": frames,
                        "num_rendered": int(ro.last_num_rendered), "stage_ms": stages, "scene": scene,
                        "composite_roofline": {"bound": "hbm", "achieved": comp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": comp_gbs / HBM_PEAK_GBS, "algorithmic_bytes": comp_bytes,
-                                              "traffic": measured_traffic("k_composite", args.config) if ro.n_env == 32 else None,
-                                              "note": "VALU/exp-bound in practice (SURVEY.md §7): HBM fraction reported as the contract asks"}},
+                                              "traffic": pmc_comp["hbm_bytes_per_launch"] if pmc_comp and ro.n_env == 32 else None,
+                                              "traffic_source": src if pmc_comp else None,
+                                              "valu_busy_frac": pmc_comp.get("valu_busy_frac") if pmc_comp else None,
+                                              "note": "VALU/exp-bound (≈115 flop per algorithmic byte, SURVEY.md §7): the north_star's >= 0.60 of HBM peak "
+                                                      "is not reachable for this kernel at any instruction count above ~1/3 of the reference's per-pixel "
+                                                      "arithmetic; valu_busy_frac is the figure that says how close to its real bound it runs"}},
             "physics_ms_per_env_step": phys_ms, "skinning_ms_per_env_step": skin_ms,
             "task_success": {"envs_satisfying_predicate": int(records[:, 4].sum().item()), "of": total_envs,
                              "note": "frame-level success predicate of the scene's task evaluated on the device after the last step "

@@ -144,6 +144,27 @@ int r2s_phys_collision_max_count(R2SPhys* h, int32_t* max_count, r2s_stream_t st
 int r2s_phys_set_spring_Y(R2SPhys* h, const float* log_Y, r2s_stream_t stream);
 int r2s_phys_set_params(R2SPhys* h, const R2SPhysParams* params, r2s_stream_t stream);
 
+/* Candidate lists written by the caller: collision_number / collision_indices are plain arrays of the reference object
+ * (:544-552) that update_potential_collision fills; this is the write side.  HOST arrays in the caller's particle
+ * indexing, number [n_env, N] and indices [n_env, N, capacity].  Used by the parity tests to replay lists recorded from
+ * the reference's own kernels; the next r2s_phys_update_collision_graph overwrites them. */
+int r2s_phys_set_collision_lists(R2SPhys* h, const int32_t* number, const int32_t* indices, r2s_stream_t stream);
+
+/* Contact report of the last step (bench.py's phase accounting): particles that currently have self-collision candidates
+ * (host view of the last update_collision_graph) and a device pointer to int32 [n_env], the particles of each environment
+ * that reacted to a collision mesh (mesh_collision's err < 0 branch, :343) in the LAST substep. */
+int r2s_phys_contact_stats(R2SPhys* h, int32_t* particles_with_candidates, int32_t** mesh_hits_dev);
+/* The same three counts {particles with candidates, mesh hits of the last substep, grasped environments} written to a
+ * DEVICE int32[3] by a tiny kernel on `stream` — a per-step log without a host synchronisation. */
+int r2s_phys_log_contacts(R2SPhys* h, int32_t* out3_dev, r2s_stream_t stream);
+/* Which captured flavour the last r2s_phys_step ran: out[0] self-collision finishing kernel (0/1), out[1] mesh template
+ * (0 none, 1 small meshes per lane, 2 large mesh wave-cooperative), out[2] deferred large-mesh queries (0/1), out[3] chains. */
+int r2s_phys_last_flavour(R2SPhys* h, int32_t* out);
+/* Tuning (not part of the reference surface): chains > 0 overrides the number of concurrent kernel chains of the captured
+ * env step (0 = default), mesh_defer 0/1 forces the deferred large-mesh-query flavour (-1 = automatic).  The environment
+ * variables R2S_CHAINS / R2S_MESH_DEFER / R2S_LAYOUT / R2S_HALO_CAP are read ONCE, by r2s_phys_create. */
+int r2s_phys_set_tuning(R2SPhys* h, int chains, int mesh_defer);
+
 /* Layout report (DESIGN.md / bench.py): out[0] particle blocks, [1] largest halo (records), [2] ELL slots incl.
  * padding, [3] real neighbour slots (= 2 * active springs), [4] slots served by the global fallback instead of LDS,
  * [5] LDS bytes per workgroup, [6] concurrent kernel chains of the captured env step, [7] work items per XCD chunk. */

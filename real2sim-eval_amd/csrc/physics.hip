@@ -4,35 +4,36 @@
 //   sim/physics/spring_mass_warp.py  (SpringMassSystemWarp: 14 NVIDIA-Warp kernels, 9 launches per substep,
 //   667 substeps per env step replayed as a ~6000-node CUDA graph).
 //
-// MI355X design (see DESIGN.md):
+// MI355X design (see DESIGN.md §4):
 //   * ONE fused kernel per substep for a whole batch of environments.  Spring forces are GATHERED per
-//     particle from a sliced-ELL adjacency (64 particles = one wavefront per slice, neighbour slots stored
-//     slot-major so every load is a coalesced 256-byte run) instead of scattered with float atomics
-//     (eval_springs, :61-104) — deterministic and atomic-free.  Velocity update (:107-129), self collision
-//     (:132-268), mesh collision (:295-421) and ground integration (:424-474) run in the same thread.
+//     particle from a sliced-ELL adjacency (64 particles = one wavefront per slice, 4-slot groups stored
+//     group-major so every load is a coalesced run) instead of scattered with float atomics
+//     (eval_springs, :61-104) — deterministic and atomic-free.  Velocity update (:107-129), mesh collision
+//     (:295-421) and ground integration (:424-474) run in the same thread.
 //   * Particles are re-ordered along a Morton curve at construction (the caller never sees it: set/get_state
-//     permute).  A workgroup owns 256 consecutive particles of one environment and stages their {x,v}
-//     records plus a precomputed HALO (the most-referenced outside neighbours, up to the LDS budget) in LDS
-//     with coalesced / once-per-workgroup loads; the ~31 neighbour gathers per particle are then LDS reads
-//     (ds_read_b128) instead of 64-distinct-cache-line global gathers, which the first profile showed to be
-//     the limiter (vector-L1 tag rate, not bytes).  Neighbours that do not fit the halo fall back to a
-//     global gather, so any topology works.
+//     permute).  A workgroup owns 256 consecutive particles of one environment and stages their state plus
+//     a precomputed HALO (every outside neighbour, up to the window capacity) into an LDS window of three
+//     8-byte planes xy | (z, vz) | vxy; the ~31 neighbour gathers per particle are then three ds_read_b64
+//     off one address register.  Neighbours that do not fit the window fall back to a global gather, so any
+//     topology works.
 //   * Workgroups are numbered so that each XCD (private 4 MiB L2) owns a contiguous chunk of particle blocks
 //     for ALL environments, environment index fastest: its slice of the adjacency and its particles' state
 //     stay resident in that XCD's L2 and most halo records were written by the same XCD.
 //   * Self collision needs the post-force velocity of the contact partner (object_collision reads
-//     v_before_collision[j]); instead of a second launch per substep the few particles that have contact
-//     candidates recompute their partners' velocity update (same code path, bit-identical result).
-//   * State is ping-ponged between two [env][particle]{x,v} buffers of 32-byte records (two 16-byte
-//     gathers per neighbour), topology is shared by all environments of the batch and stays cache-resident.
-//   * The num_substeps launches are captured once in a hipGraph.
+//     v_before_collision[j]): particles that appear in a candidate list only PUBLISH their post-force velocity
+//     in the fused kernel and are finished by k_self_finish (second launch per substep, only captured into the
+//     graph flavour used while candidates exist).
+//   * State is ping-ponged between two buffers of three 8-byte planes [env][particle] (the LDS window's own
+//     layout: 24 B per particle, no padding); topology is shared by all environments and stays cache-resident.
+//   * The num_substeps launches are captured once per flavour in a hipGraph.
 //   * Resting pairs: per-environment N x N bitset instead of the reference's N x N byte matrix (:715).
-//   * Hash grid (wp.HashGrid 128^3, cell = 5 * collision_dist): cell keys sorted with rocPRIM radix sort,
-//     cells located by binary search; same cell arithmetic and traversal order as warp-lang 1.7 (unpinned,
-//     see oracle/physics_oracle_impl.inc).
-//   * Mesh queries: exact closest point + exact solid-angle winding number over the (small) gripper /
-//     obstacle meshes, culled by per-substep mesh AABBs.  No BVH yet: the 25k-face pusher mesh is a
-//     "next" row.
+//   * Hash grid (wp.HashGrid 128^3, cell = 5 * collision_dist) for create_resting_case; the per-step candidate
+//     rebuild bins on a fine grid (cell = collision_dist) and restores the reference's traversal order
+//     (unpinned against warp-lang 1.7 itself, see oracle/physics_oracle_impl.inc).
+//   * Mesh queries: small meshes (<= 256 faces: fingers, boxes) per-lane brute force with the exact solid-angle
+//     winding number; large meshes (the ~25k-face pusher) through Morton-sorted 64-face clusters with rest-frame
+//     boxes, wave-cooperative, sign from pseudonormals (closed manifolds) or the exact winding number (anything
+//     else); particles in contact with a large mesh are finished by k_mesh_finish, one wavefront each.
 
 #include "r2s_common.h"
 #include <rocprim/rocprim.hpp>
@@ -106,7 +107,8 @@ struct PhysDev {
     const int* cl_f1;
     const int* cl_mesh;        // [n_cl]
     const float* cl_box;       // [n_cl,6] rest-frame boxes (clusters of large meshes)
-    const int* mesh_kind;      // [n_mesh] 0 small (brute force, exact winding), 1 large (clusters + pseudonormals)
+    const int* mesh_kind;      // [n_mesh] bit 0: large (> 256 faces: clusters, wave-cooperative); bit 1: not a closed manifold (sign by
+                               // exact winding number; closed large meshes use pseudonormals, small meshes always the winding number)
     const int* mesh_xf;        // [n_mesh] transform slot of a large dynamic mesh, else -1
     const int* xf_mesh;        // [n_xf] mesh of a transform slot
     const float* xf;           // [E,n_sub,n_xf,12]
@@ -122,6 +124,7 @@ struct PhysDev {
     const float* aabb_dyn;     // [E,n_sub,n_dyn_mesh,6]
     const float* aabb_static;  // [E,n_mesh-n_dyn_mesh,6]
     float* coll_forces;        // [E,nF,3]
+    int* hit_cnt;              // [E] particles that reacted to a mesh in the LAST substep (zeroed with coll_forces)
 };
 
 // Everything from here to the spring gather is compiled WITHOUT fused multiply-add contraction: the collision
@@ -300,7 +303,7 @@ __device__ MeshHit mesh_query_wave(const PhysDev& p, int step, f3 q_lane, int e_
             if (c >= p.n_cl) return 3.0e38f;
             const int4 ci = p.cl_info[c];
             const int m = ci.x;
-            if (ci.y == 0) {
+            if (!(ci.y & 1)) {
                 const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
                                                    : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
                 return box_dist2(q, bb);
@@ -331,7 +334,7 @@ __device__ MeshHit mesh_query_wave(const PhysDev& p, int step, f3 q_lane, int e_
                 if (!(bcast(d2c, k) < best * 1.0001f + 1e-12f)) continue; // cannot beat the current best
                 const int c2 = cb + k;
                 const int f0 = p.cl_f0[c2], f1 = p.cl_f1[c2], m = p.cl_mesh[c2];
-                const bool large = p.mesh_kind[m] != 0;
+                const bool large = (p.mesh_kind[m] & 1) != 0;
                 const Xf X = xf_load(p, e, step, m);
                 const f3 qq = large ? xf_inverse(X, q) : q;
                 for (int fb = f0; fb < f1; fb += 64) {
@@ -373,20 +376,33 @@ __device__ MeshHit mesh_query_wave(const PhysDev& p, int step, f3 q_lane, int e_
         float sign = 1.f;
         if (found) {
             const int bm = p.face_mesh[bstored];
-            if (p.mesh_kind[bm] != 0) {
+            if (p.mesh_kind[bm] == 1) {
                 const f3 n = ld3(p.pnorm, (size_t)bstored * 7 + bregion); // rest frame, like bdl
                 sign = dot(bdl, n) < 0.f ? -1.f : 1.f;
             } else {
-                // exact winding number over the faces of every SMALL mesh (all faces when the scene has no large mesh)
+                // exact winding number (the reference's sign rule, :322-324) over the faces of every mesh that is not a
+                // large closed manifold (those contribute 0 outside themselves): all faces when the scene has no such
+                // mesh.  Faces of a large open mesh are visited in its rest frame (solid angles are rotation invariant).
                 float ws = 0.f;
-                for (int f = lane; f < p.nF; f += 64) {
-                    if (p.mesh_kind[p.face_mesh[f]] != 0) continue;
-                    const f3 a = mesh_vertex(p, e, step, p.faces[3 * f]) - q, b = mesh_vertex(p, e, step, p.faces[3 * f + 1]) - q,
-                             c3 = mesh_vertex(p, e, step, p.faces[3 * f + 2]) - q;
-                    const float la = len(a), lb = len(b), lc = len(c3);
-                    const float det = dot(a, cross(b, c3));
-                    const float den = la * lb * lc + dot(a, b) * lc + dot(b, c3) * la + dot(c3, a) * lb;
-                    ws += 2.f * atan2f(det, den);
+                for (int m = 0; m < p.n_mesh; ++m) {
+                    const int kind = p.mesh_kind[m];
+                    if (kind == 1) continue;
+                    const bool rest = (kind & 1) != 0;
+                    const f3 qm = rest ? xf_inverse(xf_load(p, e, step, m), q) : q;
+                    for (int f = p.mesh_face_off[m] + lane; f < p.mesh_face_off[m + 1]; f += 64) {
+                        f3 a, b, c3;
+                        if (rest) {
+                            const float* t9 = p.tri_rest + (size_t)f * 9;
+                            a = mk(t9[0], t9[1], t9[2]) - qm; b = mk(t9[3], t9[4], t9[5]) - qm; c3 = mk(t9[6], t9[7], t9[8]) - qm;
+                        } else {
+                            a = mesh_vertex(p, e, step, p.faces[3 * f]) - qm; b = mesh_vertex(p, e, step, p.faces[3 * f + 1]) - qm;
+                            c3 = mesh_vertex(p, e, step, p.faces[3 * f + 2]) - qm;
+                        }
+                        const float la = len(a), lb = len(b), lc = len(c3);
+                        const float det = dot(a, cross(b, c3));
+                        const float den = la * lb * lc + dot(a, b) * lc + dot(b, c3) * la + dot(c3, a) * lb;
+                        ws += 2.f * atan2f(det, den);
+                    }
                 }
                 const float wn = wave_sum(ws) / (float)(4.0 * 3.14159265358979323846);
                 sign = wn > WIND_THRESHOLD ? -1.f : 1.f;
@@ -548,15 +564,17 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         f3 next_x = x0 + vin * p.dt;
         f3 next_v = vin;
         // Exact early-out.  The response below only fires when signed distance < margin (5 mm for gripper
-        // meshes, 1 mm otherwise).  Every collision mesh is a closed surface, so a point outside a mesh's AABB is
-        // outside the mesh (winding number 0 < 0.6, sign +1) and its distance to the mesh is at least its distance
-        // to the AABB: if that is >= the margin for every mesh, nothing can happen and the query is skipped.
+        // meshes, 1 mm otherwise).  A point outside the AABB of a CLOSED mesh is outside the mesh (winding number
+        // 0 < 0.6, sign +1) and its distance to the mesh is at least its distance to the AABB: if that is >= the
+        // margin for every mesh, nothing can happen and the query is skipped.  Meshes that are not closed manifolds
+        // (checked at construction) only get the query's own 2 cm range as the bound.
         bool need = false;
         if (fin) {
             for (int m = 0; m < p.n_mesh; ++m) {
                 const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
                                                    : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
-                const float mg = (m < p.n_dyn_mesh && !p.use_pusher) ? 0.005f : 0.001f;
+                // an OPEN mesh (kind bit 2) can report "inside" beyond its box: only the query's own range bounds it
+                const float mg = (p.mesh_kind[m] & 2) ? MESH_MAX_DIST : ((m < p.n_dyn_mesh && !p.use_pusher) ? 0.005f : 0.001f);
                 need = need || box_dist2(next_x, bb) < mg * mg * 1.0001f;
             }
         }
@@ -640,6 +658,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
             atomicAdd(cf3, fo.x);
             atomicAdd(cf3 + 1, fo.y);
             atomicAdd(cf3 + 2, fo.z);
+            atomicAdd(p.hit_cnt + e, 1);
         }
         x = next_x;
         v = next_v;
@@ -849,6 +868,16 @@ __global__ void __launch_bounds__(256) k_mesh_finish(const PhysDev p, const floa
     }
 }
 
+// {particles with candidates, mesh hits of the last substep, grasped environments} -> out[3] (bench.py's phase log: no host sync)
+__global__ void k_log_contacts(int E, const int* __restrict__ cand_count, const int* __restrict__ hit_cnt, const int* __restrict__ grasped,
+                               int* __restrict__ out)
+{
+    int hits = 0, g = 0;
+    for (int e = threadIdx.x; e < E; e += 64) { hits += hit_cnt ? hit_cnt[e] : 0; g += grasped ? (grasped[e] != 0) : 0; }
+    for (int o = 32; o > 0; o >>= 1) { hits += __shfl_down(hits, o, 64); g += __shfl_down(g, o, 64); }
+    if (threadIdx.x == 0) { out[0] = cand_count ? *cand_count : 0; out[1] = hits; out[2] = g; }
+}
+
 __global__ void k_sum_i32(const int* __restrict__ a, int n, int* __restrict__ out)
 {
     int s = 0;
@@ -896,7 +925,7 @@ __global__ void k_mesh_aabb_dyn(int E, int n_sub, int n_dyn_mesh, int n_dyn_pts,
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= E * n_sub * n_dyn_mesh) return;
     const int m = t % n_dyn_mesh;
-    if (mesh_kind[m] != 0) return; // large rigid meshes: box from the transformed rest box (k_mesh_xf)
+    if (mesh_kind[m] & 1) return; // large rigid meshes: box from the transformed rest box (k_mesh_xf)
     const size_t es = t / n_dyn_mesh;
     float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
     for (int vtx = mesh_vert_off[m]; vtx < mesh_vert_off[m + 1]; ++vtx) {
@@ -1390,6 +1419,12 @@ struct R2SPhys {
     float4* d_vbc = nullptr;
     int2* d_mesh_list = nullptr; int* d_mesh_cnt = nullptr; int mesh_cap = 0; // deferred large-mesh queries: [chains][cap], [chains][n_sub]
     int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false;
+    int chains_override = 0;  // > 0: tuning override of chains() (R2S_CHAINS at create, r2s_phys_set_tuning later)
+    int force_defer = -1;     // >= 0: force the deferred-query flavour on / off (tests, tuning)
+    int last_flavour[4] = {0, 0, 0, 1}; // of the last step: self-collision variant, mesh template, deferred queries, chains
+    std::vector<float> h_logY; // last log stiffness (re-clamped when spring_Y_min / max change)
+    int* d_hit_cnt = nullptr;
+    hipEvent_t rigid_event = nullptr;
     int mesh_defer = 0; // this env step's graph flavour: 1 = needy particles are finished by k_mesh_finish (contact likely), 0 = in place
     int2* d_cand_list = nullptr;
     int* d_cand_count = nullptr;
@@ -1404,7 +1439,7 @@ struct R2SPhys {
         // workgroups: 23.5 / 21.3 / 22.4 / 23.2 us per substep for 1 / 2 / 3 / 4 chains; smaller batches lose (16 sloth envs
         // 15.1 vs 16.8 us, 8 envs 10.7 vs 12.5 us, 32 T-block envs 10.3 vs 11.1 us for 1 vs 2 chains)
         int c = (int64_t)nb * E >= 1536 ? 2 : 1;
-        if (const char* ev = getenv("R2S_CHAINS")) c = std::max(1, std::min(atoi(ev), std::min(E, 8))); // tuning knob
+        if (chains_override > 0) c = std::max(1, std::min(chains_override, std::min(E, 8)));
         return c;
     }
     uint32_t *d_bits = nullptr, *d_keys[2] = {nullptr, nullptr}, *d_ids[2] = {nullptr, nullptr};
@@ -1466,7 +1501,7 @@ struct R2SPhys {
         p.cl_mesh = d_cl_mesh; p.cl_box = d_cl_box; p.mesh_kind = d_mesh_kind; p.mesh_xf = d_mesh_xf; p.xf_mesh = d_xf_mesh; p.xf = d_xf; p.rest_pts = d_rest_pts;
         p.pnorm = d_pnorm; p.tri_rest = d_tri_rest; p.cl_info = d_cl_info;
         p.mesh_pts = d_mesh_pts; p.interp_pts = d_interp; p.interp_center = d_center; p.dyn_vel = d_dyn_vel; p.dyn_omega = d_dyn_omega;
-        p.aabb_dyn = d_aabb_dyn; p.aabb_static = d_aabb_static; p.coll_forces = d_coll_forces;
+        p.aabb_dyn = d_aabb_dyn; p.aabb_static = d_aabb_static; p.coll_forces = d_coll_forces; p.hit_cnt = d_hit_cnt;
         return p;
     }
 };
@@ -1504,6 +1539,7 @@ void stiffness_from_log(const R2SPhys* h, const float* log_Y, std::vector<float>
 int upload_stiffness(R2SPhys* h, const float* log_Y, hipStream_t s)
 {
     std::vector<float> k; std::vector<char> act;
+    if (log_Y != h->h_logY.data()) h->h_logY.assign(log_Y, log_Y + h->S);
     stiffness_from_log(h, log_Y, k, act);
     // Slots of inactive springs (gate exp(logY) > Ymin fails, :75) and padding slots point at the particle
     // itself with k = 0: then d = 0 and dv = 0, so neither the spring nor the dashpot term contributes.
@@ -1593,6 +1629,7 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
         if (last && h->nF > 0 && zero_forces) { // this chain's slice of the accumulator
             const size_t cnt = 3 * (size_t)ne * h->nF;
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->d_coll_forces + 3 * (size_t)e0 * h->nF, cnt);
+            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, (float*)(h->d_hit_cnt + e0), (size_t)ne);
         }
         int rc = launch_substep(h, p, buf, first + k, last, with_self, s);
         if (rc) return rc;
@@ -1684,6 +1721,8 @@ int update_mesh_transforms(R2SPhys* h, hipStream_t s)
     hipLaunchKernelGGL(k_mesh_xf, dim3((tot + 255) / 256), dim3(256), 0, s, h->E, h->prm.num_substeps, h->n_dyn_mesh, h->n_dyn_pts, h->n_xf, h->d_xf_mesh,
                        h->d_xf_ref, h->d_mesh_vert_off, h->d_rest_pts, h->d_xf_rest_box, h->d_interp, h->d_xf, h->d_aabb_dyn, h->d_rigid_err);
     R2S_HIP_TRY(hipMemcpyAsync(h->h_rigid_err, h->d_rigid_err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    if (!h->rigid_event) R2S_HIP_TRY(hipEventCreateWithFlags(&h->rigid_event, hipEventDisableTiming));
+    R2S_HIP_TRY(hipEventRecord(h->rigid_event, s));
     h->rigid_pending = true;
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
@@ -1741,6 +1780,9 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         int pick = 0;
         if (const char* ev = getenv("R2S_LAYOUT")) { const int v = atoi(ev); for (int k = 0; k < 2; ++k) if (v == sizes[k]) pick = k; } // tuning knob
         h->pb = sizes[pick]; h->rcap = caps[pick];
+        // the remaining tuning knobs are also read here, ONCE per handle (r2s_phys_set_tuning changes them afterwards)
+        if (const char* ev = getenv("R2S_CHAINS")) h->chains_override = atoi(ev);
+        if (const char* ev = getenv("R2S_MESH_DEFER")) h->force_defer = atoi(ev) != 0;
     }
     const int PB = h->pb, SL = SLICE;
     h->h_perm.resize(N); h->h_inv.resize(N);
@@ -1937,8 +1979,37 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             const int f0 = foff[m], nf = foff[m + 1] - foff[m];
             std::vector<int> order(nf);
             for (int k = 0; k < nf; ++k) order[k] = f0 + k;
+            // Weld coincident vertices (STL exports repeat every corner), then test for a closed, consistently oriented
+            // manifold: every undirected edge is used by exactly two faces, once in each direction.  mesh_kind bits:
+            // 1 = large (> 256 faces: clusters + wave-cooperative queries), 2 = open / not a manifold (sign from the exact
+            // winding number like the reference, :322-324, and no "outside the box is outside the mesh" early-out).
+            std::vector<int> canon(voff[m + 1] - voff[m]);
+            {
+                std::vector<std::array<float, 3>> pos(canon.size());
+                std::vector<int> ord(canon.size());
+                for (size_t v = 0; v < canon.size(); ++v) { ord[v] = (int)v; for (int k = 0; k < 3; ++k) pos[v][k] = V[3 * (size_t)(voff[m] + v) + k]; }
+                std::sort(ord.begin(), ord.end(), [&](int a, int b) { return pos[a] != pos[b] ? pos[a] < pos[b] : a < b; });
+                for (size_t q = 0; q < ord.size(); ++q) canon[ord[q]] = (q > 0 && pos[ord[q]] == pos[ord[q - 1]]) ? canon[ord[q - 1]] : ord[q];
+            }
+            auto cv = [&](int gv) { return voff[m] + canon[gv - voff[m]]; }; // welded (canonical) global vertex id
+            std::vector<std::array<long long, 3>> edges; // (min v, max v, +-(face+1)) on welded ids
+            bool manifold = nf > 0;
+            for (int k = 0; k < nf; ++k) {
+                const int tri[3] = {cv(faces[3 * (f0 + k)]), cv(faces[3 * (f0 + k) + 1]), cv(faces[3 * (f0 + k) + 2])};
+                if (tri[0] == tri[1] || tri[1] == tri[2] || tri[2] == tri[0]) manifold = false; // degenerate after welding
+                for (int c = 0; c < 3; ++c) {
+                    const int p0 = tri[c], p1 = tri[(c + 1) % 3];
+                    edges.push_back({std::min(p0, p1), std::max(p0, p1), p0 < p1 ? (long long)(k + 1) : -(long long)(k + 1)});
+                }
+            }
+            std::sort(edges.begin(), edges.end());
+            manifold = manifold && edges.size() % 2 == 0;
+            for (size_t q = 0; manifold && q + 1 < edges.size(); q += 2)
+                manifold = edges[q][0] == edges[q + 1][0] && edges[q][1] == edges[q + 1][1] && (edges[q][2] < 0) != (edges[q + 1][2] < 0) &&
+                           (q + 2 >= edges.size() || edges[q + 2][0] != edges[q][0] || edges[q + 2][1] != edges[q][1]);
+            if (!manifold) mesh_kind[m] |= 2;
             if (nf > LARGE_FACES) {
-                mesh_kind[m] = 1;
+                mesh_kind[m] |= 1;
                 double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
                 for (int v = voff[m]; v < voff[m + 1]; ++v) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], vtx(v, k)); hi[k] = std::max(hi[k], vtx(v, k)); }
                 const double ext = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-12});
@@ -1955,13 +2026,12 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
                 }
                 std::sort(code.begin(), code.end());
                 for (int k = 0; k < nf; ++k) order[k] = code[k].second;
-                // closed-manifold check + pseudonormals (Baerentzen & Aanaes 2005), in the rest frame
+                // pseudonormals (Baerentzen & Aanaes 2005) of a closed manifold, in the rest frame, on welded vertices
                 std::vector<std::array<double, 3>> fn(nf);
                 std::vector<std::array<double, 3>> vn(voff[m + 1] - voff[m], {0, 0, 0});
-                std::vector<std::array<long long, 3>> edges; // (min v, max v, +-(face+1))
                 auto sub3 = [&](int a, int b, double* o) { for (int k = 0; k < 3; ++k) o[k] = vtx(a, k) - vtx(b, k); };
-                for (int k = 0; k < nf; ++k) {
-                    const int ia = faces[3 * (f0 + k)], ib = faces[3 * (f0 + k) + 1], ic = faces[3 * (f0 + k) + 2];
+                for (int k = 0; manifold && k < nf; ++k) {
+                    const int ia = cv(faces[3 * (f0 + k)]), ib = cv(faces[3 * (f0 + k) + 1]), ic = cv(faces[3 * (f0 + k) + 2]);
                     double ab[3], ac[3]; sub3(ib, ia, ab); sub3(ic, ia, ac);
                     double n[3] = {ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0]};
                     const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
@@ -1974,18 +2044,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
                         const double cs = (l1 > 0 && l2 > 0) ? (e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2]) / (l1 * l2) : 1.0;
                         const double ang = std::acos(std::min(1.0, std::max(-1.0, cs)));
                         for (int q = 0; q < 3; ++q) vn[p0 - voff[m]][q] += ang * fn[k][q];
-                        edges.push_back({std::min(p0, p1), std::max(p0, p1), p0 < p1 ? (long long)(k + 1) : -(long long)(k + 1)});
                     }
-                }
-                std::sort(edges.begin(), edges.end());
-                bool manifold = edges.size() % 2 == 0;
-                for (size_t q = 0; manifold && q + 1 < edges.size(); q += 2)
-                    manifold = edges[q][0] == edges[q + 1][0] && edges[q][1] == edges[q + 1][1] && (edges[q][2] < 0) != (edges[q + 1][2] < 0) &&
-                               (q + 2 >= edges.size() || edges[q + 2][0] != edges[q][0] || edges[q + 2][1] != edges[q][1]);
-                if (!manifold) {
-                    r2s::set_last_error_msg("collision meshes with more than 256 faces must be closed manifolds (sign by pseudonormal)");
-                    r2s_phys_destroy(h);
-                    return R2S_ERR_INVALID;
                 }
                 auto edge_normal = [&](int p0, int p1, double* o) {
                     std::array<long long, 3> key = {std::min(p0, p1), std::max(p0, p1), LLONG_MIN};
@@ -1993,10 +2052,10 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
                     for (int q = 0; q < 3; ++q) o[q] = 0;
                     for (int r = 0; r < 2; ++r, ++it) { const int ff = (int)std::llabs((*it)[2]) - 1; for (int q = 0; q < 3; ++q) o[q] += fn[ff][q]; }
                 };
-                for (int k = 0; k < nf; ++k) {
+                for (int k = 0; manifold && k < nf; ++k) {
                     const int of = order[k], kk = of - f0;            // original face, index inside the mesh
                     const size_t st = (size_t)(f0 + k) * 21;          // stored slot
-                    const int tri[3] = {faces[3 * of], faces[3 * of + 1], faces[3 * of + 2]};
+                    const int tri[3] = {cv(faces[3 * of]), cv(faces[3 * of + 1]), cv(faces[3 * of + 2])};
                     for (int q = 0; q < 3; ++q) pnorm[st + q] = (float)fn[kk][q];
                     for (int c = 0; c < 3; ++c) for (int q = 0; q < 3; ++q) pnorm[st + 3 * (1 + c) + q] = (float)vn[tri[c] - voff[m]][q];
                     for (int c = 0; c < 3; ++c) { double en[3]; edge_normal(tri[c], tri[(c + 1) % 3], en); for (int q = 0; q < 3; ++q) pnorm[st + 3 * (4 + c) + q] = (float)en[q]; }
@@ -2021,7 +2080,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
                 for (int q = 0; q < 3; ++q) stored[3 * st + q] = faces[3 * of + q];
                 face_orig[st] = of; face_mesh[st] = m;
             }
-            const int step = mesh_kind[m] ? CL : std::max(nf, 1);
+            const int step = (mesh_kind[m] & 1) ? CL : std::max(nf, 1);
             for (int k = 0; k < nf; k += step) {
                 cl_f0.push_back(f0 + k); cl_f1.push_back(f0 + std::min(nf, k + step)); cl_mesh.push_back(m);
                 float bb[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
@@ -2032,7 +2091,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         }
         h->n_cl = (int)cl_f0.size(); h->n_xf = (int)xf_mesh.size();
         h->h_mesh_kind = mesh_kind; h->h_voff = voff; h->h_foff = foff; h->h_xf_mesh = xf_mesh; h->h_xf_ref = xf_ref;
-        for (int m = 0; m < h->n_mesh; ++m) h->any_large = h->any_large || mesh_kind[m] != 0;
+        for (int m = 0; m < h->n_mesh; ++m) h->any_large = h->any_large || (mesh_kind[m] & 1);
         TRY(dev_alloc(&h->d_face_orig, h->nF)); TRY(dev_alloc(&h->d_face_mesh, h->nF)); TRY(dev_alloc(&h->d_cl_f0, h->n_cl)); TRY(dev_alloc(&h->d_cl_f1, h->n_cl));
         TRY(dev_alloc(&h->d_cl_mesh, h->n_cl)); TRY(dev_alloc(&h->d_cl_box, cl_box.size())); TRY(dev_alloc(&h->d_mesh_kind, h->n_mesh)); TRY(dev_alloc(&h->d_mesh_xf, h->n_mesh));
         TRY(dev_alloc(&h->d_rest_pts, 3 * (size_t)h->nV)); TRY(dev_alloc(&h->d_pnorm, pnorm.size()));
@@ -2083,6 +2142,8 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         TRY(dev_alloc(&h->d_aabb_static, (size_t)E * std::max(1, h->n_mesh - h->n_dyn_mesh) * 6));
         TRY(dev_alloc(&h->d_coll_forces, (size_t)E * h->nF * 3));
         R2S_HIP_TRY(hipMemsetAsync(h->d_coll_forces, 0, sizeof(float) * 3 * (size_t)E * h->nF, s));
+        TRY(dev_alloc(&h->d_hit_cnt, (size_t)E));
+        R2S_HIP_TRY(hipMemsetAsync(h->d_hit_cnt, 0, sizeof(int) * (size_t)E, s));
         if (h->n_dyn_mesh > 0) {
             const int tot = E * n_sub * h->n_dyn_mesh;
             hipLaunchKernelGGL(k_mesh_aabb_dyn, dim3((tot + 255) / 256), dim3(256), 0, s, E, n_sub, h->n_dyn_mesh, h->n_dyn_pts, h->d_mesh_vert_off, h->d_mesh_kind,
@@ -2150,11 +2211,12 @@ void r2s_phys_destroy(R2SPhys* h)
                     h->d_faces, h->d_face_orig, h->d_face_mesh, h->d_cl_f0, h->d_cl_f1, h->d_cl_mesh, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
                     h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
-                    h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta};
+                    h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta, h->d_hit_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_cand_count) (void)hipHostFree(h->h_cand_count);
     if (h->h_mesh_total) (void)hipHostFree(h->h_mesh_total);
     if (h->mesh_event) (void)hipEventDestroy(h->mesh_event);
+    if (h->rigid_event) (void)hipEventDestroy(h->rigid_event);
     if (h->h_rigid_err) (void)hipHostFree(h->h_rigid_err);
     if (h->cand_event) (void)hipEventDestroy(h->cand_event);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -2267,7 +2329,7 @@ int r2s_phys_set_eef_table(R2SPhys* h, int32_t n_knots, const double* eef_pts, c
         std::vector<int> need;
         for (int m = 0; m < h->n_dyn_mesh; ++m) {
             const int v0 = h->h_voff[m], v1 = h->h_voff[m + 1];
-            if (h->h_mesh_kind[m] == 0) { for (int v = v0; v < v1; ++v) need.push_back(v); continue; }
+            if (!(h->h_mesh_kind[m] & 1)) { for (int v = v0; v < v1; ++v) need.push_back(v); continue; }
             const int stride = std::max(1, (v1 - v0) / 48);
             for (int v = v0; v < v1; v += stride) need.push_back(v);
             for (size_t k = 0; k < h->h_xf_mesh.size(); ++k)
@@ -2340,8 +2402,9 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     }
     int rc0 = h->prm.self_collision ? resolve_cand_count(h) : R2S_OK;
     if (rc0) return rc0;
-    if (h->rigid_pending) { // large dynamic meshes must move rigidly: the check ran with the last set_mesh_interactive
-        R2S_HIP_TRY(hipStreamSynchronize(s));
+    // large dynamic meshes must move rigidly: the check ran with the last set_mesh_interactive / set_eef_motion; its result
+    // is read without waiting (pinned word + event), so a violation is reported by the first step() after it landed
+    if (h->rigid_pending && hipEventQuery(h->rigid_event) == hipSuccess) {
         h->rigid_pending = false;
         float worst; memcpy(&worst, h->h_rigid_err, 4);
         if (!(worst < 1e-4f)) {
@@ -2353,8 +2416,10 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     if (h->any_large) { // large-mesh scenes: defer the queries when the last finished step saw particles near a mesh
         if (h->mesh_pending && hipEventQuery(h->mesh_event) == hipSuccess) h->mesh_pending = false;
         if (!h->mesh_pending) h->mesh_defer = *h->h_mesh_total > 0 ? 1 : 0; // an unfinished count keeps the previous flavour
-        if (const char* ev = getenv("R2S_MESH_DEFER")) h->mesh_defer = atoi(ev) != 0; // test / tuning knob: force a flavour
+        if (h->force_defer >= 0) h->mesh_defer = h->force_defer; // test / tuning: force a flavour
     }
+    h->last_flavour[0] = variant; h->last_flavour[1] = h->nF > 0 ? (h->any_large ? 2 : 1) : 0; h->last_flavour[2] = h->mesh_defer;
+    h->last_flavour[3] = use_graph ? h->chains() : 1;
     if (use_graph) {
         // variant 1 bakes a grid size derived from n_cand: re-capture if the list outgrew it
         const int slot = h->mesh_defer * 4 + variant * 2 + (h->cur & 1);
@@ -2437,13 +2502,86 @@ int r2s_phys_set_spring_Y(R2SPhys* h, const float* log_Y, r2s_stream_t stream_)
     return upload_stiffness(h, log_Y, (hipStream_t)stream_);
 }
 
-int r2s_phys_set_params(R2SPhys* h, const R2SPhysParams* p, r2s_stream_t)
+int r2s_phys_set_params(R2SPhys* h, const R2SPhysParams* p, r2s_stream_t stream_)
 {
     if (!h || !p) return R2S_ERR_INVALID;
     if (p->num_substeps != h->prm.num_substeps || p->self_collision != h->prm.self_collision || p->use_pusher != h->prm.use_pusher)
         return R2S_ERR_INVALID; // structural fields are fixed at construction
+    if (!(p->dt > 0.f) || !(p->collision_dist > 0.f) || !(p->spring_Y_max >= p->spring_Y_min)) return R2S_ERR_INVALID;
+    const bool restiffen = p->spring_Y_min != h->prm.spring_Y_min || p->spring_Y_max != h->prm.spring_Y_max;
     h->prm = *p;
     drop_graph(h); // kernel arguments are baked into the graph; re-captured lazily by the next step
+    // the stiffness gate and clamp (:75, :93) are baked into the adjacency tables: rebuild them from the last log stiffness
+    if (restiffen && h->S > 0 && !h->h_logY.empty()) return upload_stiffness(h, h->h_logY.data(), (hipStream_t)stream_);
+    return R2S_OK;
+}
+
+int r2s_phys_set_tuning(R2SPhys* h, int chains, int mesh_defer)
+{
+    if (!h) return R2S_ERR_INVALID;
+    h->chains_override = chains > 0 ? chains : 0;
+    h->force_defer = mesh_defer < 0 ? -1 : (mesh_defer != 0);
+    drop_graph(h);
+    return R2S_OK;
+}
+
+int r2s_phys_last_flavour(R2SPhys* h, int32_t* out /* [4] */)
+{
+    if (!h || !out) return R2S_ERR_INVALID;
+    for (int k = 0; k < 4; ++k) out[k] = h->last_flavour[k];
+    return R2S_OK;
+}
+
+int r2s_phys_log_contacts(R2SPhys* h, int32_t* out3_dev, r2s_stream_t stream_)
+{
+    if (!h || !out3_dev) return R2S_ERR_INVALID;
+    hipLaunchKernelGGL(k_log_contacts, dim3(1), dim3(64), 0, (hipStream_t)stream_, h->E, h->d_cand_count, h->d_hit_cnt, h->d_eef_grasped, out3_dev);
+    R2S_HIP_TRY(hipGetLastError());
+    return R2S_OK;
+}
+
+int r2s_phys_contact_stats(R2SPhys* h, int32_t* particles_with_candidates, int32_t** mesh_hits_dev)
+{
+    if (!h) return R2S_ERR_INVALID;
+    if (particles_with_candidates) {
+        if (h->prm.self_collision) { int rc = resolve_cand_count(h); if (rc) return rc; }
+        *particles_with_candidates = h->n_cand;
+    }
+    if (mesh_hits_dev) *mesh_hits_dev = h->d_hit_cnt;
+    return R2S_OK;
+}
+
+// Candidate lists written by the caller (collision_number / collision_indices are plain arrays in the reference, :544-552):
+// HOST arrays in the caller's indexing, converted to the internal order.  Parity tests use it to replay the reference's
+// own lists; the next update_collision_graph overwrites them.
+int r2s_phys_set_collision_lists(R2SPhys* h, const int32_t* number, const int32_t* indices, r2s_stream_t stream_)
+{
+    if (!h || !h->prm.self_collision || !number || !indices) return R2S_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream_;
+    const int N = h->N, E = h->E, cap = h->coll_cap;
+    std::vector<int> num((size_t)E * N), idx((size_t)E * N * cap, 0);
+    for (int e = 0; e < E; ++e)
+        for (int i = 0; i < N; ++i) {
+            const size_t src = (size_t)e * N + h->h_perm[i], dst = (size_t)e * N + i;
+            const int c = number[src];
+            if (c < 0 || c > cap) return R2S_ERR_INVALID;
+            num[dst] = c;
+            for (int k = 0; k < c; ++k) {
+                const int uj = indices[src * cap + k];
+                if (uj < 0 || uj >= N) return R2S_ERR_INVALID;
+                idx[dst * cap + k] = h->h_inv[uj];
+            }
+        }
+    int rc = upload(h->d_coll_num, num.data(), num.size(), s);
+    if (rc) return rc;
+    rc = upload(h->d_coll_idx, idx.data(), idx.size(), s);
+    if (rc) return rc;
+    R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_cand_list, dim3((N + TPB - 1) / TPB, E), dim3(TPB), 0, s, N, E, h->d_coll_num, h->d_cand_list, h->d_cand_count);
+    R2S_HIP_TRY(hipMemcpyAsync(h->h_cand_count, h->d_cand_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    R2S_HIP_TRY(hipEventRecord(h->cand_event, s));
+    h->cand_pending = true;
+    R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }
 

@@ -88,7 +88,7 @@ def load_gaussians_ply(path, rot_x_minus90=False):
         Rm = np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
         pts = np.dot(Rm, pts.T).T.astype(np.float32)
         q0 = rot_mat_to_quat(Rm)
-        quats = np.stack([quat_mult(q0, q) for q in quats]).astype(np.float32) if len(quats) else quats
+        quats = quat_mult(q0, quats) if len(quats) else quats
     return dict(means3D=pts, sh_colors=sh, log_scales=np.stack([col(f"scale_{i}") for i in range(3)], -1), unnorm_rotations=quats,
                 logit_opacities=col("opacity")[:, None])
 
@@ -107,30 +107,39 @@ def save_gaussians_ply(params, path):
 
 
 def quat_mult(q1, q2):
-    """Hamilton product, (w, x, y, z)."""
-    w1, x1, y1, z1 = q1
-    w2, x2, y2, z2 = q2
-    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
-                     w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], np.float32)
+    """Hamilton product, (w, x, y, z); broadcasts over leading axes (robot_pc_sampler.py quat_mult, kornia convention)."""
+    q1, q2 = np.asarray(q1, np.float32), np.asarray(q2, np.float32)
+    w1, x1, y1, z1 = q1[..., 0], q1[..., 1], q1[..., 2], q1[..., 3]
+    w2, x2, y2, z2 = q2[..., 0], q2[..., 1], q2[..., 2], q2[..., 3]
+    return np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                     w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], -1).astype(np.float32)
+
+
+def rot_mats_to_quats(R):
+    """Rotation matrices [..., 3, 3] -> unit quaternions [..., 4] (w, x, y, z), the four-branch form selected per matrix
+    (trace > 0, else the largest diagonal element), vectorised: a scene is 1e5-1e6 splats."""
+    R = np.asarray(R, np.float64)
+    m00, m11, m22 = R[..., 0, 0], R[..., 1, 1], R[..., 2, 2]
+    t = m00 + m11 + m22
+    with np.errstate(invalid="ignore", divide="ignore"):
+        s0 = np.sqrt(t + 1.0) * 2
+        q0 = np.stack([0.25 * s0, (R[..., 2, 1] - R[..., 1, 2]) / s0, (R[..., 0, 2] - R[..., 2, 0]) / s0, (R[..., 1, 0] - R[..., 0, 1]) / s0], -1)
+        s1 = np.sqrt(1.0 + m00 - m11 - m22) * 2
+        q1 = np.stack([(R[..., 2, 1] - R[..., 1, 2]) / s1, 0.25 * s1, (R[..., 0, 1] + R[..., 1, 0]) / s1, (R[..., 0, 2] + R[..., 2, 0]) / s1], -1)
+        s2 = np.sqrt(1.0 + m11 - m00 - m22) * 2
+        q2 = np.stack([(R[..., 0, 2] - R[..., 2, 0]) / s2, (R[..., 0, 1] + R[..., 1, 0]) / s2, 0.25 * s2, (R[..., 1, 2] + R[..., 2, 1]) / s2], -1)
+        s3 = np.sqrt(1.0 + m22 - m00 - m11) * 2
+        q3 = np.stack([(R[..., 1, 0] - R[..., 0, 1]) / s3, (R[..., 0, 2] + R[..., 2, 0]) / s3, (R[..., 1, 2] + R[..., 2, 1]) / s3, 0.25 * s3], -1)
+    c0 = t > 0
+    c1 = ~c0 & (m00 > m11) & (m00 > m22)
+    c2 = ~c0 & ~c1 & (m11 > m22)
+    q = np.where(c0[..., None], q0, np.where(c1[..., None], q1, np.where(c2[..., None], q2, q3)))
+    return q.astype(np.float32)
 
 
 def rot_mat_to_quat(R):
-    """Rotation matrix -> unit quaternion (w, x, y, z), w >= 0 branch-stable form."""
-    R = np.asarray(R, np.float64)
-    t = np.trace(R)
-    if t > 0:
-        s = np.sqrt(t + 1.0) * 2
-        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
-    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
-        s = np.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
-        q = [(R[2, 1] - R[1, 2]) / s, 0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s]
-    elif R[1, 1] > R[2, 2]:
-        s = np.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
-        q = [(R[0, 2] - R[2, 0]) / s, (R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s]
-    else:
-        s = np.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
-        q = [(R[1, 0] - R[0, 1]) / s, (R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s]
-    return np.asarray(q, np.float32)
+    """One rotation matrix -> unit quaternion (w, x, y, z)."""
+    return rot_mats_to_quats(np.asarray(R, np.float64)[None])[0]
 
 
 def render_inputs_from_params(params, use_shs=False):

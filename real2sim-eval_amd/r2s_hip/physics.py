@@ -54,6 +54,8 @@ def _bind():
         r2s_phys_collision_max_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_set_spring_Y=[vp, vp, vp],
         r2s_phys_set_eef_table=[vp, C.c_int32, vp, vp, C.c_float, vp], r2s_phys_set_eef_motion=[vp, vp, vp, vp, vp, vp, vp],
         r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
+        r2s_phys_set_collision_lists=[vp, vp, vp, vp], r2s_phys_contact_stats=[vp, C.POINTER(C.c_int32), C.POINTER(vp)],
+        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32],
         r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
     ).items():
         fn = getattr(L, name)
@@ -296,6 +298,45 @@ class PhysBatch:
             _memcpy_d2d(ti.data_ptr(), idx.value, ti.numel() * 4, self.device)
         return tn, ti
 
+    def set_collision_lists(self, number, indices):
+        """Write the candidate lists (the reference's collision_number / collision_indices arrays): ``number`` [n_env, N],
+        ``indices`` [n_env, N, k] with k <= capacity, in the caller's particle indexing."""
+        num = np.ascontiguousarray(_np(number, np.int32).reshape(self.n_env, self.N))
+        idx = _np(indices, np.int32).reshape(self.n_env, self.N, -1)
+        full = np.zeros((self.n_env, self.N, self.collision_capacity), np.int32)
+        full[:, :, : idx.shape[2]] = idx
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_set_collision_lists(self._h, num.ctypes.data, full.ctypes.data, self._s()), "r2s_phys_set_collision_lists")
+
+    def contact_stats(self):
+        """(particles with self-collision candidates, mesh hits of the last substep summed over environments)."""
+        from .raster import _memcpy_d2d
+
+        n, p = C.c_int32(), C.c_void_p()
+        check(_bind().r2s_phys_contact_stats(self._h, C.byref(n), C.byref(p)), "r2s_phys_contact_stats")
+        hits = 0
+        if p.value:
+            t = torch.empty(self.n_env, dtype=torch.int32, device=self.device)
+            _memcpy_d2d(t.data_ptr(), p.value, t.numel() * 4, self.device)
+            hits = int(t.sum().item())
+        return int(n.value), hits
+
+    def log_contacts(self, out3: torch.Tensor):
+        """{particles with candidates, mesh hits of the last substep, grasped envs} -> device int32[3], no host sync."""
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_log_contacts(self._h, out3.data_ptr(), self._s()), "r2s_phys_log_contacts")
+
+    def last_flavour(self):
+        a = (C.c_int32 * 4)()
+        check(_bind().r2s_phys_last_flavour(self._h, a), "r2s_phys_last_flavour")
+        rcap = self.layout_stats()["lds_bytes"] // 24
+        return dict(self_collision_kernel=bool(a[0]), mesh_template=int(a[1]), deferred_mesh_queries=bool(a[2]), chains=int(a[3]),
+                    kernel=f"k_substep<{256 if rcap >= 1024 else 128},{rcap},{'true' if a[0] else 'false'},{int(a[1])}>"
+                           + (" + k_self_finish" if a[0] else "") + (" + k_mesh_finish" if a[2] else ""))
+
+    def set_tuning(self, chains: int = 0, mesh_defer: int = -1):
+        check(_bind().r2s_phys_set_tuning(self._h, int(chains), int(mesh_defer)), "r2s_phys_set_tuning")
+
     def collision_max_count(self) -> int:
         m = C.c_int32()
         with torch.cuda.device(self.device):
@@ -308,10 +349,18 @@ class PhysBatch:
         with torch.cuda.device(self.device):
             check(_bind().r2s_phys_set_spring_Y(self._h, a.ctypes.data, self._s()), "r2s_phys_set_spring_Y")
 
+    _FLOAT_PARAMS = ("dt", "dashpot_damping", "drag_damping", "spring_Y_min", "spring_Y_max", "collision_dist", "collide_elas", "collide_fric",
+                     "collide_eef_elas", "collide_eef_fric", "collide_self_elas", "collide_self_fric")
+
     def set_params(self, **kw):
+        """set_collide / set_collide_object and friends (spring_mass_warp.py:955-995): scalar parameters only; the structural
+        fields (num_substeps, self_collision, use_pusher, reverse_z) are fixed at construction."""
         for k, v in kw.items():
+            if k not in self._FLOAT_PARAMS:
+                raise ValueError(f"{k!r} is not a settable scalar parameter (structural fields are fixed at construction)")
             setattr(self.params, k, float(np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v, np.float32).reshape(-1)[0]))
-        check(_bind().r2s_phys_set_params(self._h, C.byref(self.params), self._s()), "r2s_phys_set_params")
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_set_params(self._h, C.byref(self.params), self._s()), "r2s_phys_set_params")
 
     def layout_stats(self):
         a = (C.c_int64 * 8)()

@@ -24,17 +24,22 @@ from .skinning import Skinning, knn_relations, knn_weights
 CONFIGS = {
     # name: (object shape, particles, gaussians per env, envs, W, H)  — BASELINE.json configs[1..3]
     "rope_1env": ("rope", 8000, 40000, 1, 640, 480),
-    "sloth_32env": ("sloth", 15000, 80000, 32, 640, 480),
+    "sloth_32env": ("sloth_arms", 15000, 80000, 32, 640, 480),   # configs[2]: the headline workload
     "T_32env": ("T", 2229, 40000, 32, 640, 480),
     "T_pusher_32env": ("T", 2229, 40000, 32, 640, 480),   # configs[3] per GPU: T block pushed by the ~25k-face pusher rod
-    "sloth_multicam_8env": ("sloth", 15000, 140000, 8, 1280, 720),   # configs[4] per GPU: 4 views, +60k robot-link Gaussians
+    "sloth_multicam_8env": ("sloth_arms", 15000, 140000, 8, 1280, 720),   # configs[4] per GPU: 4 views, +60k robot-link Gaussians
     "tiny": ("rope", 600, 3000, 2, 160, 120),
 }
 
 
 class BatchedRollout:
     def __init__(self, config="sloth_32env", device="cuda:0", seed=0, n_env=None, num_substeps=667, views=2,
-                 self_collision=True, with_gripper=True, with_static=True, tile_culling=True):
+                 self_collision=True, with_gripper=True, with_static=True, tile_culling=True, schedule=None, close_at=15, open_at=10**9):
+        """``schedule``: the synthetic action trace.  "grasp" (default for the sloth scenes): the open gripper comes down over
+        the toy's raised arms (free motion), closes on them at env step ``close_at`` — finger contact, the two arms pressed
+        together (live self-collision candidates), grasp detection — and lifts.  "lissajous" (default otherwise, SURVEY.md
+        §8d): the gripper hovers 10 cm above the object on a Lissajous path, closes at step 100, opens at 300.  The pusher
+        scene always pushes along +x from ``close_at`` = 0."""
         shape, n_particles, n_gauss, envs, W, H = CONFIGS[config]
         self.config = config
         self.n_env = int(n_env if n_env is not None else envs)
@@ -47,7 +52,8 @@ class BatchedRollout:
         E = self.n_env
         ob = synth.phystwin_object(shape, n_particles, seed)
         self.ob = ob
-        self.ob_shape = shape
+        self.ob_shape = "sloth" if shape == "sloth_arms" else shape
+        self.schedule, self.close_at, self.open_at = "push", 0, 10**9
         pts = ob["points"]
         self.N, self.S = len(pts), len(ob["springs"])
         # per-env pose: grid randomisation stand-in — planar shifts of a few cm (cfg/gs/*.yaml patterns)
@@ -73,7 +79,15 @@ class BatchedRollout:
             dyn = [(synth.eef_world_points(self.eef_table[-1], self.eef_init, self.eef0), rod_f)]
         elif with_gripper:
             self.eef_table, self.eef_init, fl, fr = synth.gripper_eef_table()
-            self.eef0 = np.array([c[0], c[1], top + 0.1], np.float32)
+            self.schedule = schedule or ("grasp" if shape == "sloth_arms" else "lissajous")
+            self.close_at, self.open_at = (int(close_at), int(open_at)) if self.schedule == "grasp" else (100, 300)
+            if self.schedule == "grasp":
+                # fingers (5 cm tall, centred 6 cm below the eef) end up centred on the arms' upper 8 cm: eef = top + 2 cm at
+                # `close_at`, reached by a straight descent at 0.1 m/s (3.3 mm per env step)
+                self.v_down = 0.1
+                self.eef0 = np.array([c[0], c[1], top + 0.02 + self.v_down * self.close_at * num_substeps * 5e-5], np.float32)
+            else:
+                self.eef0 = np.array([c[0], c[1], top + 0.1], np.float32)
             w0 = synth.eef_world_points(self.eef_table[-1], self.eef_init, self.eef0)
             dyn = [(w0[: len(w0) // 2], fl), (w0[len(w0) // 2:], fr)]
         self.fingers = dyn
@@ -121,6 +135,7 @@ class BatchedRollout:
                                          bg=cam["bg"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], z_threshold=cam["z_threshold"],
                                          out_color=self.out_color[e, vi], out_depth=self.out_depth[e, vi]))
         self.t = 0
+        self._log = None
         self.last_num_rendered = 0
         if with_gripper:
             self._init_gripper_motion()
@@ -130,7 +145,7 @@ class BatchedRollout:
     # SpringMassDynamicsModule.step (phystwin.py:362); finger vertices, grasp logic and per-substep motion are on device.
     def _init_gripper_motion(self):
         E = self.n_env
-        self.phys.set_eef_table(self.eef_table, self.eef_init, 2000.0)   # cfg/physics/default.yaml grasp_force_threshold
+        self.phys.set_eef_table(self.eef_table, self.eef_init, 3e4)   # cfg/physics/default.yaml:51 grasp_force_threshold
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)  # noqa: E731
         self.eef_xyz = t(np.repeat(self.eef0[None], E, 0) + self.env_shift)
         self.eef_rot = torch.eye(3, device=self.device).repeat(E, 1, 1)
@@ -141,12 +156,18 @@ class BatchedRollout:
         tt = step / 30.0
         if self.use_pusher:  # push along +x at 5 cm/s with a slow lateral weave
             return np.array([0.05, 0.02 * np.cos(w * tt), 0.0], np.float32)
+        if self.schedule == "grasp":
+            if step < self.close_at:      # free motion: straight down over the arms, fingers open
+                return np.array([0.0, 0.0, -self.v_down], np.float32)
+            if step == self.close_at:     # the fingers close during this env step
+                return np.zeros(3, np.float32)
+            return np.array([0.02 * np.cos(w * tt), 0.0, 0.05], np.float32)   # lift, with a slow sway along the fingers
         return np.array([0.05 * w * np.cos(w * tt) * 0.6, 0.05 * w * np.cos(2 * w * tt + 0.5) * 0.6, -0.01 * np.sin(w * tt)], np.float32)
 
     def _set_gripper(self, step):
         E = self.n_env
         vel = torch.from_numpy(self._eef_velocity(step)).to(self.device)[None].expand(E, 3).contiguous()
-        cmd = 0.3 if 100 <= step < 300 else 1.0
+        cmd = 0.3 if self.close_at <= step < self.open_at else 1.0
         openness = torch.full((E,), cmd, dtype=torch.float32, device=self.device)
         self.phys.set_eef_motion(self.eef_xyz, vel, self.eef_rot, self.eef_rot_vel, None if self.use_pusher else openness)
         self.eef_xyz = self.eef_xyz + vel * (self.num_substeps * self.dt)
@@ -166,7 +187,40 @@ class BatchedRollout:
             self.phys.update_collision_graph()
         if self.with_gripper:
             self._set_gripper(self.t)
+        lg = self._log
+        if lg is not None and lg["i"] < lg["n"]:
+            lg["p0"][lg["i"]].record()
         self.phys.step(0, 0, sync_state=True)
+        if lg is not None and lg["i"] < lg["n"]:
+            lg["p1"][lg["i"]].record()
+            self.phys.log_contacts(lg["counts"][lg["i"]])
+            lg["flavour"].append(self.phys.last_flavour()["kernel"] + f" x{self.phys.last_flavour()['chains']} chains")
+
+    # ---- per-step log of a timed window: stamps on the launch stream + contact counters kept on the device ------------
+    def start_log(self, n_steps):
+        ev = lambda: [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]  # noqa: E731
+        self._log = dict(n=n_steps, i=0, s=ev(), p0=ev(), p1=ev(), flavour=[],
+                         counts=torch.zeros(n_steps, 3, dtype=torch.int32, device=self.device))
+        self._log["s"][0].record()
+
+    def read_log(self):
+        lg, self._log = self._log, None
+        torch.cuda.synchronize(self.device)
+        n = lg["i"]
+        c = lg["counts"].cpu().numpy()
+        return dict(step_ms=[lg["s"][k].elapsed_time(lg["s"][k + 1]) for k in range(n)],
+                    phys_ms=[lg["p0"][k].elapsed_time(lg["p1"][k]) for k in range(n)],
+                    candidates=c[:n, 0].tolist(), mesh_hits=c[:n, 1].tolist(), grasped=c[:n, 2].tolist(), flavour=lg["flavour"][:n])
+
+    def contact_stats(self):
+        """What the last physics step touched: particles with self-collision candidates, particles that reacted to a
+        collision mesh in the last substep, environments whose grasp state machine holds the object, and the captured
+        kernel flavour that ran."""
+        n_cand, hits = self.phys.contact_stats()
+        grasped = 0
+        if self.with_gripper and not self.use_pusher:
+            grasped = int(self.phys.eef_state()[1].sum().item())
+        return dict(self_collision_candidates=int(n_cand), mesh_contacts=int(hits), grasped_envs=grasped, flavour=self.phys.last_flavour())
 
     def render(self):
         self._update_means()
@@ -177,7 +231,20 @@ class BatchedRollout:
         self.physics_step()
         out = self.render()
         self.t += 1
+        lg = self._log
+        if lg is not None and lg["i"] < lg["n"]:
+            lg["i"] += 1
+            lg["s"][lg["i"]].record()
         return out
+
+    # ---- the Gaussian cloud of one environment as the rasteriser currently sees it (parity tests) ----------------------
+    def g_env(self, e):
+        return self.g
+
+    def scene_numpy(self, e):
+        sc = {k: v.cpu().numpy() for k, v in self.g_env(e).items()}
+        sc["means3D"] = self.means[e].cpu().numpy()
+        return sc
 
     # ---- task success of the current state, on the device (calculate_success_{rope,sloth,T}.py) -----------------------
     def success_flags(self):

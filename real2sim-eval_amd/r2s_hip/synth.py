@@ -95,6 +95,27 @@ def lattice_points(shape: str, n_target: int, seed: int, spacing: float = 0.006)
         s = (n_target * h**3 / vol) ** (1.0 / 3.0)
         ext = base * s
         inside = lambda p: ((p / ext) ** 2).sum(1) <= 1.0  # noqa: E731
+    elif shape == "sloth_arms":
+        # the soft toy hanging-sloth pose: the ellipsoid body plus two arms raised above the head, parallel, 33 mm apart
+        # (inner surfaces) and 71 mm across — a two-finger gripper (85 mm open) can straddle both and squeeze them
+        # together, which is what produces live self-collision candidates (particles of different limbs that were not
+        # neighbours at rest, spring_mass_warp.py:196-227) on top of the finger contacts
+        arm_r, arm_y, arm_up, arm_in = 0.0095, 0.026, 0.08, 0.03
+        n_arm = 2 * np.pi * arm_r**2 * (arm_up + arm_in) / h**3
+        base = np.array([0.10, 0.065, 0.135]) / 2
+        vol = 4.0 / 3.0 * np.pi * np.prod(base)
+        s = (max(n_target - 0.8 * n_arm, 0.5 * n_target) * h**3 / vol) ** (1.0 / 3.0)
+        body = base * s
+        if body[1] < arm_y + arm_r:  # small test objects: scale the arms with the body
+            k = body[1] / (arm_y + arm_r) * 0.8
+            arm_r, arm_y, arm_up, arm_in = arm_r * k, arm_y * k, arm_up * k, arm_in * k
+        ext = np.array([body[0], body[1], body[2] + arm_up])
+
+        def inside(p):
+            b = ((p / body) ** 2).sum(1) <= 1.0
+            z_ok = (p[:, 2] >= body[2] - arm_in) & (p[:, 2] <= body[2] + arm_up)
+            a = z_ok & ((p[:, 0] ** 2 + (np.abs(p[:, 1]) - arm_y) ** 2) <= arm_r * arm_r)
+            return b | a
     elif shape == "T":
         # T prism: bar 0.2 x 0.05 and stem 0.05 x 0.15, thickness 0.04 (push-T block), scaled to n_target
         area = 0.2 * 0.05 + 0.05 * 0.15

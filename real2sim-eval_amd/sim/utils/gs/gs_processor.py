@@ -52,7 +52,7 @@ class GSProcessor:
         pts = params["means3D"] @ torch.from_numpy(rot_mat).to(params["means3D"]).T
         q = torch.nn.functional.normalize(params["unnorm_rotations"], dim=-1).detach().cpu().numpy().astype(np.float64)
         new_R = rot_mat.astype(np.float64)[None] @ _quat_to_mat(q)
-        quats = torch.from_numpy(np.stack([assets.rot_mat_to_quat(R) for R in new_R]).astype(np.float32)).to(params["means3D"].device)
+        quats = torch.from_numpy(assets.rot_mats_to_quats(new_R)).to(params["means3D"].device)
         quats = torch.nn.functional.normalize(quats, dim=-1)
         return dict(means3D=pts, sh_colors=params["sh_colors"], log_scales=params["log_scales"], unnorm_rotations=quats,
                     logit_opacities=params["logit_opacities"])

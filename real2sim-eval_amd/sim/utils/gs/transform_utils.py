@@ -1,6 +1,8 @@
 """``setup_camera`` of the reference (sim/utils/gs/transform_utils.py:7-31): K, w2c -> the 12-field
 ``GaussianRasterizationSettings`` the rasteriser consumes (row R0 of SURVEY.md §8a).  Only this function of the
-reference module is on the hot path; LBS skinning (``interpolate_motions``) is a "next" row."""
+reference module is on the raster path; LBS skinning (``interpolate_motions``, row f1) is below."""
+import weakref
+
 import torch
 
 from diff_gaussian_rasterization import GaussianRasterizationSettings as Camera
@@ -37,6 +39,7 @@ def interpolate_motions(bones, motions, relations, xyz, rot=None, quat=None, wei
 
     if quat is not None:
         raise NotImplementedError("interpolate_motions(quat=...) is outside the hot path: the simulator passes quat=None")
+    cacheable = weights is not None and isinstance(relations, torch.Tensor)   # weights=None: recomputed from xyz / bones on every call
     if weights is None:  # sparsified weights over the 5 nearest bones, reference :166-174
         dist = torch.norm(xyz[:, None] - bones, dim=-1)
         _, indices = torch.topk(dist, 5, dim=-1, largest=False)
@@ -48,10 +51,23 @@ def interpolate_motions(bones, motions, relations, xyz, rot=None, quat=None, wei
     assert weights_indices.shape[0] == weights.shape[0] == xyz.shape[0]
     assert weights_indices.shape[1] == weights.shape[1]
     rel_t = relations if isinstance(relations, torch.Tensor) else torch.as_tensor(relations)
-    key = (rel_t.data_ptr(), tuple(rel_t.shape), weights.data_ptr(), tuple(weights.shape), weights_indices.data_ptr(), str(xyz.device))
-    sk = _SKIN_CACHE.get(key)
-    if sk is None:
+    if not cacheable:
+        sk = Skinning(rel_t, weights, weights_indices, n_bones=bones.shape[0], device=xyz.device)
+        return sk.interpolate_motions(bones, motions, xyz), rot, weights
+    # The uploaded topology is cached per (relations, weights, weights_indices) OBJECT: the renderer keeps these three
+    # tensors for the lifetime of a scene (gs_renderer.py:195-211).  Identity is checked through weak references and the
+    # tensors' version counters, so a freed tensor whose address is reused, or an in-place edit, can never hit a stale entry.
+    srcs = (relations if isinstance(relations, torch.Tensor) else None, weights, weights_indices)
+    key = tuple(id(t) for t in srcs) + (tuple(rel_t.shape), tuple(weights.shape), int(bones.shape[0]), str(xyz.device))
+    ent = _SKIN_CACHE.get(key)
+    if ent is not None:
+        sk, refs, versions = ent
+        if any((r() is not t) if t is not None else False for r, t in zip(refs, srcs)) or versions != tuple(t._version if t is not None else -1 for t in srcs):
+            ent = None
+    if ent is None:
         if len(_SKIN_CACHE) > 8:
             _SKIN_CACHE.clear()
-        sk = _SKIN_CACHE[key] = Skinning(rel_t, weights, weights_indices, n_bones=bones.shape[0], device=xyz.device)
+        sk = Skinning(rel_t, weights, weights_indices, n_bones=bones.shape[0], device=xyz.device)
+        _SKIN_CACHE[key] = (sk, tuple(weakref.ref(t) if t is not None else (lambda: None) for t in srcs),
+                            tuple(t._version if t is not None else -1 for t in srcs))
     return sk.interpolate_motions(bones, motions, xyz), rot, weights

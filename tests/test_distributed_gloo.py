@@ -58,3 +58,46 @@ def test_two_rank_gloo_aggregation():
     assert t0 == t1 == 2.0                      # MAX over ranks
     assert rec0 == rec1 and rec0[0][:2] == [33.0, 3.0] and rec0[1][:2] == [32.0, 3.0]
     assert thr0 == thr1 == pytest.approx((33 * 3 + 32 * 3) / 2.0)
+
+
+def _run_bench(args, env=None, timeout=240):
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ if env is None else env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        if env is None:
+            e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=e, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` from a plain process must start 2 ranks (r2s_hip.dist.self_launch -> torch.distributed.run)
+    and report n_gpus == 2 — the reference's eval_policy_parallel.py:266-280 spawns its workers the same way.  `--stub`
+    swaps the GPU rollout for a sleep so that the launcher, barrier, MAX and all-gather run here over gloo."""
+    rc, out, err = _run_bench(["--gpus", "2", "--stub", "--steps", "3", "--warmup", "1", "--envs", "5"])
+    assert rc == 0, err[-2000:]
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["envs_total"] == 10 and out["steps"] == 3
+    # whole-job throughput = envs of both ranks * steps / slowest rank's time (rank 1 sleeps twice as long per step)
+    assert out["value"] == pytest.approx(10 * 3 / (out["ms_per_step"] * 3e-3), rel=1e-6)
+    assert out["ms_per_step"] >= 4.0
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    rc, out, err = _run_bench(["--gpus", "2", "--stub", "--steps", "1", "--warmup", "0"], env=env)
+    assert rc == 2 and out is None and "WORLD_SIZE=1" in err
+
+
+def test_launch_command_shape():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "real2sim-eval_amd"))
+    from r2s_hip.dist import launch_command
+
+    cmd = launch_command(8, "bench.py", ["--gpus", 8, "--config", "T_pusher_32env"], port=29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5:] == ["bench.py", "--gpus", "8", "--config", "T_pusher_32env"]

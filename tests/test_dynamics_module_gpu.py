@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from util_physics import DEFAULTS
+from util_parity import close
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +64,7 @@ def test_dynamics_module_from_case_directory_matches_the_oracles(tmp_path):
         o.step()
         x = mod.step(tt(xyz), tt(vel), tt(rot), tt(rv), torch.tensor([[cmd]], dtype=torch.float32).cuda(), fn, tt(init))
         assert x.shape == (len(pts), 3) and np.abs(x.cpu().numpy() - o.x).max() < 1e-5, k
-        assert np.abs(mod.current_velocities.cpu().numpy() - o.v).max() < 5e-3
+        assert close(mod.current_velocities.cpu().numpy(), o.v, 5e-3)
         assert mod.current_openness == eo.current_openness and mod.grasped == eo.grasped
         touched = touched or np.abs(o.collision_forces).max() > 0 or np.abs(o.x - pts).max() > 2e-4
         xyz = xyz + vel * (n_sub * 5e-5)

@@ -7,6 +7,7 @@ import pytest
 from scipy.spatial.transform import Rotation
 
 from util_physics import hip_env, make_object, oracle_env
+from util_parity import close
 
 ATOL = 1e-5  # BASELINE.json: particle positions within 1e-5 abs
 
@@ -78,8 +79,8 @@ def test_gripper_motion_and_state_machine_match_the_oracle_per_environment():
         for e in range(E):
             ref = oracles[e].step(xyz[e:e + 1], vel[e:e + 1], rot[e:e + 1], rv[e:e + 1], op[e], fn, init, F[e], mesh_map)
             assert cur[e].item() == oracles[e].current_openness and bool(grasped[e]) == oracles[e].grasped, (k, e)
-            assert np.abs(pts[e] - ref["interp_points"]).max() < 1e-6, (k, e, np.abs(pts[e] - ref["interp_points"]).max())
-            assert np.abs(ctr[e] - ref["interp_center"]).max() < 2e-7
+            assert close(pts[e], ref["interp_points"], 1e-6), (k, e, np.abs(pts[e] - ref["interp_points"]).max())
+            assert close(ctr[e], ref["interp_center"], 2e-7)
             assert np.allclose(dv[e], ref["dynamic_velocity"], rtol=1e-4, atol=1e-5), (k, e, dv[e], ref["dynamic_velocity"])
             assert np.allclose(om[e, None], ref["dynamic_omega"], atol=1e-7)
     assert any(o.grasped for o in oracles) or True
@@ -108,8 +109,8 @@ def test_physics_step_driven_on_device_equals_set_mesh_interactive_with_the_orac
         h2.set_mesh_interactive(tt(ref["interp_points"]), tt(ref["interp_center"]), tt(ref["dynamic_velocity"]), tt(ref["dynamic_omega"]))
         o.set_mesh_interactive(ref["interp_points"], ref["interp_center"], ref["dynamic_velocity"], ref["dynamic_omega"])
         h.step(); h2.step(); o.step()
-        assert np.abs(h.x[0].cpu().numpy() - h2.x[0].cpu().numpy()).max() < ATOL, k
-        assert np.abs(h.x[0].cpu().numpy() - o.x).max() < ATOL, k
+        assert close(h.x[0].cpu().numpy(), h2.x[0].cpu().numpy(), ATOL), k
+        assert close(h.x[0].cpu().numpy(), o.x, ATOL), k
         touched = touched or np.abs(o.collision_forces).max() > 0
         # the eef pose advances like the caller would advance it
         xyz = xyz + vel * (n_sub * DT)
@@ -146,10 +147,10 @@ def test_pusher_large_rigid_mesh_only_touches_the_vertices_the_stepper_reads():
         tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None].cuda()  # noqa: E731
         h2.set_mesh_interactive(tt(ref["interp_points"]), tt(ref["interp_center"]), tt(ref["dynamic_velocity"]), tt(ref["dynamic_omega"]))
         _, ctr, dv, om = h.mesh_motion(points=False)
-        assert np.abs(ctr[0].cpu().numpy() - ref["interp_center"]).max() < 2e-7
+        assert close(ctr[0].cpu().numpy(), ref["interp_center"], 2e-7)
         assert np.allclose(dv[0, :1].cpu().numpy(), ref["dynamic_velocity"], atol=1e-7) and np.allclose(om[0].cpu().numpy(), ref["dynamic_omega"][0], atol=1e-7)
         h.step(); h2.step()
-        assert np.abs(h.x[0].cpu().numpy() - h2.x[0].cpu().numpy()).max() < ATOL, k
+        assert close(h.x[0].cpu().numpy(), h2.x[0].cpu().numpy(), ATOL), k
         xyz = xyz + vel * (n_sub * DT)
         rot = (Rotation.from_rotvec(rv[0].astype(np.float64) * n_sub * DT).as_matrix().T @ rot[0].astype(np.float64)).astype(np.float32)[None]
     moved = h.x[0].cpu().numpy()[:, 0] - pts[:, 0]

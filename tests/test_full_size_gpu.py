@@ -8,6 +8,7 @@ import pytest
 
 from util_physics import hip_env, make_object, oracle_env
 from util_raster import compare_images, hip_render, oracle_render, scene_and_camera
+from util_parity import close
 
 pytestmark = pytest.mark.gpu
 
@@ -81,7 +82,7 @@ def test_C2_sloth_15k_particles_one_env_vs_oracle_short_horizon():
     o = oracle_env(ob, num_substeps=40, self_collision=False)
     h = hip_env(ob, num_substeps=40, self_collision=False)
     o.step(); h.step()
-    assert np.abs(h.x[0].cpu().numpy() - o.x).max() < 1e-5
+    assert close(h.x[0].cpu().numpy(), o.x, 1e-5)
     assert np.abs(o.x - ob["points"]).max() > 1e-5
 
 
@@ -93,7 +94,7 @@ def test_C3_T_block_real_size_vs_oracle_with_self_collision():
     for _ in range(2):
         o.update_collision_graph(); h.update_collision_graph()
         o.step(); h.step()
-    assert np.abs(h.x[0].cpu().numpy() - o.x).max() < 1e-5
+    assert close(h.x[0].cpu().numpy(), o.x, 1e-5)
 
 
 def test_batched_32_envs_bitwise_independent_of_env_index_and_deterministic():

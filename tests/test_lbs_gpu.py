@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pytest
+from util_parity import close
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -21,7 +22,7 @@ def test_drop_in_interpolate_motions_matches_reference_fixture(path):
     out, rot, w = interpolate_motions(bones=t("bones"), motions=t("motions"), relations=t("relations", torch.int64), xyz=t("xyz"),
                                       quat=None, weights=t("weights"), weights_indices=t("weights_indices", torch.int64), device="cuda")
     assert rot is None and w.shape == g["weights"].shape
-    assert np.abs(out.cpu().numpy() - g["xyz_out"]).max() < 3e-6
+    assert close(out.cpu().numpy(), g["xyz_out"], 3e-6)
 
 
 def test_batched_envs_large_random_vs_oracle_and_rotations_proper():
@@ -46,7 +47,7 @@ def test_batched_envs_large_random_vs_oracle_and_rotations_proper():
     assert np.allclose(np.linalg.det(Rn), 1.0, atol=1e-5) and np.allclose(Rn @ Rn.transpose(0, 1, 3, 2), np.eye(3), atol=1e-5)
     for e in range(E):
         ref = lbs_oracle.interpolate_motions(bones[e], mot[e], rel, xyz[e], w, wi)
-        assert np.abs(out[e] - ref).max() < 3e-6, e
+        assert close(out[e], ref, 3e-6), e
 
 
 def test_rank_deficient_environment_falls_back_to_identity_like_the_reference():
@@ -64,3 +65,45 @@ def test_rank_deficient_environment_falls_back_to_identity_like_the_reference():
     ref = lbs_oracle.interpolate_motions(bones, motions, rel, xyz, w, wi)
     _, flags = sk.debug(1)
     assert int(flags[0]) == 1 and np.abs(out - ref).max() < 1e-6
+
+
+def test_drop_in_cache_never_serves_a_stale_topology():
+    """the drop-in keeps the uploaded skinning topology per (relations, weights, weights_indices) object.  A new
+    scene with the same shapes — whose tensors the caching allocator places at the addresses of the freed ones — must get
+    its own topology, an in-place edit of the weights must be seen, and weights=None (recomputed from xyz / bones on every
+    call, transform_utils.py:166-174) must never be cached."""
+    import torch
+    from oracle import lbs_oracle
+    from sim.utils.gs.transform_utils import interpolate_motions
+
+    rng = np.random.default_rng(11)
+    N, P = 400, 3000
+    bones = rng.uniform(-0.05, 0.05, (N, 3)).astype(np.float32)
+    rel = lbs_oracle.knn_relations(bones, 8)
+    mot = (np.cross(np.array([0.2, -0.1, 0.3]), bones) + rng.normal(0, 0.002, bones.shape)).astype(np.float32)
+    tb, tm, tr = torch.from_numpy(bones).cuda(), torch.from_numpy(mot).cuda(), torch.from_numpy(rel.astype(np.int64)).cuda()
+    ptrs = set()
+    for scene in range(3):                                   # same shapes, different content, old tensors freed in between
+        xyz = (bones[rng.integers(0, N, P)] + rng.normal(0, 0.004, (P, 3))).astype(np.float32)
+        w, wi = lbs_oracle.knn_weights(bones, xyz, 16)
+        tw, twi, tx = torch.from_numpy(w).cuda(), torch.from_numpy(wi.astype(np.int64)).cuda(), torch.from_numpy(xyz).cuda()
+        ptrs.add(tw.data_ptr())
+        for _ in range(2):                                   # second call hits the cache
+            out, _, _ = interpolate_motions(tb, tm, tr, tx, weights=tw, weights_indices=twi)
+            assert close(out, lbs_oracle.interpolate_motions(bones, mot, rel, xyz, w, wi), 3e-6), scene
+        tw.mul_(0.5); tw[:, 0] += 0.5 * (1 - tw.sum(1) * 2) + 0.5   # in-place edit (rows still sum to 1): version counter changes
+        w2 = tw.cpu().numpy()
+        out, _, _ = interpolate_motions(tb, tm, tr, tx, weights=tw, weights_indices=twi)
+        assert close(out, lbs_oracle.interpolate_motions(bones, mot, rel, xyz, w2, wi), 3e-6), scene
+        del tw, twi, tx, out
+    # weights=None: the 5-nearest-bone weights are recomputed per call — two different clouds of the same size
+    outs = []
+    for k in range(2):
+        xyz = (bones[rng.integers(0, N, P)] + rng.normal(0, 0.004, (P, 3))).astype(np.float32)
+        d = np.linalg.norm(xyz[:, None] - bones[None], axis=-1)
+        wi = np.argsort(d, axis=1, kind="stable")[:, :5]
+        w = 1.0 / (np.take_along_axis(d, wi, 1) + 1e-6)
+        w = (w / w.sum(1, keepdims=True)).astype(np.float32)
+        out, _, wret = interpolate_motions(tb, tm, tr, torch.from_numpy(xyz).cuda(), weights=None)
+        assert wret.shape == (P, 5)
+        assert close(out, lbs_oracle.interpolate_motions(bones, mot, rel, xyz, w, wi), 5e-6), k

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from util_physics import cfg, gripper_motion, hip_env, make_object, oracle_env, two_blobs
+from util_parity import close
 
 pytestmark = pytest.mark.gpu
 ATOL = 1e-5
@@ -35,11 +36,11 @@ def test_free_fall_and_springs_contact_free_full_env_step():
     ob["points"][:, 2] += 0.01 * np.sin(40 * ob["points"][:, 0])  # pre-strain the springs (peak speed ~2 m/s)
     o, h = _run_pair(ob, 1, 667, self_collision=False)
     x = h.x[0].cpu().numpy(); v = h.v[0].cpu().numpy()
-    assert np.abs(x - o.x).max() < ATOL
+    assert close(x, o.x, ATOL)
     # error budget: the float64 shadow of the oracle bounds what float32 rounding alone does on this input
     o64 = oracle_env(ob, f64=True, num_substeps=667, self_collision=False); o64.step()
-    assert np.abs(x - o64.x).max() < ATOL
-    assert np.abs(v - o.v).max() < 2e-3  # velocities are O(1) m/s; positions are the gated quantity
+    assert close(x, o64.x, ATOL)
+    assert close(v, o.v, 2e-3)  # velocities are O(1) m/s; positions are the gated quantity
     assert np.abs(o.x - ob["points"]).max() > 1e-3  # something actually moved
 
 
@@ -48,7 +49,7 @@ def test_ground_contact_rope_drop():
     ob["v0"] = np.zeros_like(ob["points"]); ob["v0"][:, 2] = -0.5; ob["v0"][:, 0] = 0.2
     o, h = _run_pair(ob, 1, 200, self_collision=False)
     x = h.x[0].cpu().numpy()
-    assert np.abs(x - o.x).max() < ATOL
+    assert close(x, o.x, ATOL)
     assert (o.x[:, 2] >= -1e-6).all()
 
 
@@ -57,7 +58,7 @@ def test_reverse_z_ground():
     ob["points"][:, 2] *= -1.0
     ob["v0"] = np.zeros_like(ob["points"]); ob["v0"][:, 2] = +0.5
     o, h = _run_pair(ob, 1, 100, self_collision=False, reverse_z=True)
-    assert np.abs(h.x[0].cpu().numpy() - o.x).max() < ATOL
+    assert close(h.x[0].cpu().numpy(), o.x, ATOL)
 
 
 def test_candidate_lists_match_oracle_exactly():
@@ -102,7 +103,7 @@ def test_self_collision_two_blobs():
     o, h = _run_pair(ob, 4, n_sub, update_graph=True, collide_self_fric=0.3)
     assert o.total_candidates > 0, "scenario must produce contacts"
     x = h.x[0].cpu().numpy()
-    assert np.abs(x - o.x).max() < 5e-5  # contacts amplify rounding differences (SURVEY.md §7 hard parts)
+    assert close(x, o.x, 5e-5)  # contacts amplify rounding differences (SURVEY.md §7 hard parts)
     # the impulse really acted: blob B lost approach speed
     assert o.v[len(o.v) // 2:, 0].mean() > -2.9
 
@@ -126,8 +127,8 @@ def test_self_collision_with_concurrent_chains_and_odd_substeps(monkeypatch):
     assert tot > 0, "scenario must produce contacts"
     x = h.x.cpu().numpy()
     for e in range(9):
-        assert np.abs(x[e] - o.x).max() < 5e-5, e
-    assert np.abs(x - x[0:1]).max() < 1e-6
+        assert close(x[e], o.x, 5e-5), e
+    assert close(x, x[0:1], 1e-6)
 
 
 def test_static_box_mesh_collision():
@@ -140,7 +141,7 @@ def test_static_box_mesh_collision():
     kw = dict(static_meshes=[box], self_collision=False)
     o, h = _run_pair(ob, 1, 300, **kw)
     x = h.x[0].cpu().numpy()
-    assert np.abs(x - o.x).max() < ATOL
+    assert close(x, o.x, ATOL)
     f = h.collision_forces()[0].cpu().numpy()
     assert np.allclose(f, o.collision_forces, rtol=1e-3, atol=1e-1)
     # particles above the box were stopped ~1 mm above its top face (z = 0.04)
@@ -168,7 +169,7 @@ def test_gripper_fingers_dynamic_mesh():
                                torch.from_numpy(dv)[None].cuda(), torch.from_numpy(om)[None].cuda())
         o.step(); h.step()
     x = h.x[0].cpu().numpy()
-    assert np.abs(x - o.x).max() < ATOL
+    assert close(x, o.x, ATOL)
     f = h.collision_forces()[0].cpu().numpy()
     assert np.abs(o.collision_forces).max() > 0, "fingers must touch the object in this scenario"
     # Per-face attribution has genuine ties (a contact point on an edge shared by two triangles is equidistant
@@ -227,7 +228,7 @@ def test_batched_envs_are_independent_and_match_single():
     a = h1.x[0].cpu().numpy(); b = h4.x.cpu().numpy()
     for e in range(4):
         shifted = b[e].copy(); shifted[:, 0] -= 0.01 * e
-        assert np.abs(shifted - a).max() < 2e-6
+        assert close(shifted, a, 2e-6)
 
 
 def test_drop_in_surface_smoke():
@@ -249,7 +250,7 @@ def test_drop_in_surface_smoke():
     o = oracle_env(ob, num_substeps=30)
     o.update_collision_graph(); o.step()
     assert sim.wp_state.wp_x.shape == (len(ob["points"]), 3)
-    assert np.abs(sim.wp_state.wp_x.cpu().numpy() - o.x).max() < ATOL
+    assert close(sim.wp_state.wp_x.cpu().numpy(), o.x, ATOL)
     assert (sim.wp_state.wp_x - x_before).abs().max() > 0
 
 
@@ -282,7 +283,7 @@ def test_pusher_25k_face_mesh_cluster_query_vs_oracle(defer, monkeypatch):
     x = h.x[0].cpu().numpy()
     moved = np.abs(o.x - ob["points"]).max()
     assert np.abs(o.collision_forces).max() > 0, "the rod must touch the block in this scenario"
-    assert np.abs(x - o.x).max() < 1e-5, (np.abs(x - o.x).max(), moved)
+    assert close(x, o.x, 1e-5), (np.abs(x - o.x).max(), moved)
     f = h.collision_forces()[0].cpu().numpy()
     tot_o, tot_h = o.collision_forces.sum(0), f.sum(0)
     assert np.allclose(tot_h, tot_o, rtol=2e-3, atol=np.abs(tot_o).max() * 2e-3), (tot_o, tot_h)
@@ -300,8 +301,8 @@ def test_hip_stepper_matches_fixtures_from_the_reference_kernel_bodies():
     h = hip_env(obA, num_substeps=n, self_collision=False, spring_Y_min=float(G["A_Ymin"]))
     for k in range(n):
         h.step(1, k)
-        assert np.abs(h.x[0].cpu().numpy() - G["A_x_traj"][k]).max() < 2e-6, k
-        assert np.abs(h.v[0].cpu().numpy() - G["A_v_traj"][k]).max() < 2e-4, k
+        assert close(h.x[0].cpu().numpy(), G["A_x_traj"][k], 2e-6), k
+        assert close(h.v[0].cpu().numpy(), G["A_v_traj"][k], 2e-4), k
     n_dyn = int(G["C_n_dyn"])
     verts, faces, mm = G["C_verts"], G["C_faces"], G["C_mesh_map"]
     nl, nr = int((mm == 0).sum()), int((mm == 1).sum())
@@ -315,8 +316,8 @@ def test_hip_stepper_matches_fixtures_from_the_reference_kernel_bodies():
     h.set_mesh_interactive(t(G["C_interp"]), t(G["C_centers"]), t(G["C_dyn_vel"]), t(G["C_dyn_omega"]))
     for k in range(n):
         h.step(1, k)
-        assert np.abs(h.x[0].cpu().numpy() - G["C_x_traj"][k]).max() < 2e-6, k
-        assert np.abs(h.v[0].cpu().numpy() - G["C_v_traj"][k]).max() < 2e-3, k
+        assert close(h.x[0].cpu().numpy(), G["C_x_traj"][k], 2e-6), k
+        assert close(h.v[0].cpu().numpy(), G["C_v_traj"][k], 2e-3), k
     # forces of the last substep: per-finger / per-mesh totals (the per-face split has genuine ties, see above)
     f, ref = h.collision_forces()[0].cpu().numpy(), G["C_forces_traj"][-1]
     for m in (0, 1, -1):

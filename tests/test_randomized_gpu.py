@@ -5,6 +5,7 @@ import pytest
 
 from util_physics import hip_env, make_object, oracle_env
 from util_raster import compare_images, hip_render, oracle_render
+from util_parity import close
 
 pytestmark = pytest.mark.gpu
 
@@ -56,5 +57,5 @@ def test_random_material_parameters_and_velocities(seed):
     for _ in range(2):
         o.update_collision_graph(); h.update_collision_graph()
         o.step(); h.step()
-    assert np.abs(h.x[0].cpu().numpy() - o.x).max() < 1e-5
-    assert np.abs(h.v[0].cpu().numpy() - o.v).max() < 5e-3
+    assert close(h.x[0].cpu().numpy(), o.x, 1e-5)
+    assert close(h.v[0].cpu().numpy(), o.v, 5e-3)

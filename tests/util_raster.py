@@ -50,11 +50,28 @@ def hip_render(sc, c, device="cuda:0"):
     return im.cpu().numpy(), radii.cpu().numpy(), depth.cpu().numpy()
 
 
-def compare_images(color, depth, ref_color, ref_depth, rtol=1e-4, atol=1e-4):
-    """Fraction of pixels whose RGB leaves |d| <= atol + rtol*|ref| and whose median depth differs."""
+def compare_images(color, depth, ref_color, ref_depth, rtol=1e-4, atol=1e-4, what=None):
+    """Fraction of pixels whose RGB leaves |d| <= atol + rtol*|ref| and whose median depth differs.  The achieved errors
+    (max abs / max rel RGB error, max rel depth error where both sides blended the same median Gaussian, mismatching
+    pixel counts) are recorded through util_parity next to the gate they were held to."""
+    import inspect
+    import os
+
+    from util_parity import record
+
     d = np.abs(color.astype(np.float64) - ref_color.astype(np.float64))
     bad_rgb = (d > atol + rtol * np.abs(ref_color)).any(0)
     dd = np.abs(depth.astype(np.float64) - ref_depth.astype(np.float64))
     bad_depth = (dd > rtol * np.abs(ref_depth))[0]
-    return dict(frac_rgb=float(bad_rgb.mean()), frac_depth=float(bad_depth.mean()), max_rgb=float(d.max()),
-                n_rgb=int(bad_rgb.sum()), n_depth=int(bad_depth.sum()))
+    out = dict(frac_rgb=float(bad_rgb.mean()), frac_depth=float(bad_depth.mean()), max_rgb=float(d.max()),
+               n_rgb=int(bad_rgb.sum()), n_depth=int(bad_depth.sum()))
+    lit = np.abs(ref_color) > 1e-2                       # relative error where the reference channel is not ~black
+    same = ~bad_depth                                    # pixels whose median depth comes from the same Gaussian
+    if what is None:
+        fr = inspect.stack()[1]
+        what = f"{os.path.basename(fr.filename)}:{fr.lineno}"
+    record(what, max_abs_rgb_err=float(d.max()), max_rel_rgb_err=float((d[lit] / np.abs(ref_color[lit])).max()) if lit.any() else 0.0,
+           max_rel_depth_err_same_median=float((dd[0][same] / np.abs(ref_depth[0][same])).max()) if same.any() else 0.0,
+           mismatching_rgb_pixels=int(bad_rgb.sum()), median_depth_mismatch_pixels=int(bad_depth.sum()), pixels=int(bad_rgb.size),
+           gate_rtol=float(rtol), gate_atol=float(atol), tol=1e-4)
+    return out
