@@ -33,7 +33,7 @@
 //   * Mesh queries: small meshes (<= 256 faces: fingers, boxes) per-lane brute force with the exact solid-angle
 //     winding number; large meshes (the ~25k-face pusher) through Morton-sorted 64-face clusters with rest-frame
 //     boxes, wave-cooperative, sign from pseudonormals (closed manifolds) or the exact winding number (anything
-//     else); particles in contact with a large mesh are finished by k_mesh_finish, one wavefront each.
+//     else); particles in contact with a large mesh are finished by k_contact_finish, one wavefront each.
 
 #include "r2s_common.h"
 #include <rocprim/rocprim.hpp>
@@ -55,6 +55,7 @@ constexpr int GRID_DIM = 128;          // wp.HashGrid(128,128,128), spring_mass_
 constexpr int GRID_CELL_BITS = 21;     // 128^3 cells
 constexpr float MESH_MAX_DIST = 0.02f; // :323
 constexpr float WIND_THRESHOLD = 0.6f; // :323
+constexpr float NEAR_PAD = 0.03f;      // "contact is likely next step": within margin + 3 cm of a mesh box (0.9 m/s of approach per env step)
 
 struct PhysDev {
     int N, E, n_sub;
@@ -88,10 +89,14 @@ struct PhysDev {
     const int* coll_idx;       // [E,N,cap]
     int coll_cap;
     float4* vbc;               // [E,N] v_before_collision published by particles that have candidates; also the velocity of
-                               // particles whose large-mesh query is deferred to k_mesh_finish
+                               // particles whose large-mesh query is deferred to k_contact_finish
+    float4* vdef;              // [E,N] velocity of the particles whose mesh query is deferred to k_contact_finish (vbc must keep the
+                               // pre-impulse value while other particles' self-collision loops still read it)
     int2* mesh_list;           // (env, particle) of the particles deferred in this substep (one list per chain, reused)
-    int* mesh_cnt;             // [n_sub] entries of mesh_list per substep (zeroed once per env step)
-    int mesh_cap, mesh_defer;  // defer = 1: needy particles go to the list; 0: they are only counted and queried in place
+    int* mesh_cnt;             // [n_sub + 1] entries of mesh_list per substep; [n_sub] = particles NEAR a mesh over the whole env step
+                               // (margin + NEAR_PAD: what the host picks the next step's flavour from); zeroed once per env step
+    int mesh_cap, mesh_defer;  // defer = 1: needy particles go to the list; 0: they are queried in place
+    int* cand_mark;            // [E,N] = substep + 1 when a particle with candidates was handed to the mesh list in that substep
     const int2* cand_list;     // (env, particle) of every particle with candidates
     const int* cand_count;
     // meshes
@@ -194,6 +199,7 @@ struct MeshHit {
     float sign;
     int face; // ORIGINAL (caller) face id
     f3 pt;    // closest point, world frame
+    int mm, fm; // mesh_map / face_map of `face` (filled by mesh_query_regs only; the other queries leave the lookup to the caller)
 };
 
 __device__ __forceinline__ float box_dist2(f3 q, const float* bb)
@@ -281,7 +287,7 @@ __device__ __forceinline__ f3 mesh_vertex(const PhysDev& p, int e, int step, int
 //                    which equals the winding-number sign for closed meshes.
 __device__ MeshHit mesh_query_wave(const PhysDev& p, int step, f3 q_lane, int e_lane, bool want)
 {
-    MeshHit out = {false, 0.f, 0, mk(0.f, 0.f, 0.f)};
+    MeshHit out = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
     const int lane = (int)(threadIdx.x & 63);
     unsigned long long pending = __builtin_amdgcn_ballot_w64(want);
     const float MAXD2 = MESH_MAX_DIST * MESH_MAX_DIST;
@@ -424,7 +430,7 @@ __device__ MeshHit mesh_query_wave(const PhysDev& p, int step, f3 q_lane, int e_
 // instantiated for both and the handle picks by scene.
 __device__ MeshHit mesh_query_lane(const PhysDev& p, int e, int step, f3 q, bool want)
 {
-    MeshHit r = {false, 0.f, 0, mk(0.f, 0.f, 0.f)};
+    MeshHit r = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
     if (!want) return r;
     float best = MESH_MAX_DIST * MESH_MAX_DIST;
     const float cull = best * 1.0001f + 1e-12f;
@@ -457,6 +463,90 @@ __device__ MeshHit mesh_query_lane(const PhysDev& p, int e, int step, f3 q, bool
     const float wn = wsum / (float)(4.0 * 3.14159265358979323846);
     r.sign = wn > WIND_THRESHOLD ? -1.f : 1.f;
     return r;
+}
+
+// Small scenes (every mesh small, <= 128 faces in total: two 44-face fingers + a box obstacle): k_contact_finish<3> keeps the
+// substep's triangles in registers, two per lane, loaded ONCE per particle (index -> vertex: two dependent round trips) and
+// used by the closest-point search, the winding number AND the re-query of a finger contact; the generic cooperative
+// query walks cluster -> box -> face index -> vertex chains again for each of them (~15 us per particle, measured).
+struct TriRegs {
+    f3 a[2], b[2], c[2];
+    int mm[2], fm[2]; // mesh_map / face_map of the two faces
+    bool ok[2];
+    f3 ctr, om, dv0, dv1; // the substep's eef centre, angular velocity and the two finger velocities (same for every lane)
+};
+__device__ __forceinline__ TriRegs load_tris(const PhysDev& p, int e, int step, int lane)
+{
+    TriRegs t;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int f = lane + 64 * k;
+        t.ok[k] = f < p.nF;
+        const int fc = min(f, p.nF - 1);
+        const int ia = p.faces[3 * fc], ib = p.faces[3 * fc + 1], ic = p.faces[3 * fc + 2]; // stored order == caller order for small meshes
+        t.a[k] = mesh_vertex(p, e, step, ia); t.b[k] = mesh_vertex(p, e, step, ib); t.c[k] = mesh_vertex(p, e, step, ic);
+        t.mm[k] = p.mesh_map[fc]; t.fm[k] = p.face_map[fc];
+    }
+    t.ctr = ld3(p.interp_center, (size_t)e * p.n_sub + step); t.om = ld3(p.dyn_omega, e);
+    t.dv0 = ld3(p.dyn_vel, (size_t)e * 2); t.dv1 = ld3(p.dyn_vel, (size_t)e * 2 + 1);
+    return t;
+}
+// Same answer as mesh_query_wave / mesh_query_lane on such a scene: lexicographic minimum of (distance^2, face id) over the
+// faces closer than max_dist, sign from the exact winding number over all faces.
+__device__ MeshHit mesh_query_regs(const TriRegs& t, f3 q_lane, bool want)
+{
+    MeshHit out = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned long long pending = __builtin_amdgcn_ballot_w64(want);
+    const float MAXD2 = MESH_MAX_DIST * MESH_MAX_DIST;
+    while (pending) {
+        const int L = __builtin_ctzll(pending);
+        pending &= pending - 1;
+        const f3 q = mk(bcast(q_lane.x, L), bcast(q_lane.y, L), bcast(q_lane.z, L));
+        unsigned long long key = ~0ull;
+        f3 cpb = mk(0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float u, v;
+            int region;
+            closest_bary(t.a[k], t.b[k], t.c[k], q, u, v, region);
+            const f3 cp = t.a[k] * u + t.b[k] * v + t.c[k] * (1.f - u - v);
+            const f3 d = cp - q;
+            const float d2 = dot(d, d);
+            const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)(lane + 64 * k);
+            if (t.ok[k] && d2 < MAXD2 && kk < key) { key = kk; cpb = cp; }
+        }
+        const unsigned long long mn = wave_min_u64(key);
+        const bool found = mn != ~0ull;
+        float sign = 1.f;
+        f3 pt = mk(0.f, 0.f, 0.f);
+        int wmm = 0, wfm = 0;
+        if (found) {
+            const int w = __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == mn));
+            pt = mk(bcast(cpb.x, w), bcast(cpb.y, w), bcast(cpb.z, w));
+            const bool second = (mn & 0xffffffffull) >= 64;
+            wmm = bcasti(second ? t.mm[1] : t.mm[0], w); wfm = bcasti(second ? t.fm[1] : t.fm[0], w);
+            float ws = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const f3 a = t.a[k] - q, b = t.b[k] - q, c3 = t.c[k] - q;
+                const float la = len(a), lb = len(b), lc = len(c3);
+                const float det = dot(a, cross(b, c3));
+                const float den = la * lb * lc + dot(a, b) * lc + dot(b, c3) * la + dot(c3, a) * lb;
+                if (t.ok[k]) ws += 2.f * atan2f(det, den);
+            }
+            const float wn = wave_sum(ws) / (float)(4.0 * 3.14159265358979323846);
+            sign = wn > WIND_THRESHOLD ? -1.f : 1.f;
+        }
+        if (lane == L) {
+            out.result = found;
+            out.sign = sign;
+            out.face = (int)(unsigned)(mn & 0xffffffffull);
+            out.pt = pt;
+            out.mm = wmm; out.fm = wfm;
+        }
+    }
+    return out;
 }
 
 // ---- spring forces: gather form of eval_springs (:61-104) ----------------------------------------
@@ -545,17 +635,41 @@ __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* _
 
 #pragma clang fp contract(off)
 
+// Exact early-out of the mesh query.  The response only fires when signed distance < margin (5 mm for gripper meshes, 1 mm
+// otherwise).  A point outside the AABB of a CLOSED mesh is outside the mesh (winding number 0 < 0.6, sign +1) and its
+// distance to the mesh is at least its distance to the AABB: if that is >= the margin for every mesh, nothing can happen and
+// the query is skipped.  Meshes that are not closed manifolds (checked at construction) only get the query's own 2 cm range
+// as the bound.  `pad` widens the test (particles whose velocity is not final yet); `near` = within NEAR_PAD of a margin.
+__device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 next_x, float pad, bool& near)
+{
+    bool need = false;
+    near = false;
+    for (int m = 0; m < p.n_mesh; ++m) {
+        const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
+                                           : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
+        const float mg = ((p.mesh_kind[m] & 2) ? MESH_MAX_DIST : ((m < p.n_dyn_mesh && !p.use_pusher) ? 0.005f : 0.001f)) + pad;
+        const float d2 = box_dist2(next_x, bb);
+        need = need || d2 < mg * mg * 1.0001f;
+        near = near || d2 < (mg + NEAR_PAD) * (mg + NEAR_PAD);
+    }
+    return need;
+}
+
 // ---- everything after the velocity update: mesh collision, ground, store ------------------------------------
 // Called by EVERY lane of a wavefront at the same point (the mesh queries inside are wave-cooperative); `fin` says
 // whether this lane has a particle to finish.  Shared by the fused substep and the self-collision finishing kernel.
 // MESH: 0 no meshes, 1 small meshes only (per-lane queries), 2 a large mesh is present (wave-cooperative queries)
-// MAIN + p.mesh_defer (large-mesh scenes, main kernel only): a particle that needs a mesh query is not queried here — a wave-cooperative
-// query costs ~5 us of dependent round trips and the particles that need one sit next to each other, so one wavefront
-// would run dozens back to back while the rest of the chip waits.  It publishes its velocity, appends itself to the
-// substep's list and is finished by k_mesh_finish, one WAVEFRONT per particle, all of them in flight at once.
+// MAIN + p.mesh_defer (the fused kernel and k_self_finish): a particle that needs a mesh query is not queried here.  A query
+// is thousands of instructions (closest point over the near meshes' faces + the exact winding number over all faces, twice
+// for finger contacts) or, for a large mesh, ~5 us of dependent round trips — and the particles that need one sit next to
+// each other, so one wavefront would run dozens back to back while the rest of the chip waits (measured: 36 touching
+// particles stretched a 9 us substep to 195 us).  Instead it stores its velocity, appends itself to the substep's list and
+// is finished by k_contact_finish, one WAVEFRONT per particle, all of them in flight at once.  Without p.mesh_defer (the
+// flavour captured while nothing is near a mesh) the rare needy particle is queried in place.
+// MESH: 3 = small scene with the triangles in registers (k_contact_finish<3>; one particle per wavefront)
 template <int MESH, bool MAIN = false>
 __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v, bool fin,
-                                            float4* __restrict__ xv_out)
+                                            float4* __restrict__ xv_out, const TriRegs* tr = nullptr)
 {
     f3 x = x0;
     // mesh_collision, :295-421 — advances x by v*dt for EVERY particle (:321, :420)
@@ -563,35 +677,24 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         f3 vin = v;
         f3 next_x = x0 + vin * p.dt;
         f3 next_v = vin;
-        // Exact early-out.  The response below only fires when signed distance < margin (5 mm for gripper
-        // meshes, 1 mm otherwise).  A point outside the AABB of a CLOSED mesh is outside the mesh (winding number
-        // 0 < 0.6, sign +1) and its distance to the mesh is at least its distance to the AABB: if that is >= the
-        // margin for every mesh, nothing can happen and the query is skipped.  Meshes that are not closed manifolds
-        // (checked at construction) only get the query's own 2 cm range as the bound.
-        bool need = false;
-        if (fin) {
-            for (int m = 0; m < p.n_mesh; ++m) {
-                const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
-                                                   : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
-                // an OPEN mesh (kind bit 2) can report "inside" beyond its box: only the query's own range bounds it
-                const float mg = (p.mesh_kind[m] & 2) ? MESH_MAX_DIST : ((m < p.n_dyn_mesh && !p.use_pusher) ? 0.005f : 0.001f);
-                need = need || box_dist2(next_x, bb) < mg * mg * 1.0001f;
-            }
-        }
-        if (MAIN) { // main kernel of a large-mesh scene: count the particles that need a query (the host picks next step's
-                    // graph from the total) and, in deferring mode, hand them to k_mesh_finish
-            if (need) {
+        bool need = false, near = false;
+        if (fin) need = mesh_need(p, e, step, next_x, 0.f, near);
+        if (MAIN) { // count the particles near a mesh (the host picks the next step's graph flavour from the total) and, in
+                    // deferring mode, hand the ones that need a query to k_contact_finish
+            if (near) atomicAdd(p.mesh_cnt + p.n_sub, 1);
+            if (need && p.mesh_defer) {
                 const int slot = atomicAdd(p.mesh_cnt + step, 1);
-                if (p.mesh_defer && slot < p.mesh_cap) {
-                    p.vbc[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
+                if (slot < p.mesh_cap) {
+                    p.vdef[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
                     p.mesh_list[slot] = make_int2(e, i);
-                    fin = false; // finished by k_mesh_finish
+                    fin = false; // finished by k_contact_finish
                     need = false;
                 }
                 // list full (never with the sizing below): fall through to the in-place query
             }
         }
-        MeshHit q = MESH == 2 ? mesh_query_wave(p, step, next_x, e, need) // wave-cooperative, convergent call site 1
+        MeshHit q = MESH == 3 ? mesh_query_regs(*tr, next_x, need)
+                  : MESH == 2 ? mesh_query_wave(p, step, next_x, e, need) // wave-cooperative, convergent call site 1
                               : mesh_query_lane(p, e, step, next_x, need);
         // per-lane response; lanes that must re-query (gripper branch, :394-408) park their state and meet again below
         bool requery = false;
@@ -600,7 +703,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         bool hit = false;
         if (q.result) {
             int is_gripper;
-            const int mm = p.mesh_map[q.face];
+            const int mm = MESH == 3 ? q.mm : p.mesh_map[q.face];
             if (!p.use_pusher) is_gripper = mm == 0 ? 1 : (mm == 1 ? 2 : 0);
             else is_gripper = mm >= 0 ? 1 : 0;
             f3 delta = next_x - q.pt;
@@ -613,9 +716,9 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
                 f3 rdv = mk(0.f, 0.f, 0.f);
                 float ce, cf;
                 if (is_gripper >= 1) {
-                    const f3 ctr = ld3(p.interp_center, (size_t)e * p.n_sub + step);
-                    const f3 om = ld3(p.dyn_omega, e);
-                    const f3 dv = ld3(p.dyn_vel, (size_t)e * 2 + (is_gripper == 1 ? 0 : 1));
+                    const f3 ctr = MESH == 3 ? tr->ctr : ld3(p.interp_center, (size_t)e * p.n_sub + step);
+                    const f3 om = MESH == 3 ? tr->om : ld3(p.dyn_omega, e);
+                    const f3 dv = MESH == 3 ? (is_gripper == 1 ? tr->dv0 : tr->dv1) : ld3(p.dyn_vel, (size_t)e * 2 + (is_gripper == 1 ? 0 : 1));
                     rdv = dv + cross(om, x0 - ctr);
                     vin = vin - rdv;
                     ce = p.cee; cf = p.cef;
@@ -638,7 +741,8 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
                 }
             }
         }
-        const MeshHit q2 = MESH == 2 ? mesh_query_wave(p, step, next_x, e, requery) // convergent call site 2
+        const MeshHit q2 = MESH == 3 ? mesh_query_regs(*tr, next_x, requery)
+                         : MESH == 2 ? mesh_query_wave(p, step, next_x, e, requery) // convergent call site 2
                                      : mesh_query_lane(p, e, step, next_x, requery);
         if (requery) {
             if (q2.result) {
@@ -654,7 +758,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         }
         if (hit && write_forces) {
             const f3 fo = (v_normal_new - v_normal) / p.dt;
-            float* cf3 = p.coll_forces + ((size_t)e * p.nF + p.face_map[q.face]) * 3;
+            float* cf3 = p.coll_forces + ((size_t)e * p.nF + (MESH == 3 ? q.fm : p.face_map[q.face])) * 3;
             atomicAdd(cf3, fo.x);
             atomicAdd(cf3 + 1, fo.y);
             atomicAdd(cf3 + 2, fo.z);
@@ -789,10 +893,24 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __r
     if (SELF) {
         if (valid && p.coll_num[eb + i] > 0) {
             p.vbc[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
-            fin = false; // finished by k_self_finish
+            fin = false; // finished by k_self_finish / k_contact_finish
+            if (MESH != 0 && p.mesh_defer) {
+                // Will it also need a mesh query?  Its velocity is not final (the impulses come later), so the test is widened
+                // by 2 mm (= 40 m/s of velocity change in one substep); over-inclusion is harmless, the query itself is exact.
+                // Such a particle goes to the mesh list TAGGED: k_contact_finish applies its impulses and queries in one go.
+                bool near;
+                if (mesh_need(p, e, step, x0 + v * p.dt, 0.002f, near)) {
+                    const int slot = atomicAdd(p.mesh_cnt + step, 1);
+                    if (slot < p.mesh_cap) {
+                        p.mesh_list[slot] = make_int2(e, i | (int)0x80000000);
+                        p.cand_mark[eb + i] = step + 1;
+                    }
+                }
+                if (near) atomicAdd(p.mesh_cnt + p.n_sub, 1);
+            }
         }
     }
-    finish_wave<MESH, MESH == 2>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out);
+    finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out);
     R2S_STAMP(3);
 }
 
@@ -802,69 +920,120 @@ __global__ void __launch_bounds__(B) k_substep(const PhysDev p, const float4* __
 {
     substep_body<B, RCAP, SELF, MESH>(p, xv_in, xv_out, step, write_forces);
 }
+// object_collision for ONE particle by a whole wavefront / a group of lanes: the lanes stride over its candidates (up to 500,
+// each a dependent gather of the partner's position and published velocity), `G` = lanes per particle (a power of two).
+template <int G>
+__device__ __forceinline__ f3 self_impulse(const PhysDev& p, const float4* __restrict__ xv_in, size_t eb, int i, bool act, f3 x0, f3 v, int sub)
+{
+    float valid = 0.f, m1 = 1.f;
+    f3 Jsum = mk(0.f, 0.f, 0.f);
+    if (act) {
+        m1 = p.masses[i];
+        const int mask1 = p.masks[i];
+        const int cnt = p.coll_num[eb + i];
+        for (int k = sub; k < cnt; k += G) {
+            const int j = p.coll_idx[(eb + i) * (size_t)p.coll_cap + k];
+            const f3 x2 = xyz(xv_in[(eb + j) * 2]);
+            const f3 v2 = xyz(p.vbc[eb + j]); // j lists i too (the candidate relation is symmetric; a capped row still has
+                                               // coll_num > 0), so j published its velocity in the fused kernel
+            const float m2 = p.masses[j];
+            const f3 dis = x2 - x0;
+            const float dis_len = len(dis);
+            const f3 rv = v2 - v;
+            if (mask1 != p.masks[j] && dis_len < p.cd && dot(dis, rv) < -1e-4f) {
+                valid += 1.f;
+                const f3 nrm = dis / fmaxf(dis_len, 1e-6f);
+                const f3 v_rel_n = nrm * dot(rv, nrm);
+                const float inv = 1.f / m1 + 1.f / m2;
+                const f3 impulse_n = (v_rel_n * (-(1.f + p.cse))) / inv;
+                const float vnl = len(v_rel_n);
+                const f3 v_rel_t = rv - v_rel_n;
+                const float vtl = fmaxf(len(v_rel_t), 1e-6f);
+                const float a = fmaxf(0.f, 1.f - p.csf * (1.f + p.cse) * vnl / vtl);
+                const f3 impulse_t = (v_rel_t * (a - 1.f)) / inv;
+                Jsum = Jsum + (impulse_n + impulse_t);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) { // xor shuffles stay inside the aligned group of G lanes
+        valid += __shfl_xor(valid, o); Jsum.x += __shfl_xor(Jsum.x, o); Jsum.y += __shfl_xor(Jsum.y, o); Jsum.z += __shfl_xor(Jsum.z, o);
+    }
+    return (act && valid > 0.f) ? v - (Jsum / valid) / m1 : v;
+}
+
 // object_collision + loop (:132-193, :230-268) for the particles on the candidate list, then the rest of the substep.
+// 16 lanes per particle: the lanes stride over its candidates (up to 500, each a dependent gather of the partner's position
+// and published velocity — serial in one lane that was 25+ us for a squeezed limb), the group sums J and the hit count, and
+// the group's first lane carries the particle through finish_wave (which defers it to k_contact_finish if it also touches a
+// mesh).  The per-pair arithmetic is the reference's, the sum order over candidates is lane-strided instead of sequential.
 template <int MESH>
 __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
                                                      int write_forces)
 {
+    constexpr int G = 16;
     const int n = *p.cand_count;
+    const int sub = (int)(threadIdx.x & (G - 1)), grp = (int)(threadIdx.x / G), gpb = (int)(blockDim.x / G);
     // wave-uniform trip count: every lane of a wavefront reaches the cooperative mesh queries of finish_wave together
-    for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
-        const int t = base + (int)threadIdx.x;
+    for (int base = blockIdx.x * gpb; base < n; base += gridDim.x * gpb) {
+        const int t = base + grp;
         const int2 ei = p.cand_list[t < n ? t : 0];
         const bool act = t < n && ei.x >= p.e0 && ei.x < p.e0 + p.ne; // this chain's environments only
         const int e = ei.x, i = ei.y;
         const size_t eb = (size_t)e * p.N;
         const f3 x0 = xyz(xv_in[(eb + i) * 2]);
-        f3 v = xyz(p.vbc[eb + i]);
-        if (act) {
-            const float m1 = p.masses[i];
-            const int mask1 = p.masks[i];
-            const int cnt = p.coll_num[eb + i];
-            float valid = 0.f;
-            f3 Jsum = mk(0.f, 0.f, 0.f);
-            for (int k = 0; k < cnt; ++k) {
-                const int j = p.coll_idx[(eb + i) * (size_t)p.coll_cap + k];
-                const f3 x2 = xyz(xv_in[(eb + j) * 2]);
-                const f3 v2 = xyz(p.vbc[eb + j]); // j lists i too (the candidate relation is symmetric), so it published
-                const float m2 = p.masses[j];
-                const f3 dis = x2 - x0;
-                const float dis_len = len(dis);
-                const f3 rv = v2 - v;
-                if (mask1 != p.masks[j] && dis_len < p.cd && dot(dis, rv) < -1e-4f) {
-                    valid += 1.f;
-                    const f3 nrm = dis / fmaxf(dis_len, 1e-6f);
-                    const f3 v_rel_n = nrm * dot(rv, nrm);
-                    const float inv = 1.f / m1 + 1.f / m2;
-                    const f3 impulse_n = (v_rel_n * (-(1.f + p.cse))) / inv;
-                    const float vnl = len(v_rel_n);
-                    const f3 v_rel_t = rv - v_rel_n;
-                    const float vtl = fmaxf(len(v_rel_t), 1e-6f);
-                    const float a = fmaxf(0.f, 1.f - p.csf * (1.f + p.cse) * vnl / vtl);
-                    const f3 impulse_t = (v_rel_t * (a - 1.f)) / inv;
-                    Jsum = Jsum + (impulse_n + impulse_t);
-                }
-            }
-            if (valid > 0.f) v = v - (Jsum / valid) / m1;
-        }
-        finish_wave<MESH>(p, e, i, eb, step, write_forces, x0, v, act, xv_out);
+        const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub);
+        finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out);
     }
 }
 
-// The particles the main kernel deferred (large-mesh scenes): one wavefront per particle — lane 0 carries it through
-// finish_wave, the other 63 lanes only lend their hands to the cooperative queries.
-__global__ void __launch_bounds__(256) k_mesh_finish(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
-                                                     int write_forces)
+// ONE finishing kernel per substep for everything the fused kernel could not finish in its own thread (captured into the
+// graph flavours used while something is near a mesh):
+//   part 1  the mesh list, one WAVEFRONT per particle: particles whose query was deferred, and — tagged — particles that
+//           also have self-collision candidates (their impulses are applied first, 64 lanes over the candidates);
+//           MESHQ = 3: every mesh small, the substep's triangles live in registers; MESHQ = 2: generic cooperative query;
+//   part 2  (WITH_SELF) the remaining particles of the candidate list, 16 lanes each, finished in place.
+// Both parts only read what the fused kernel published, so they need no order between them: one launch boundary per
+// substep instead of two (k_self_finish + a mesh kernel), and the two kinds of work overlap.
+template <int MESHQ, bool WITH_SELF>
+__global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
+                                                        int write_forces)
 {
-    const int n = min(p.mesh_cnt[step], p.mesh_cap);
+    // The few wavefronts of this kernel are a chain of dependent round trips that the whole env step waits for, and they share
+    // the chip with the other chain's fused kernel: let them win the instruction-issue arbitration on their SIMDs.
+#ifndef R2S_NO_FINISH_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const int lane = (int)(threadIdx.x & 63), wpb = (int)(blockDim.x >> 6);
-    for (int t = blockIdx.x * wpb + (int)(threadIdx.x >> 6); t < n; t += gridDim.x * wpb) {
+    const int n_mesh = min(p.mesh_cnt[step], p.mesh_cap);
+    for (int t = blockIdx.x * wpb + (int)(threadIdx.x >> 6); t < n_mesh; t += gridDim.x * wpb) {
         const int2 ei = p.mesh_list[t];
-        const int e = ei.x, i = ei.y;
+        const bool tagged = ei.y < 0;
+        const int e = ei.x, i = ei.y & 0x7fffffff;
         const size_t eb = (size_t)e * p.N;
+        TriRegs tr;
+        if (MESHQ == 3) tr = load_tris(p, e, step, lane); // in flight while the impulses are summed
         const f3 x0 = xyz(xv_in[(eb + i) * 2]);
-        const f3 v = xyz(p.vbc[eb + i]);
-        finish_wave<2, false>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out);
+        f3 v = xyz(tagged ? p.vbc[eb + i] : p.vdef[eb + i]);
+        if (WITH_SELF && tagged) v = self_impulse<64>(p, xv_in, eb, i, true, x0, v, lane);
+        finish_wave<MESHQ, false>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr);
+    }
+    if (WITH_SELF) {
+        constexpr int G = 16;
+        const int n = *p.cand_count;
+        const int sub = (int)(threadIdx.x & (G - 1)), grp = (int)(threadIdx.x / G), gpb = (int)(blockDim.x / G);
+        for (int base = blockIdx.x * gpb; base < n; base += gridDim.x * gpb) { // wave-uniform trip count
+            const int t = base + grp;
+            const int2 ei = p.cand_list[t < n ? t : 0];
+            const int e = ei.x, i = ei.y;
+            const size_t eb = (size_t)e * p.N;
+            const bool act = t < n && e >= p.e0 && e < p.e0 + p.ne && p.cand_mark[eb + i] != step + 1; // not already done in part 1
+            const f3 x0 = xyz(xv_in[(eb + i) * 2]);
+            const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub);
+            // the widened test of the fused kernel said "no mesh in reach": the in-place query below is never taken, it only
+            // keeps the kernel correct should a velocity change exceed the 2 mm pad
+            finish_wave<MESHQ == 3 ? 1 : 2, false>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out);
+        }
     }
 }
 
@@ -878,10 +1047,10 @@ __global__ void k_log_contacts(int E, const int* __restrict__ cand_count, const 
     if (threadIdx.x == 0) { out[0] = cand_count ? *cand_count : 0; out[1] = hits; out[2] = g; }
 }
 
-__global__ void k_sum_i32(const int* __restrict__ a, int n, int* __restrict__ out)
+__global__ void k_sum_i32(const int* __restrict__ a, int n, int stride, int* __restrict__ out)
 {
     int s = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s += a[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += a[(size_t)i * stride];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
@@ -1417,7 +1586,9 @@ struct R2SPhys {
     int* d_masks = nullptr;
     int *d_coll_num = nullptr, *d_coll_idx = nullptr, *d_max_count = nullptr;
     float4* d_vbc = nullptr;
-    int2* d_mesh_list = nullptr; int* d_mesh_cnt = nullptr; int mesh_cap = 0; // deferred large-mesh queries: [chains][cap], [chains][n_sub]
+    int2* d_mesh_list = nullptr; int* d_mesh_cnt = nullptr; int mesh_cap = 0; // deferred mesh queries: [chains][cap], [chains][n_sub + 1]
+    float4* d_vdef = nullptr;
+    int* d_cand_mark = nullptr;
     int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false;
     int chains_override = 0;  // > 0: tuning override of chains() (R2S_CHAINS at create, r2s_phys_set_tuning later)
     int force_defer = -1;     // >= 0: force the deferred-query flavour on / off (tests, tuning)
@@ -1425,14 +1596,13 @@ struct R2SPhys {
     std::vector<float> h_logY; // last log stiffness (re-clamped when spring_Y_min / max change)
     int* d_hit_cnt = nullptr;
     hipEvent_t rigid_event = nullptr;
-    int mesh_defer = 0; // this env step's graph flavour: 1 = needy particles are finished by k_mesh_finish (contact likely), 0 = in place
+    int mesh_defer = 0; // this env step's graph flavour: 1 = needy particles are finished by k_contact_finish (contact likely), 0 = in place
     int2* d_cand_list = nullptr;
     int* d_cand_count = nullptr;
     int* h_cand_count = nullptr; // pinned; filled asynchronously by update_collision_graph
     hipEvent_t cand_event = nullptr;
     bool cand_pending = false;
     int n_cand = 0;              // particles with candidates after the last update (host view)
-    int graph_cand_cap = 0, n_cand_launch = 0;
     int chains() const // parallel kernel chains of the captured env step
     {
         // two chains pay once a single kernel would not fit the chip in one go (6 workgroups per CU): 32 sloth envs = 1888
@@ -1494,7 +1664,7 @@ struct R2SPhys {
         p.self_collision = prm.self_collision; p.use_pusher = prm.use_pusher;
         p.coll_num = d_coll_num; p.coll_idx = d_coll_idx; p.coll_cap = coll_cap;
         p.vbc = d_vbc; p.cand_list = d_cand_list; p.cand_count = d_cand_count;
-        p.mesh_list = d_mesh_list; p.mesh_cnt = d_mesh_cnt; p.mesh_cap = mesh_cap; p.mesh_defer = mesh_defer;
+        p.mesh_list = d_mesh_list; p.mesh_cnt = d_mesh_cnt; p.mesh_cap = mesh_cap; p.mesh_defer = mesh_defer; p.vdef = d_vdef; p.cand_mark = d_cand_mark;
         p.n_mesh = n_mesh; p.n_dyn_mesh = n_dyn_mesh; p.nF = nF; p.nV = nV; p.n_dyn_pts = n_dyn_pts;
         p.faces = d_faces; p.mesh_map = d_mesh_map; p.face_map = d_face_map; p.mesh_face_off = d_mesh_face_off;
         p.face_orig = d_face_orig; p.face_mesh = d_face_mesh; p.n_cl = n_cl; p.n_xf = n_xf; p.cl_f0 = d_cl_f0; p.cl_f1 = d_cl_f1;
@@ -1591,14 +1761,23 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
     float4* out = h->xv[in_buf ^ 1];
     if (h->pb == 256) launch_substep_layout<256, 1024>(p, grid, in, out, step, write_forces, with_self, mesh, s);
     else launch_substep_layout<128, 768>(p, grid, in, out, step, write_forces, with_self, mesh, s);
-    if (with_self) {
+    // What the fused kernel left unfinished: with something near a mesh (mesh_defer) ONE combined finishing kernel per substep —
+    // deferred mesh queries, one wavefront per particle, plus the self-collision impulses; otherwise only k_self_finish
+    // while candidates exist (mesh queries of the rare needy particle in place).
+    if (mesh != 0 && p.mesh_defer) {
+        const bool small = mesh == 1 && h->nF <= 128; // every mesh small: the substep's triangles fit two per lane
+        const dim3 g(512);                            // 2048 wavefronts, grid-stride
+#define R2S_FIN(Q, S) hipLaunchKernelGGL((k_contact_finish<Q, S>), g, dim3(256), 0, s, p, in, out, step, write_forces)
+        if (small) { if (with_self) R2S_FIN(3, true); else R2S_FIN(3, false); }
+        else { if (with_self) R2S_FIN(2, true); else R2S_FIN(2, false); }
+#undef R2S_FIN
+    } else if (with_self) {
         // grid-stride over the device-side candidate list; sized for the host's view of the count
-        const unsigned blocks = (unsigned)std::min(1024, std::max(1, (h->n_cand + 255) / 256));
+        const unsigned blocks = 512; // grid-stride over the device-side candidate list, 16 lanes per listed particle
         if (mesh == 2) hipLaunchKernelGGL((k_self_finish<2>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
         else if (mesh == 1) hipLaunchKernelGGL((k_self_finish<1>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
         else hipLaunchKernelGGL((k_self_finish<0>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
     }
-    if (mesh == 2 && p.mesh_defer) hipLaunchKernelGGL(k_mesh_finish, dim3(512), dim3(256), 0, s, p, in, out, step, write_forces); // 2048 wavefronts, grid-stride
     return R2S_OK;
 }
 
@@ -1618,10 +1797,14 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
     if (ne < 0) ne = h->E;
     p.e0 = e0; p.ne = ne; p.cb = (h->nb * ne + 7) / 8;
     const int chain = chain_id;
-    if (h->any_large) { // this chain's slice of the deferred-query list and counters
+    if (h->nF > 0) { // this chain's slice of the deferred-query list and counters ([n_sub] = the near-a-mesh count of the env step)
         p.mesh_list = h->d_mesh_list + (size_t)chain * h->mesh_cap;
-        p.mesh_cnt = h->d_mesh_cnt + (size_t)chain * h->prm.num_substeps;
-        hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((h->prm.num_substeps + 255) / 256)), dim3(256), 0, s, (float*)p.mesh_cnt, (size_t)h->prm.num_substeps);
+        p.mesh_cnt = h->d_mesh_cnt + (size_t)chain * (h->prm.num_substeps + 1);
+        hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((h->prm.num_substeps + 256) / 256)), dim3(256), 0, s, (float*)p.mesh_cnt, (size_t)h->prm.num_substeps + 1);
+        if (with_self && p.mesh_defer) { // marks of the previous env step must not match this step's substep numbers
+            const size_t cnt = (size_t)ne * h->N;
+            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (float*)(h->d_cand_mark + (size_t)e0 * h->N), cnt);
+        }
     }
     int buf = start_buf;
     for (int k = 0; k < n; ++k) {
@@ -2161,16 +2344,17 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     R2S_HIP_TRY(hipMemsetAsync(h->d_coll_num, 0, sizeof(int) * (size_t)E * N, s));
     TRY(dev_alloc(&h->d_max_count, 4));
     R2S_HIP_TRY(hipMemsetAsync(h->d_max_count, 0, sizeof(int) * 4, s));
-    if (h->any_large) { // deferred large-mesh queries
+    if (h->nF > 0) { // deferred mesh queries
         h->mesh_cap = std::max(4096, E * std::min(N, 2048));
         TRY(dev_alloc(&h->d_mesh_list, (size_t)8 * h->mesh_cap));
-        TRY(dev_alloc(&h->d_mesh_cnt, (size_t)8 * h->prm.num_substeps));
+        TRY(dev_alloc(&h->d_mesh_cnt, (size_t)8 * (h->prm.num_substeps + 1)));
+        TRY(dev_alloc(&h->d_vdef, (size_t)E * N));
+        if (h->prm.self_collision) { TRY(dev_alloc(&h->d_cand_mark, (size_t)E * N)); R2S_HIP_TRY(hipMemsetAsync(h->d_cand_mark, 0, sizeof(int) * (size_t)E * N, s)); }
         TRY(dev_alloc(&h->d_mesh_total, 4));
         R2S_HIP_TRY(hipHostMalloc((void**)&h->h_mesh_total, 64, hipHostMallocDefault));
         *h->h_mesh_total = 0;
         R2S_HIP_TRY(hipEventCreateWithFlags(&h->mesh_event, hipEventDisableTiming));
-        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_cnt, 0, sizeof(int) * 8 * (size_t)h->prm.num_substeps, s));
-        if (!h->prm.self_collision) TRY(dev_alloc(&h->d_vbc, (size_t)E * N));
+        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_cnt, 0, sizeof(int) * 8 * (size_t)(h->prm.num_substeps + 1), s));
     }
     if (h->prm.self_collision) {
         TRY(dev_alloc(&h->d_vbc, (size_t)E * N));
@@ -2195,7 +2379,16 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         TRY(r2s_phys_create_resting_case(h, stream_));
     }
     R2S_HIP_TRY(hipStreamSynchronize(s));
-    TRY(capture_graph(h, 0, 0));
+    // Capture every flavour the env step can take — {no candidates, candidates} x {nothing near a mesh, deferred mesh queries}
+    // x both parities of the state buffer (667 substeps is odd) — now: a flavour switch in the middle of a rollout (first
+    // contact, first candidates) must not pay ~5 ms of capture.  All finishing kernels have fixed grid-stride grids.
+    for (int defer = 0; defer <= (h->nF > 0 ? 1 : 0); ++defer)
+        for (int variant = 0; variant <= (h->prm.self_collision ? 1 : 0); ++variant)
+            for (int par = 0; par < ((h->prm.num_substeps & 1) ? 2 : 1); ++par) {
+                h->mesh_defer = defer;
+                TRY(capture_graph(h, variant, par));
+            }
+    h->mesh_defer = 0;
 #undef TRY
     *out = h;
     return R2S_OK;
@@ -2207,7 +2400,7 @@ void r2s_phys_destroy(R2SPhys* h)
     (void)hipDeviceSynchronize();
     drop_graph(h);
     void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
-                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_mesh_list, h->d_mesh_cnt, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
+                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_mesh_list, h->d_mesh_cnt, h->d_vdef, h->d_cand_mark, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
                     h->d_faces, h->d_face_orig, h->d_face_mesh, h->d_cl_f0, h->d_cl_f1, h->d_cl_mesh, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
                     h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
@@ -2413,7 +2606,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         }
     }
     const int variant = (h->prm.self_collision && h->n_cand > 0) ? 1 : 0;
-    if (h->any_large) { // large-mesh scenes: defer the queries when the last finished step saw particles near a mesh
+    if (h->nF > 0) { // defer the mesh queries to k_contact_finish when the last finished step saw particles near a mesh
         if (h->mesh_pending && hipEventQuery(h->mesh_event) == hipSuccess) h->mesh_pending = false;
         if (!h->mesh_pending) h->mesh_defer = *h->h_mesh_total > 0 ? 1 : 0; // an unfinished count keeps the previous flavour
         if (h->force_defer >= 0) h->mesh_defer = h->force_defer; // test / tuning: force a flavour
@@ -2421,18 +2614,12 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     h->last_flavour[0] = variant; h->last_flavour[1] = h->nF > 0 ? (h->any_large ? 2 : 1) : 0; h->last_flavour[2] = h->mesh_defer;
     h->last_flavour[3] = use_graph ? h->chains() : 1;
     if (use_graph) {
-        // variant 1 bakes a grid size derived from n_cand: re-capture if the list outgrew it
+        // every flavour was captured at construction (capture_all); only set_params / set_tuning drop them
         const int slot = h->mesh_defer * 4 + variant * 2 + (h->cur & 1);
-        const bool stale = variant == 1 && h->n_cand > h->graph_cand_cap;
-        if (stale) { // every captured self-collision flavour bakes the old grid size
-            for (int k = 0; k < 8; ++k) if ((k & 2) && h->graph_exec[k]) { (void)hipGraphExecDestroy(h->graph_exec[k]); (void)hipGraphDestroy(h->graph[k]); h->graph_exec[k] = nullptr; h->graph[k] = nullptr; }
-        }
         if (!h->graph_exec[slot]) {
-            if (variant == 1) h->graph_cand_cap = std::max(h->n_cand * 2, 4096), h->n_cand_launch = h->graph_cand_cap;
-            const int keep = h->n_cand;
-            if (variant == 1) h->n_cand = h->graph_cand_cap; // size the finishing grid generously
+            const int keep = h->mesh_defer;
             int rc = capture_graph(h, variant, h->cur);
-            h->n_cand = keep;
+            h->mesh_defer = keep;
             if (rc) return rc;
         }
         R2S_HIP_TRY(hipGraphLaunch(h->graph_exec[slot], s));
@@ -2441,9 +2628,9 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         if (rc) return rc;
     }
     h->cur ^= (n & 1);
-    if (h->any_large && !h->mesh_pending) { // how many queries this step needed -> pinned memory, read at a later step without waiting
+    if (h->nF > 0 && !h->mesh_pending) { // particles near a mesh during this step -> pinned memory, read at a later step without waiting
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(256), 0, s, h->d_mesh_cnt, 8 * h->prm.num_substeps, h->d_mesh_total);
+        hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(64), 0, s, h->d_mesh_cnt + h->prm.num_substeps, 8, h->prm.num_substeps + 1, h->d_mesh_total);
         R2S_HIP_TRY(hipMemcpyAsync(h->h_mesh_total, h->d_mesh_total, sizeof(int), hipMemcpyDeviceToHost, s));
         R2S_HIP_TRY(hipEventRecord(h->mesh_event, s));
         h->mesh_pending = true;

@@ -34,12 +34,16 @@ CONFIGS = {
 
 class BatchedRollout:
     def __init__(self, config="sloth_32env", device="cuda:0", seed=0, n_env=None, num_substeps=667, views=2,
-                 self_collision=True, with_gripper=True, with_static=True, tile_culling=True, schedule=None, close_at=15, open_at=10**9):
+                 self_collision=True, with_gripper=True, with_static=True, tile_culling=True, schedule=None, close_at=15, open_at=10**9,
+                 settle_steps=None):
         """``schedule``: the synthetic action trace.  "grasp" (default for the sloth scenes): the open gripper comes down over
         the toy's raised arms (free motion), closes on them at env step ``close_at`` — finger contact, the two arms pressed
         together (live self-collision candidates), grasp detection — and lifts.  "lissajous" (default otherwise, SURVEY.md
         §8d): the gripper hovers 10 cm above the object on a Lissajous path, closes at step 100, opens at 300.  The pusher
-        scene always pushes along +x from ``close_at`` = 0."""
+        scene pushes along +x and reaches the block at ``close_at``.  ``settle_steps`` (default 40 for "grasp"): env steps run
+        inside the constructor with the gripper parked 15 cm higher, so that the toy is AT REST when the rollout starts
+        (SURVEY.md §8d places the objects resting on the table; a jittered lattice with random stiffness is not in equilibrium
+        under gravity and its arms sway by ~1 cm for the first second)."""
         shape, n_particles, n_gauss, envs, W, H = CONFIGS[config]
         self.config = config
         self.n_env = int(n_env if n_env is not None else envs)
@@ -75,7 +79,10 @@ class BatchedRollout:
             rel[:, 1] *= -1
             rel[:, 2] *= -1
             self.eef_table = np.repeat((self.eef_init.astype(np.float64) + rel)[None], 2, axis=0)   # rigid: two equal knots
-            self.eef0 = np.array([pts[:, 0].min() - 0.02, c[1], 0.2], np.float32)
+            # the rod (radius 5 mm, 1 mm contact margin) pushes along +x at 5 cm/s and reaches the block's -x face at env step `close_at`
+            self.schedule, self.close_at = "push", int(close_at)
+            y_face = float(np.median(pts[pts[:, 0] < pts[:, 0].min() + 0.01, 1]))   # the T's bar: the part that reaches furthest in -x
+            self.eef0 = np.array([pts[:, 0].min() - 0.006 - 0.05 * self.close_at * num_substeps * 5e-5, y_face, 0.2], np.float32)
             dyn = [(synth.eef_world_points(self.eef_table[-1], self.eef_init, self.eef0), rod_f)]
         elif with_gripper:
             self.eef_table, self.eef_init, fl, fr = synth.gripper_eef_table()
@@ -139,6 +146,18 @@ class BatchedRollout:
         self.last_num_rendered = 0
         if with_gripper:
             self._init_gripper_motion()
+        n_settle = (40 if self.schedule == "grasp" else 0) if settle_steps is None else int(settle_steps)
+        if n_settle > 0 and with_gripper:
+            park = torch.tensor([0.0, 0.0, 0.15], device=self.device)
+            zero = torch.zeros(E, 3, device=self.device)
+            for _ in range(n_settle):
+                if self.phys.self_collision:
+                    self.phys.update_collision_graph()
+                self.phys.set_eef_motion(self.eef_xyz + park, zero, self.eef_rot, self.eef_rot_vel, None if self.use_pusher else torch.ones(E, device=self.device))
+                self.phys.step(0, 0, sync_state=False)
+            self.phys.set_eef_table(self.eef_table, self.eef_init, 3e4)   # forget the parked pose: current_openness = None, grasped = False
+            self.phys.sync_state()
+            self._update_means()
 
     # ---- end-effector trace: fixed Lissajous path at <= 0.1 m/s; the gripper closes at step 100 and opens at 300 ------
     # (SURVEY.md §8d).  Only the eef pose / rates / commanded opening are produced here — what BaseEnv hands to

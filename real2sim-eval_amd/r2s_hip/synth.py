@@ -96,14 +96,16 @@ def lattice_points(shape: str, n_target: int, seed: int, spacing: float = 0.006)
         ext = base * s
         inside = lambda p: ((p / ext) ** 2).sum(1) <= 1.0  # noqa: E731
     elif shape == "sloth_arms":
-        # the soft toy hanging-sloth pose: the ellipsoid body plus two arms raised above the head, parallel, 33 mm apart
-        # (inner surfaces) and 71 mm across — a two-finger gripper (85 mm open) can straddle both and squeeze them
-        # together, which is what produces live self-collision candidates (particles of different limbs that were not
-        # neighbours at rest, spring_mass_warp.py:196-227) on top of the finger contacts
-        arm_r, arm_y, arm_up, arm_in = 0.0095, 0.026, 0.08, 0.03
+        # the soft toy sitting with its arms raised: the ellipsoid body cut flat at a quarter of its height (a standing
+        # ellipsoid topples within a second) plus two arms above the head, parallel, 35 mm apart (inner surfaces) and 61 mm
+        # across — a two-finger gripper (85 mm open) can straddle both and squeeze them together, which is what produces
+        # live self-collision candidates (particles of different limbs that were not neighbours at rest,
+        # spring_mass_warp.py:196-227) on top of the finger contacts
+        arm_r, arm_y, arm_up, arm_in = 0.010, 0.024, 0.08, 0.03
         n_arm = 2 * np.pi * arm_r**2 * (arm_up + arm_in) / h**3
         base = np.array([0.10, 0.065, 0.135]) / 2
-        vol = 4.0 / 3.0 * np.pi * np.prod(base)
+        cut = 0.5                                                    # keep z >= -cut * c: 27/32 of the ellipsoid's volume
+        vol = 4.0 / 3.0 * np.pi * np.prod(base) * (0.5 + 0.75 * cut - 0.25 * cut**3)
         s = (max(n_target - 0.8 * n_arm, 0.5 * n_target) * h**3 / vol) ** (1.0 / 3.0)
         body = base * s
         if body[1] < arm_y + arm_r:  # small test objects: scale the arms with the body
@@ -112,7 +114,7 @@ def lattice_points(shape: str, n_target: int, seed: int, spacing: float = 0.006)
         ext = np.array([body[0], body[1], body[2] + arm_up])
 
         def inside(p):
-            b = ((p / body) ** 2).sum(1) <= 1.0
+            b = (((p / body) ** 2).sum(1) <= 1.0) & (p[:, 2] >= -cut * body[2])
             z_ok = (p[:, 2] >= body[2] - arm_in) & (p[:, 2] <= body[2] + arm_up)
             a = z_ok & ((p[:, 0] ** 2 + (np.abs(p[:, 1]) - arm_y) ** 2) <= arm_r * arm_r)
             return b | a
@@ -213,10 +215,11 @@ def cylinder_mesh(center, radius=0.005, length=0.2, n_seg=64, n_rings=190, axis=
     return (v + np.asarray(center, np.float64)).astype(np.float32), np.array(f, np.int32)
 
 
-def finger_mesh(center, size=(0.02, 0.01, 0.05), n_faces=44):
+def finger_mesh(center, size=(0.02, 0.01, 0.05), n_faces=44, pad_normal=None):
     """A closed box re-tessellated to ``n_faces`` triangles (the real finger collision meshes have 44,
     assets/robots/xarm/xarm7_with_gripper_collision.urdf:425,519): the two large side faces are split
-    into strips."""
+    into strips.  ``pad_normal``: outward normal of the finger's gripping side; the three largest triangles of that side
+    are moved to face indices 1, 18 and 19 — the faces whose forces the grasp test sums (phystwin.py:386-391)."""
     v, f = box_mesh(center, size)
     v, f = list(map(list, v)), [list(t) for t in f]
     # split triangles (longest edge midpoint) until the face count is reached
@@ -236,7 +239,19 @@ def finger_mesh(center, size=(0.02, 0.01, 0.05), n_faces=44):
         m = len(v) - 1
         f.append([i0, m, i2])
         f.append([m, i1, i2])
-    return np.array(v, np.float32), np.array(f[:n_faces] if len(f) > n_faces else f, np.int32)
+    v, f = np.array(v, np.float32), np.array(f[:n_faces] if len(f) > n_faces else f, np.int32)
+    if pad_normal is not None and len(f) > 19:
+        a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+        nrm = np.cross(b - a, c - a)
+        area = 0.5 * np.linalg.norm(nrm, axis=1)
+        on_pad = (nrm @ np.asarray(pad_normal, np.float32)) > 0.9 * 2 * area
+        pads = np.argsort(-(area * on_pad), kind="stable")[:3]
+        order = list(range(len(f)))
+        for slot, src in zip((1, 18, 19), pads):
+            k = order.index(src)
+            order[slot], order[k] = order[k], order[slot]
+        f = f[order]
+    return v, f
 
 
 # ------------------------------------------------------------------------------------------------
@@ -272,8 +287,8 @@ def gripper_eef_table(n_knots=101, init_eef_xyz=(0.37, 0.05, 0.35), gap_closed=0
     for k in range(n_knots):
         o = k / (n_knots - 1.0)
         half = 0.5 * (gap_closed + o * (gap_open - gap_closed)) + 0.5 * finger_size[1]
-        vl, fl = finger_mesh((0.0, -half, -drop), finger_size)
-        vr, fr = finger_mesh((0.0, +half, -drop), finger_size)
+        vl, fl = finger_mesh((0.0, -half, -drop), finger_size, pad_normal=(0.0, 1.0, 0.0))    # gripping sides face each other
+        vr, fr = finger_mesh((0.0, +half, -drop), finger_size, pad_normal=(0.0, -1.0, 0.0))
         rel = np.concatenate([vl, vr]).astype(np.float64)
         rel[:, 1] *= -1
         rel[:, 2] *= -1

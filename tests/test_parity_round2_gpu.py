@@ -121,12 +121,14 @@ def test_C1_rope_8k_particles_40_substeps_with_gripper_vs_oracle():
     from util_physics import gripper_motion
 
     ob = make_object("rope", 8000, seed=60, lift=0.0)
-    c, top = ob["points"].mean(0), ob["points"][:, 2].max()
-    fingers = [synth.finger_mesh((c[0], c[1] - 0.016, top + 0.027)), synth.finger_mesh((c[0], c[1] + 0.016, top + 0.027))]
+    c = ob["points"].mean(0)
+    zc = 0.5 * (ob["points"][:, 2].min() + ob["points"][:, 2].max())
+    # the rope (radius 12 mm) lies along x; the fingers straddle it at its own height, inner faces 2 mm off its surface
+    fingers = [synth.finger_mesh((c[0], c[1] - 0.019, zc + 0.01)), synth.finger_mesh((c[0], c[1] + 0.019, zc + 0.01))]
     n_sub = 40
     o = oracle_env(ob, num_substeps=n_sub, dynamic_meshes=fingers)
     h = hip_env(ob, num_substeps=n_sub, dynamic_meshes=fingers)
-    interp, centers, dv, om = gripper_motion(fingers, n_sub, 5e-5, vel=(0.0, 0.0, -1.5), closing=1.0)
+    interp, centers, dv, om = gripper_motion(fingers, n_sub, 5e-5, vel=(0.0, 0.0, -0.5), closing=1.0)
     o.set_mesh_interactive(interp, centers, dv, om)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None].cuda()  # noqa: E731
     h.set_mesh_interactive(t(interp), t(centers), t(dv), t(om))

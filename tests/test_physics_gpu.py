@@ -289,6 +289,64 @@ def test_pusher_25k_face_mesh_cluster_query_vs_oracle(defer, monkeypatch):
     assert np.allclose(tot_h, tot_o, rtol=2e-3, atol=np.abs(tot_o).max() * 2e-3), (tot_o, tot_h)
 
 
+@pytest.mark.parametrize("kind", ["unwelded", "open"])
+def test_large_meshes_that_are_not_welded_closed_manifolds_are_accepted_like_the_reference(kind):
+    """wp.mesh_query_point_sign_winding_number (spring_mass_warp.py:322-324) takes any triangle soup.  A > 256-face
+    mesh whose vertices are repeated per triangle (an STL export) must be welded and treated like the closed manifold it is;
+    an OPEN one (caps missing) cannot use pseudonormals and falls back to the exact winding number instead of being
+    rejected.  Both against the oracle's brute-force query."""
+    import torch
+    from r2s_hip import synth
+    from util_physics import rigid_motion
+
+    n_sub = 12
+    ob = make_object("T", 700, seed=12)
+    top = ob["points"][:, 2].max(); x_lo = ob["points"][:, 0].min()
+    y_face = float(np.median(ob["points"][ob["points"][:, 0] < x_lo + 0.005, 1]))       # the T's bar reaches furthest in -x
+    v, f = synth.cylinder_mesh((x_lo - 0.0052, y_face, top * 0.5 + 0.01), radius=0.005, length=0.08, n_seg=16, n_rings=12)
+    assert len(f) > 256
+    if kind == "unwelded":
+        v, f = v[f.reshape(-1)].copy(), np.arange(3 * len(f), dtype=np.int32).reshape(-1, 3)
+    else:
+        f = f[: 2 * 16 * 12].copy()              # side wall only
+        assert len(f) > 256
+    rod = (v, f)
+    interp, centers, dv, om = rigid_motion(rod, n_sub, 5e-5, vel=(2.0, 0.0, 0.0), omega=(0.0, 0.0, 2.0))
+    kw = dict(dynamic_meshes=[rod], self_collision=False, use_pusher=True, collide_eef_fric=0.2)
+    o = oracle_env(ob, num_substeps=n_sub, **kw)
+    h = hip_env(ob, num_substeps=n_sub, **kw)
+    o.set_mesh_interactive(interp, centers, dv, om)
+    t = lambda a: torch.from_numpy(a)[None].cuda()  # noqa: E731
+    h.set_mesh_interactive(t(interp), t(centers), t(dv), t(om))
+    o.step(); h.step()
+    assert h.last_flavour()["mesh_template"] == 2
+    assert np.abs(o.collision_forces).max() > 0, "the rod must touch the block in this scenario"
+    assert close(h.x[0], o.x, 1e-5, what=f"{kind} large mesh vs oracle")
+
+
+def test_a_large_dynamic_mesh_that_deforms_is_reported_by_a_later_step():
+    """The rigidity check of large dynamic meshes is read without blocking the stream (pinned word + event): the violation
+    surfaces at the first step() after the check has landed, as R2S_ERR_INVALID."""
+    import torch
+    from r2s_hip import synth
+    from r2s_hip._lib import R2SError
+    from util_physics import rigid_motion
+
+    n_sub = 4
+    ob = make_object("T", 300, seed=13)
+    rod = synth.cylinder_mesh((0.0, 0.0, 0.5), radius=0.005, length=0.08, n_seg=16, n_rings=12)
+    h = hip_env(ob, num_substeps=n_sub, dynamic_meshes=[rod], self_collision=False, use_pusher=True)
+    interp, centers, dv, om = rigid_motion(rod, n_sub, 5e-5)
+    interp = interp.copy(); interp[:, ::2, 0] *= 1.05            # stretch every other vertex: not a rigid motion
+    t = lambda a: torch.from_numpy(a)[None].cuda()  # noqa: E731
+    h.set_mesh_interactive(t(interp), t(centers), t(dv), t(om))
+    torch.cuda.synchronize()
+    with pytest.raises(R2SError):
+        for _ in range(3):
+            h.step()
+            torch.cuda.synchronize()
+
+
 def test_hip_stepper_matches_fixtures_from_the_reference_kernel_bodies():
     """tests/golden/physics_kernels.npz was produced by executing the reference's own kernel source (make_physics_golden.py):
     the HIP stepper reproduces the springs / gate / ground trajectory (A) and the finger + static-box contact trajectory with
