@@ -70,10 +70,10 @@ struct PhysDev {
     const uint2* adj_idx;      // 4 x u16: BYTE offset (record * 8) of the neighbour in the block's LDS window; padding /
                                // inactive slots point at the owner itself (zero force)
     const float4* adj_k;       // clamp(exp(logY), Ymin, Ymax)
-    const float4* adj_ir;      // 1 / rest length
+    const float4* adj_ir;      // a = k / rest length
     const int* rslice_off;     // [n_slices] second sliced ELL: neighbours NOT in the LDS window, gathered from global memory
     const int* rslice_deg;     // [n_slices]
-    const int4* radj;          // {global particle id, bits(k), bits(1/rest), 0}; padding points at the owner
+    const int4* radj;          // {global particle id, bits(k), bits(k/rest), 0}; padding points at the owner
     const int* halo_off;       // [nb+1]
     const int* halo_ids;       // halo particle ids per block (LDS records B.. in this order)
     const int* perm;           // internal -> user index
@@ -557,69 +557,80 @@ __device__ MeshHit mesh_query_regs(const TriRegs& t, f3 q_lane, bool want)
 #pragma clang fp contract(fast)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// One neighbour: (x,y) components in packed-f32 pairs (v_pk_add/mul/fma_f32), z scalar.
-__device__ __forceinline__ void spring_term(v2f xy, float zj, v2f vxy, float vzj, f3 xi, f3 vi, float k, float inv_rest, float dashpot,
+// One neighbour, 19 VALU instructions: with d = xj - xi (NOT normalised), r = 1 / |d|, L = |d|, t = (vj - vi) . d
+//     F = [k (L / rest - 1) + c (dv . d r)] d r  =  [(a L - k) + (c r) t] r d,      a = k / rest (per slot, precomputed),
+// so the unit vector is never formed (3 multiplies), L / rest - 1 and the stiffness product fold into one FMA, and the
+// 1e-6 floor of the reference's normalisation (d / max(L, 1e-6), :84) becomes a 1e-30 seed of the squared length: padding
+// slots (d = 0, k = a = 0, dv = 0) contribute exactly 0 without a v_max, real springs (rest > 1e-4) never get near it.
+// (x, y) pairs ride in packed registers (v_pk_add / v_pk_fma: one instruction, same issue time as two scalar ones).
+__device__ __forceinline__ void spring_term(v2f xy, float zj, v2f vxy, float vzj, f3 xi, f3 vi, float k, float a, float dashpot,
                                             v2f& fxy, float& fz)
 {
     const v2f dxy = xy - (v2f){xi.x, xi.y};
     const float dz = zj - xi.z;
-    const v2f sq = dxy * dxy;
-    const float d2 = fmaf(dz, dz, sq.x + sq.y);
-    const float rinv = __builtin_amdgcn_rsqf(fmaxf(d2, 1e-12f)); // 1 / max(L, 1e-6)
+    const float d2 = fmaf(dxy.x, dxy.x, fmaf(dxy.y, dxy.y, fmaf(dz, dz, 1e-30f)));
+    const float rinv = __builtin_amdgcn_rsqf(d2);
     const float L = d2 * rinv;
-    const v2f uxy = dxy * rinv;
-    const float uz = dz * rinv;
     const v2f dvxy = vxy - (v2f){vi.x, vi.y};
-    const v2f pr = dvxy * uxy;
-    const float v_rel = fmaf(vzj - vi.z, uz, pr.x + pr.y);
-    const float mag = fmaf(k, fmaf(L, inv_rest, -1.0f), dashpot * v_rel);
-    fxy += uxy * mag;
-    fz = fmaf(uz, mag, fz);
+    const float dvz = vzj - vi.z;
+    const float t = fmaf(dvxy.x, dxy.x, fmaf(dvxy.y, dxy.y, dvz * dz));
+    const float mag = fmaf(dashpot * rinv, t, fmaf(a, L, -k));
+    const float sc = mag * rinv;
+    fxy += dxy * sc;
+    fz = fmaf(dz, sc, fz);
 }
 
 // Hot path.  The block's LDS window is three 8-byte planes  xy[RCAP] | (z, vz)[RCAP] | vxy[RCAP]  with a compile-time
 // capacity, and the adjacency stores the neighbour's BYTE offset (record * 8): a slot is three ds_read_b64 off ONE
 // address register with immediate plane offsets — no address arithmetic beyond unpacking the u16.  The adjacency is
-// read in groups of 4 slots (one 8-byte + two 16-byte coalesced loads per lane); the index word of group g+1 is in
-// flight while group g is evaluated (ping-pong registers, no copies) and that of group 0 is issued BEFORE the staging
-// barrier (see substep_body).
-// Register budget: only the 8-byte index word of group g+1 is prefetched while group g is evaluated; the stiffness and
-// rest-length words (32 B per lane) of a group are loaded when the group starts — their latency hides behind the other
-// wavefronts of the SIMD and the group's own LDS gathers.  That keeps the gather at <= 64 VGPRs = 8 wavefronts per SIMD.
+// read in groups of 4 slots (one 8-byte + two 16-byte coalesced loads per lane).  ALL THREE words of group g+1 are in
+// flight while group g is evaluated (ping-pong registers, no copies), and those of group 0 are issued BEFORE the staging
+// barrier (see substep_body): the adjacency is an L2 stream shared by the environments, ~0.6 us away under load, and a
+// wavefront walks 9 groups — with the stiffness words loaded at the start of their own group (round 1) every group
+// exposed that latency and the gather was bound by it, not by VALU issue (cutting 15 % of its instructions changed nothing).
+struct AdjGroup {
+    uint2 idx;     // 4 x u16 window byte offsets
+    float4 k, a;   // stiffness, stiffness / rest length
+};
+__device__ __forceinline__ AdjGroup adj_load(const PhysDev& p, int t)
+{
+    AdjGroup g;
+    g.idx = p.adj_idx[t]; g.k = p.adj_k[t]; g.a = p.adj_ir[t];
+    return g;
+}
 template <int RCAP>
-__device__ __forceinline__ void spring_group(const PhysDev& p, int t, uint2 idx, const __attribute__((address_space(3))) char* win, f3 xi,
+__device__ __forceinline__ void spring_group(const PhysDev& p, const AdjGroup& g, const __attribute__((address_space(3))) char* win, f3 xi,
                                              f3 vi, v2f& fxy, float& fz)
 {
     typedef __attribute__((address_space(3))) const v2f lds_f2;
-    const float4 kk = p.adj_k[t], rr = p.adj_ir[t];
-    const unsigned off[GROUP] = {idx.x & 0xffffu, idx.x >> 16, idx.y & 0xffffu, idx.y >> 16};
-    const float k[GROUP] = {kk.x, kk.y, kk.z, kk.w};
-    const float ir[GROUP] = {rr.x, rr.y, rr.z, rr.w};
+    const unsigned off[GROUP] = {g.idx.x & 0xffffu, g.idx.x >> 16, g.idx.y & 0xffffu, g.idx.y >> 16};
+    const float k[GROUP] = {g.k.x, g.k.y, g.k.z, g.k.w};
+    const float a[GROUP] = {g.a.x, g.a.y, g.a.z, g.a.w};
 #pragma unroll
     for (int u = 0; u < GROUP; ++u) {
         const v2f xy = *(lds_f2*)(win + off[u]);
         const v2f zz = *(lds_f2*)(win + off[u] + RCAP * 8);
         const v2f vxy = *(lds_f2*)(win + off[u] + RCAP * 16);
-        spring_term(xy, zz.x, vxy, zz.y, xi, vi, k[u], ir[u], p.dashpot, fxy, fz);
+        spring_term(xy, zz.x, vxy, zz.y, xi, vi, k[u], a[u], p.dashpot, fxy, fz);
     }
 }
 
 template <int RCAP>
 __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* __restrict__ xv,
                                                const __attribute__((address_space(3))) char* win, size_t env_base, int sl, int ln, f3 xi,
-                                               f3 vi, int gbase, int ngroups, uint2 idx0)
+                                               f3 vi, int gbase, int ngroups, AdjGroup g0)
 {
     v2f fxy = {0.f, 0.f};
     float fz = 0.f;
-    uint2 a = idx0, b = idx0;
+    AdjGroup a = g0, b = g0;
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) { // ngroups is wave-uniform (one slice per wavefront): scalar branches
-        b = p.adj_idx[gbase + (g + 1) * SLICE];
-        spring_group<RCAP>(p, gbase + g * SLICE, a, win, xi, vi, fxy, fz);
-        if (g + 2 < ngroups) a = p.adj_idx[gbase + (g + 2) * SLICE];
-        spring_group<RCAP>(p, gbase + (g + 1) * SLICE, b, win, xi, vi, fxy, fz);
+        b = adj_load(p, gbase + (g + 1) * SLICE);
+        spring_group<RCAP>(p, a, win, xi, vi, fxy, fz);
+        if (g + 2 < ngroups) a = adj_load(p, gbase + (g + 2) * SLICE);
+        spring_group<RCAP>(p, b, win, xi, vi, fxy, fz);
     }
-    if (g < ngroups) spring_group<RCAP>(p, gbase + g * SLICE, a, win, xi, vi, fxy, fz);
+    if (g < ngroups) spring_group<RCAP>(p, a, win, xi, vi, fxy, fz);
     // neighbours outside the LDS window: slot-major coalesced adjacency, records gathered from global memory
     // (only when a block's halo exceeds the window capacity; never for the benchmark objects)
     const int4* __restrict__ ra = p.radj + p.rslice_off[sl] + ln;
@@ -842,8 +853,9 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __r
     const int sl = __builtin_amdgcn_readfirstlane(ic / SLICE);
     const int gbase = __builtin_amdgcn_readfirstlane(p.slice_off[sl] / GROUP) + lane;
     const int ngroups = __builtin_amdgcn_readfirstlane(p.slice_deg[sl] / GROUP);
-    uint2 g0 = make_uint2(0u, 0u);
-    if (ngroups > 0) g0 = p.adj_idx[gbase];
+    AdjGroup g0;
+    g0.idx = make_uint2(0u, 0u); g0.k = make_float4(0.f, 0.f, 0.f, 0.f); g0.a = g0.k;
+    if (ngroups > 0) g0 = adj_load(p, gbase);
     // stage the block's own records (record r < B is particle b*B + r) and its halo (record B + k is halo particle k).
     // All loads of a thread are issued before its first LDS write: two dependent round trips (halo id, then state)
     // per workgroup instead of two per staging round.
@@ -1727,12 +1739,12 @@ int upload_stiffness(R2SPhys* h, const float* log_Y, hipStream_t s)
                 const int t = h->h_slice_off[sl] + n * SLICE + ln;
                 const int o = h->h_slice_off[sl] + (n / GROUP) * (SLICE * GROUP) + ln * GROUP + n % GROUP;
                 const int sp = h->h_adj_spring[t], self = h->h_adj_self[t];
-                if (sp >= 0 && act[sp]) { ell_idx[o] = (unsigned short)(h->h_adj_loc[t] * 8); ell_k[o] = k[sp]; ell_ir[o] = 1.0f / h->h_rest[sp]; }
+                if (sp >= 0 && act[sp]) { ell_idx[o] = (unsigned short)(h->h_adj_loc[t] * 8); ell_k[o] = k[sp]; ell_ir[o] = k[sp] / h->h_rest[sp]; }
                 else ell_idx[o] = (unsigned short)((self % h->pb) * 8);
             }
     for (int t = 0; t < h->rell_len; ++t) {
         const int sp = h->h_radj_spring[t], self = h->h_radj_self[t];
-        rell[t] = (sp >= 0 && act[sp]) ? make_int4(h->h_radj_nbr[t], fbits(k[sp]), fbits(1.0f / h->h_rest[sp]), 0) : make_int4(self, 0, 0, 0);
+        rell[t] = (sp >= 0 && act[sp]) ? make_int4(h->h_radj_nbr[t], fbits(k[sp]), fbits(k[sp] / h->h_rest[sp]), 0) : make_int4(self, 0, 0, 0);
     }
     int rc = upload(h->d_adj_idx, ell_idx.data(), ell_idx.size(), s);
     if (rc) return rc;
