@@ -39,6 +39,13 @@ void r2s_skin_destroy(R2SSkin* h);
 int r2s_skin_interpolate_motions(R2SSkin* h, int32_t n_env, const float* bones, const float* motions, const float* xyz,
                                  float* xyz_out, r2s_stream_t stream);
 
+/* The same with explicit environment strides (in floats) for xyz and xyz_out: the points of environment e start at
+ * xyz + e * xyz_env_stride.  Lets the skinned Gaussians live inside the rasteriser's per-environment set (object splats
+ * followed by the table / robot scan) and be updated in place, instead of being copied there (gs_renderer.py:886-903 builds
+ * the scene with torch.cat every step). */
+int r2s_skin_interpolate_motions_strided(R2SSkin* h, int32_t n_env, const float* bones, const float* motions, const float* xyz,
+                                         int64_t xyz_env_stride, float* xyz_out, int64_t out_env_stride, r2s_stream_t stream);
+
 /* Device pointer to the per-bone rotations of the last call, [n_env, n_bones, 9] row-major (parity taps), and the
  * per-environment "rank-deficient fit -> identity" flags [n_env]. */
 int r2s_skin_debug(R2SSkin* h, const float** rotations, const int32_t** identity_flags);

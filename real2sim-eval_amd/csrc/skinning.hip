@@ -126,14 +126,14 @@ __global__ void __launch_bounds__(256) k_bone_fit(int N, int k_rel, const int* _
 // call on the benchmark scene before, for 0.25 GB of algorithmic traffic).  weights / widx are stored [k][t] (coalesced).
 __global__ void __launch_bounds__(256) k_skin(int N, int P, int k_wgt, const int* __restrict__ order, const float* __restrict__ weights,
                                               const int* __restrict__ widx, const BoneRec* __restrict__ rec, const int* __restrict__ ident_flag,
-                                              const float* __restrict__ xyz, float* __restrict__ out)
+                                              const float* __restrict__ xyz, long long xyz_stride, float* __restrict__ out, long long out_stride)
 {
 #pragma clang fp contract(off)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
     if (t >= P) return;
     const int pt = order[t];
-    const size_t ep = ((size_t)e * P + pt) * 3;
+    const size_t ep = (size_t)e * xyz_stride + (size_t)pt * 3, eo = (size_t)e * out_stride + (size_t)pt * 3; // env strides in floats
     const float x = xyz[ep], y = xyz[ep + 1], z = xyz[ep + 2];
     const bool ident = ident_flag[e] != 0;
     float ax = 0.f, ay = 0.f, az = 0.f;
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) k_skin(int N, int P, int k_wgt, const int
         tx = tx + q3.x + q2.y; ty = ty + q3.y + q2.z; tz = tz + q3.z + q2.w;
         ax += tx * w; ay += ty * w; az += tz * w;
     }
-    out[ep] = ax; out[ep + 1] = ay; out[ep + 2] = az;
+    out[eo] = ax; out[eo + 1] = ay; out[eo + 2] = az;
 }
 
 } // namespace
@@ -217,8 +217,15 @@ void r2s_skin_destroy(R2SSkin* h)
 int r2s_skin_interpolate_motions(R2SSkin* h, int32_t n_env, const float* bones, const float* motions, const float* xyz, float* xyz_out,
                                  r2s_stream_t stream_)
 {
+    return r2s_skin_interpolate_motions_strided(h, n_env, bones, motions, xyz, h ? 3 * (int64_t)h->P : 0, xyz_out, h ? 3 * (int64_t)h->P : 0, stream_);
+}
+
+int r2s_skin_interpolate_motions_strided(R2SSkin* h, int32_t n_env, const float* bones, const float* motions, const float* xyz, int64_t xyz_env_stride,
+                                         float* xyz_out, int64_t out_env_stride, r2s_stream_t stream_)
+{
     hipStream_t s = (hipStream_t)stream_;
     if (!h || n_env <= 0 || !bones || !motions || (h->P > 0 && (!xyz || !xyz_out))) return R2S_ERR_INVALID;
+    if (h->P > 0 && (xyz_env_stride < 3 * (int64_t)h->P || out_env_stride < 3 * (int64_t)h->P) && n_env > 1) return R2S_ERR_INVALID;
     if (n_env > h->cap_env) {
         if (h->d_rec) (void)hipFree(h->d_rec);
         if (h->d_flag) (void)hipFree(h->d_flag);
@@ -232,7 +239,7 @@ int r2s_skin_interpolate_motions(R2SSkin* h, int32_t n_env, const float* bones, 
     hipLaunchKernelGGL(k_bone_fit, dim3((h->N + 255) / 256, n_env), dim3(256), 0, s, h->N, h->k_rel, h->d_rel, bones, motions, h->d_rec, h->d_flag);
     if (h->P > 0)
         hipLaunchKernelGGL(k_skin, dim3((h->P + 255) / 256, n_env), dim3(256), 0, s, h->N, h->P, h->k_wgt, h->d_order, h->d_w, h->d_widx, h->d_rec, h->d_flag, xyz,
-                           xyz_out);
+                           (long long)xyz_env_stride, xyz_out, (long long)out_env_stride);
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }

@@ -108,11 +108,19 @@ class BatchedRollout:
         self._springs_dev = torch.from_numpy(np.ascontiguousarray(ob["springs"], np.int32)).to(self.device)
         self._target_dev = torch.from_numpy(np.ascontiguousarray(pts + np.array([0.10, 0.0, 0.0], np.float32))).to(self.device)  # push-T goal: 10 cm along +x
         self._box = (np.array([c[0] + 0.25, c[1] + 0.2, 0.135]), 0.5 * np.array([0.2, 0.13, 0.27]))
-        # Gaussians: object splats ride on particles, table splats are static
-        sc = synth.gaussian_scene(n_gauss, seed, object_points=pts)
+        # Gaussians: object splats ride on particles, table splats are static; configs[4] adds 60k splats on the robot's links
+        self.with_robot = "multicam" in config
+        n_scene = n_gauss - 60000 if self.with_robot else n_gauss
+        sc = synth.gaussian_scene(n_scene, seed, object_points=pts)
+        n_tab = int(n_scene * 0.35)
+        self.n_obj = n_scene - n_tab
+        if self.with_robot:
+            self.arm_offsets = synth.arm_offsets(seed)
+            self.arm_base = synth.arm_fk(np.deg2rad(synth.ARM_INIT_QPOS_DEG), finger=0.05)
+            rs, rlink = synth.robot_scan(n_gauss - n_scene, seed, self.arm_offsets, self.arm_base)
+            self.scan_mask = np.concatenate([np.full(n_tab, -1, np.int32), rlink])   # total_mask of the table + robot scan
+            sc = {k: np.concatenate([sc[k], rs[k]]) for k in sc}
         self.P = len(sc["means3D"])
-        n_tab = int(n_gauss * 0.35)
-        self.n_obj = self.P - n_tab
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)  # noqa: E731
         # LBS topology, once per scene (gs_renderer.py:195-211): 8-NN among bones (= particles), 16 nearest bones per Gaussian
         obj0 = sc["means3D"][: self.n_obj]
@@ -121,10 +129,17 @@ class BatchedRollout:
         self.means = torch.empty(E, self.P, 3, dtype=torch.float32, device=self.device)
         self.means[:, : self.n_obj] = t(obj0)[None] + t(self.env_shift)[:, None]
         self.means[:, self.n_obj:] = t(sc["means3D"][self.n_obj:])[None]
-        self.obj_xyz = self.means[:, : self.n_obj].contiguous()   # skinned object Gaussians of the last rendered state
-        self.obj_tmp = torch.empty_like(self.obj_xyz)
+        self.t = 0
         self.bones = self.phys.x.clone()                          # particle positions the Gaussians currently correspond to
         self.g = {k: t(v) for k, v in sc.items() if k != "means3D"}
+        self.rot_env = None
+        if self.with_robot:
+            # per-environment rotations (the robot's splats turn with their links); object / table rows are the shared values
+            from .robot import RobotGaussians
+            self.rot_env = torch.nn.functional.normalize(self.g["rotations"], dim=-1)[None].repeat(E, 1, 1).contiguous()
+            self.robot = RobotGaussians(synth.ARM_LINKS, synth.ARM_LISTED, self.arm_offsets, self.arm_base, sc["means3D"][self.n_obj:],
+                                        sc["rotations"][self.n_obj:], self.scan_mask, device=self.device)
+            self._robot_first = True
         self.raster = RasterBatch(self.device)
         self.raster.set_tile_culling(tile_culling)  # exact-output instance culling (include/r2s_raster.h)
         self.cams = [synth.side_camera(W, H), synth.wrist_camera(W, H, eef_pos=(c[0], c[1], top + 0.30)),
@@ -134,7 +149,7 @@ class BatchedRollout:
         self.out_depth = torch.empty(E, views, 1, H, W, dtype=torch.float32, device=self.device)
         self._update_means()
         self._sets = [RasterBatch.make_set(self.means[e], self.g["opacities"], shs=self.g["shs"], scales=self.g["scales"],
-                                           rotations=self.g["rotations"]) for e in range(E)]
+                                           rotations=self.rot_env[e] if self.with_robot else self.g["rotations"]) for e in range(E)]
         self._frames = []
         for e in range(E):
             for vi, cam in enumerate(self.cam_t):
@@ -191,14 +206,29 @@ class BatchedRollout:
         self.phys.set_eef_motion(self.eef_xyz, vel, self.eef_rot, self.eef_rot_vel, None if self.use_pusher else openness)
         self.eef_xyz = self.eef_xyz + vel * (self.num_substeps * self.dt)
 
+    def _arm_qpos(self, step):
+        """Synthetic joint trajectory per environment (stand-in for the policy's qpos): slow sinusoids about the init pose."""
+        base = np.deg2rad(synth.ARM_INIT_QPOS_DEG)
+        ph = np.arange(self.n_env)[:, None] * 0.7 + np.arange(7)[None] * 1.3
+        q = base[None] + 0.25 * np.sin(0.08 * step + ph)
+        finger = 0.05 * (0.5 + 0.5 * np.cos(0.05 * step + np.arange(self.n_env)))
+        return q, finger
+
     def _update_means(self):
-        """Incremental skinning as update_rendervar does it: bones = particles at the last render, motions = what they
-        moved since, applied to the last skinned Gaussian positions (gs_renderer.py:738-747, :762-769, :1096)."""
+        """Scene assembly for the rasteriser, in place in its per-environment Gaussian sets (no torch.cat, no copies):
+        * object splats: incremental skinning as update_rendervar does it — bones = particles at the last render, motions = what
+          they moved since, applied to the last skinned Gaussian positions (gs_renderer.py:738-747, :762-769, :1096);
+        * robot splats (configs[4]): rigidly with their links (robot_pc_transformations.py:12-55), FK poses as input."""
         x = self.phys.x
-        self.skin.interpolate_motions(self.bones, x - self.bones, self.obj_xyz, out=self.obj_tmp)
-        self.obj_xyz, self.obj_tmp = self.obj_tmp, self.obj_xyz
+        obj = self.means[:, : self.n_obj]
+        self.skin.interpolate_motions(self.bones, x - self.bones, obj, out=obj)
         self.bones.copy_(x)
-        self.means[:, : self.n_obj] = self.obj_xyz
+        if self.with_robot:
+            q, finger = self._arm_qpos(self.t)
+            pose = np.stack([synth.arm_fk(q[e], finger[e]) for e in range(self.n_env)])
+            self.link_pose = torch.from_numpy(pose).to(self.device)
+            self.robot.transform(self.link_pose, self.means[:, self.n_obj:], self.rot_env[:, self.n_obj:], normalize=True, write_static=self._robot_first)
+            self._robot_first = False
 
     # ---- one batched env step -----------------------------------------------------------------------------------
     def physics_step(self):
@@ -258,7 +288,9 @@ class BatchedRollout:
 
     # ---- the Gaussian cloud of one environment as the rasteriser currently sees it (parity tests) ----------------------
     def g_env(self, e):
-        return self.g
+        if not self.with_robot:
+            return self.g
+        return dict(self.g, rotations=self.rot_env[e])
 
     def scene_numpy(self, e):
         sc = {k: v.cpu().numpy() for k, v in self.g_env(e).items()}

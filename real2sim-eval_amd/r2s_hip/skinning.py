@@ -27,6 +27,8 @@ def _bind():
         L.r2s_skin_destroy.argtypes = [vp]
         L.r2s_skin_interpolate_motions.restype = C.c_int
         L.r2s_skin_interpolate_motions.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+        L.r2s_skin_interpolate_motions_strided.restype = C.c_int
+        L.r2s_skin_interpolate_motions_strided.argtypes = [vp, i32, vp, vp, vp, C.c_int64, vp, C.c_int64, vp]
         L.r2s_skin_debug.restype = C.c_int
         L.r2s_skin_debug.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
         _bound = True
@@ -67,18 +69,24 @@ class Skinning:
             pass
 
     def interpolate_motions(self, bones, motions, xyz, out=None):
-        """bones, motions: [n_env, n_bones, 3] (or [n_bones, 3]); xyz: [n_env, n_points, 3] -> transformed xyz (same shape)."""
+        """bones, motions: [n_env, n_bones, 3] (or [n_bones, 3]); xyz: [n_env, n_points, 3] -> transformed xyz (same shape).
+        ``xyz`` / ``out`` may be views with an environment stride (rows contiguous), e.g. the first ``n_points`` rows of the
+        rasteriser's per-environment Gaussian set — ``out`` may be ``xyz`` itself (in place)."""
         single = bones.dim() == 2
         b = bones.to(self.device, torch.float32).contiguous().reshape(-1, self.n_bones, 3)
         m = motions.to(self.device, torch.float32).contiguous().reshape(-1, self.n_bones, 3)
-        x = xyz.to(self.device, torch.float32).contiguous().reshape(-1, self.n_points, 3)
+        x = xyz.to(self.device, torch.float32)
+        x = x.reshape(-1, self.n_points, 3) if x.dim() == 2 else x
+        if not (x.stride(2) == 1 and x.stride(1) == 3):
+            x = x.contiguous()
         E = b.shape[0]
-        assert m.shape[0] == E and x.shape[0] == E
+        assert m.shape[0] == E and x.shape[0] == E and x.shape[1] == self.n_points
         if out is None:
-            out = torch.empty_like(x)
+            out = torch.empty(E, self.n_points, 3, dtype=torch.float32, device=self.device)
+        assert out.shape == x.shape and out.stride(2) == 1 and out.stride(1) == 3 and out.dtype == torch.float32
         with torch.cuda.device(self.device):
-            check(_bind().r2s_skin_interpolate_motions(self._h, E, b.data_ptr(), m.data_ptr(), x.data_ptr(), out.data_ptr(),
-                                                       cur_stream(self.device)), "r2s_skin_interpolate_motions")
+            check(_bind().r2s_skin_interpolate_motions_strided(self._h, E, b.data_ptr(), m.data_ptr(), x.data_ptr(), int(x.stride(0)), out.data_ptr(),
+                                                               int(out.stride(0)), cur_stream(self.device)), "r2s_skin_interpolate_motions_strided")
         return out[0] if single else out
 
     def debug(self, n_env=1):

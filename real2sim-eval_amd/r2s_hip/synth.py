@@ -304,3 +304,63 @@ def eef_world_points(eef_pts, init_eef_xyz, eef_xyz, eef_rot=None):
     rel[:, 2] *= -1
     R = np.eye(3) if eef_rot is None else np.asarray(eef_rot, np.float64)
     return (np.asarray(eef_xyz, np.float64) + rel @ R.T).astype(np.float32)
+
+
+# ---- synthetic articulated arm (stand-in for SAPIEN's FK of assets/robots/xarm/xarm7_with_gripper.urdf) ---------------------
+ARM_LINKS = 18                                                    # len(sapien_robot.get_links()), robot_pc_transformations.py:32
+ARM_LISTED = (1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16)  # link_id_list: base, link1-7, six finger links (:33)
+ARM_INIT_QPOS_DEG = (0, -45, 0, 30, 0, 75, 0)                     # init_qpos of transform_gs_xarm_gripper
+
+
+def _rot(axis, a):
+    c, s_ = np.cos(a), np.sin(a)
+    R = np.eye(4)
+    i, j = {"x": (1, 2), "y": (2, 0), "z": (0, 1)}[axis]
+    R[i, i], R[i, j], R[j, i], R[j, j] = c, -s_, s_, c
+    return R
+
+
+def _trans(x, y, z):
+    T = np.eye(4)
+    T[:3, 3] = (x, y, z)
+    return T
+
+
+def arm_fk(qpos7, finger=0.05, base_xyz=(-0.25, 0.05, 0.0)):
+    """Poses [18,4,4] float32 of a 7-joint serial arm with a two-finger hand: link 0 world, 1 base, 2-8 the arm links (revolute
+    joints about z, y, z, y, z, y, z, 0.11 m apart), 9 eef, 10-15 three links per finger (prismatic along -y / +y by `finger`),
+    16 a palm link, 17 tcp.  Only the SHAPE of the data matters here: the device kernel takes these matrices as input."""
+    T = _trans(*base_xyz)
+    out = [np.eye(4), T.copy()]
+    axes = "zyzyzyz"
+    for k in range(7):
+        T = T @ _trans(0, 0, 0.11) @ _rot(axes[k], float(qpos7[k]))
+        out.append(T.copy())
+    eef = T @ _trans(0, 0, 0.08)
+    out.append(eef.copy())
+    for side in (-1.0, 1.0):
+        for k in range(3):
+            out.append(eef @ _trans(0, side * (0.015 + finger * 0.5), 0.03 * (k + 1)))
+    out.append(eef @ _trans(0, 0, 0.02))
+    out.append(eef @ _trans(0, 0, 0.12))
+    return np.stack(out).astype(np.float32)
+
+
+def arm_offsets(seed=0):
+    """RobotPcSampler.offsets: the URDF collision origin of every link (float64 4x4) — small rigid offsets here."""
+    rng = np.random.default_rng(seed + 31337)
+    return np.stack([_trans(*rng.uniform(-0.01, 0.01, 3)) @ _rot("xyz"[k % 3], rng.uniform(-0.2, 0.2)) for k in range(ARM_LINKS)])
+
+
+def robot_scan(n_robot, seed, offsets, base_pose):
+    """Gaussians scanned on the robot at its base configuration (world frame), with the link id of each (total_mask)."""
+    rng = np.random.default_rng(seed + 2718)
+    link = np.asarray(ARM_LISTED)[rng.integers(0, len(ARM_LISTED), n_robot)]
+    local = rng.uniform(-1, 1, (n_robot, 3)) * np.array([0.03, 0.03, 0.055])
+    M = np.asarray(base_pose, np.float64) @ np.asarray(offsets, np.float64)
+    means = np.einsum("nij,nj->ni", M[link][:, :3, :3], local) + M[link][:, :3, 3]
+    scales = np.exp(rng.normal(np.log(0.004), 0.5, (n_robot, 3))).astype(np.float32)
+    q = rng.normal(size=(n_robot, 4)) * rng.uniform(0.5, 2.0, (n_robot, 1))          # stored unnormalised, like a trained scan
+    opac = (1.0 / (1.0 + np.exp(-rng.normal(2.0, 2.0, (n_robot, 1))))).astype(np.float32)
+    shs = rng.normal(0, 1, (n_robot, 1, 3)).astype(np.float32)
+    return dict(means3D=means.astype(np.float32), scales=scales, rotations=q.astype(np.float32), opacities=opac, shs=shs), link.astype(np.int32)
