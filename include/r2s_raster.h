@@ -123,6 +123,18 @@ int64_t r2s_raster_forward_batch(
     int64_t* num_rendered_per_frame,
     r2s_stream_t stream);
 
+/* Sync-free mode (off by default).  The reference reads the instance count back between the scan and the key emission
+ * (a blocking cudaMemcpy, rasterizer_impl.cu:284) to size its binning buffer; r2s_raster_forward_batch normally does the
+ * same once per batch.  With this mode on, only the FIRST batch does: later batches size the binning scratch from the last
+ * known count + 25 %, pad the sort with sentinel keys, take the count on the device where a kernel needs it, and return
+ * without touching the host — the return value is then the most recent count the host has seen (an earlier batch's).
+ * r2s_raster_ctx_poll(ctx, wait, &num_rendered, &overflows) looks at the last batch without blocking (wait = 0: returns 1
+ * while it is still running) or blocking (wait = 1): its count, the number of batches so far whose capacity was too small
+ * (such a batch lost its deepest instances; the next call re-sizes by synchronising once), and a deferred
+ * R2S_ERR_PREFILTERED.  Not used by r2s_raster_forward (the drop-in returns the exact count like the reference). */
+void r2s_raster_ctx_set_async(R2SRasterCtx* ctx, int enable);
+int r2s_raster_ctx_poll(R2SRasterCtx* ctx, int wait, int64_t* num_rendered, int32_t* overflows);
+
 /* Timing hooks for bench.py: HIP-event time (ms) of each stage of the LAST
  * r2s_raster_forward_batch call on this context, measured on the launch stream.
  * stage: 0 preprocess, 1 scan, 2 emit, 3 sort, 4 ranges, 5 composite.  Enabled by

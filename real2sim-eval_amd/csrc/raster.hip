@@ -297,10 +297,11 @@ __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ 
                                                    const uint64_t* __restrict__ gkeys, const uint32_t* __restrict__ order,
                                                    const int* __restrict__ radii_all, const GeomRec* __restrict__ geom,
                                                    const uint32_t* __restrict__ offsets, uint32_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals, int cull)
+                                                   uint32_t* __restrict__ vals, int cull, uint32_t cap, int* __restrict__ overflow)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G) return;
+    if (i == G - 1 && offsets[i] > cap) *overflow = 1; // sync-free mode: the scratch was sized from an earlier batch and is too small
     const uint32_t g = order[i];
     const int r = radii_all[g];
     if (r <= 0) return;
@@ -314,16 +315,19 @@ __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ 
     for (uint32_t y = y0; y < y1; ++y)
         for (uint32_t x = x0; x < x1; ++x) {
             if (cull && !tile_can_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, lt, (int)x, (int)y, W, H)) continue;
-            keys[off] = tile_base + y * (uint32_t)gx + x;
-            vals[off] = g;
+            if (off < cap) { keys[off] = tile_base + y * (uint32_t)gx + x; vals[off] = g; }
             ++off;
         }
 }
 
 // identifyTileRanges, rasterizer_impl.cu:116-138.
-__global__ void __launch_bounds__(256) k_tile_ranges(uint32_t L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges)
+// L comes from device memory (the last scan element, clamped to the scratch capacity): the sync-free mode launches it over
+// the capacity without knowing the count on the host.
+__global__ void __launch_bounds__(256) k_tile_ranges(const uint32_t* __restrict__ last_offset, uint32_t cap, const uint32_t* __restrict__ keys,
+                                                     uint2* __restrict__ ranges)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t L = min(*last_offset, cap);
     if (i >= L) return;
     const uint32_t cur = keys[i];
     if (i == 0) ranges[cur].x = 0;
@@ -340,6 +344,13 @@ __global__ void __launch_bounds__(256) k_tile_ranges(uint32_t L, const uint32_t*
 // Workgroup order of the compositor: tiles sorted by the length of their instance list, longest first.  On the benchmark
 // scene 5 % of the tiles (the object region) hold 85 % of the instances; started in tile order, the deep tiles of the last
 // frames run alone at the end of the kernel (1.26 ms); started first, the short ones fill the gaps (0.97 ms).
+// sync-free mode: the tail of the key array (instances the batch did not produce) sorts behind every real tile
+__global__ void __launch_bounds__(256) k_fill_sentinel(const uint32_t* __restrict__ last_offset, uint32_t cap, uint32_t sentinel, uint32_t* __restrict__ keys)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap && i >= *last_offset) keys[i] = sentinel;
+}
+
 __global__ void __launch_bounds__(256) k_tile_len_keys(uint32_t n, const uint2* __restrict__ ranges, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -354,9 +365,6 @@ __global__ void __launch_bounds__(256) k_tile_len_keys(uint32_t n, const uint2* 
 // The per-pixel arithmetic and its order (power -> alpha -> test_T -> colour -> median depth) follow
 // forward.cu:339-380 exactly; rgb and depth travel through LDS with the rest of the record instead of
 // being re-read from global memory inside the pixel loop (forward.cu:362).
-#ifndef R2S_COMP
-#define R2S_COMP 2
-#endif
 #ifdef R2S_COMP_STATS // instrumented build (scratch/comp_stats.py): lane efficiency of the compositor
 __device__ unsigned long long g_comp_stats[4]; // wave iterations, hit lanes, iterations without a hit, lanes still alive
 extern "C" int r2s_raster_debug_comp_stats(unsigned long long* out, int reset)
@@ -432,37 +440,6 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
         }
         __syncthreads();
         const uint32_t base = (uint32_t)(i * TILE_THREADS);
-#if R2S_COMP == 1
-        for (int sw = 0; sw < 4; ++sw) {
-            unsigned long long bits = s_live[wave][sw]; // wave-uniform
-            if (__builtin_amdgcn_ballot_w64(!done) == 0) break; // whole quadrant finished (forward.cu:315 per block)
-            while (bits) {
-                const int j = sw * 64 + __builtin_ctzll(bits);
-                bits &= bits - 1;
-                if (done) continue;
-                const float4 a = s_q0[j];
-                const float2 b = s_q1[j];
-                const float dx = a.x - pfx, dy = a.y - pfy;
-                const float power = fmaf(dx, fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy); // = log2(e) * forward.cu:342's power
-                if (power > 0.0f) continue;
-                const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
-                if (alpha < 1.0f / 255.0f) continue;
-                const float test_T = T * (1.f - alpha);
-                if (test_T < 0.0001f) {
-                    done = true;
-                    continue;
-                }
-                const float4 c = s_q2[j];
-                const float w = alpha * T;
-                C0 += c.x * w;
-                C1 += c.y * w;
-                C2 += c.z * w;
-                if (T > 0.5f && test_T < 0.5f) D = c.w;
-                T = test_T;
-                last_contributor = base + (uint32_t)j + 1u; // position in the tile's list, as forward.cu:335,380
-            }
-        }
-#else
         for (int sw = 0; sw < 4; ++sw) {
             if (__builtin_amdgcn_ballot_w64(!done) == 0) break; // whole quadrant finished (forward.cu:315 per block)
             // the live word is wave-uniform: keep it in SGPRs so the walk is s_ff1 / s_andn2 and a scalar branch
@@ -501,7 +478,6 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                 last_contributor = blend ? base + (uint32_t)j + 1u : last_contributor; // as forward.cu:335,380
             }
         }
-#endif
     }
     if (inside) {
         const size_t pix = (size_t)W * py + px;
@@ -561,9 +537,19 @@ struct R2SRasterCtx {
     FrameDev* d_frames = nullptr;
     FrameDev* h_frames = nullptr; // pinned
     int frames_cap = 0;
-    uint64_t* h_read = nullptr; // pinned: [0] last offset, [1] error flag
+    uint64_t* h_read = nullptr; // pinned: [0] last offset, [1] error flag, [2] overflow flag (sync-free mode)
+    // sync-free mode (r2s_raster_ctx_set_async): the instance count is NOT read back between scan and emit; the binning
+    // scratch is sized from the last known count x 1.25 and the count / error / overflow words of a call are read later
+    bool async_mode = false;
+    uint32_t L_cap = 0;          // capacity the binning scratch was sized for; 0 = not known yet (next call synchronises once)
+    int64_t last_L = 0;          // most recent count the host has seen
+    hipEvent_t done_ev = nullptr;
+    bool pending = false;
+    int overflows = 0;           // sync-free batches whose capacity was too small (their images miss instances)
+    int late_error = 0;          // error of a sync-free call, reported by the next poll        // a sync-free call whose words have not been looked at yet
     bool timing = false;
     int cull = 0; // exact-output tile culling of instances (batched API option)
+    bool tile_order = true; // longest-first workgroup order of the compositor (R2S_NO_TILE_ORDER at context creation: A/B knob)
     hipEvent_t ev[7] = {};
     bool ev_ok = false;
     float stage_ms[6] = {};
@@ -694,6 +680,21 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     R2S_HIP_TRY(hipMemcpyAsync(c->d_frames, c->h_frames, sizeof(FrameDev) * F, hipMemcpyHostToDevice, stream));
     R2S_HIP_TRY(hipMemsetAsync(err_flag, 0, sizeof(int) * 4, stream));
 
+    // Sync-free pass: possible once a capacity is known (the first call of the mode reads the count back like the reference).
+    // A previous sync-free call is looked at first: its count updates the capacity, an overflow makes THIS call synchronise
+    // and re-size (the overflowing batch itself lost its deepest instances: reported through r2s_raster_ctx_poll).
+    bool sync_free = c->async_mode && c->L_cap > 0 && G > 0 && !c->timing && !per_frame_out;
+    if (c->pending) {
+        R2S_HIP_TRY(hipEventSynchronize(c->done_ev)); // long finished: it was recorded a whole env step ago
+        c->pending = false;
+        c->last_L = (int64_t)(c->h_read[0] & 0xFFFFFFFFull);
+        if ((int)(c->h_read[1] & 0xFFFFFFFFull) != 0) c->late_error = R2S_ERR_PREFILTERED;
+        if ((int)(c->h_read[2] & 0xFFFFFFFFull) != 0) { c->overflows++; c->L_cap = 0; sync_free = false; }
+        else if (c->L_cap > 0) {
+            const uint64_t want = (uint64_t)c->last_L + c->last_L / 4 + 4096;
+            if (want > c->L_cap || want < c->L_cap / 2) c->L_cap = (uint32_t)std::min<uint64_t>(want, 0xFFFFFFF0ull); // follow the scene
+        }
+    }
     mark(0);
     uint32_t L = 0;
     const uint64_t* gkeys_sorted = nullptr;
@@ -713,42 +714,51 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         // offsets[i] = instances of the first i+1 Gaussians in (frame, depth) order; frames stay contiguous
         R2S_HIP_TRY(rocprim::inclusive_scan(scan_tmp, scan_bytes, tiles_sorted, offsets, G, rocprim::plus<uint32_t>(), stream));
         mark(2);
-        // The reference's blocking read of the instance count (rasterizer_impl.cu:284), once per batch.
         R2S_HIP_TRY(hipMemcpyAsync(&c->h_read[0], offsets + (G - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         R2S_HIP_TRY(hipMemcpyAsync(&c->h_read[1], err_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
-        R2S_HIP_TRY(hipStreamSynchronize(stream));
-        L = (uint32_t)(c->h_read[0] & 0xFFFFFFFFull);
-        if ((int)(c->h_read[1] & 0xFFFFFFFFull) != 0) return R2S_ERR_PREFILTERED;
+        if (!sync_free) {
+            // The reference's blocking read of the instance count (rasterizer_impl.cu:284), once per batch.
+            R2S_HIP_TRY(hipStreamSynchronize(stream));
+            L = (uint32_t)(c->h_read[0] & 0xFFFFFFFFull);
+            if ((int)(c->h_read[1] & 0xFFFFFFFFull) != 0) return R2S_ERR_PREFILTERED;
+            c->last_L = L;
+            if (c->async_mode) c->L_cap = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 4 + 4096, 0xFFFFFFF0ull); // first call of the mode
+        }
     } else {
         mark(1); mark(2);
     }
 
     // ---- binning scratch (BinningState, rasterizer_impl.h:56-67) ----
-    const uint32_t bits = higher_msb((uint32_t)F * (uint32_t)tiles);
+    // sized for the instance count, or — sync-free — for the capacity derived from an earlier batch (scenes move slowly:
+    // the count changes by a fraction of a per cent per env step; 25 % headroom, and an overflow flag if it ever is not enough)
+    const uint32_t cap = sync_free ? c->L_cap : L;
+    const uint32_t bits = higher_msb((uint32_t)F * (uint32_t)tiles + (sync_free ? 1u : 0u)); // + 1: the sentinel key F * tiles
     uint32_t *keys_a = nullptr, *keys_b = nullptr;
     uint32_t *vals_a = nullptr, *vals_b = nullptr;
     const uint32_t* keys_sorted = nullptr;
     const uint32_t* vals_sorted = nullptr;
-    if (L > 0) {
+    if (cap > 0 && G > 0) {
         rocprim::double_buffer<uint32_t> dk((uint32_t*)nullptr, (uint32_t*)nullptr);
         rocprim::double_buffer<uint32_t> dv((uint32_t*)nullptr, (uint32_t*)nullptr);
         size_t sort_bytes = 0;
-        R2S_HIP_TRY(rocprim::radix_sort_pairs<TileSortConfig>(nullptr, sort_bytes, dk, dv, (size_t)L, 0u, bits, stream));
+        R2S_HIP_TRY(rocprim::radix_sort_pairs<TileSortConfig>(nullptr, sort_bytes, dk, dv, (size_t)cap, 0u, bits, stream));
         r2s::Carver sz(nullptr);
-        sz.take<uint32_t>(L); sz.take<uint32_t>(L); sz.take<uint32_t>(L); sz.take<uint32_t>(L); sz.take<char>(sort_bytes);
+        sz.take<uint32_t>(cap); sz.take<uint32_t>(cap); sz.take<uint32_t>(cap); sz.take<uint32_t>(cap); sz.take<char>(sort_bytes);
         char* p = c->scratch(1, sz.bytes());
         if (!p) return R2S_ERR_ALLOC;
         r2s::Carver cv(p);
-        keys_a = cv.take<uint32_t>(L); keys_b = cv.take<uint32_t>(L);
-        vals_a = cv.take<uint32_t>(L); vals_b = cv.take<uint32_t>(L);
+        keys_a = cv.take<uint32_t>(cap); keys_b = cv.take<uint32_t>(cap);
+        vals_a = cv.take<uint32_t>(cap); vals_b = cv.take<uint32_t>(cap);
         char* sort_tmp = cv.take<char>(sort_bytes);
 
+        if (sync_free) // instances this batch does not produce: sentinel keys that sort behind every (frame, tile)
+            hipLaunchKernelGGL(k_fill_sentinel, dim3((cap + 255) / 256), dim3(256), 0, stream, offsets + (G - 1), cap, (uint32_t)F * (uint32_t)tiles, keys_a);
         hipLaunchKernelGGL(k_emit_keys, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
-                           order, radii_all, geom, offsets, keys_a, vals_a, c->cull);
+                           order, radii_all, geom, offsets, keys_a, vals_a, c->cull, cap, err_flag + 1);
         mark(3);
         rocprim::double_buffer<uint32_t> dkey(keys_a, keys_b);
         rocprim::double_buffer<uint32_t> dval(vals_a, vals_b);
-        R2S_HIP_TRY(rocprim::radix_sort_pairs<TileSortConfig>(sort_tmp, sort_bytes, dkey, dval, (size_t)L, 0u, bits, stream));
+        R2S_HIP_TRY(rocprim::radix_sort_pairs<TileSortConfig>(sort_tmp, sort_bytes, dkey, dval, (size_t)cap, 0u, bits, stream));
         keys_sorted = dkey.current();
         vals_sorted = dval.current();
         mark(4);
@@ -756,10 +766,14 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         mark(3); mark(4);
     }
     R2S_HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)F * tiles, stream));
-    if (L > 0)
-        hipLaunchKernelGGL(k_tile_ranges, dim3((L + 255) / 256), dim3(256), 0, stream, L, keys_sorted, ranges);
+    if (cap > 0 && G > 0)
+        hipLaunchKernelGGL(k_tile_ranges, dim3((cap + 255) / 256), dim3(256), 0, stream, offsets + (G - 1), cap, keys_sorted, ranges);
+    if (sync_free) { // count, culling error and overflow words of THIS call land in pinned memory behind the pipeline
+        R2S_HIP_TRY(hipMemcpyAsync(&c->h_read[2], err_flag + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
+        L = cap;
+    }
     const uint32_t* tile_order = nullptr;
-    if (L > 0 && FT >= 4096 && !getenv("R2S_NO_TILE_ORDER")) { // big batches: start the deepest tiles first (knob: A/B measurement)
+    if (L > 0 && FT >= 4096 && c->tile_order) { // big batches: start the deepest tiles first
         hipLaunchKernelGGL(k_tile_len_keys, dim3((unsigned)((FT + 255) / 256)), dim3(256), 0, stream, (uint32_t)FT, ranges, tl_keys[0], tl_vals[0]);
         rocprim::double_buffer<uint32_t> dk(tl_keys[0], tl_keys[1]), dv(tl_vals[0], tl_vals[1]);
         R2S_HIP_TRY(rocprim::radix_sort_pairs(tl_tmp, tl_bytes, dk, dv, FT, 0u, 14u, stream));
@@ -770,6 +784,11 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
                        vals_sorted, geom, c->aux_T, c->aux_n, tile_order);
     mark(6);
     R2S_HIP_TRY(hipGetLastError());
+    if (sync_free) {
+        if (!c->done_ev) R2S_HIP_TRY(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
+        R2S_HIP_TRY(hipEventRecord(c->done_ev, stream));
+        c->pending = true;
+    }
 
     // per-frame instance counts: offsets at frame boundaries are not read back (that would add syncs);
     // the caller gets the total, and per-frame counts only in timing/debug mode.
@@ -798,7 +817,7 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         }
     }
     c->dbg.total_gaussians = (int64_t)G;
-    c->dbg.num_rendered = (int64_t)L;
+    c->dbg.num_rendered = sync_free ? c->last_L : (int64_t)L;
     c->dbg.depths = depths;
     c->dbg.radii = radii_all;
     c->dbg.geom = reinterpret_cast<const float*>(geom);
@@ -807,7 +826,7 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     c->dbg.keys_sorted = keys_sorted;
     c->dbg.point_list = vals_sorted;
     c->dbg.ranges = reinterpret_cast<const uint32_t*>(ranges);
-    return (int64_t)L;
+    return sync_free ? c->last_L : (int64_t)L; // sync-free: the most recent count the host has seen (an earlier batch's)
 }
 
 } // namespace
@@ -819,6 +838,7 @@ int r2s_raster_ctx_create(R2SRasterCtx** out)
 {
     if (!out) return R2S_ERR_INVALID;
     *out = new (std::nothrow) R2SRasterCtx();
+    if (*out && getenv("R2S_NO_TILE_ORDER")) (*out)->tile_order = false; // A/B knob, read once per context
     return *out ? R2S_OK : R2S_ERR_ALLOC;
 }
 
@@ -829,6 +849,7 @@ void r2s_raster_ctx_destroy(R2SRasterCtx* c)
     if (c->d_frames) (void)hipFree(c->d_frames);
     if (c->h_frames) (void)hipHostFree(c->h_frames);
     if (c->h_read) (void)hipHostFree(c->h_read);
+    if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     if (c->ev_ok) for (auto& e : c->ev) (void)hipEventDestroy(e);
     delete c;
 }
@@ -839,6 +860,24 @@ size_t r2s_raster_ctx_scratch_bytes(const R2SRasterCtx* c)
 }
 
 void r2s_raster_ctx_set_timing(R2SRasterCtx* c, int enable) { if (c) c->timing = enable != 0; }
+void r2s_raster_ctx_set_async(R2SRasterCtx* c, int enable) { if (c) { c->async_mode = enable != 0; if (!enable) c->L_cap = 0; } }
+
+int r2s_raster_ctx_poll(R2SRasterCtx* c, int wait, int64_t* num_rendered, int32_t* overflows)
+{
+    if (!c) return R2S_ERR_INVALID;
+    if (c->pending && (wait || hipEventQuery(c->done_ev) == hipSuccess)) {
+        R2S_HIP_TRY(hipEventSynchronize(c->done_ev));
+        c->pending = false;
+        c->last_L = (int64_t)(c->h_read[0] & 0xFFFFFFFFull);
+        if ((int)(c->h_read[1] & 0xFFFFFFFFull) != 0) c->late_error = R2S_ERR_PREFILTERED;
+        if ((int)(c->h_read[2] & 0xFFFFFFFFull) != 0) { c->overflows++; c->L_cap = 0; }
+    }
+    if (num_rendered) *num_rendered = c->last_L;
+    if (overflows) *overflows = c->overflows;
+    const int rc = c->late_error;
+    c->late_error = 0;
+    return rc ? rc : (c->pending ? 1 : R2S_OK);
+}
 void r2s_raster_ctx_set_tile_culling(R2SRasterCtx* c, int enable) { if (c) c->cull = enable != 0; }
 float r2s_raster_ctx_stage_ms(const R2SRasterCtx* c, int stage) { return (c && stage >= 0 && stage < 6) ? c->stage_ms[stage] : -1.f; }
 void r2s_raster_ctx_set_aux(R2SRasterCtx* c, float* final_T, uint32_t* n_contrib) { if (c) { c->aux_T = final_T; c->aux_n = n_contrib; } }

@@ -74,6 +74,10 @@ def lib() -> C.CDLL:
     L.r2s_raster_forward_batch.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp]
     L.r2s_raster_ctx_set_timing.restype = None
     L.r2s_raster_ctx_set_timing.argtypes = [vp, i32]
+    L.r2s_raster_ctx_set_async.restype = None
+    L.r2s_raster_ctx_set_async.argtypes = [vp, i32]
+    L.r2s_raster_ctx_poll.restype = i32
+    L.r2s_raster_ctx_poll.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(C.c_int32)]
     L.r2s_raster_ctx_set_tile_culling.restype = None
     L.r2s_raster_ctx_set_tile_culling.argtypes = [vp, i32]
     L.r2s_raster_ctx_stage_ms.restype = f32

@@ -142,6 +142,7 @@ class BatchedRollout:
             self._robot_first = True
         self.raster = RasterBatch(self.device)
         self.raster.set_tile_culling(tile_culling)  # exact-output instance culling (include/r2s_raster.h)
+        self.raster.set_async(True)                 # no host read of the instance count inside the pipeline after the first batch
         self.cams = [synth.side_camera(W, H), synth.wrist_camera(W, H, eef_pos=(c[0], c[1], top + 0.30)),
                      synth.orbit_camera(W, H, 60.0, target=c), synth.orbit_camera(W, H, -110.0, target=c)][:views]
         self.cam_t = [{k: (t(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()} for cam in self.cams]
@@ -157,6 +158,9 @@ class BatchedRollout:
                                          bg=cam["bg"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], z_threshold=cam["z_threshold"],
                                          out_color=self.out_color[e, vi], out_depth=self.out_depth[e, vi]))
         self.t = 0
+        self._vel_trace = None
+        self._cand_fresh = False
+        self._prepared = None
         self._log = None
         self.last_num_rendered = 0
         if with_gripper:
@@ -200,9 +204,12 @@ class BatchedRollout:
 
     def _set_gripper(self, step):
         E = self.n_env
-        vel = torch.from_numpy(self._eef_velocity(step)).to(self.device)[None].expand(E, 3).contiguous()
-        cmd = 0.3 if self.close_at <= step < self.open_at else 1.0
-        openness = torch.full((E,), cmd, dtype=torch.float32, device=self.device)
+        if self._vel_trace is None or step >= len(self._vel_trace):   # the whole action trace lives on the device: no per-step upload
+            n = max(1024, 2 * (step + 1))
+            self._vel_trace = torch.from_numpy(np.stack([self._eef_velocity(k) for k in range(n)])).to(self.device)
+            self._open_cmd = torch.tensor([0.3 if self.close_at <= k < self.open_at else 1.0 for k in range(n)], dtype=torch.float32, device=self.device)
+        vel = self._vel_trace[step][None].expand(E, 3).contiguous()
+        openness = self._open_cmd[step].expand(E).contiguous()
         self.phys.set_eef_motion(self.eef_xyz, vel, self.eef_rot, self.eef_rot_vel, None if self.use_pusher else openness)
         self.eef_xyz = self.eef_xyz + vel * (self.num_substeps * self.dt)
 
@@ -226,13 +233,22 @@ class BatchedRollout:
         if self.with_robot:
             q, finger = self._arm_qpos(self.t)
             pose = np.stack([synth.arm_fk(q[e], finger[e]) for e in range(self.n_env)])
-            self.link_pose = torch.from_numpy(pose).to(self.device)
+            k = self._pose_k = (getattr(self, "_pose_k", -1) + 1) % 64      # pinned ring: the upload never blocks the host
+            if not hasattr(self, "_pose_pin"):
+                self._pose_pin = torch.empty(64, *pose.shape, dtype=torch.float32).pin_memory()
+                self._pose_dev = torch.empty(64, *pose.shape, dtype=torch.float32, device=self.device)
+            self._pose_pin[k].copy_(torch.from_numpy(pose))
+            self._pose_dev[k].copy_(self._pose_pin[k], non_blocking=True)
+            self.link_pose = self._pose_dev[k]
             self.robot.transform(self.link_pose, self.means[:, self.n_obj:], self.rot_env[:, self.n_obj:], normalize=True, write_static=self._robot_first)
             self._robot_first = False
 
     # ---- one batched env step -----------------------------------------------------------------------------------
     def physics_step(self):
-        if self.phys.self_collision:
+        # update_collision_graph works on the positions the previous step left (phystwin.py:365-366 calls it first thing in
+        # step()); it is enqueued right AFTER the previous physics graph instead, so that its candidate count — which picks the
+        # graph flavour on the host — has long landed when the next step starts, and the host never waits for the GPU
+        if self.phys.self_collision and not self._cand_fresh:
             self.phys.update_collision_graph()
         if self.with_gripper:
             self._set_gripper(self.t)
@@ -244,6 +260,9 @@ class BatchedRollout:
             lg["p1"][lg["i"]].record()
             self.phys.log_contacts(lg["counts"][lg["i"]])
             lg["flavour"].append(self.phys.last_flavour()["kernel"] + f" x{self.phys.last_flavour()['chains']} chains")
+        if self.phys.self_collision:
+            self.phys.update_collision_graph()
+            self._cand_fresh = True
 
     # ---- per-step log of a timed window: stamps on the launch stream + contact counters kept on the device ------------
     def start_log(self, n_steps):
@@ -273,7 +292,9 @@ class BatchedRollout:
 
     def render(self):
         self._update_means()
-        self.last_num_rendered = self.raster.forward(self._sets, self._frames, self.W, self.H)
+        if self._prepared is None:
+            self._prepared = self.raster.prepare(self._sets, self._frames)
+        self.last_num_rendered = self.raster.forward(self._prepared, None, self.W, self.H)
         return self.out_color, self.out_depth
 
     def step(self):

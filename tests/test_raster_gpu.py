@@ -168,3 +168,56 @@ def test_batched_frames_match_single_frame_calls_and_tile_culling_is_output_exac
         _, col_ref, _, dep_ref = oracle_render(sc, cam)
         r = compare_images(c1, d1, col_ref, dep_ref)
         assert r["frac_rgb"] <= MAX_BAD_FRAC and r["frac_depth"] <= MAX_BAD_FRAC, r
+
+
+def test_sync_free_batches_are_bit_identical_and_report_overflow():
+    """r2s_raster_ctx_set_async: after the first batch nothing is read back between scan and emit (the reference blocks on a
+    cudaMemcpy there, rasterizer_impl.cu:284).  Images must equal the synchronous mode bit for bit; a batch that outgrows the
+    capacity derived from its predecessor is reported, and the batch after it is correct again."""
+    import torch
+    from r2s_hip import synth
+    from r2s_hip.raster import RasterBatch
+
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    W, H = 320, 240
+    cams = [synth.side_camera(W, H), synth.wrist_camera(W, H)]
+
+    def batch(rb, scene, out_c, out_d):
+        s = rb.make_set(t(scene["means3D"]), t(scene["opacities"]), shs=t(scene["shs"]), scales=t(scene["scales"]), rotations=t(scene["rotations"]))
+        frames = [dict(set=0, viewmatrix=t(c["viewmatrix"]), projmatrix=t(c["projmatrix"]), campos=t(c["campos"]), bg=t(c["bg"]), tanfovx=c["tanfovx"],
+                       tanfovy=c["tanfovy"], z_threshold=c["z_threshold"], out_color=out_c[v], out_depth=out_d[v]) for v, c in enumerate(cams)]
+        return rb.prepare([s], frames)
+
+    small, big = synth.gaussian_scene(3000, 90), synth.gaussian_scene(30000, 91)
+    ref = {}
+    for name, sc in (("small", small), ("big", big)):
+        rb = RasterBatch(dev)
+        oc = torch.zeros(2, 3, H, W, device=dev); od = torch.zeros(2, 1, H, W, device=dev)
+        n = rb.forward(batch(rb, sc, oc, od), None, W, H)
+        torch.cuda.synchronize()
+        ref[name] = (n, oc.clone(), od.clone())
+    rb = RasterBatch(dev)
+    rb.set_async(True)
+    oc = torch.zeros(2, 3, H, W, device=dev); od = torch.zeros(2, 1, H, W, device=dev)
+    prep_small, prep_big = batch(rb, small, oc, od), batch(rb, big, oc, od)
+    for k in range(3):          # first call synchronises once, the next two are sync-free
+        oc.zero_(); od.zero_()
+        n = rb.forward(prep_small, None, W, H)
+        torch.cuda.synchronize()
+        assert n == ref["small"][0]
+        assert torch.equal(oc, ref["small"][1]) and torch.equal(od, ref["small"][2]), k
+    running, n_seen, overflows = rb.poll(wait=True)
+    assert not running and n_seen == ref["small"][0] and overflows == 0
+    # ten times more instances than the capacity was sized for: flagged, never written out of bounds
+    rb.forward(prep_big, None, W, H)
+    running, n_seen, overflows = rb.poll(wait=True)
+    assert overflows == 1 and n_seen == ref["big"][0]
+    oc.zero_(); od.zero_()
+    n = rb.forward(prep_big, None, W, H)   # re-sizes (one synchronisation) and renders correctly
+    torch.cuda.synchronize()
+    assert n == ref["big"][0] and torch.equal(oc, ref["big"][1]) and torch.equal(od, ref["big"][2])
+    oc.zero_(); od.zero_()
+    rb.forward(prep_big, None, W, H)       # sync-free again
+    torch.cuda.synchronize()
+    assert torch.equal(oc, ref["big"][1]) and torch.equal(od, ref["big"][2]) and rb.poll(wait=True)[2] == 1
