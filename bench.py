@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--stub", action="store_true", help="CPU stand-in workload over gloo (launcher test)")
+    ap.add_argument("--sink", default=None, help="directory: also run the observation sink (row f4) every step — packed 8-bit frames + state "
+                                                 "to pinned ring buffers, JPEG / pickle written by a host thread; not part of the headline")
     args = ap.parse_args()
 
     from r2s_hip import dist as rdist
@@ -175,6 +177,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    sink = None
+    if args.sink:
+        from r2s_hip.sink import ObservationSink
+        sink = ObservationSink(os.path.join(args.sink, f"rank{rank}"), ro.n_env, ro.views, ro.H, ro.W, device=dev, slots=6,
+                               state_bytes=2 * ro.n_env * ro.N * 12 + 4096)
     for _ in range(args.warmup):
         ro.step()
     barrier()
@@ -182,11 +189,20 @@ def main():
     # step boundaries + the physics graph alone.  Contact counters are logged on the device, read after the window.
     ro.start_log(args.steps)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
         ro.step()
+        if sink is not None:
+            sink.submit(k, ro.out_color, state=dict(x=ro.phys.x, v=ro.phys.v))
     barrier()
     elapsed = time.perf_counter() - t0
     log = ro.read_log()
+    sink_report = None
+    if sink is not None:
+        t1 = time.perf_counter()
+        sink.close()
+        sink_report = {"frames_written": sink.frames_written, "steps_written": sink.steps_written, "producer_stalls": sink.stalls,
+                       "drain_after_window_s": time.perf_counter() - t1, "format": sink.ext,
+                       "note": "submit() only enqueues a pack kernel + one async D2H per step; encoding and file writes run in worker processes"}
     # N > 1: slowest rank's time (MAX) and the metric all-gather of north_star — one fixed-size record per rank
     elapsed = rdist.max_over_ranks(elapsed, dev)
     n_success = int(ro.success_flags().sum().item())  # device-side task predicate (row f4); outside the timed region
@@ -304,6 +320,8 @@ def main():
                              "note": "frame-level success predicate of the scene's task evaluated on the device after the last step "
                                      "(synthetic action trace: not a policy result)"},
         }
+        if sink_report is not None:
+            out["observation_sink"] = sink_report
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(ro, args.cpu_budget)
