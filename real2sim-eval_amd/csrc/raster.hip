@@ -25,6 +25,9 @@
 namespace {
 
 constexpr int TILE = 16;         // BLOCK_X == BLOCK_Y, cuda_rasterizer/config.h:15-16
+#ifndef R2S_TILE_CLASS_BITS
+#define R2S_TILE_CLASS_BITS 14   // workgroup order of the compositor: sort key = list length, 14 bits (see k_tile_len_keys)
+#endif
 constexpr int TILE_THREADS = 256;
 
 struct FrameDev {
@@ -356,7 +359,13 @@ __global__ void __launch_bounds__(256) k_tile_len_keys(uint32_t n, const uint2* 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint2 r = ranges[i];
-    keys[i] = 16383u - min(r.y - r.x, 16383u); // 14 bits are plenty to order the long lists; ties do not matter
+    // Longest lists first.  Coarser length classes (64 classes of 128 instances, 256 of 32, 1024 of 8) — which keep neighbouring
+    // tiles next to each other inside a class for L2 reuse — were measured and are not faster (0.97 / 0.98 / 0.99 / 1.00 ms for
+    // 14 / 10 / 8 / 6 key bits on the benchmark scene): balance matters more than the 1.3x re-fetch, so the full length is the key.
+#ifndef R2S_TILE_CLASS_SHIFT
+#define R2S_TILE_CLASS_SHIFT 0
+#endif
+    keys[i] = ((1u << R2S_TILE_CLASS_BITS) - 1u) - min((r.y - r.x) >> R2S_TILE_CLASS_SHIFT, (1u << R2S_TILE_CLASS_BITS) - 1u);
     vals[i] = i;
 }
 
@@ -374,6 +383,7 @@ extern "C" int r2s_raster_debug_comp_stats(unsigned long long* out, int reset)
     return rc;
 }
 #endif
+template <bool AUX>
 __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __restrict__ frames, int gx, int gy, int W, int H,
                                                             const uint2* __restrict__ ranges,
                                                             const uint32_t* __restrict__ point_list,
@@ -398,9 +408,10 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
     const int n = (int)(range.y - range.x);
     const int rounds = (n + TILE_THREADS - 1) / TILE_THREADS;
 
-    __shared__ float4 s_q0[TILE_THREADS]; // px, py, A, B   (conic pre-scaled, see below)
-    __shared__ float2 s_q1[TILE_THREADS]; // C, opacity
-    __shared__ float4 s_q2[TILE_THREADS]; // r, g, b, depth
+    // one 48-byte record per staged instance: (px, py, A, B) | (C, opacity, -, -) | (depth, r, g, b) — conic pre-scaled, see
+    // below.  ONE address register serves the three broadcast reads (the instance index is scalar: every extra LDS address
+    // is a v_mov), and (g, b) land in an even register pair, so the compiler's packed FMA needs no operand shuffles.
+    __shared__ float4 s_rec[TILE_THREADS * 3];
     // s_live[q][w]: which of the 64 instances staged by wavefront w can reach alpha >= 1/255 somewhere in quadrant q
     // (the same conservative bound as the tile culling, on the 8x8 pixel rectangle).  A quadrant's wavefront walks
     // only its set bits, so an instance costs nothing in the quadrants it cannot touch.
@@ -422,9 +433,9 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
             // conic pre-scaled once per staged instance: power * log2(e) = A dx^2 + B dx dy + C dy^2 with
             // A = -0.5 a log2e, B = -b log2e, C = -0.5 c log2e, so the pixel loop is 7 plain VALU ops + one v_exp_f32
             constexpr float LOG2E = 1.4426950408889634f;
-            s_q0[tid] = make_float4(a.x, a.y, -0.5f * LOG2E * a.z, -LOG2E * a.w);
-            s_q1[tid] = make_float2(-0.5f * LOG2E * b.x, b.y);
-            s_q2[tid] = make_float4(b.w, c.x, c.y, b.z);
+            s_rec[3 * tid] = make_float4(a.x, a.y, -0.5f * LOG2E * a.z, -LOG2E * a.w);
+            s_rec[3 * tid + 1] = make_float4(-0.5f * LOG2E * b.x, b.y, 0.f, 0.f);
+            s_rec[3 * tid + 2] = make_float4(b.z, b.w, c.x, c.y);
             const float lt = logf(1.0f / (255.0f * b.y));
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
@@ -449,8 +460,10 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
             while (bits) {
                 const int j = sw * 64 + __builtin_ctzll(bits);
                 bits &= bits - 1;
-                const float4 a = s_q0[j];
-                const float2 b = s_q1[j];
+                const float4* rec = s_rec + 3 * j;
+                const float4 a = rec[0];
+                const float2 b = make_float2(rec[1].x, rec[1].y);
+                const float4 c = rec[2]; // depth, r, g, b — issued with the other two reads (one address register, no second v_mov)
                 const float dx = a.x - pfx, dy = a.y - pfy;
                 const float power = fmaf(dx, fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy); // = log2(e) * forward.cu:342's power
                 const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
@@ -463,19 +476,22 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                                      atomicAdd(&g_comp_stats[2], hb == 0 ? 1ull : 0ull); atomicAdd(&g_comp_stats[3], (unsigned long long)__builtin_popcountll(ab)); }
                 }
 #endif
-                if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
+                {   // "no lane hit" as a scalar test of the ballot (the i1 == 0 form compiles to v_cndmask + v_cmp)
+                    const unsigned long long hb = __builtin_amdgcn_ballot_w64(hit);
+                    if (((unsigned)hb | (unsigned)(hb >> 32)) == 0u) continue;
+                }
                 const float test_T = T * (1.f - alpha);
-                const bool term = hit && test_T < 0.0001f;
+                const bool keep = test_T >= 0.0001f;           // forward.cu:354: test_T < 0.0001f ends the pixel (one compare, not two)
+                const bool term = hit && !keep;
                 done = done || term;
-                const bool blend = hit && !term;
-                const float4 c = s_q2[j];
+                const bool blend = hit && keep;
                 const float w = blend ? alpha * T : 0.0f;
-                C0 += c.x * w;
-                C1 += c.y * w;
-                C2 += c.z * w;
-                D = (blend && T > 0.5f && test_T < 0.5f) ? c.w : D;
+                C0 += c.y * w;
+                C1 += c.z * w;
+                C2 += c.w * w;
+                D = (blend && T > 0.5f && test_T < 0.5f) ? c.x : D;
                 T = blend ? test_T : T;
-                last_contributor = blend ? base + (uint32_t)j + 1u : last_contributor; // as forward.cu:335,380
+                if (AUX) last_contributor = blend ? base + (uint32_t)j + 1u : last_contributor; // as forward.cu:335,380
             }
         }
     }
@@ -666,7 +682,7 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     const size_t FT = (size_t)F * tiles;
     {
         rocprim::double_buffer<uint32_t> dk((uint32_t*)nullptr, (uint32_t*)nullptr), dv((uint32_t*)nullptr, (uint32_t*)nullptr);
-        R2S_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tl_bytes, dk, dv, FT, 0u, 14u, stream));
+        R2S_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tl_bytes, dk, dv, FT, 0u, (unsigned)R2S_TILE_CLASS_BITS, stream));
         r2s::Carver sz(nullptr);
         sz.take<uint2>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>(FT); sz.take<char>(tl_bytes);
         char* p = c->scratch(2, sz.bytes());
@@ -776,12 +792,16 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     if (L > 0 && FT >= 4096 && c->tile_order) { // big batches: start the deepest tiles first
         hipLaunchKernelGGL(k_tile_len_keys, dim3((unsigned)((FT + 255) / 256)), dim3(256), 0, stream, (uint32_t)FT, ranges, tl_keys[0], tl_vals[0]);
         rocprim::double_buffer<uint32_t> dk(tl_keys[0], tl_keys[1]), dv(tl_vals[0], tl_vals[1]);
-        R2S_HIP_TRY(rocprim::radix_sort_pairs(tl_tmp, tl_bytes, dk, dv, FT, 0u, 14u, stream));
+        R2S_HIP_TRY(rocprim::radix_sort_pairs(tl_tmp, tl_bytes, dk, dv, FT, 0u, (unsigned)R2S_TILE_CLASS_BITS, stream));
         tile_order = dv.current();
     }
     mark(5);
-    hipLaunchKernelGGL(k_composite, dim3((uint32_t)F * tiles), dim3(TILE_THREADS), 0, stream, c->d_frames, gx, gy, W, H, ranges,
-                       vals_sorted, geom, c->aux_T, c->aux_n, tile_order);
+    if (c->aux_T || c->aux_n) // the backward-only auxiliaries (final_T, n_contrib) cost two VALU instructions per blend: only on request
+        hipLaunchKernelGGL(k_composite<true>, dim3((uint32_t)F * tiles), dim3(TILE_THREADS), 0, stream, c->d_frames, gx, gy, W, H, ranges,
+                           vals_sorted, geom, c->aux_T, c->aux_n, tile_order);
+    else
+        hipLaunchKernelGGL(k_composite<false>, dim3((uint32_t)F * tiles), dim3(TILE_THREADS), 0, stream, c->d_frames, gx, gy, W, H, ranges,
+                           vals_sorted, geom, c->aux_T, c->aux_n, tile_order);
     mark(6);
     R2S_HIP_TRY(hipGetLastError());
     if (sync_free) {
