@@ -933,6 +933,9 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __r
     R2S_STAMP(3);
 }
 
+// (A <256,896> layout — 21.5 KB of LDS, 7 workgroups per CU, the fused kernel held to 72 VGPRs, so that only 96 instead of 352
+// of the benchmark's 1888 work items are left for a second round — was measured in round 2: 23.3 vs 22.1 us per substep with
+// two chains, 24.4 vs 24.8 with one.  More residency does not pay; the layouts stay <256,1024> and <128,768>.)
 template <int B, int RCAP, bool SELF, int MESH>
 __global__ void __launch_bounds__(B) k_substep(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
                                                int write_forces)
