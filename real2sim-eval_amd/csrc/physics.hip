@@ -685,7 +685,10 @@ __device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 
 // is finished by k_contact_finish, one WAVEFRONT per particle, all of them in flight at once.  Without p.mesh_defer (the
 // flavour captured while nothing is near a mesh) the rare needy particle is queried in place.
 // MESH: 3 = small scene with the triangles in registers (k_contact_finish<3>; one particle per wavefront)
-template <int MESH, bool MAIN = false>
+// NEED: 0 = decide by the exact early-out; 1 = query without testing (the fused kernel already found the particle in reach of a
+// mesh: saves the finishing kernel one dependent round trip for the boxes); 2 = never query (the fused kernel's WIDENED test
+// found nothing in reach: mesh_collision then only advances the position, :321 / :420)
+template <int MESH, bool MAIN = false, int NEED = 0>
 __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v, bool fin,
                                             float4* __restrict__ xv_out, const TriRegs* tr = nullptr)
 {
@@ -696,7 +699,8 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         f3 next_x = x0 + vin * p.dt;
         f3 next_v = vin;
         bool need = false, near = false;
-        if (fin) need = mesh_need(p, e, step, next_x, 0.f, near);
+        if (NEED == 1) need = fin;
+        else if (NEED == 0 && fin) need = mesh_need(p, e, step, next_x, 0.f, near);
         if (MAIN) { // count the particles near a mesh (the host picks the next step's graph flavour from the total) and, in
                     // deferring mode, hand the ones that need a query to k_contact_finish
             if (near) atomicAdd(p.mesh_cnt + p.n_sub, 1);
@@ -910,7 +914,8 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __r
     // here and are finished by k_self_finish, which reads the partners' published values; everyone else is done.
     bool fin = valid;
     if (SELF) {
-        if (valid && p.coll_num[eb + i] > 0) {
+        const int ncand = valid ? p.coll_num[eb + i] : 0;
+        if (ncand > 0) {
             p.vbc[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
             fin = false; // finished by k_self_finish / k_contact_finish
             if (MESH != 0 && p.mesh_defer) {
@@ -921,7 +926,7 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __r
                 if (mesh_need(p, e, step, x0 + v * p.dt, 0.002f, near)) {
                     const int slot = atomicAdd(p.mesh_cnt + step, 1);
                     if (slot < p.mesh_cap) {
-                        p.mesh_list[slot] = make_int2(e, i | (int)0x80000000);
+                        p.mesh_list[slot] = make_int2(e | (ncand << 12), i | (int)0x80000000);
                         p.cand_mark[eb + i] = step + 1;
                     }
                 }
@@ -945,15 +950,15 @@ __global__ void __launch_bounds__(B) k_substep(const PhysDev p, const float4* __
 // object_collision for ONE particle by a whole wavefront / a group of lanes: the lanes stride over its candidates (up to 500,
 // each a dependent gather of the partner's position and published velocity), `G` = lanes per particle (a power of two).
 template <int G>
-__device__ __forceinline__ f3 self_impulse(const PhysDev& p, const float4* __restrict__ xv_in, size_t eb, int i, bool act, f3 x0, f3 v, int sub)
+__device__ __forceinline__ f3 self_impulse(const PhysDev& p, const float4* __restrict__ xv_in, size_t eb, int i, bool act, f3 x0, f3 v, int sub,
+                                           int cnt)
 {
     float valid = 0.f, m1 = 1.f;
     f3 Jsum = mk(0.f, 0.f, 0.f);
     if (act) {
         m1 = p.masses[i];
         const int mask1 = p.masks[i];
-        const int cnt = p.coll_num[eb + i];
-        for (int k = sub; k < cnt; k += G) {
+        for (int k = sub; k < cnt; k += G) { // cnt rides in the list entry: the candidate indices load in the same round trip as x0 / v
             const int j = p.coll_idx[(eb + i) * (size_t)p.coll_cap + k];
             const f3 x2 = xyz(xv_in[(eb + j) * 2]);
             const f3 v2 = xyz(p.vbc[eb + j]); // j lists i too (the candidate relation is symmetric; a capped row still has
@@ -1000,11 +1005,11 @@ __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const floa
     for (int base = blockIdx.x * gpb; base < n; base += gridDim.x * gpb) {
         const int t = base + grp;
         const int2 ei = p.cand_list[t < n ? t : 0];
-        const bool act = t < n && ei.x >= p.e0 && ei.x < p.e0 + p.ne; // this chain's environments only
-        const int e = ei.x, i = ei.y;
+        const bool act = t < n && (ei.x & 0xfff) >= p.e0 && (ei.x & 0xfff) < p.e0 + p.ne; // this chain's environments only
+        const int e = ei.x & 0xfff, i = ei.y, cnt = ei.x >> 12;
         const size_t eb = (size_t)e * p.N;
         const f3 x0 = xyz(xv_in[(eb + i) * 2]);
-        const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub);
+        const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub, cnt);
         finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out);
     }
 }
@@ -1026,35 +1031,42 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const f
 #ifndef R2S_NO_FINISH_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
+    // Latency is everything here (a wavefront per particle, a handful of dependent round trips, the env step waits): the list
+    // entry is loaded together with the count (speculatively: entries past the count are stale, never used), it carries the
+    // candidate count so that the candidate indices load with x0 / v, and the box test is skipped (NEED = 1 / 2).
     const int lane = (int)(threadIdx.x & 63), wpb = (int)(blockDim.x >> 6);
+    const int t0 = blockIdx.x * wpb + (int)(threadIdx.x >> 6);
+    int2 ei = p.mesh_list[min(t0, p.mesh_cap - 1)];
     const int n_mesh = min(p.mesh_cnt[step], p.mesh_cap);
-    for (int t = blockIdx.x * wpb + (int)(threadIdx.x >> 6); t < n_mesh; t += gridDim.x * wpb) {
-        const int2 ei = p.mesh_list[t];
+    for (int t = t0; t < n_mesh; t += gridDim.x * wpb) {
+        if (t != t0) ei = p.mesh_list[t];
         const bool tagged = ei.y < 0;
-        const int e = ei.x, i = ei.y & 0x7fffffff;
+        const int e = ei.x & 0xfff, i = ei.y & 0x7fffffff, cnt = ei.x >> 12;
         const size_t eb = (size_t)e * p.N;
         TriRegs tr;
         if (MESHQ == 3) tr = load_tris(p, e, step, lane); // in flight while the impulses are summed
         const f3 x0 = xyz(xv_in[(eb + i) * 2]);
         f3 v = xyz(tagged ? p.vbc[eb + i] : p.vdef[eb + i]);
-        if (WITH_SELF && tagged) v = self_impulse<64>(p, xv_in, eb, i, true, x0, v, lane);
-        finish_wave<MESHQ, false>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr);
+        if (WITH_SELF && tagged) v = self_impulse<64>(p, xv_in, eb, i, true, x0, v, lane, cnt);
+        finish_wave<MESHQ, false, 1>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr);
     }
     if (WITH_SELF) {
         constexpr int G = 16;
-        const int n = *p.cand_count;
         const int sub = (int)(threadIdx.x & (G - 1)), grp = (int)(threadIdx.x / G), gpb = (int)(blockDim.x / G);
+        const int g0 = blockIdx.x * gpb + grp;
+        int2 ci = p.cand_list[min(g0, p.E * p.N - 1)];
+        const int n = *p.cand_count;
         for (int base = blockIdx.x * gpb; base < n; base += gridDim.x * gpb) { // wave-uniform trip count
             const int t = base + grp;
-            const int2 ei = p.cand_list[t < n ? t : 0];
-            const int e = ei.x, i = ei.y;
+            if (t != g0) ci = p.cand_list[t < n ? t : 0];
+            const int e = ci.x & 0xfff, i = ci.y, cnt = ci.x >> 12;
             const size_t eb = (size_t)e * p.N;
             const bool act = t < n && e >= p.e0 && e < p.e0 + p.ne && p.cand_mark[eb + i] != step + 1; // not already done in part 1
             const f3 x0 = xyz(xv_in[(eb + i) * 2]);
-            const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub);
-            // the widened test of the fused kernel said "no mesh in reach": the in-place query below is never taken, it only
-            // keeps the kernel correct should a velocity change exceed the 2 mm pad
-            finish_wave<MESHQ == 3 ? 1 : 2, false>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out);
+            const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub, cnt);
+            // the fused kernel's test — widened by 2 mm = 40 m/s of velocity change in one substep — found no mesh in reach of this
+            // particle: no query, mesh_collision only advances it
+            finish_wave<MESHQ == 3 ? 1 : 2, false, 2>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out);
         }
     }
 }
@@ -1570,7 +1582,8 @@ __global__ void k_cand_list(int N, int E, const int* __restrict__ coll_num, int2
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
     if (i >= N) return;
-    if (coll_num[(size_t)e * N + i] > 0) list[atomicAdd(count, 1)] = make_int2(e, i);
+    const int c = coll_num[(size_t)e * N + i];
+    if (c > 0) list[atomicAdd(count, 1)] = make_int2(e | (c << 12), i); // env (< 2048) | candidate count << 12
 }
 
 } // namespace
