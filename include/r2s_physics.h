@@ -157,6 +157,10 @@ int r2s_phys_contact_stats(R2SPhys* h, int32_t* particles_with_candidates, int32
 /* The same three counts {particles with candidates, mesh hits of the last substep, grasped environments} written to a
  * DEVICE int32[3] by a tiny kernel on `stream` — a per-step log without a host synchronisation. */
 int r2s_phys_log_contacts(R2SPhys* h, int32_t* out3_dev, r2s_stream_t stream);
+/* Diagnostics: out[k], k < num_substeps = particles whose mesh query the fused kernel deferred to the finishing kernel in
+ * substep k of the last env step; out[num_substeps] != 0 if any particle was near a collision mesh.  HOST int32
+ * [num_substeps + 1]; synchronises `stream`. */
+int r2s_phys_deferred_counts(R2SPhys* h, int32_t* out, r2s_stream_t stream);
 /* Which captured flavour the last r2s_phys_step ran: out[0] self-collision finishing kernel (0/1), out[1] mesh template
  * (0 none, 1 small meshes per lane, 2 large mesh wave-cooperative), out[2] deferred large-mesh queries (0/1), out[3] chains. */
 int r2s_phys_last_flavour(R2SPhys* h, int32_t* out);

@@ -111,15 +111,20 @@ struct PhysDev {
     const int* cl_f0;          // [n_cl] stored-face range of a cluster
     const int* cl_f1;
     const int* cl_mesh;        // [n_cl]
-    const float* cl_box;       // [n_cl,6] rest-frame boxes (clusters of large meshes)
+    const float* cl_box;       // [6][n_cl] rest-frame boxes (clusters of large meshes), component-major: one lane per cluster loads coalesced
     const int* mesh_kind;      // [n_mesh] bit 0: large (> 256 faces: clusters, wave-cooperative); bit 1: not a closed manifold (sign by
                                // exact winding number; closed large meshes use pseudonormals, small meshes always the winding number)
     const int* mesh_xf;        // [n_mesh] transform slot of a large dynamic mesh, else -1
     const int* xf_mesh;        // [n_xf] mesh of a transform slot
     const float* xf;           // [E,n_sub,n_xf,12]
     const float* rest_pts;     // [nV,3] vertices at construction (= rest frame of rigid meshes)
-    const float* tri_rest;     // [nF,9] rest-frame corners of every stored face (one load instead of index -> vertex)
-    const int4* cl_info;       // [n_cl] {mesh, kind, transform slot of the mesh (-1 none), 0}: one load instead of three dependent ones
+    const float* tri_rest;     // rest-frame corners of every stored face in blocks of 64 faces, [nF/64][9][64]: one lane per face loads
+                               // coalesced (nine 36-byte-strided dword loads per lane cost the texture path 18 cache lines each)
+    const int4* cl_info;       // [n_cl] {mesh, kind | (transform slot + 1) << 2 | faces << 8, transform slot of the mesh (-1 none), first stored face}: the whole cluster record in one load
+    int n_sup, n_small;        // super-clusters (eight consecutive clusters of a large mesh); small meshes of a scene that has a large one
+    const float* sup_box;      // [6][n_sup] rest-frame boxes, component-major
+    const int4* sup_info;      // [n_sup] {first cluster, clusters, transform slot (-1 none), mesh kind}
+    const int* small_mesh;     // [n_small] mesh ids
     const float* pnorm;        // [nF,7,3] pseudonormals of stored faces of large meshes: face, a, b, c, ab, bc, ca
     const float* mesh_pts;     // [E,nV,3] (static part is live; dynamic part = positions at t=0)
     const float* interp_pts;   // [E,n_sub,n_dyn_pts,3]
@@ -194,12 +199,31 @@ __device__ __forceinline__ void closest_bary(f3 a, f3 b, f3 c, f3 q, float& u, f
     u = 1.f - vv - ww; v = vv; region = 0;
 }
 
+// -DR2S_PHASE_PROBE: wall-clock stamps of one finishing wavefront per particle (k_contact_finish), in program order
+#ifdef R2S_PHASE_PROBE
+__device__ long long g_query_probe[1024 * 32];
+struct QProbe { int wave, n; };
+#define R2S_QP_PARAM , QProbe& qp
+#define R2S_QP_ARG , qp
+#define R2S_QP_DECL(w) QProbe qp = {(w), 0}
+#define R2S_QSTAMP() do { if ((threadIdx.x & 63) == 0 && qp.wave >= 0 && qp.wave < 1024 && qp.n < 32) g_query_probe[qp.wave * 32 + qp.n] = (long long)wall_clock64(); ++qp.n; } while (0)
+extern "C" int r2s_phys_debug_query_probe(long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_query_probe), sizeof(long long) * (size_t)n * 32);
+}
+#else
+#define R2S_QP_PARAM
+#define R2S_QP_ARG
+#define R2S_QP_DECL(w) do { } while (0)
+#define R2S_QSTAMP() do { } while (0)
+#endif
+
 struct MeshHit {
     bool result;
     float sign;
     int face; // ORIGINAL (caller) face id
     f3 pt;    // closest point, world frame
-    int mm, fm; // mesh_map / face_map of `face` (filled by mesh_query_regs only; the other queries leave the lookup to the caller)
+    int mm, fm; // mesh_map / face_map of `face` (filled by mesh_query_regs and mesh_query_wave; mesh_query_lane leaves the lookup to the caller)
 };
 
 __device__ __forceinline__ float box_dist2(f3 q, const float* bb)
@@ -210,22 +234,35 @@ __device__ __forceinline__ float box_dist2(f3 q, const float* bb)
     return dx * dx + dy * dy + dz * dz;
 }
 
-// wavefront-wide reductions (all 64 lanes must be active)
+// wavefront-wide reductions (all 64 lanes must be active).  The callers are lone wavefronts whose instruction stream is the
+// critical path of a substep, so the lane exchanges are DPP modifiers (a few cycles each) and four readlanes, not twelve
+// dependent ds_bpermute round trips through the LDS crossbar (~0.3 us per 64-bit reduction, measured in k_contact_finish).
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = min(v, dpp_u32<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = min(v, dpp_u32<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = min(v, dpp_u32<0x141>(v)); // row_half_mirror: the other quad pair of each 8 lanes
+    v = min(v, dpp_u32<0x140>(v)); // row_mirror: the other half of each row of 16
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, m), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), m);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        v = o < v ? o : v;
-    }
-    return v;
+    const unsigned hi = (unsigned)(v >> 32);
+    const unsigned mh = wave_min_u32(hi);
+    const unsigned ml = wave_min_u32(hi == mh ? (unsigned)v : 0xffffffffu);
+    return ((unsigned long long)mh << 32) | ml;
 }
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+    v += __uint_as_float(dpp_u32<0xB1>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_u32<0x4E>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_u32<0x141>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_u32<0x140>(__float_as_uint(v)));
+    return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)))
+         + (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
 }
 __device__ __forceinline__ float bcast(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ __forceinline__ int bcasti(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -273,154 +310,239 @@ __device__ __forceinline__ f3 mesh_vertex(const PhysDev& p, int e, int step, int
     return ld3(p.mesh_pts, (size_t)e * p.nV + vid);
 }
 
-// wp.mesh_query_point_sign_winding_number(mesh, q, max_dist=0.02, accuracy=3.0, threshold=0.6) restated, wave-cooperative.
-// Every lane of the wavefront calls this at the same point; lanes with `want` get their query answered one after the
-// other by all 64 lanes together:
+// wp.mesh_query_point_sign_winding_number(mesh, q, max_dist=0.02, accuracy=3.0, threshold=0.6) restated for scenes with a
+// large mesh, answered by a whole WORKGROUP for one point:
 //   closest point  = lexicographic minimum of (squared distance, original face id) over every face with distance^2 <
-//                    max_dist^2 — the first strict minimum of a sequential scan.  Faces are grouped in clusters (a small
-//                    mesh = one cluster with its per-substep AABB; a large mesh = Morton-sorted runs of 64 faces with
-//                    rest-frame boxes, queried in the rest frame through the substep's rigid transform); one lane per
-//                    cluster prunes by box distance, then one lane per face of each surviving cluster.
-//   sign           = winding number > 0.6 ? -1 : +1 with the EXACT solid-angle sum when the scene is small (<= 512
-//                    faces, every mesh small), lanes striding the faces; for a large mesh (closed manifold, checked at
-//                    construction) the angle-weighted pseudonormal of the closest feature decides (Baerentzen & Aanaes),
-//                    which equals the winding-number sign for closed meshes.
-__device__ MeshHit mesh_query_wave(const PhysDev& p, int step, f3 q_lane, int e_lane, bool want)
+//                    max_dist^2 — the first strict minimum of a sequential scan.  The faces of a large mesh are Morton-sorted
+//                    runs of 64 (clusters) in groups of eight (super-clusters), with rest-frame boxes on both levels, queried
+//                    in the rest frame through the substep's rigid transform; small meshes of the same scene are visited
+//                    through the face table with their per-substep boxes.
+//   sign           = for a large closed manifold (checked at construction) the angle-weighted pseudonormal of the closest
+//                    feature (Baerentzen & Aanaes), which equals the winding-number sign for closed meshes; otherwise the
+//                    exact winding number over the faces of every mesh that is not a large closed manifold.
+// What bounds this code is not memory latency but the INSTRUCTION STREAM of a lone wavefront (about 2 ns per instruction with
+// nothing else to issue: a first version that scanned 512 cluster boxes per wavefront, eight per lane, spent 3.4 of its 20 us
+// there — in-kernel wall-clock stamps, tools/probes/query_probe.py): so the work per wavefront is kept short —
+//   1. every wavefront: one super-cluster box per lane, the eight clusters of the nearest one, the 64 faces of the nearest of
+//      those (a tight `best` before anything else is looked at);
+//   2. every wavefront: the super-clusters still closer than `best` (one lane each), their clusters (eight super-clusters per
+//      round, one lane per cluster): the clusters still closer than `best` are the candidates;
+//   3. candidate r is visited by wavefront r % WPB (one lane per face); the wavefronts' results meet in LDS.
+// Steps 1-2 are computed redundantly (identically) by every wavefront, so there is one barrier per query, executed whether or
+// not the query is wanted (`want` must be uniform over the workgroup).
+__device__ __forceinline__ const float* tri_ptr(const PhysDev& p, int f) { return p.tri_rest + ((size_t)(f >> 6) * 9) * 64 + (f & 63); } // + k * 64
+__device__ __forceinline__ Xf xf_load_slot(const PhysDev& p, int e, int step, int k)
+{
+    Xf X;
+    const float* src = p.xf + (((size_t)e * p.n_sub + step) * p.n_xf + k) * 12;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) X.r[j] = src[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) X.t[j] = src[9 + j];
+    return X;
+}
+
+constexpr int QWPB = 4; // wavefronts per query (k_contact_finish's workgroup)
+struct QShare {
+    unsigned long long key[2][QWPB]; // double-buffered by query parity: a fast wavefront's next result must not overwrite
+    float pt[2][QWPB][6];            // what a slow one is still reading (closest point, q - p; mesh frame)
+    int meta[2][QWPB][4];            // stored face, feature region, mesh kind, transform slot
+    volatile int sup[QWPB][8];       // per wavefront: lanes that own the super-clusters of the current round
+};
+
+__device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, f3 q, int e, bool want, QShare& sm, int& parity, const Xf& X0 R2S_QP_PARAM)
 {
     MeshHit out = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
-    const int lane = (int)(threadIdx.x & 63);
-    unsigned long long pending = __builtin_amdgcn_ballot_w64(want);
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const float MAXD2 = MESH_MAX_DIST * MESH_MAX_DIST;
-    while (pending) {
-        const int L = __builtin_ctzll(pending);
-        pending &= pending - 1;
-        const f3 q = mk(bcast(q_lane.x, L), bcast(q_lane.y, L), bcast(q_lane.z, L));
-        const int e = bcasti(e_lane, L);
-        float best = MAXD2;
-        unsigned long long bestkey = ~0ull;
-        f3 bpt = mk(0.f, 0.f, 0.f), bdl = mk(0.f, 0.f, 0.f); // closest point (world), q - p in the mesh's rest frame
-        int bstored = 0, bregion = 0;
-        // the query point in the rest frame of each large dynamic mesh, once per query (at most two such meshes are
-        // kept in registers; further ones are transformed per cluster)
-        f3 q_rest0 = q, q_rest1 = q;
-        if (p.n_xf > 0) q_rest0 = xf_inverse(xf_load(p, e, step, p.xf_mesh[0]), q);
-        if (p.n_xf > 1) q_rest1 = xf_inverse(xf_load(p, e, step, p.xf_mesh[1]), q);
-        auto cluster_d2 = [&](int c) -> float {
-            if (c >= p.n_cl) return 3.0e38f;
-            const int4 ci = p.cl_info[c];
-            const int m = ci.x;
-            if (!(ci.y & 1)) {
-                const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
-                                                   : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
-                return box_dist2(q, bb);
-            }
-            const int k = ci.z;
-            const f3 qr = k < 0 ? q : (k == 0 ? q_rest0 : (k == 1 ? q_rest1 : xf_inverse(xf_load(p, e, step, m), q)));
-            return box_dist2(qr, p.cl_box + (size_t)c * 6);
+    float best = MAXD2;
+    unsigned long long bestkey = ~0ull;
+    f3 bcp = mk(0.f, 0.f, 0.f), bdl = mk(0.f, 0.f, 0.f); // closest point and q - p, both in the mesh's frame
+    int bstored = 0, bregion = 0, bkind = 0, bxf = -1;
+    // X0: the first large dynamic mesh's transform of this (env, substep), loaded by the caller together with the particle's
+    // state (one load for both queries of a particle); further ones (rare) are fetched where needed
+    if (want) {
+        const f3 q_rest0 = p.n_xf > 0 ? xf_inverse(X0, q) : q;
+        auto rest_point = [&](int k) -> f3 { // the query point in the frame the triangles of transform slot k are stored in
+            return k < 0 ? q : (k == 0 ? q_rest0 : xf_inverse(xf_load_slot(p, e, step, k), q));
         };
-        // pass 0 visits only the cluster whose box is nearest (so `best` is tight before anything else is looked at);
-        // pass 1 visits every other cluster whose box is still closer than `best` — typically two or three
-        unsigned long long nearest = ~0ull;
-        for (int cb = 0; cb < p.n_cl; cb += 64) {
-            const float d2c = cluster_d2(cb + lane);
-            const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2c) << 32) | (unsigned)(cb + lane);
-            nearest = k2 < nearest ? k2 : nearest;
+        auto box6 = [&](const float* base, int stride, int idx, f3 qq) -> float { // component-major boxes
+            const float dx = fmaxf(fmaxf(base[idx] - qq.x, qq.x - base[3 * stride + idx]), 0.f);
+            const float dy = fmaxf(fmaxf(base[stride + idx] - qq.y, qq.y - base[4 * stride + idx]), 0.f);
+            const float dz = fmaxf(fmaxf(base[2 * stride + idx] - qq.z, qq.z - base[5 * stride + idx]), 0.f);
+            return dx * dx + dy * dy + dz * dz;
+        };
+        // one lane per face of a run of stored faces (a = b = c3 come in the frame `qq` is in)
+        auto reduce = [&](unsigned long long key, f3 cp, f3 qq, int region, int stored, int kind, int slot) {
+            const unsigned long long mn = wave_min_u64(key);
+            if (mn < bestkey) {
+                bestkey = mn;
+                best = __uint_as_float((unsigned)(mn >> 32));
+                const int w = __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == mn));
+                bcp = mk(bcast(cp.x, w), bcast(cp.y, w), bcast(cp.z, w));
+                bdl = qq - bcp;
+                bstored = bcasti(stored, w); bregion = bcasti(region, w);
+                bkind = kind; bxf = slot;
+            }
+        };
+        auto visit = [&](int f0, int nf, int kind, int slot) { // a cluster of a large mesh: rest-frame triangle records
+            const f3 qq = rest_point(slot);
+            const bool act = lane < nf;
+            const int f = act ? f0 + lane : f0;
+            const float* t9 = tri_ptr(p, f);
+            const f3 a = mk(t9[0], t9[64], t9[128]), b = mk(t9[192], t9[256], t9[320]), c3 = mk(t9[384], t9[448], t9[512]);
+            const int forig = p.face_orig[f];
+            float u, v;
+            int region;
+            closest_bary(a, b, c3, qq, u, v, region);
+            const f3 cp = a * u + b * v + c3 * (1.f - u - v);
+            const f3 d = cp - qq;
+            const float d2 = dot(d, d);
+            const unsigned long long key = (act && d2 < MAXD2) ? (((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)forig) : ~0ull;
+            reduce(key, cp, qq, region, f, kind, slot);
+        };
+        // ---- small meshes of the scene (gripper fingers next to a large obstacle): world frame, through the face table
+        for (int k = 0; k < p.n_small; ++k) {
+            const int m = p.small_mesh[k];
+            const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
+                                               : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
+            if (!(box_dist2(q, bb) < best * 1.0001f + 1e-12f)) continue;
+            const int kind = p.mesh_kind[m];
+            for (int fb = p.mesh_face_off[m]; fb < p.mesh_face_off[m + 1]; fb += 64) {
+                const int f = fb + lane;
+                unsigned long long key = ~0ull;
+                f3 cp = mk(0.f, 0.f, 0.f);
+                int region = 0;
+                if (f < p.mesh_face_off[m + 1]) {
+                    const f3 a = mesh_vertex(p, e, step, p.faces[3 * f]), b = mesh_vertex(p, e, step, p.faces[3 * f + 1]),
+                             c3 = mesh_vertex(p, e, step, p.faces[3 * f + 2]);
+                    float u, v;
+                    closest_bary(a, b, c3, q, u, v, region);
+                    cp = a * u + b * v + c3 * (1.f - u - v);
+                    const f3 d = cp - q;
+                    const float d2 = dot(d, d);
+                    if (d2 < MAXD2) key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)p.face_orig[f];
+                }
+                reduce(key, cp, q, region, f, kind, -1);
+            }
         }
-        nearest = wave_min_u64(nearest);
-        const int first = (int)(unsigned)(nearest & 0xffffffffull);
-        for (int pass = 0; pass < 2; ++pass)
-        for (int cb = pass == 0 ? (first & ~63) : 0; cb < (pass == 0 ? (first & ~63) + 64 : p.n_cl); cb += 64) {
-            const int c = cb + lane;
-            const float d2c = cluster_d2(c);
-            unsigned long long cm = __builtin_amdgcn_ballot_w64(pass == 0 ? (c == first && d2c < MAXD2 * 1.0001f + 1e-12f)
-                                                                          : (c != first && d2c < best * 1.0001f + 1e-12f));
-            while (cm) {
-                const int k = __builtin_ctzll(cm);
-                cm &= cm - 1;
-                if (!(bcast(d2c, k) < best * 1.0001f + 1e-12f)) continue; // cannot beat the current best
-                const int c2 = cb + k;
-                const int f0 = p.cl_f0[c2], f1 = p.cl_f1[c2], m = p.cl_mesh[c2];
-                const bool large = (p.mesh_kind[m] & 1) != 0;
-                const Xf X = xf_load(p, e, step, m);
-                const f3 qq = large ? xf_inverse(X, q) : q;
-                for (int fb = f0; fb < f1; fb += 64) {
-                    const int f = fb + lane;
-                    unsigned long long key = ~0ull;
-                    float u = 0.f, v = 0.f;
-                    int region = 0;
-                    f3 cp = mk(0.f, 0.f, 0.f);
-                    if (f < f1) {
-                        f3 a, b, c3;
-                        if (large) {
-                            const float* t9 = p.tri_rest + (size_t)f * 9;
-                            a = mk(t9[0], t9[1], t9[2]); b = mk(t9[3], t9[4], t9[5]); c3 = mk(t9[6], t9[7], t9[8]);
-                        } else {
-                            const int ia = p.faces[3 * f], ib = p.faces[3 * f + 1], ic = p.faces[3 * f + 2];
-                            a = mesh_vertex(p, e, step, ia); b = mesh_vertex(p, e, step, ib); c3 = mesh_vertex(p, e, step, ic);
-                        }
-                        closest_bary(a, b, c3, qq, u, v, region);
-                        cp = a * u + b * v + c3 * (1.f - u - v);
-                        const f3 d = cp - qq;
-                        const float d2 = dot(d, d);
-                        if (d2 < MAXD2) key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)p.face_orig[f];
+        // ---- large meshes
+        int C0 = -1; // the cluster every wavefront has visited
+        for (int sb = 0; sb < p.n_sup; sb += 64) {
+            const int s = min(sb + lane, p.n_sup - 1);
+            const int4 si = p.sup_info[s]; // {first cluster, clusters, transform slot, mesh kind}
+            float d2s = box6(p.sup_box, p.n_sup, s, rest_point(si.z));
+            if (sb + lane >= p.n_sup) d2s = 3.0e38f;
+            if (sb == 0 && bestkey == ~0ull) { // step 1: nearest first
+                const unsigned long long near = wave_min_u64(((unsigned long long)__float_as_uint(d2s) << 32) | (unsigned)lane);
+                if (__uint_as_float((unsigned)(near >> 32)) < best * 1.0001f + 1e-12f) {
+                    const int L = (int)(near & 63);
+                    const int c0 = bcasti(si.x, L), ncl = bcasti(si.y, L), slot = bcasti(si.z, L), kind = bcasti(si.w, L);
+                    const float d2c = lane < ncl ? box6(p.cl_box, p.n_cl, c0 + lane, rest_point(slot)) : 3.0e38f;
+                    const unsigned long long nc = wave_min_u64(((unsigned long long)__float_as_uint(d2c) << 32) | (unsigned)lane);
+                    if (__uint_as_float((unsigned)(nc >> 32)) < best * 1.0001f + 1e-12f) {
+                        C0 = c0 + (int)(nc & 63);
+                        const int4 ci = p.cl_info[C0];
+                        visit(ci.w, ci.y >> 8, kind, slot);
                     }
-                    const unsigned long long mn = wave_min_u64(key);
-                    if (mn < bestkey) {
-                        bestkey = mn;
-                        best = __uint_as_float((unsigned)(mn >> 32));
-                        const int w = __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == mn));
-                        const f3 cpw = mk(bcast(cp.x, w), bcast(cp.y, w), bcast(cp.z, w));
-                        bdl = qq - cpw;
-                        bpt = large ? xf_apply(X, cpw) : cpw;
-                        bstored = fb + w;
-                        bregion = bcasti(region, w);
-                    }
+                }
+                R2S_QSTAMP(); // nearest cluster done
+            }
+            // step 2: the super-clusters still in reach, eight per round
+            unsigned long long smask = __builtin_amdgcn_ballot_w64(d2s < best * 1.0001f + 1e-12f);
+            int r = 0; // running candidate number (the same in every wavefront)
+            while (smask) {
+                const int rank = __builtin_popcountll(smask & ((1ull << lane) - 1ull));
+                if (((smask >> lane) & 1ull) && rank < 8) sm.sup[wave][rank] = lane;
+                const int cnt = min(__builtin_popcountll(smask), 8);
+                for (int k = 0; k < cnt; ++k) smask &= smask - 1;
+                const int idx = lane >> 3, j = lane & 7;
+                const int owner = sm.sup[wave][idx];
+                const int c0 = __shfl(si.x, owner), ncl = __shfl(si.y, owner), slot = __shfl(si.z, owner), kind = __shfl(si.w, owner);
+                const bool valid = idx < cnt && j < ncl;
+                const int c = valid ? c0 + j : 0;
+                const float d2c = valid ? box6(p.cl_box, p.n_cl, c, rest_point(slot)) : 3.0e38f;
+                unsigned long long cm = __builtin_amdgcn_ballot_w64(d2c < best * 1.0001f + 1e-12f && c != C0);
+                while (cm) { // step 3: this wavefront's share of the candidates
+                    const int L = __builtin_ctzll(cm);
+                    cm &= cm - 1;
+                    if ((r++ % QWPB) != wave) continue;
+                    if (!(bcast(d2c, L) < best * 1.0001f + 1e-12f)) continue; // cannot beat this wavefront's best any more
+                    const int cc = bcasti(c, L);
+                    const int4 ci = p.cl_info[cc];
+                    visit(ci.w, ci.y >> 8, bcasti(kind, L), bcasti(slot, L));
                 }
             }
         }
-        const bool found = bestkey != ~0ull;
-        float sign = 1.f;
-        if (found) {
-            const int bm = p.face_mesh[bstored];
-            if (p.mesh_kind[bm] == 1) {
-                const f3 n = ld3(p.pnorm, (size_t)bstored * 7 + bregion); // rest frame, like bdl
-                sign = dot(bdl, n) < 0.f ? -1.f : 1.f;
-            } else {
-                // exact winding number (the reference's sign rule, :322-324) over the faces of every mesh that is not a
-                // large closed manifold (those contribute 0 outside themselves): all faces when the scene has no such
-                // mesh.  Faces of a large open mesh are visited in its rest frame (solid angles are rotation invariant).
-                float ws = 0.f;
-                for (int m = 0; m < p.n_mesh; ++m) {
-                    const int kind = p.mesh_kind[m];
-                    if (kind == 1) continue;
-                    const bool rest = (kind & 1) != 0;
-                    const f3 qm = rest ? xf_inverse(xf_load(p, e, step, m), q) : q;
-                    for (int f = p.mesh_face_off[m] + lane; f < p.mesh_face_off[m + 1]; f += 64) {
-                        f3 a, b, c3;
-                        if (rest) {
-                            const float* t9 = p.tri_rest + (size_t)f * 9;
-                            a = mk(t9[0], t9[1], t9[2]) - qm; b = mk(t9[3], t9[4], t9[5]) - qm; c3 = mk(t9[6], t9[7], t9[8]) - qm;
-                        } else {
-                            a = mesh_vertex(p, e, step, p.faces[3 * f]) - qm; b = mesh_vertex(p, e, step, p.faces[3 * f + 1]) - qm;
-                            c3 = mesh_vertex(p, e, step, p.faces[3 * f + 2]) - qm;
-                        }
-                        const float la = len(a), lb = len(b), lc = len(c3);
-                        const float det = dot(a, cross(b, c3));
-                        const float den = la * lb * lc + dot(a, b) * lc + dot(b, c3) * la + dot(c3, a) * lb;
-                        ws += 2.f * atan2f(det, den);
+        R2S_QSTAMP(); // this wavefront's candidates done
+    }
+    // ---- the wavefronts' results meet (always: the number of barriers must not depend on the data)
+    const int par = parity;
+    parity ^= 1;
+    if (lane == 0) {
+        sm.key[par][wave] = bestkey;
+        sm.pt[par][wave][0] = bcp.x; sm.pt[par][wave][1] = bcp.y; sm.pt[par][wave][2] = bcp.z;
+        sm.pt[par][wave][3] = bdl.x; sm.pt[par][wave][4] = bdl.y; sm.pt[par][wave][5] = bdl.z;
+        sm.meta[par][wave][0] = bstored; sm.meta[par][wave][1] = bregion; sm.meta[par][wave][2] = bkind; sm.meta[par][wave][3] = bxf;
+    }
+    __syncthreads();
+    if (!want) return out;
+    int fw = 0;
+    bestkey = sm.key[par][0];
+#pragma unroll
+    for (int w = 1; w < QWPB; ++w) {
+        const unsigned long long k = sm.key[par][w];
+        if (k < bestkey) { bestkey = k; fw = w; }
+    }
+    bcp = mk(sm.pt[par][fw][0], sm.pt[par][fw][1], sm.pt[par][fw][2]);
+    bdl = mk(sm.pt[par][fw][3], sm.pt[par][fw][4], sm.pt[par][fw][5]);
+    bstored = sm.meta[par][fw][0]; bregion = sm.meta[par][fw][1]; bkind = sm.meta[par][fw][2]; bxf = sm.meta[par][fw][3];
+    const bool found = bestkey != ~0ull;
+    const int bface = found ? (int)(unsigned)(bestkey & 0xffffffffull) : 0; // a miss reports face 0, like warp's zero-initialised query
+    float sign = 1.f;
+    const int mm = p.mesh_map[bface], fm = p.face_map[bface]; // in flight with the pseudonormal
+    f3 bpt = bcp;
+    if (found) {
+        if (bxf >= 0) bpt = bxf == 0 ? xf_apply(X0, bcp) : xf_apply(xf_load_slot(p, e, step, bxf), bcp);
+        if (bkind == 1) {
+            const f3 n = ld3(p.pnorm, (size_t)bstored * 7 + bregion); // rest frame, like bdl
+            sign = dot(bdl, n) < 0.f ? -1.f : 1.f;
+        } else {
+            // exact winding number (the reference's sign rule, :322-324) over the faces of every mesh that is not a
+            // large closed manifold (those contribute 0 outside themselves).  Faces of a large open mesh are visited in
+            // its rest frame (solid angles are rotation invariant).
+            float ws = 0.f;
+            for (int m = 0; m < p.n_mesh; ++m) {
+                const int kind = p.mesh_kind[m];
+                if (kind == 1) continue;
+                const bool rest = (kind & 1) != 0;
+                const f3 qm = rest ? xf_inverse(xf_load(p, e, step, m), q) : q;
+                for (int f = p.mesh_face_off[m] + lane; f < p.mesh_face_off[m + 1]; f += 64) {
+                    f3 a, b, c3;
+                    if (rest) {
+                        const float* t9 = tri_ptr(p, f);
+                        a = mk(t9[0], t9[64], t9[128]) - qm; b = mk(t9[192], t9[256], t9[320]) - qm; c3 = mk(t9[384], t9[448], t9[512]) - qm;
+                    } else {
+                        a = mesh_vertex(p, e, step, p.faces[3 * f]) - qm; b = mesh_vertex(p, e, step, p.faces[3 * f + 1]) - qm;
+                        c3 = mesh_vertex(p, e, step, p.faces[3 * f + 2]) - qm;
                     }
+                    const float la = len(a), lb = len(b), lc = len(c3);
+                    const float det = dot(a, cross(b, c3));
+                    const float den = la * lb * lc + dot(a, b) * lc + dot(b, c3) * la + dot(c3, a) * lb;
+                    ws += 2.f * atan2f(det, den);
                 }
-                const float wn = wave_sum(ws) / (float)(4.0 * 3.14159265358979323846);
-                sign = wn > WIND_THRESHOLD ? -1.f : 1.f;
             }
-        }
-        if (lane == L) {
-            out.result = found;
-            out.sign = sign;
-            out.face = (int)(unsigned)(bestkey & 0xffffffffull);
-            out.pt = bpt;
+            const float wn = wave_sum(ws) / (float)(4.0 * 3.14159265358979323846);
+            sign = wn > WIND_THRESHOLD ? -1.f : 1.f;
         }
     }
+    R2S_QSTAMP(); // sign done
+    out.result = found && lane == 0; // the answer belongs to the particle of lane 0 (the other lanes only helped)
+    out.sign = sign;
+    out.face = bface;
+    out.pt = bpt;
+    out.mm = mm;
+    out.fm = fm;
     return out;
 }
 
@@ -520,7 +642,7 @@ __device__ MeshHit mesh_query_regs(const TriRegs& t, f3 q_lane, bool want)
         const bool found = mn != ~0ull;
         float sign = 1.f;
         f3 pt = mk(0.f, 0.f, 0.f);
-        int wmm = 0, wfm = 0;
+        int wmm = bcasti(t.mm[0], 0), wfm = bcasti(t.fm[0], 0); // a miss reports face 0, like warp's zero-initialised query
         if (found) {
             const int w = __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == mn));
             pt = mk(bcast(cpb.x, w), bcast(cpb.y, w), bcast(cpb.z, w));
@@ -541,7 +663,7 @@ __device__ MeshHit mesh_query_regs(const TriRegs& t, f3 q_lane, bool want)
         if (lane == L) {
             out.result = found;
             out.sign = sign;
-            out.face = (int)(unsigned)(mn & 0xffffffffull);
+            out.face = found ? (int)(unsigned)(mn & 0xffffffffull) : 0;
             out.pt = pt;
             out.mm = wmm; out.fm = wfm;
         }
@@ -690,7 +812,7 @@ __device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 
 // found nothing in reach: mesh_collision then only advances the position, :321 / :420)
 template <int MESH, bool MAIN = false, int NEED = 0>
 __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v, bool fin,
-                                            float4* __restrict__ xv_out, const TriRegs* tr = nullptr)
+                                            float4* __restrict__ xv_out, const TriRegs* tr, QShare* qs, int* qpar, const Xf* xf0, bool store R2S_QP_PARAM)
 {
     f3 x = x0;
     // mesh_collision, :295-421 — advances x by v*dt for EVERY particle (:321, :420)
@@ -703,8 +825,12 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         else if (NEED == 0 && fin) need = mesh_need(p, e, step, next_x, 0.f, near);
         if (MAIN) { // count the particles near a mesh (the host picks the next step's graph flavour from the total) and, in
                     // deferring mode, hand the ones that need a query to k_contact_finish
-            if (near) atomicAdd(p.mesh_cnt + p.n_sub, 1);
-            if (need && p.mesh_defer) {
+            // only "anything near?" is consumed (the host picks the next step's flavour from it): one plain store per wavefront.
+            // (A per-lane atomicAdd on this single word — thousands per substep while an object sits next to a mesh — serialised
+            // in the L2 and cost more than all the queries: +28 us per substep in the pusher scene, whatever the query did.)
+            const unsigned long long nm = __builtin_amdgcn_ballot_w64(near);
+            if (nm && (int)(threadIdx.x & 63) == __builtin_ctzll(nm)) p.mesh_cnt[p.n_sub] = 1;
+            if (need && (p.mesh_defer || MESH == 2)) { // large scenes always defer: the fused kernel carries no query code
                 const int slot = atomicAdd(p.mesh_cnt + step, 1);
                 if (slot < p.mesh_cap) {
                     p.vdef[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
@@ -715,9 +841,16 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
                 // list full (never with the sizing below): fall through to the in-place query
             }
         }
-        MeshHit q = MESH == 3 ? mesh_query_regs(*tr, next_x, need)
-                  : MESH == 2 ? mesh_query_wave(p, step, next_x, e, need) // wave-cooperative, convergent call site 1
-                              : mesh_query_lane(p, e, step, next_x, need);
+        // large scenes (MESH 2): never queried in the fused kernel; in k_contact_finish by the whole workgroup for the particle of
+        // lane 0 (every wavefront of the workgroup runs this function on the same particle; `store` marks the one that writes)
+        constexpr bool IN_PLACE = !(MAIN && MESH == 2) && NEED != 2;
+        MeshHit q = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
+        if (IN_PLACE)
+            q = MESH == 3 ? mesh_query_regs(*tr, next_x, need)
+              : MESH == 2 ? mesh_query_block(p, step, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), e,
+                                             bcasti((int)need, 0) != 0, *qs, *qpar, *xf0 R2S_QP_ARG) // workgroup-cooperative, call site 1
+                          : mesh_query_lane(p, e, step, next_x, need);
+        R2S_QSTAMP(); // first query back
         // per-lane response; lanes that must re-query (gripper branch, :394-408) park their state and meet again below
         bool requery = false;
         f3 normal = mk(0.f, 0.f, 0.f), v_normal = mk(0.f, 0.f, 0.f), v_normal_new = mk(0.f, 0.f, 0.f);
@@ -725,7 +858,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         bool hit = false;
         if (q.result) {
             int is_gripper;
-            const int mm = MESH == 3 ? q.mm : p.mesh_map[q.face];
+            const int mm = MESH >= 2 ? q.mm : p.mesh_map[q.face];
             if (!p.use_pusher) is_gripper = mm == 0 ? 1 : (mm == 1 ? 2 : 0);
             else is_gripper = mm >= 0 ? 1 : 0;
             f3 delta = next_x - q.pt;
@@ -763,9 +896,13 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
                 }
             }
         }
-        const MeshHit q2 = MESH == 3 ? mesh_query_regs(*tr, next_x, requery)
-                         : MESH == 2 ? mesh_query_wave(p, step, next_x, e, requery) // convergent call site 2
-                                     : mesh_query_lane(p, e, step, next_x, requery);
+        MeshHit q2 = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
+        if (IN_PLACE)
+            q2 = MESH == 3 ? mesh_query_regs(*tr, next_x, requery)
+               : MESH == 2 ? mesh_query_block(p, step, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), e,
+                                              bcasti((int)requery, 0) != 0, *qs, *qpar, *xf0 R2S_QP_ARG) // call site 2
+                           : mesh_query_lane(p, e, step, next_x, requery);
+        R2S_QSTAMP(); // response + second query back
         if (requery) {
             if (q2.result) {
                 const f3 delta = next_x - q2.pt;
@@ -778,9 +915,9 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
             }
             q = q2; // face of the LAST query (0 if the re-query missed)
         }
-        if (hit && write_forces) {
+        if (hit && write_forces && store) {
             const f3 fo = (v_normal_new - v_normal) / p.dt;
-            float* cf3 = p.coll_forces + ((size_t)e * p.nF + (MESH == 3 ? q.fm : p.face_map[q.face])) * 3;
+            float* cf3 = p.coll_forces + ((size_t)e * p.nF + (MESH >= 2 ? q.fm : p.face_map[q.face])) * 3;
             atomicAdd(cf3, fo.x);
             atomicAdd(cf3 + 1, fo.y);
             atomicAdd(cf3 + 2, fo.z);
@@ -791,7 +928,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
     }
 
     // integrate_ground_collision, :424-474
-    if (fin) {
+    if (fin && store) {
         const f3 normal = mk(0.f, 0.f, 1.f) * p.rf;
         const float x_z = x.z, v_z = v.z;
         const float next_x_z = (x_z + v_z * p.dt) * p.rf;
@@ -918,7 +1055,7 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __r
         if (ncand > 0) {
             p.vbc[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
             fin = false; // finished by k_self_finish / k_contact_finish
-            if (MESH != 0 && p.mesh_defer) {
+            if (MESH != 0 && (p.mesh_defer || MESH == 2)) {
                 // Will it also need a mesh query?  Its velocity is not final (the impulses come later), so the test is widened
                 // by 2 mm (= 40 m/s of velocity change in one substep); over-inclusion is harmless, the query itself is exact.
                 // Such a particle goes to the mesh list TAGGED: k_contact_finish applies its impulses and queries in one go.
@@ -930,11 +1067,13 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __r
                         p.cand_mark[eb + i] = step + 1;
                     }
                 }
-                if (near) atomicAdd(p.mesh_cnt + p.n_sub, 1);
+                const unsigned long long nm = __builtin_amdgcn_ballot_w64(near);
+                if (nm && lane == __builtin_ctzll(nm)) p.mesh_cnt[p.n_sub] = 1;
             }
         }
     }
-    finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out);
+    R2S_QP_DECL(-1);
+    finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out, nullptr, nullptr, nullptr, nullptr, true R2S_QP_ARG);
     R2S_STAMP(3);
 }
 
@@ -1010,7 +1149,8 @@ __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const floa
         const size_t eb = (size_t)e * p.N;
         const f3 x0 = xyz(xv_in[(eb + i) * 2]);
         const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub, cnt);
-        finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out);
+        R2S_QP_DECL(-1);
+        finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out, nullptr, nullptr, nullptr, nullptr, true R2S_QP_ARG);
     }
 }
 
@@ -1034,29 +1174,55 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const f
     // Latency is everything here (a wavefront per particle, a handful of dependent round trips, the env step waits): the list
     // entry is loaded together with the count (speculatively: entries past the count are stale, never used), it carries the
     // candidate count so that the candidate indices load with x0 / v, and the box test is skipped (NEED = 1 / 2).
-    const int lane = (int)(threadIdx.x & 63), wpb = (int)(blockDim.x >> 6);
-    const int t0 = blockIdx.x * wpb + (int)(threadIdx.x >> 6);
+    // MESHQ 3: one WAVEFRONT per listed particle; MESHQ 2: one WORKGROUP (its four wavefronts run the same code on the same
+    // particle — identical results — and share the triangle visits of the query; only the first one stores)
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), wpb = MESHQ == 2 ? 1 : (int)(blockDim.x >> 6);
+    const int t0 = MESHQ == 2 ? (int)blockIdx.x : (int)blockIdx.x * wpb + wave;
+    __shared__ QShare qshare;
+    int qpar = 0;
+#ifdef R2S_PHASE_PROBE
+    const long long probe_entry = (long long)wall_clock64();
+#endif
     int2 ei = p.mesh_list[min(t0, p.mesh_cap - 1)];
     const int n_mesh = min(p.mesh_cnt[step], p.mesh_cap);
-    for (int t = t0; t < n_mesh; t += gridDim.x * wpb) {
+    for (int t = t0; t < n_mesh; t += gridDim.x * wpb) { // MESHQ 2: a workgroup-uniform trip count (barriers inside)
         if (t != t0) ei = p.mesh_list[t];
         const bool tagged = ei.y < 0;
         const int e = ei.x & 0xfff, i = ei.y & 0x7fffffff, cnt = ei.x >> 12;
         const size_t eb = (size_t)e * p.N;
         TriRegs tr;
         if (MESHQ == 3) tr = load_tris(p, e, step, lane); // in flight while the impulses are summed
+        Xf X0; // the substep's rigid transform of the first large dynamic mesh: in flight with the particle's state
+#pragma unroll
+        for (int j = 0; j < 9; ++j) X0.r[j] = (j % 4 == 0) ? 1.f : 0.f;
+        X0.t[0] = X0.t[1] = X0.t[2] = 0.f;
+        if (MESHQ == 2 && p.n_xf > 0) X0 = xf_load_slot(p, __builtin_amdgcn_readfirstlane(e), step, 0);
         const f3 x0 = xyz(xv_in[(eb + i) * 2]);
         f3 v = xyz(tagged ? p.vbc[eb + i] : p.vdef[eb + i]);
         if (WITH_SELF && tagged) v = self_impulse<64>(p, xv_in, eb, i, true, x0, v, lane, cnt);
-        finish_wave<MESHQ, false, 1>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr);
+        R2S_QP_DECL(step == p.n_sub - 2 ? t * (MESHQ == 2 ? 4 : 1) + (MESHQ == 2 ? wave : 0) : -1); // stamps of the last-but-one substep (no force accumulation)
+#ifdef R2S_PHASE_PROBE
+        if (lane == 0 && qp.wave >= 0 && qp.wave < 1024) g_query_probe[qp.wave * 32 + 31] = probe_entry;
+#endif
+        R2S_QSTAMP(); // entry loaded, x0 / v (and the impulses) done
+        finish_wave<MESHQ, false, 1>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr, &qshare, &qpar, &X0, MESHQ != 2 || wave == 0 R2S_QP_ARG);
+        R2S_QSTAMP(); // stored
     }
     if (WITH_SELF) {
+#ifdef R2S_PHASE_PROBE
+        const int gw = (int)blockIdx.x * 4 + wave; // stamps 28 / 29 / 30: part 2 entered / left, kernel entry of this wavefront
+        if (lane == 0 && gw < 1024 && step == p.n_sub - 2) { g_query_probe[gw * 32 + 28] = (long long)wall_clock64(); g_query_probe[gw * 32 + 30] = probe_entry; }
+#endif
         constexpr int G = 16;
         const int sub = (int)(threadIdx.x & (G - 1)), grp = (int)(threadIdx.x / G), gpb = (int)(blockDim.x / G);
-        const int g0 = blockIdx.x * gpb + grp;
+        // part 1 fills the grid from its first workgroup, part 2 from its LAST: a wavefront that spent 7 us on a mesh particle
+        // should not also be the one that starts a candidate particle afterwards (in-kernel stamps: the kernel ended at 10.8 us,
+        // 3.3 us after the last mesh particle, with most of the grid idle)
+        const int rb = (int)(gridDim.x - 1 - blockIdx.x);
+        const int g0 = rb * gpb + grp;
         int2 ci = p.cand_list[min(g0, p.E * p.N - 1)];
         const int n = *p.cand_count;
-        for (int base = blockIdx.x * gpb; base < n; base += gridDim.x * gpb) { // wave-uniform trip count
+        for (int base = rb * gpb; base < n; base += gridDim.x * gpb) { // wave-uniform trip count
             const int t = base + grp;
             if (t != g0) ci = p.cand_list[t < n ? t : 0];
             const int e = ci.x & 0xfff, i = ci.y, cnt = ci.x >> 12;
@@ -1066,8 +1232,12 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const f
             const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub, cnt);
             // the fused kernel's test — widened by 2 mm = 40 m/s of velocity change in one substep — found no mesh in reach of this
             // particle: no query, mesh_collision only advances it
-            finish_wave<MESHQ == 3 ? 1 : 2, false, 2>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out);
+            R2S_QP_DECL(-1);
+            finish_wave<MESHQ == 3 ? 1 : 2, false, 2>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out, nullptr, nullptr, nullptr, nullptr, true R2S_QP_ARG);
         }
+#ifdef R2S_PHASE_PROBE
+        if (lane == 0 && gw < 1024 && step == p.n_sub - 2) g_query_probe[gw * 32 + 29] = (long long)wall_clock64();
+#endif
     }
 }
 
@@ -1656,7 +1826,7 @@ struct R2SPhys {
     int *d_face_orig = nullptr, *d_face_mesh = nullptr, *d_cl_f0 = nullptr, *d_cl_f1 = nullptr, *d_cl_mesh = nullptr, *d_mesh_kind = nullptr,
         *d_mesh_xf = nullptr, *d_xf_mesh = nullptr, *d_xf_ref = nullptr;
     float *d_cl_box = nullptr, *d_xf = nullptr, *d_rest_pts = nullptr, *d_pnorm = nullptr, *d_xf_rest_box = nullptr, *d_tri_rest = nullptr;
-    int4* d_cl_info = nullptr;
+    int4* d_cl_info = nullptr; int4* d_sup_info = nullptr; float* d_sup_box = nullptr; int* d_small_mesh = nullptr; int n_sup = 0, n_small = 0;
     unsigned* d_rigid_err = nullptr;
     unsigned* h_rigid_err = nullptr; // pinned
     bool rigid_pending = false;
@@ -1705,6 +1875,7 @@ struct R2SPhys {
         p.face_orig = d_face_orig; p.face_mesh = d_face_mesh; p.n_cl = n_cl; p.n_xf = n_xf; p.cl_f0 = d_cl_f0; p.cl_f1 = d_cl_f1;
         p.cl_mesh = d_cl_mesh; p.cl_box = d_cl_box; p.mesh_kind = d_mesh_kind; p.mesh_xf = d_mesh_xf; p.xf_mesh = d_xf_mesh; p.xf = d_xf; p.rest_pts = d_rest_pts;
         p.pnorm = d_pnorm; p.tri_rest = d_tri_rest; p.cl_info = d_cl_info;
+        p.n_sup = n_sup; p.n_small = n_small; p.sup_box = d_sup_box; p.sup_info = d_sup_info; p.small_mesh = d_small_mesh;
         p.mesh_pts = d_mesh_pts; p.interp_pts = d_interp; p.interp_center = d_center; p.dyn_vel = d_dyn_vel; p.dyn_omega = d_dyn_omega;
         p.aabb_dyn = d_aabb_dyn; p.aabb_static = d_aabb_static; p.coll_forces = d_coll_forces; p.hit_cnt = d_hit_cnt;
         return p;
@@ -1799,7 +1970,7 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
     // What the fused kernel left unfinished: with something near a mesh (mesh_defer) ONE combined finishing kernel per substep —
     // deferred mesh queries, one wavefront per particle, plus the self-collision impulses; otherwise only k_self_finish
     // while candidates exist (mesh queries of the rare needy particle in place).
-    if (mesh != 0 && p.mesh_defer) {
+    if (mesh != 0 && (p.mesh_defer || mesh == 2)) {
         const bool small = mesh == 1 && h->nF <= 128; // every mesh small: the substep's triangles fit two per lane
         const dim3 g(512);                            // 2048 wavefronts, grid-stride
 #define R2S_FIN(Q, S) hipLaunchKernelGGL((k_contact_finish<Q, S>), g, dim3(256), 0, s, p, in, out, step, write_forces)
@@ -1809,8 +1980,7 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
     } else if (with_self) {
         // grid-stride over the device-side candidate list; sized for the host's view of the count
         const unsigned blocks = 512; // grid-stride over the device-side candidate list, 16 lanes per listed particle
-        if (mesh == 2) hipLaunchKernelGGL((k_self_finish<2>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
-        else if (mesh == 1) hipLaunchKernelGGL((k_self_finish<1>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
+        if (mesh == 1) hipLaunchKernelGGL((k_self_finish<1>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
         else hipLaunchKernelGGL((k_self_finish<0>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
     }
     return R2S_OK;
@@ -2311,6 +2481,11 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             }
         }
         h->n_cl = (int)cl_f0.size(); h->n_xf = (int)xf_mesh.size();
+        if (h->n_xf > 62) { // the cluster record holds the transform slot in 6 bits
+            r2s::set_last_error_msg("more than 62 large dynamic collision meshes (unsupported)");
+            r2s_phys_destroy(h);
+            return R2S_ERR_INVALID;
+        }
         h->h_mesh_kind = mesh_kind; h->h_voff = voff; h->h_foff = foff; h->h_xf_mesh = xf_mesh; h->h_xf_ref = xf_ref;
         for (int m = 0; m < h->n_mesh; ++m) h->any_large = h->any_large || (mesh_kind[m] & 1);
         TRY(dev_alloc(&h->d_face_orig, h->nF)); TRY(dev_alloc(&h->d_face_mesh, h->nF)); TRY(dev_alloc(&h->d_cl_f0, h->n_cl)); TRY(dev_alloc(&h->d_cl_f1, h->n_cl));
@@ -2323,18 +2498,47 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         *h->h_rigid_err = 0;
         TRY(upload(h->d_face_orig, face_orig.data(), face_orig.size(), s)); TRY(upload(h->d_face_mesh, face_mesh.data(), face_mesh.size(), s));
         TRY(upload(h->d_cl_f0, cl_f0.data(), cl_f0.size(), s)); TRY(upload(h->d_cl_f1, cl_f1.data(), cl_f1.size(), s)); TRY(upload(h->d_cl_mesh, cl_mesh.data(), cl_mesh.size(), s));
-        TRY(upload(h->d_cl_box, cl_box.data(), cl_box.size(), s)); TRY(upload(h->d_mesh_kind, mesh_kind.data(), mesh_kind.size(), s));
+        {
+            std::vector<float> box_t(cl_box.size());
+            for (int c = 0; c < h->n_cl; ++c)
+                for (int k = 0; k < 6; ++k) box_t[(size_t)k * h->n_cl + c] = cl_box[(size_t)c * 6 + k];
+            TRY(upload(h->d_cl_box, box_t.data(), box_t.size(), s));
+        }
+        TRY(upload(h->d_mesh_kind, mesh_kind.data(), mesh_kind.size(), s));
         TRY(upload(h->d_mesh_xf, mesh_xf.data(), mesh_xf.size(), s)); TRY(upload(h->d_rest_pts, d->mesh_vertices, 3 * (size_t)h->nV, s));
         TRY(upload(h->d_pnorm, pnorm.data(), pnorm.size(), s)); TRY(upload(h->d_xf_mesh, xf_mesh.data(), xf_mesh.size(), s));
         {
-            std::vector<float> tri(9 * (size_t)h->nF);
+            std::vector<float> tri(9 * 64 * (size_t)((h->nF + 63) / 64), 0.f);
             for (int f = 0; f < h->nF; ++f)
                 for (int c = 0; c < 3; ++c)
-                    for (int k = 0; k < 3; ++k) tri[(size_t)f * 9 + c * 3 + k] = d->mesh_vertices[3 * (size_t)stored[3 * f + c] + k];
+                    for (int k = 0; k < 3; ++k) tri[((size_t)(f >> 6) * 9 + c * 3 + k) * 64 + (f & 63)] = d->mesh_vertices[3 * (size_t)stored[3 * f + c] + k];
             std::vector<int4> info(h->n_cl);
-            for (int c = 0; c < h->n_cl; ++c) info[c] = make_int4(cl_mesh[c], mesh_kind[cl_mesh[c]], mesh_xf[cl_mesh[c]], 0);
+            for (int c = 0; c < h->n_cl; ++c) info[c] = make_int4(cl_mesh[c], mesh_kind[cl_mesh[c]] | ((mesh_xf[cl_mesh[c]] + 1) << 2) | ((cl_f1[c] - cl_f0[c]) << 8), mesh_xf[cl_mesh[c]], cl_f0[c]);
             TRY(dev_alloc(&h->d_tri_rest, tri.size())); TRY(upload(h->d_tri_rest, tri.data(), tri.size(), s));
             TRY(dev_alloc(&h->d_cl_info, info.size())); TRY(upload(h->d_cl_info, info.data(), info.size(), s));
+            // super-clusters: runs of eight consecutive clusters of one large mesh (Morton order keeps them compact)
+            std::vector<int4> sup;
+            std::vector<float> sbox;
+            std::vector<int> small;
+            for (int c = 0; c < h->n_cl;) {
+                const int m = cl_mesh[c];
+                if (!(mesh_kind[m] & 1)) { small.push_back(m); ++c; continue; }
+                int n = 1;
+                while (n < 8 && c + n < h->n_cl && cl_mesh[c + n] == m) ++n;
+                float bb[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
+                for (int k = c; k < c + n; ++k)
+                    for (int q = 0; q < 3; ++q) { bb[q] = std::min(bb[q], cl_box[(size_t)k * 6 + q]); bb[3 + q] = std::max(bb[3 + q], cl_box[(size_t)k * 6 + 3 + q]); }
+                sup.push_back(make_int4(c, n, mesh_xf[m], mesh_kind[m]));
+                for (int q = 0; q < 6; ++q) sbox.push_back(bb[q]);
+                c += n;
+            }
+            h->n_sup = (int)sup.size(); h->n_small = (int)small.size();
+            std::vector<float> sbox_t(sbox.size());
+            for (int k = 0; k < h->n_sup; ++k)
+                for (int q = 0; q < 6; ++q) sbox_t[(size_t)q * h->n_sup + k] = sbox[(size_t)k * 6 + q];
+            TRY(dev_alloc(&h->d_sup_info, std::max<size_t>(sup.size(), 1))); TRY(upload(h->d_sup_info, sup.data(), sup.size(), s));
+            TRY(dev_alloc(&h->d_sup_box, std::max<size_t>(sbox_t.size(), 1))); TRY(upload(h->d_sup_box, sbox_t.data(), sbox_t.size(), s));
+            TRY(dev_alloc(&h->d_small_mesh, std::max<size_t>(small.size(), 1))); TRY(upload(h->d_small_mesh, small.data(), small.size(), s));
         }
         TRY(upload(h->d_xf_ref, xf_ref.data(), xf_ref.size(), s)); TRY(upload(h->d_xf_rest_box, xf_rest_box.data(), xf_rest_box.size(), s));
         faces = stored; // the device face table is in stored (cluster) order
@@ -2383,7 +2587,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     TRY(dev_alloc(&h->d_max_count, 4));
     R2S_HIP_TRY(hipMemsetAsync(h->d_max_count, 0, sizeof(int) * 4, s));
     if (h->nF > 0) { // deferred mesh queries
-        h->mesh_cap = std::max(4096, E * std::min(N, 2048));
+        h->mesh_cap = std::max(4096, E * N); // a particle is listed at most once per substep: the list cannot overflow
         TRY(dev_alloc(&h->d_mesh_list, (size_t)8 * h->mesh_cap));
         TRY(dev_alloc(&h->d_mesh_cnt, (size_t)8 * (h->prm.num_substeps + 1)));
         TRY(dev_alloc(&h->d_vdef, (size_t)E * N));
@@ -2420,13 +2624,13 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     // Capture every flavour the env step can take — {no candidates, candidates} x {nothing near a mesh, deferred mesh queries}
     // x both parities of the state buffer (667 substeps is odd) — now: a flavour switch in the middle of a rollout (first
     // contact, first candidates) must not pay ~5 ms of capture.  All finishing kernels have fixed grid-stride grids.
-    for (int defer = 0; defer <= (h->nF > 0 ? 1 : 0); ++defer)
+    for (int defer = h->any_large ? 1 : 0; defer <= (h->nF > 0 ? 1 : 0); ++defer) // a scene with a large mesh always defers
         for (int variant = 0; variant <= (h->prm.self_collision ? 1 : 0); ++variant)
             for (int par = 0; par < ((h->prm.num_substeps & 1) ? 2 : 1); ++par) {
                 h->mesh_defer = defer;
                 TRY(capture_graph(h, variant, par));
             }
-    h->mesh_defer = 0;
+    h->mesh_defer = h->any_large ? 1 : 0;
 #undef TRY
     *out = h;
     return R2S_OK;
@@ -2440,7 +2644,7 @@ void r2s_phys_destroy(R2SPhys* h)
     void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
                     h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_mesh_list, h->d_mesh_cnt, h->d_vdef, h->d_cand_mark, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
                     h->d_faces, h->d_face_orig, h->d_face_mesh, h->d_cl_f0, h->d_cl_f1, h->d_cl_mesh, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
-                    h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
+                    h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_sup_info, h->d_sup_box, h->d_small_mesh, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
                     h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta, h->d_hit_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -2648,6 +2852,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         if (h->mesh_pending && hipEventQuery(h->mesh_event) == hipSuccess) h->mesh_pending = false;
         if (!h->mesh_pending) h->mesh_defer = *h->h_mesh_total > 0 ? 1 : 0; // an unfinished count keeps the previous flavour
         if (h->force_defer >= 0) h->mesh_defer = h->force_defer; // test / tuning: force a flavour
+        if (h->any_large) h->mesh_defer = 1;
     }
     h->last_flavour[0] = variant; h->last_flavour[1] = h->nF > 0 ? (h->any_large ? 2 : 1) : 0; h->last_flavour[2] = h->mesh_defer;
     h->last_flavour[3] = use_graph ? h->chains() : 1;
@@ -2773,6 +2978,22 @@ int r2s_phys_contact_stats(R2SPhys* h, int32_t* particles_with_candidates, int32
         *particles_with_candidates = h->n_cand;
     }
     if (mesh_hits_dev) *mesh_hits_dev = h->d_hit_cnt;
+    return R2S_OK;
+}
+
+// Diagnostics: how many particles the fused kernel handed to k_contact_finish in each substep of the last env step
+// (summed over the kernel chains), out[n_sub] = 1 if anything was near a mesh.  Synchronises the stream.
+int r2s_phys_deferred_counts(R2SPhys* h, int32_t* out, r2s_stream_t stream_)
+{
+    if (!h || !out) return R2S_ERR_INVALID;
+    const int n = h->prm.num_substeps + 1;
+    for (int k = 0; k < n; ++k) out[k] = 0;
+    if (h->nF == 0) return R2S_OK;
+    std::vector<int> tmp((size_t)8 * n);
+    R2S_HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_mesh_cnt, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    R2S_HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    for (int c = 0; c < 8; ++c)
+        for (int k = 0; k < n; ++k) out[k] += tmp[(size_t)c * n + k];
     return R2S_OK;
 }
 

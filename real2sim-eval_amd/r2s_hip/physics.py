@@ -55,7 +55,7 @@ def _bind():
         r2s_phys_set_eef_table=[vp, C.c_int32, vp, vp, C.c_float, vp], r2s_phys_set_eef_motion=[vp, vp, vp, vp, vp, vp, vp],
         r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
         r2s_phys_set_collision_lists=[vp, vp, vp, vp], r2s_phys_contact_stats=[vp, C.POINTER(C.c_int32), C.POINTER(vp)],
-        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32],
+        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32],
         r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
     ).items():
         fn = getattr(L, name)
@@ -325,6 +325,13 @@ class PhysBatch:
         """{particles with candidates, mesh hits of the last substep, grasped envs} -> device int32[3], no host sync."""
         with torch.cuda.device(self.device):
             check(_bind().r2s_phys_log_contacts(self._h, out3.data_ptr(), self._s()), "r2s_phys_log_contacts")
+
+    def deferred_counts(self) -> np.ndarray:
+        """Deferred mesh queries per substep of the last env step (+ a trailing 'anything near a mesh' flag); diagnostics."""
+        out = np.zeros(self.num_substeps + 1, np.int32)
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_deferred_counts(self._h, out.ctypes.data, self._s()), "r2s_phys_deferred_counts")
+        return out
 
     def last_flavour(self):
         a = (C.c_int32 * 4)()

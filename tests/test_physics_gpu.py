@@ -254,11 +254,11 @@ def test_drop_in_surface_smoke():
     assert (sim.wp_state.wp_x - x_before).abs().max() > 0
 
 
-@pytest.mark.parametrize("defer", ["0", "1"], ids=["queries in place", "queries deferred to k_mesh_finish"])
+@pytest.mark.parametrize("defer", ["0", "1"], ids=["flavour request: in place (a large scene defers anyway)", "queries deferred to k_contact_finish"])
 def test_pusher_25k_face_mesh_cluster_query_vs_oracle(defer, monkeypatch):
     """configs[3] ingredient: a ~25k-face closed pusher mesh (cluster hierarchy + rigid transform + pseudonormal sign on
-    the GPU) against the oracle's brute-force closest point + exact winding number — with the queries done inside the
-    fused kernel and with the flavour used while in contact (one wavefront per touching particle)."""
+    the GPU) against the oracle's brute-force closest point + exact winding number.  A scene with a large mesh always
+    hands its queries to k_contact_finish (one workgroup per touching particle), whatever flavour is asked for."""
     import torch
 
     monkeypatch.setenv("R2S_MESH_DEFER", defer)

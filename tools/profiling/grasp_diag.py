@@ -30,6 +30,9 @@ for t in range(steps):
         num, _ = ro.phys.collision_lists()
         nz = num[num > 0].float()
         print(f"   candidates per listed particle: mean {float(nz.mean()):.1f} max {int(nz.max())} p90 {float(nz.quantile(0.9)):.0f}; listed {int((num > 0).sum())}")
+    if os.environ.get("R2S_DIAG_DEFER"):
+        dc = ro.phys.deferred_counts()
+        print(f"   deferred mesh queries per substep: mean {dc[:-1].mean():.1f} max {int(dc[:-1].max())} last {int(dc[-2])}; near flag {int(dc[-1])}")
     print(f"step {t:2d}: phys {ms:7.3f} ms ({ms / k * 1e3:6.2f} us/substep) cand {st['self_collision_candidates']:6d} hits {st['mesh_contacts']:5d} "
           f"grasped {st['grasped_envs']} open {float(op[0]):.3f} |F|max {float(f.abs().max()):9.1f} eef_z {float(ro.eef_xyz[0, 2]):.4f} "
           f"top_z {float(x[0, :, 2].max()):.4f} max|dx| {float((x - x0).abs().max()):.4f} finite {bool(torch.isfinite(x).all())} {st['flavour']['kernel']}")
