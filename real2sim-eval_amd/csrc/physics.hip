@@ -588,86 +588,85 @@ __device__ MeshHit mesh_query_lane(const PhysDev& p, int e, int step, f3 q, bool
 }
 
 // Small scenes (every mesh small, <= 128 faces in total: two 44-face fingers + a box obstacle): k_contact_finish<3> keeps the
-// substep's triangles in registers, two per lane, loaded ONCE per particle (index -> vertex: two dependent round trips) and
-// used by the closest-point search, the winding number AND the re-query of a finger contact; the generic cooperative
-// query walks cluster -> box -> face index -> vertex chains again for each of them (~15 us per particle, measured).
+// substep's triangles in registers, loaded ONCE per particle (index -> vertex: two dependent round trips) and used by the
+// closest-point search, the winding number AND the re-query of a finger contact.  TWO wavefronts per particle, one triangle
+// per lane: the instruction stream of a lone wavefront is what a listed particle costs (about 3 ns per instruction with
+// nothing else to issue; closest point + solid angle of a triangle are ~300 instructions), so two triangles per lane in
+// one wavefront cost 2.3 us per query and one triangle per lane in two wavefronts about half (in-kernel stamps,
+// tools/probes/query_probe.py).  Both wavefronts run the whole finishing code on the same particle; the first one stores.
 struct TriRegs {
-    f3 a[2], b[2], c[2];
-    int mm[2], fm[2]; // mesh_map / face_map of the two faces
-    bool ok[2];
+    f3 a, b, c;
+    int mm, fm, face; // mesh_map / face_map of the lane's face
+    bool ok;
     f3 ctr, om, dv0, dv1; // the substep's eef centre, angular velocity and the two finger velocities (same for every lane)
 };
-__device__ __forceinline__ TriRegs load_tris(const PhysDev& p, int e, int step, int lane)
+// the lane's face: corner ids and caller-side maps do not depend on the particle — loaded at kernel entry, in flight with the list entry
+struct TriIds { int ia, ib, ic, mm, fm, face; bool ok; };
+__device__ __forceinline__ TriIds load_tri_ids(const PhysDev& p, int lane, int wave)
+{
+    TriIds d;
+    const int f = lane + 64 * wave;
+    d.ok = f < p.nF;
+    d.face = min(f, p.nF - 1);
+    d.ia = p.faces[3 * d.face]; d.ib = p.faces[3 * d.face + 1]; d.ic = p.faces[3 * d.face + 2]; // stored order == caller order for small meshes
+    d.mm = p.mesh_map[d.face]; d.fm = p.face_map[d.face];
+    return d;
+}
+__device__ __forceinline__ TriRegs load_tris(const PhysDev& p, int e, int step, const TriIds& d)
 {
     TriRegs t;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int f = lane + 64 * k;
-        t.ok[k] = f < p.nF;
-        const int fc = min(f, p.nF - 1);
-        const int ia = p.faces[3 * fc], ib = p.faces[3 * fc + 1], ic = p.faces[3 * fc + 2]; // stored order == caller order for small meshes
-        t.a[k] = mesh_vertex(p, e, step, ia); t.b[k] = mesh_vertex(p, e, step, ib); t.c[k] = mesh_vertex(p, e, step, ic);
-        t.mm[k] = p.mesh_map[fc]; t.fm[k] = p.face_map[fc];
-    }
+    t.ok = d.ok; t.face = d.face; t.mm = d.mm; t.fm = d.fm;
+    t.a = mesh_vertex(p, e, step, d.ia); t.b = mesh_vertex(p, e, step, d.ib); t.c = mesh_vertex(p, e, step, d.ic);
     t.ctr = ld3(p.interp_center, (size_t)e * p.n_sub + step); t.om = ld3(p.dyn_omega, e);
     t.dv0 = ld3(p.dyn_vel, (size_t)e * 2); t.dv1 = ld3(p.dyn_vel, (size_t)e * 2 + 1);
     return t;
 }
-// Same answer as mesh_query_wave / mesh_query_lane on such a scene: lexicographic minimum of (distance^2, face id) over the
-// faces closer than max_dist, sign from the exact winding number over all faces.
-__device__ MeshHit mesh_query_regs(const TriRegs& t, f3 q_lane, bool want)
+// Same answer as mesh_query_lane on such a scene: lexicographic minimum of (distance^2, face id) over the faces closer than
+// max_dist, sign from the exact winding number over all faces.  `q` and `want` are uniform over the workgroup (the particle of
+// lane 0); one barrier per call whether or not the query is wanted.
+__device__ __forceinline__ MeshHit mesh_query_regs(const TriRegs& t, f3 q, bool want, QShare& sm, int& parity)
 {
     MeshHit out = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
-    const int lane = (int)(threadIdx.x & 63);
-    unsigned long long pending = __builtin_amdgcn_ballot_w64(want);
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const float MAXD2 = MESH_MAX_DIST * MESH_MAX_DIST;
-    while (pending) {
-        const int L = __builtin_ctzll(pending);
-        pending &= pending - 1;
-        const f3 q = mk(bcast(q_lane.x, L), bcast(q_lane.y, L), bcast(q_lane.z, L));
-        unsigned long long key = ~0ull;
-        f3 cpb = mk(0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            float u, v;
-            int region;
-            closest_bary(t.a[k], t.b[k], t.c[k], q, u, v, region);
-            const f3 cp = t.a[k] * u + t.b[k] * v + t.c[k] * (1.f - u - v);
-            const f3 d = cp - q;
-            const float d2 = dot(d, d);
-            const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)(lane + 64 * k);
-            if (t.ok[k] && d2 < MAXD2 && kk < key) { key = kk; cpb = cp; }
-        }
+    const int par = parity;
+    parity ^= 1;
+    if (want) {
+        float u, v;
+        int region;
+        closest_bary(t.a, t.b, t.c, q, u, v, region);
+        const f3 cp = t.a * u + t.b * v + t.c * (1.f - u - v);
+        const f3 d = cp - q;
+        const float d2 = dot(d, d);
+        const unsigned long long key = (t.ok && d2 < MAXD2) ? (((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)t.face) : ~0ull;
+        const f3 a = t.a - q, b = t.b - q, c3 = t.c - q;
+        const float la = len(a), lb = len(b), lc = len(c3);
+        const float det = dot(a, cross(b, c3));
+        const float den = la * lb * lc + dot(a, b) * lc + dot(b, c3) * la + dot(c3, a) * lb;
+        const float ws = wave_sum(t.ok ? 2.f * atan2f(det, den) : 0.f);
         const unsigned long long mn = wave_min_u64(key);
-        const bool found = mn != ~0ull;
-        float sign = 1.f;
-        f3 pt = mk(0.f, 0.f, 0.f);
-        int wmm = bcasti(t.mm[0], 0), wfm = bcasti(t.fm[0], 0); // a miss reports face 0, like warp's zero-initialised query
-        if (found) {
-            const int w = __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == mn));
-            pt = mk(bcast(cpb.x, w), bcast(cpb.y, w), bcast(cpb.z, w));
-            const bool second = (mn & 0xffffffffull) >= 64;
-            wmm = bcasti(second ? t.mm[1] : t.mm[0], w); wfm = bcasti(second ? t.fm[1] : t.fm[0], w);
-            float ws = 0.f;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const f3 a = t.a[k] - q, b = t.b[k] - q, c3 = t.c[k] - q;
-                const float la = len(a), lb = len(b), lc = len(c3);
-                const float det = dot(a, cross(b, c3));
-                const float den = la * lb * lc + dot(a, b) * lc + dot(b, c3) * la + dot(c3, a) * lb;
-                if (t.ok[k]) ws += 2.f * atan2f(det, den);
-            }
-            const float wn = wave_sum(ws) / (float)(4.0 * 3.14159265358979323846);
-            sign = wn > WIND_THRESHOLD ? -1.f : 1.f;
-        }
-        if (lane == L) {
-            out.result = found;
-            out.sign = sign;
-            out.face = found ? (int)(unsigned)(mn & 0xffffffffull) : 0;
-            out.pt = pt;
-            out.mm = wmm; out.fm = wfm;
+        const int w = mn != ~0ull ? __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == mn)) : 0;
+        const f3 pt = mk(bcast(cp.x, w), bcast(cp.y, w), bcast(cp.z, w));
+        const int wmm = bcasti(t.mm, w), wfm = bcasti(t.fm, w), mm0 = bcasti(t.mm, 0), fm0 = bcasti(t.fm, 0);
+        if (lane == 0) {
+            sm.key[par][wave] = mn;
+            sm.pt[par][wave][0] = pt.x; sm.pt[par][wave][1] = pt.y; sm.pt[par][wave][2] = pt.z; sm.pt[par][wave][3] = ws;
+            sm.meta[par][wave][0] = wmm; sm.meta[par][wave][1] = wfm; sm.meta[par][wave][2] = mm0; sm.meta[par][wave][3] = fm0;
         }
     }
+    __syncthreads();
+    if (!want) return out;
+    const unsigned long long k0 = sm.key[par][0], k1 = sm.key[par][1];
+    const int fw = k1 < k0 ? 1 : 0;
+    const unsigned long long mn = fw ? k1 : k0;
+    const bool found = mn != ~0ull;
+    const float wn = (sm.pt[par][0][3] + sm.pt[par][1][3]) / (float)(4.0 * 3.14159265358979323846);
+    out.result = found && lane == 0; // the answer belongs to the particle of lane 0
+    out.sign = wn > WIND_THRESHOLD ? -1.f : 1.f;
+    out.face = found ? (int)(unsigned)(mn & 0xffffffffull) : 0; // a miss reports face 0, like warp's zero-initialised query
+    out.pt = mk(sm.pt[par][fw][0], sm.pt[par][fw][1], sm.pt[par][fw][2]);
+    out.mm = found ? sm.meta[par][fw][0] : sm.meta[par][0][2];
+    out.fm = found ? sm.meta[par][fw][1] : sm.meta[par][0][3];
     return out;
 }
 
@@ -846,7 +845,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         constexpr bool IN_PLACE = !(MAIN && MESH == 2) && NEED != 2;
         MeshHit q = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
         if (IN_PLACE)
-            q = MESH == 3 ? mesh_query_regs(*tr, next_x, need)
+            q = MESH == 3 ? mesh_query_regs(*tr, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), bcasti((int)need, 0) != 0, *qs, *qpar)
               : MESH == 2 ? mesh_query_block(p, step, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), e,
                                              bcasti((int)need, 0) != 0, *qs, *qpar, *xf0 R2S_QP_ARG) // workgroup-cooperative, call site 1
                           : mesh_query_lane(p, e, step, next_x, need);
@@ -898,7 +897,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         }
         MeshHit q2 = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
         if (IN_PLACE)
-            q2 = MESH == 3 ? mesh_query_regs(*tr, next_x, requery)
+            q2 = MESH == 3 ? mesh_query_regs(*tr, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), bcasti((int)requery, 0) != 0, *qs, *qpar)
                : MESH == 2 ? mesh_query_block(p, step, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), e,
                                               bcasti((int)requery, 0) != 0, *qs, *qpar, *xf0 R2S_QP_ARG) // call site 2
                            : mesh_query_lane(p, e, step, next_x, requery);
@@ -1174,24 +1173,26 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const f
     // Latency is everything here (a wavefront per particle, a handful of dependent round trips, the env step waits): the list
     // entry is loaded together with the count (speculatively: entries past the count are stale, never used), it carries the
     // candidate count so that the candidate indices load with x0 / v, and the box test is skipped (NEED = 1 / 2).
-    // MESHQ 3: one WAVEFRONT per listed particle; MESHQ 2: one WORKGROUP (its four wavefronts run the same code on the same
-    // particle — identical results — and share the triangle visits of the query; only the first one stores)
-    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), wpb = MESHQ == 2 ? 1 : (int)(blockDim.x >> 6);
-    const int t0 = MESHQ == 2 ? (int)blockIdx.x : (int)blockIdx.x * wpb + wave;
+    // one WORKGROUP per listed particle — four wavefronts (MESHQ 2) or two (MESHQ 3, 128 threads) that run the same code on the
+    // same particle (identical results) and share the triangles of the queries; only the first wavefront stores
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int t0 = (int)blockIdx.x;
     __shared__ QShare qshare;
     int qpar = 0;
 #ifdef R2S_PHASE_PROBE
     const long long probe_entry = (long long)wall_clock64();
 #endif
     int2 ei = p.mesh_list[min(t0, p.mesh_cap - 1)];
+    TriIds tid = {0, 0, 0, 0, 0, 0, false};
+    if (MESHQ == 3) tid = load_tri_ids(p, lane, wave);
     const int n_mesh = min(p.mesh_cnt[step], p.mesh_cap);
-    for (int t = t0; t < n_mesh; t += gridDim.x * wpb) { // MESHQ 2: a workgroup-uniform trip count (barriers inside)
+    for (int t = t0; t < n_mesh; t += gridDim.x) { // a workgroup-uniform trip count (barriers inside)
         if (t != t0) ei = p.mesh_list[t];
         const bool tagged = ei.y < 0;
         const int e = ei.x & 0xfff, i = ei.y & 0x7fffffff, cnt = ei.x >> 12;
         const size_t eb = (size_t)e * p.N;
         TriRegs tr;
-        if (MESHQ == 3) tr = load_tris(p, e, step, lane); // in flight while the impulses are summed
+        if (MESHQ == 3) tr = load_tris(p, e, step, tid); // in flight while the impulses are summed
         Xf X0; // the substep's rigid transform of the first large dynamic mesh: in flight with the particle's state
 #pragma unroll
         for (int j = 0; j < 9; ++j) X0.r[j] = (j % 4 == 0) ? 1.f : 0.f;
@@ -1200,17 +1201,17 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const f
         const f3 x0 = xyz(xv_in[(eb + i) * 2]);
         f3 v = xyz(tagged ? p.vbc[eb + i] : p.vdef[eb + i]);
         if (WITH_SELF && tagged) v = self_impulse<64>(p, xv_in, eb, i, true, x0, v, lane, cnt);
-        R2S_QP_DECL(step == p.n_sub - 2 ? t * (MESHQ == 2 ? 4 : 1) + (MESHQ == 2 ? wave : 0) : -1); // stamps of the last-but-one substep (no force accumulation)
+        R2S_QP_DECL(step == p.n_sub - 2 ? t * (MESHQ == 2 ? 4 : 2) + wave : -1); // stamps of the last-but-one substep (no force accumulation)
 #ifdef R2S_PHASE_PROBE
         if (lane == 0 && qp.wave >= 0 && qp.wave < 1024) g_query_probe[qp.wave * 32 + 31] = probe_entry;
 #endif
         R2S_QSTAMP(); // entry loaded, x0 / v (and the impulses) done
-        finish_wave<MESHQ, false, 1>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr, &qshare, &qpar, &X0, MESHQ != 2 || wave == 0 R2S_QP_ARG);
+        finish_wave<MESHQ, false, 1>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr, &qshare, &qpar, &X0, wave == 0 R2S_QP_ARG);
         R2S_QSTAMP(); // stored
     }
     if (WITH_SELF) {
 #ifdef R2S_PHASE_PROBE
-        const int gw = (int)blockIdx.x * 4 + wave; // stamps 28 / 29 / 30: part 2 entered / left, kernel entry of this wavefront
+        const int gw = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave; // stamps 28 / 29 / 30: part 2 entered / left, kernel entry of this wavefront
         if (lane == 0 && gw < 1024 && step == p.n_sub - 2) { g_query_probe[gw * 32 + 28] = (long long)wall_clock64(); g_query_probe[gw * 32 + 30] = probe_entry; }
 #endif
         constexpr int G = 16;
@@ -1972,8 +1973,8 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
     // while candidates exist (mesh queries of the rare needy particle in place).
     if (mesh != 0 && (p.mesh_defer || mesh == 2)) {
         const bool small = mesh == 1 && h->nF <= 128; // every mesh small: the substep's triangles fit two per lane
-        const dim3 g(512);                            // 2048 wavefronts, grid-stride
-#define R2S_FIN(Q, S) hipLaunchKernelGGL((k_contact_finish<Q, S>), g, dim3(256), 0, s, p, in, out, step, write_forces)
+        const dim3 g(small ? 1024 : 512);             // 2048 wavefronts, grid-stride: workgroups of two (small) or four wavefronts
+#define R2S_FIN(Q, S) hipLaunchKernelGGL((k_contact_finish<Q, S>), g, dim3(small ? 128 : 256), 0, s, p, in, out, step, write_forces)
         if (small) { if (with_self) R2S_FIN(3, true); else R2S_FIN(3, false); }
         else { if (with_self) R2S_FIN(2, true); else R2S_FIN(2, false); }
 #undef R2S_FIN
