@@ -30,10 +30,14 @@
 //   * Hash grid (wp.HashGrid 128^3, cell = 5 * collision_dist) for create_resting_case; the per-step candidate
 //     rebuild bins on a fine grid (cell = collision_dist) and restores the reference's traversal order
 //     (unpinned against warp-lang 1.7 itself, see oracle/physics_oracle_impl.inc).
-//   * Mesh queries: small meshes (<= 256 faces: fingers, boxes) per-lane brute force with the exact solid-angle
-//     winding number; large meshes (the ~25k-face pusher) through Morton-sorted 64-face clusters with rest-frame
-//     boxes, wave-cooperative, sign from pseudonormals (closed manifolds) or the exact winding number (anything
-//     else); particles in contact with a large mesh are finished by k_contact_finish, one wavefront each.
+//   * Mesh queries (wp.mesh_query_point_sign_winding_number, :322-324).  While nothing is near a mesh the fused kernel
+//     answers the rare query of a small scene itself (per-lane brute force, exact solid-angle winding number).  While
+//     something is near — and always in a scene with a large mesh (> 256 faces: the ~25k-face pusher) — the fused
+//     kernel only LISTS the particles that need a query and k_contact_finish finishes them, one workgroup per
+//     particle: two wavefronts with the scene's <= 128 triangles in registers (one per lane), or four wavefronts over
+//     a two-level box hierarchy of Morton-sorted 64-face clusters in the mesh's rest frame (sign from pseudonormals
+//     for closed manifolds, the exact winding number for anything else).  What a listed particle costs is the
+//     instruction stream of a lone wavefront (~3 ns per instruction), not memory latency: see mesh_query_block.
 
 #include "r2s_common.h"
 #include <rocprim/rocprim.hpp>
@@ -223,7 +227,8 @@ struct MeshHit {
     float sign;
     int face; // ORIGINAL (caller) face id
     f3 pt;    // closest point, world frame
-    int mm, fm; // mesh_map / face_map of `face` (filled by mesh_query_regs and mesh_query_wave; mesh_query_lane leaves the lookup to the caller)
+    int mm, fm; // mesh_map / face_map of `face` (filled by mesh_query_regs and mesh_query_block; mesh_query_lane leaves the lookup to the caller)
+    int hint;   // mesh_query_block: the cluster of the closest face (where a re-query a few micrometres away should look first)
 };
 
 __device__ __forceinline__ float box_dist2(f3 q, const float* bb)
@@ -346,19 +351,19 @@ constexpr int QWPB = 4; // wavefronts per query (k_contact_finish's workgroup)
 struct QShare {
     unsigned long long key[2][QWPB]; // double-buffered by query parity: a fast wavefront's next result must not overwrite
     float pt[2][QWPB][6];            // what a slow one is still reading (closest point, q - p; mesh frame)
-    int meta[2][QWPB][4];            // stored face, feature region, mesh kind, transform slot
+    int meta[2][QWPB][5];            // stored face, feature region, mesh kind, transform slot, cluster
     volatile int sup[QWPB][8];       // per wavefront: lanes that own the super-clusters of the current round
 };
 
-__device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, f3 q, int e, bool want, QShare& sm, int& parity, const Xf& X0 R2S_QP_PARAM)
+__device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, f3 q, int e, bool want, int hint, QShare& sm, int& parity, const Xf& X0 R2S_QP_PARAM)
 {
-    MeshHit out = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
+    MeshHit out = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0, -1};
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const float MAXD2 = MESH_MAX_DIST * MESH_MAX_DIST;
     float best = MAXD2;
     unsigned long long bestkey = ~0ull;
     f3 bcp = mk(0.f, 0.f, 0.f), bdl = mk(0.f, 0.f, 0.f); // closest point and q - p, both in the mesh's frame
-    int bstored = 0, bregion = 0, bkind = 0, bxf = -1;
+    int bstored = 0, bregion = 0, bkind = 0, bxf = -1, bcl = -1;
     // X0: the first large dynamic mesh's transform of this (env, substep), loaded by the caller together with the particle's
     // state (one load for both queries of a particle); further ones (rare) are fetched where needed
     if (want) {
@@ -373,7 +378,7 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
             return dx * dx + dy * dy + dz * dz;
         };
         // one lane per face of a run of stored faces (a = b = c3 come in the frame `qq` is in)
-        auto reduce = [&](unsigned long long key, f3 cp, f3 qq, int region, int stored, int kind, int slot) {
+        auto reduce = [&](unsigned long long key, f3 cp, f3 qq, int region, int stored, int kind, int slot, int cluster) {
             const unsigned long long mn = wave_min_u64(key);
             if (mn < bestkey) {
                 bestkey = mn;
@@ -382,10 +387,10 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
                 bcp = mk(bcast(cp.x, w), bcast(cp.y, w), bcast(cp.z, w));
                 bdl = qq - bcp;
                 bstored = bcasti(stored, w); bregion = bcasti(region, w);
-                bkind = kind; bxf = slot;
+                bkind = kind; bxf = slot; bcl = cluster;
             }
         };
-        auto visit = [&](int f0, int nf, int kind, int slot) { // a cluster of a large mesh: rest-frame triangle records
+        auto visit = [&](int cluster, int f0, int nf, int kind, int slot) { // a cluster of a large mesh: rest-frame triangle records
             const f3 qq = rest_point(slot);
             const bool act = lane < nf;
             const int f = act ? f0 + lane : f0;
@@ -399,7 +404,7 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
             const f3 d = cp - qq;
             const float d2 = dot(d, d);
             const unsigned long long key = (act && d2 < MAXD2) ? (((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)forig) : ~0ull;
-            reduce(key, cp, qq, region, f, kind, slot);
+            reduce(key, cp, qq, region, f, kind, slot, cluster);
         };
         // ---- small meshes of the scene (gripper fingers next to a large obstacle): world frame, through the face table
         for (int k = 0; k < p.n_small; ++k) {
@@ -423,17 +428,23 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
                     const float d2 = dot(d, d);
                     if (d2 < MAXD2) key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)p.face_orig[f];
                 }
-                reduce(key, cp, q, region, f, kind, -1);
+                reduce(key, cp, q, region, f, kind, -1, -1);
             }
         }
         // ---- large meshes
         int C0 = -1; // the cluster every wavefront has visited
+        if (hint >= 0) { // a re-query next to the previous answer: its cluster first, no search for the nearest box
+            C0 = hint;
+            const int4 ci = p.cl_info[C0];
+            visit(C0, ci.w, ci.y >> 8, ci.y & 3, ci.z);
+            R2S_QSTAMP(); // nearest cluster done
+        }
         for (int sb = 0; sb < p.n_sup; sb += 64) {
             const int s = min(sb + lane, p.n_sup - 1);
             const int4 si = p.sup_info[s]; // {first cluster, clusters, transform slot, mesh kind}
             float d2s = box6(p.sup_box, p.n_sup, s, rest_point(si.z));
             if (sb + lane >= p.n_sup) d2s = 3.0e38f;
-            if (sb == 0 && bestkey == ~0ull) { // step 1: nearest first
+            if (sb == 0 && bestkey == ~0ull && hint < 0) { // step 1: nearest first
                 const unsigned long long near = wave_min_u64(((unsigned long long)__float_as_uint(d2s) << 32) | (unsigned)lane);
                 if (__uint_as_float((unsigned)(near >> 32)) < best * 1.0001f + 1e-12f) {
                     const int L = (int)(near & 63);
@@ -443,7 +454,7 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
                     if (__uint_as_float((unsigned)(nc >> 32)) < best * 1.0001f + 1e-12f) {
                         C0 = c0 + (int)(nc & 63);
                         const int4 ci = p.cl_info[C0];
-                        visit(ci.w, ci.y >> 8, kind, slot);
+                        visit(C0, ci.w, ci.y >> 8, kind, slot);
                     }
                 }
                 R2S_QSTAMP(); // nearest cluster done
@@ -470,7 +481,7 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
                     if (!(bcast(d2c, L) < best * 1.0001f + 1e-12f)) continue; // cannot beat this wavefront's best any more
                     const int cc = bcasti(c, L);
                     const int4 ci = p.cl_info[cc];
-                    visit(ci.w, ci.y >> 8, bcasti(kind, L), bcasti(slot, L));
+                    visit(cc, ci.w, ci.y >> 8, bcasti(kind, L), bcasti(slot, L));
                 }
             }
         }
@@ -483,7 +494,7 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
         sm.key[par][wave] = bestkey;
         sm.pt[par][wave][0] = bcp.x; sm.pt[par][wave][1] = bcp.y; sm.pt[par][wave][2] = bcp.z;
         sm.pt[par][wave][3] = bdl.x; sm.pt[par][wave][4] = bdl.y; sm.pt[par][wave][5] = bdl.z;
-        sm.meta[par][wave][0] = bstored; sm.meta[par][wave][1] = bregion; sm.meta[par][wave][2] = bkind; sm.meta[par][wave][3] = bxf;
+        sm.meta[par][wave][0] = bstored; sm.meta[par][wave][1] = bregion; sm.meta[par][wave][2] = bkind; sm.meta[par][wave][3] = bxf; sm.meta[par][wave][4] = bcl;
     }
     __syncthreads();
     if (!want) return out;
@@ -496,7 +507,7 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
     }
     bcp = mk(sm.pt[par][fw][0], sm.pt[par][fw][1], sm.pt[par][fw][2]);
     bdl = mk(sm.pt[par][fw][3], sm.pt[par][fw][4], sm.pt[par][fw][5]);
-    bstored = sm.meta[par][fw][0]; bregion = sm.meta[par][fw][1]; bkind = sm.meta[par][fw][2]; bxf = sm.meta[par][fw][3];
+    bstored = sm.meta[par][fw][0]; bregion = sm.meta[par][fw][1]; bkind = sm.meta[par][fw][2]; bxf = sm.meta[par][fw][3]; bcl = sm.meta[par][fw][4];
     const bool found = bestkey != ~0ull;
     const int bface = found ? (int)(unsigned)(bestkey & 0xffffffffull) : 0; // a miss reports face 0, like warp's zero-initialised query
     float sign = 1.f;
@@ -543,6 +554,7 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
     out.pt = bpt;
     out.mm = mm;
     out.fm = fm;
+    out.hint = found ? bcl : -1;
     return out;
 }
 
@@ -795,17 +807,18 @@ __device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 
 }
 
 // ---- everything after the velocity update: mesh collision, ground, store ------------------------------------
-// Called by EVERY lane of a wavefront at the same point (the mesh queries inside are wave-cooperative); `fin` says
-// whether this lane has a particle to finish.  Shared by the fused substep and the self-collision finishing kernel.
-// MESH: 0 no meshes, 1 small meshes only (per-lane queries), 2 a large mesh is present (wave-cooperative queries)
+// Called by EVERY lane of a workgroup at the same point (the mesh queries of MESH 2 / 3 are workgroup-cooperative, with a
+// barrier inside); `fin` says whether this lane has a particle to finish, `store` whether it is the one that writes it back.
+// Shared by the fused substep and the finishing kernels.
+// MESH: 0 no meshes, 1 small meshes only (per-lane queries), 2 a large mesh is present (never queried in the fused kernel)
 // MAIN + p.mesh_defer (the fused kernel and k_self_finish): a particle that needs a mesh query is not queried here.  A query
 // is thousands of instructions (closest point over the near meshes' faces + the exact winding number over all faces, twice
-// for finger contacts) or, for a large mesh, ~5 us of dependent round trips — and the particles that need one sit next to
+// for finger contacts) or, for a large mesh, a walk through its box hierarchy — and the particles that need one sit next to
 // each other, so one wavefront would run dozens back to back while the rest of the chip waits (measured: 36 touching
 // particles stretched a 9 us substep to 195 us).  Instead it stores its velocity, appends itself to the substep's list and
-// is finished by k_contact_finish, one WAVEFRONT per particle, all of them in flight at once.  Without p.mesh_defer (the
+// is finished by k_contact_finish, one WORKGROUP per particle, all of them in flight at once.  Without p.mesh_defer (the
 // flavour captured while nothing is near a mesh) the rare needy particle is queried in place.
-// MESH: 3 = small scene with the triangles in registers (k_contact_finish<3>; one particle per wavefront)
+// MESH: 3 = small scene with the triangles in registers (k_contact_finish<3>; two wavefronts per particle)
 // NEED: 0 = decide by the exact early-out; 1 = query without testing (the fused kernel already found the particle in reach of a
 // mesh: saves the finishing kernel one dependent round trip for the boxes); 2 = never query (the fused kernel's WIDENED test
 // found nothing in reach: mesh_collision then only advances the position, :321 / :420)
@@ -824,9 +837,9 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         else if (NEED == 0 && fin) need = mesh_need(p, e, step, next_x, 0.f, near);
         if (MAIN) { // count the particles near a mesh (the host picks the next step's graph flavour from the total) and, in
                     // deferring mode, hand the ones that need a query to k_contact_finish
-            // only "anything near?" is consumed (the host picks the next step's flavour from it): one plain store per wavefront.
-            // (A per-lane atomicAdd on this single word — thousands per substep while an object sits next to a mesh — serialised
-            // in the L2 and cost more than all the queries: +28 us per substep in the pusher scene, whatever the query did.)
+            // only "anything near?" is consumed (the host picks the next step's flavour from it): one plain store per wavefront
+            // instead of a per-lane atomicAdd on a single word (thousands per substep while an object sits next to a mesh:
+            // 1.5 - 2 us per substep in the pusher and grasp scenes)
             const unsigned long long nm = __builtin_amdgcn_ballot_w64(near);
             if (nm && (int)(threadIdx.x & 63) == __builtin_ctzll(nm)) p.mesh_cnt[p.n_sub] = 1;
             if (need && (p.mesh_defer || MESH == 2)) { // large scenes always defer: the fused kernel carries no query code
@@ -847,7 +860,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         if (IN_PLACE)
             q = MESH == 3 ? mesh_query_regs(*tr, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), bcasti((int)need, 0) != 0, *qs, *qpar)
               : MESH == 2 ? mesh_query_block(p, step, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), e,
-                                             bcasti((int)need, 0) != 0, *qs, *qpar, *xf0 R2S_QP_ARG) // workgroup-cooperative, call site 1
+                                             bcasti((int)need, 0) != 0, -1, *qs, *qpar, *xf0 R2S_QP_ARG) // workgroup-cooperative, call site 1
                           : mesh_query_lane(p, e, step, next_x, need);
         R2S_QSTAMP(); // first query back
         // per-lane response; lanes that must re-query (gripper branch, :394-408) park their state and meet again below
@@ -899,7 +912,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         if (IN_PLACE)
             q2 = MESH == 3 ? mesh_query_regs(*tr, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), bcasti((int)requery, 0) != 0, *qs, *qpar)
                : MESH == 2 ? mesh_query_block(p, step, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), e,
-                                              bcasti((int)requery, 0) != 0, *qs, *qpar, *xf0 R2S_QP_ARG) // call site 2
+                                              bcasti((int)requery, 0) != 0, bcasti(q.hint, 0), *qs, *qpar, *xf0 R2S_QP_ARG) // call site 2
                            : mesh_query_lane(p, e, step, next_x, requery);
         R2S_QSTAMP(); // response + second query back
         if (requery) {
@@ -1155,9 +1168,10 @@ __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const floa
 
 // ONE finishing kernel per substep for everything the fused kernel could not finish in its own thread (captured into the
 // graph flavours used while something is near a mesh):
-//   part 1  the mesh list, one WAVEFRONT per particle: particles whose query was deferred, and — tagged — particles that
+//   part 1  the mesh list, one WORKGROUP per particle: particles whose query was deferred, and — tagged — particles that
 //           also have self-collision candidates (their impulses are applied first, 64 lanes over the candidates);
-//           MESHQ = 3: every mesh small, the substep's triangles live in registers; MESHQ = 2: generic cooperative query;
+//           MESHQ = 3: every mesh small, the substep's triangles live in registers (two wavefronts, 128 threads);
+//           MESHQ = 2: a large mesh, box hierarchy (four wavefronts);
 //   part 2  (WITH_SELF) the remaining particles of the candidate list, 16 lanes each, finished in place.
 // Both parts only read what the fused kernel published, so they need no order between them: one launch boundary per
 // substep instead of two (k_self_finish + a mesh kernel), and the two kinds of work overlap.
@@ -1969,7 +1983,7 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
     if (h->pb == 256) launch_substep_layout<256, 1024>(p, grid, in, out, step, write_forces, with_self, mesh, s);
     else launch_substep_layout<128, 768>(p, grid, in, out, step, write_forces, with_self, mesh, s);
     // What the fused kernel left unfinished: with something near a mesh (mesh_defer) ONE combined finishing kernel per substep —
-    // deferred mesh queries, one wavefront per particle, plus the self-collision impulses; otherwise only k_self_finish
+    // deferred mesh queries, one workgroup per particle, plus the self-collision impulses; otherwise only k_self_finish
     // while candidates exist (mesh queries of the rare needy particle in place).
     if (mesh != 0 && (p.mesh_defer || mesh == 2)) {
         const bool small = mesh == 1 && h->nF <= 128; // every mesh small: the substep's triangles fit two per lane
