@@ -203,6 +203,19 @@ __device__ __forceinline__ void closest_bary(f3 a, f3 b, f3 c, f3 q, float& u, f
     u = 1.f - vv - ww; v = vv; region = 0;
 }
 
+// Particle state of all environments: three planes of 8 bytes, [3][n_env * N] — xy | (z, vz) | vxy — which is the LDS window's
+// own layout (24 B per particle, no padding; the fused kernel stages a record with three 8-byte loads and three 8-byte LDS
+// writes, nothing to repack).
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct StateC { const v2f* p; size_t n; };
+struct StateM { v2f* p; size_t n; operator StateC() const { return {p, n}; } };
+__device__ __forceinline__ f3 st_x(StateC s, size_t i) { const v2f a = s.p[i], b = s.p[s.n + i]; return mk(a.x, a.y, b.x); }
+__device__ __forceinline__ float4 st_x4(StateC s, size_t i) { const v2f a = s.p[i], b = s.p[s.n + i]; return make_float4(a.x, a.y, b.x, 0.f); }
+__device__ __forceinline__ void st_store(StateM s, size_t i, f3 x, f3 v)
+{
+    s.p[i] = (v2f){x.x, x.y}; s.p[s.n + i] = (v2f){x.z, v.z}; s.p[2 * s.n + i] = (v2f){v.x, v.y};
+}
+
 // -DR2S_PHASE_PROBE: wall-clock stamps of one finishing wavefront per particle (k_contact_finish), in program order
 #ifdef R2S_PHASE_PROBE
 __device__ long long g_query_probe[1024 * 32];
@@ -688,7 +701,6 @@ __device__ __forceinline__ MeshHit mesh_query_regs(const TriRegs& t, f3 q, bool 
 // in adjacency order instead of atomic order.  The hot loop: FMA contraction allowed, 1-ulp rsq instead of
 // sqrt + three divides (the reference's own float atomics reorder sums far more than this perturbs them).
 #pragma clang fp contract(fast)
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 // One neighbour, 19 VALU instructions: with d = xj - xi (NOT normalised), r = 1 / |d|, L = |d|, t = (vj - vi) . d
 //     F = [k (L / rest - 1) + c (dv . d r)] d r  =  [(a L - k) + (c r) t] r d,      a = k / rest (per slot, precomputed),
@@ -756,7 +768,7 @@ __device__ __forceinline__ void spring_group(const PhysDev& p, const AdjGroup& g
 }
 
 template <int RCAP>
-__device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* __restrict__ xv,
+__device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const StateC xv,
                                                const __attribute__((address_space(3))) char* win, size_t env_base, int sl, int ln, f3 xi,
                                                f3 vi, int gbase, int ngroups, AdjGroup g0)
 {
@@ -777,9 +789,9 @@ __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const float4* _
     const int rdeg = p.rslice_deg[sl];
     for (int n = 0; n < rdeg; ++n) {
         const int4 en = ra[n * SLICE];
-        const size_t gi = (env_base + (size_t)en.x) * 2;
-        const float4 xj = xv[gi], vj = xv[gi + 1];
-        spring_term((v2f){xj.x, xj.y}, xj.z, (v2f){vj.x, vj.y}, vj.z, xi, vi, __int_as_float(en.y), __int_as_float(en.z), p.dashpot, fxy, fz);
+        const size_t gi = env_base + (size_t)en.x;
+        const v2f jxy = xv.p[gi], jz = xv.p[xv.n + gi], jv = xv.p[2 * xv.n + gi];
+        spring_term(jxy, jz.x, jv, jz.y, xi, vi, __int_as_float(en.y), __int_as_float(en.z), p.dashpot, fxy, fz);
     }
     return {fxy.x, fxy.y, fz};
 }
@@ -824,7 +836,7 @@ __device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 
 // found nothing in reach: mesh_collision then only advances the position, :321 / :420)
 template <int MESH, bool MAIN = false, int NEED = 0>
 __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v, bool fin,
-                                            float4* __restrict__ xv_out, const TriRegs* tr, QShare* qs, int* qpar, const Xf* xf0, bool store R2S_QP_PARAM)
+                                            const StateM xv_out, const TriRegs* tr, QShare* qs, int* qpar, const Xf* xf0, bool store R2S_QP_PARAM)
 {
     f3 x = x0;
     // mesh_collision, :295-421 — advances x by v*dt for EVERY particle (:321, :420)
@@ -960,14 +972,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
             toi = 0.f;
         }
         const f3 xn = x + v * toi + v1 * (p.dt - toi);
-#ifdef R2S_NT_STORE
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store((v4f){xn.x, xn.y, xn.z, 0.f}, (v4f*)(xv_out + (eb + i) * 2));
-        __builtin_nontemporal_store((v4f){v1.x, v1.y, v1.z, 0.f}, (v4f*)(xv_out + (eb + i) * 2 + 1));
-#else
-        xv_out[(eb + i) * 2] = make_float4(xn.x, xn.y, xn.z, 0.f);
-        xv_out[(eb + i) * 2 + 1] = make_float4(v1.x, v1.y, v1.z, 0.f);
-#endif
+        st_store(xv_out, eb + i, xn, v1);
     }
 }
 
@@ -993,7 +998,7 @@ extern "C" int r2s_phys_debug_phase_probe(long long* out, int n)
 #endif
 
 template <int B, int RCAP, bool SELF, int MESH>
-__device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
+__device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_in, const StateM xv_out, int step,
                                              int write_forces)
 {
     static_assert(B % SLICE == 0 && RCAP >= B && RCAP * 8 <= 65536, "window offsets are u16 bytes");
@@ -1027,27 +1032,27 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __r
         const int r = tid + k * B;
         part[k] = r < B ? i : (r < per_env ? p.halo_ids[h0 + r - B] : p.N);
     }
-    float4 qx[K], qv[K];
+    v2f qa[K], qb[K], qc[K]; // xy | (z, vz) | vxy: the state planes are the window's planes
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const size_t g = (eb + (size_t)min(part[k], p.N - 1)) * 2;
-        if (part[k] < p.N) { qx[k] = xv_in[g]; qv[k] = xv_in[g + 1]; }
-        else { qx[k] = make_float4(0.f, 0.f, 0.f, 0.f); qv[k] = qx[k]; }
+        const size_t g = eb + (size_t)min(part[k], p.N - 1);
+        if (part[k] < p.N) { qa[k] = xv_in.p[g]; qb[k] = xv_in.p[xv_in.n + g]; qc[k] = xv_in.p[2 * xv_in.n + g]; }
+        else { qa[k] = (v2f){0.f, 0.f}; qb[k] = qa[k]; qc[k] = qa[k]; }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int r = tid + k * B;
         if (r < RCAP && part[k] < p.N) {
-            win_s[r] = (v2f){qx[k].x, qx[k].y};
-            win_s[RCAP + 1 + r] = (v2f){qx[k].z, qv[k].z};
-            win_s[2 * (RCAP + 1) + r] = (v2f){qv[k].x, qv[k].y};
+            win_s[r] = qa[k];
+            win_s[RCAP + 1 + r] = qb[k];
+            win_s[2 * (RCAP + 1) + r] = qc[k];
         }
     }
     __syncthreads();
     R2S_STAMP(1);
     // no early exit: lanes without a particle stay in the wavefront (the mesh queries at the end are wave-cooperative)
     // and simply compute on clamped indices without storing anything
-    const f3 x0 = mk(qx[0].x, qx[0].y, qx[0].z), v0 = mk(qv[0].x, qv[0].y, qv[0].z); // round 0 staged this lane's own record
+    const f3 x0 = mk(qa[0].x, qa[0].y, qb[0].x), v0 = mk(qc[0].x, qc[0].y, qb[0].y); // round 0 staged this lane's own record
     const float m1 = p.masses[ic];
 
     // eval_springs + update_vel_from_force
@@ -1093,7 +1098,7 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const float4* __r
 // of the benchmark's 1888 work items are left for a second round — was measured in round 2: 23.3 vs 22.1 us per substep with
 // two chains, 24.4 vs 24.8 with one.  More residency does not pay; the layouts stay <256,1024> and <128,768>.)
 template <int B, int RCAP, bool SELF, int MESH>
-__global__ void __launch_bounds__(B) k_substep(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
+__global__ void __launch_bounds__(B) k_substep(const PhysDev p, const StateC xv_in, const StateM xv_out, int step,
                                                int write_forces)
 {
     substep_body<B, RCAP, SELF, MESH>(p, xv_in, xv_out, step, write_forces);
@@ -1101,7 +1106,7 @@ __global__ void __launch_bounds__(B) k_substep(const PhysDev p, const float4* __
 // object_collision for ONE particle by a whole wavefront / a group of lanes: the lanes stride over its candidates (up to 500,
 // each a dependent gather of the partner's position and published velocity), `G` = lanes per particle (a power of two).
 template <int G>
-__device__ __forceinline__ f3 self_impulse(const PhysDev& p, const float4* __restrict__ xv_in, size_t eb, int i, bool act, f3 x0, f3 v, int sub,
+__device__ __forceinline__ f3 self_impulse(const PhysDev& p, const StateC xv_in, size_t eb, int i, bool act, f3 x0, f3 v, int sub,
                                            int cnt)
 {
     float valid = 0.f, m1 = 1.f;
@@ -1111,7 +1116,7 @@ __device__ __forceinline__ f3 self_impulse(const PhysDev& p, const float4* __res
         const int mask1 = p.masks[i];
         for (int k = sub; k < cnt; k += G) { // cnt rides in the list entry: the candidate indices load in the same round trip as x0 / v
             const int j = p.coll_idx[(eb + i) * (size_t)p.coll_cap + k];
-            const f3 x2 = xyz(xv_in[(eb + j) * 2]);
+            const f3 x2 = st_x(xv_in, eb + j);
             const f3 v2 = xyz(p.vbc[eb + j]); // j lists i too (the candidate relation is symmetric; a capped row still has
                                                // coll_num > 0), so j published its velocity in the fused kernel
             const float m2 = p.masses[j];
@@ -1146,7 +1151,7 @@ __device__ __forceinline__ f3 self_impulse(const PhysDev& p, const float4* __res
 // the group's first lane carries the particle through finish_wave (which defers it to k_contact_finish if it also touches a
 // mesh).  The per-pair arithmetic is the reference's, the sum order over candidates is lane-strided instead of sequential.
 template <int MESH>
-__global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
+__global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const StateC xv_in, const StateM xv_out, int step,
                                                      int write_forces)
 {
     constexpr int G = 16;
@@ -1159,7 +1164,7 @@ __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const floa
         const bool act = t < n && (ei.x & 0xfff) >= p.e0 && (ei.x & 0xfff) < p.e0 + p.ne; // this chain's environments only
         const int e = ei.x & 0xfff, i = ei.y, cnt = ei.x >> 12;
         const size_t eb = (size_t)e * p.N;
-        const f3 x0 = xyz(xv_in[(eb + i) * 2]);
+        const f3 x0 = st_x(xv_in, eb + i);
         const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub, cnt);
         R2S_QP_DECL(-1);
         finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out, nullptr, nullptr, nullptr, nullptr, true R2S_QP_ARG);
@@ -1176,7 +1181,7 @@ __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const floa
 // Both parts only read what the fused kernel published, so they need no order between them: one launch boundary per
 // substep instead of two (k_self_finish + a mesh kernel), and the two kinds of work overlap.
 template <int MESHQ, bool WITH_SELF>
-__global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const float4* __restrict__ xv_in, float4* __restrict__ xv_out, int step,
+__global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const StateC xv_in, const StateM xv_out, int step,
                                                         int write_forces)
 {
     // The few wavefronts of this kernel are a chain of dependent round trips that the whole env step waits for, and they share
@@ -1212,7 +1217,7 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const f
         for (int j = 0; j < 9; ++j) X0.r[j] = (j % 4 == 0) ? 1.f : 0.f;
         X0.t[0] = X0.t[1] = X0.t[2] = 0.f;
         if (MESHQ == 2 && p.n_xf > 0) X0 = xf_load_slot(p, __builtin_amdgcn_readfirstlane(e), step, 0);
-        const f3 x0 = xyz(xv_in[(eb + i) * 2]);
+        const f3 x0 = st_x(xv_in, eb + i);
         f3 v = xyz(tagged ? p.vbc[eb + i] : p.vdef[eb + i]);
         if (WITH_SELF && tagged) v = self_impulse<64>(p, xv_in, eb, i, true, x0, v, lane, cnt);
         R2S_QP_DECL(step == p.n_sub - 2 ? t * (MESHQ == 2 ? 4 : 2) + wave : -1); // stamps of the last-but-one substep (no force accumulation)
@@ -1243,7 +1248,7 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const f
             const int e = ci.x & 0xfff, i = ci.y, cnt = ci.x >> 12;
             const size_t eb = (size_t)e * p.N;
             const bool act = t < n && e >= p.e0 && e < p.e0 + p.ne && p.cand_mark[eb + i] != step + 1; // not already done in part 1
-            const f3 x0 = xyz(xv_in[(eb + i) * 2]);
+            const f3 x0 = st_x(xv_in, eb + i);
             const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub, cnt);
             // the fused kernel's test — widened by 2 mm = 40 m/s of velocity change in one substep — found no mesh in reach of this
             // particle: no query, mesh_collision only advances it
@@ -1275,23 +1280,25 @@ __global__ void k_sum_i32(const int* __restrict__ a, int n, int stride, int* __r
 }
 
 // ---- state pack / unpack: caller order [env][user index][3]  <->  internal [env][Morton index]{x,v} -------
-__global__ void k_pack(int N, int E, const int* __restrict__ inv, const float* __restrict__ x, const float* __restrict__ v, float4* __restrict__ xv)
+__global__ void k_pack(int N, int E, const int* __restrict__ inv, const float* __restrict__ x, const float* __restrict__ v, const StateM xv)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
     if (u >= N) return;
-    const size_t src = ((size_t)e * N + u) * 3, dst = ((size_t)e * N + inv[u]) * 2;
-    if (x) xv[dst] = make_float4(x[src], x[src + 1], x[src + 2], 0.f);
-    if (v) xv[dst + 1] = make_float4(v[src], v[src + 1], v[src + 2], 0.f);
+    const size_t src = ((size_t)e * N + u) * 3, dst = (size_t)e * N + inv[u];
+    float* f = (float*)xv.p; // x and v may be set separately: plane 1 holds one component of each
+    if (x) { xv.p[dst] = (v2f){x[src], x[src + 1]}; f[2 * (xv.n + dst)] = x[src + 2]; }
+    if (v) { xv.p[2 * xv.n + dst] = (v2f){v[src], v[src + 1]}; f[2 * (xv.n + dst) + 1] = v[src + 2]; }
 }
-__global__ void k_unpack(int N, int E, const int* __restrict__ inv, const float4* __restrict__ xv, float* __restrict__ x, float* __restrict__ v)
+__global__ void k_unpack(int N, int E, const int* __restrict__ inv, const StateC xv, float* __restrict__ x, float* __restrict__ v)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
     if (u >= N) return;
-    const size_t dst = ((size_t)e * N + u) * 3, src = ((size_t)e * N + inv[u]) * 2;
-    if (x) { const float4 a = xv[src]; x[dst] = a.x; x[dst + 1] = a.y; x[dst + 2] = a.z; }
-    if (v) { const float4 a = xv[src + 1]; v[dst] = a.x; v[dst + 1] = a.y; v[dst + 2] = a.z; }
+    const size_t dst = ((size_t)e * N + u) * 3, src = (size_t)e * N + inv[u];
+    const v2f b = xv.p[xv.n + src];
+    if (x) { const v2f a = xv.p[src]; x[dst] = a.x; x[dst + 1] = a.y; x[dst + 2] = b.x; }
+    if (v) { const v2f c = xv.p[2 * xv.n + src]; v[dst] = c.x; v[dst + 1] = c.y; v[dst + 2] = b.y; }
 }
 // candidate lists back to the caller's indexing (debug / parity taps)
 __global__ void k_lists_to_user(int N, int E, int cap, const int* __restrict__ perm, const int* __restrict__ num, const int* __restrict__ idx,
@@ -1561,13 +1568,13 @@ __device__ __forceinline__ int grid_cell(int x, int y, int z)
 
 // One (cell key, USER index) pair per particle, emitted in user order so that the stable sort leaves every cell's
 // points in ascending user index — the traversal order of warp's grid (its ids are the caller's indices).
-__global__ void k_grid_keys(int N, int E, const int* __restrict__ inv, const float4* __restrict__ xv, float cell_inv,
+__global__ void k_grid_keys(int N, int E, const int* __restrict__ inv, const StateC xv, float cell_inv,
                             uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
     if (u >= N) return;
-    const float4 q = xv[((size_t)e * N + inv[u]) * 2];
+    const float4 q = st_x4(xv, (size_t)e * N + inv[u]);
     const int c = grid_cell((int)(q.x * cell_inv), (int)(q.y * cell_inv), (int)(q.z * cell_inv));
     keys[(size_t)e * N + u] = ((uint32_t)e << GRID_CELL_BITS) | (uint32_t)c;
     vals[(size_t)e * N + u] = (uint32_t)u;
@@ -1597,14 +1604,14 @@ __device__ __forceinline__ QBox query_box(float4 q, float r, float cell_inv)
 // build_resting_collision_pairs, :272-291 (bitset instead of N x N bytes; rows/bits are INTERNAL indices, the
 // `index < i` test is on USER indices like the reference)
 __global__ void k_build_resting(int N, int E, int words, const int* __restrict__ perm, const int* __restrict__ inv,
-                                const float4* __restrict__ xv, float radius, float cell_inv, const uint32_t* __restrict__ keys,
+                                const StateC xv, float radius, float cell_inv, const uint32_t* __restrict__ keys,
                                 const uint32_t* __restrict__ ids, uint32_t* __restrict__ bits)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
     if (i >= N) return;
     const int ui = perm[i];
-    const float4 q = xv[((size_t)e * N + i) * 2];
+    const float4 q = st_x4(xv, (size_t)e * N + i);
     const QBox b = query_box(q, radius, cell_inv);
     uint32_t* my = bits + ((size_t)e * N) * words;
     for (int z = b.zs; z <= b.ze; ++z)
@@ -1624,7 +1631,7 @@ __global__ void k_build_resting(int N, int E, int words, const int* __restrict__
 }
 
 // update_potential_collision, :196-227 (same candidate order: cells x-fastest, user ids ascending inside a cell)
-__global__ void k_candidates(int N, int E, int words, int cap, const int* __restrict__ inv, const float4* __restrict__ xv,
+__global__ void k_candidates(int N, int E, int words, int cap, const int* __restrict__ inv, const StateC xv,
                              const int* __restrict__ masks, float cd, float radius, float cell_inv, const uint32_t* __restrict__ keys,
                              const uint32_t* __restrict__ ids, const uint32_t* __restrict__ bits, int* __restrict__ coll_idx,
                              int* __restrict__ coll_num, int* __restrict__ max_count)
@@ -1633,7 +1640,7 @@ __global__ void k_candidates(int N, int E, int words, int cap, const int* __rest
     const int e = blockIdx.y;
     if (i >= N) return;
     const size_t eb = (size_t)e * N;
-    const float4 q = xv[(eb + i) * 2];
+    const float4 q = st_x4(xv, eb + i);
     const f3 x1 = xyz(q);
     const int mask1 = masks[i];
     // The reference visits every cell overlapping [x - 5cd, x + 5cd] and keeps j only if |xj - xi| < cd.  Such a j
@@ -1651,7 +1658,7 @@ __global__ void k_candidates(int N, int E, int words, int cap, const int* __rest
                 for (int k = s; k < t; ++k) {
                     const int j = inv[ids[k]];
                     if (j == i) continue;
-                    const f3 dis = xyz(xv[(eb + j) * 2]) - x1;
+                    const f3 dis = st_x(xv, eb + j) - x1;
                     if (!(len(dis) < cd)) continue;          // cheap test first; same set as the reference order
                     if (row[j >> 5] & (1u << (j & 31))) continue; // resting pair (stored symmetrically)
                     if (mask1 == masks[j]) continue;
@@ -1681,16 +1688,16 @@ __global__ void k_cell_clear(int N, int E, const uint32_t* __restrict__ keys, in
 // key is (rank of the coarse-cell offset in 0..26, user index).  Identical lists, ~15x fewer distance tests.
 __device__ __forceinline__ uint32_t fine_cell(int x, int y, int z) { return ((uint32_t)(z & 127) << 14) | ((uint32_t)(y & 127) << 7) | (uint32_t)(x & 127); }
 
-__global__ void k_fine_keys(int N, int E, const float4* __restrict__ xv, float cd_inv, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+__global__ void k_fine_keys(int N, int E, const StateC xv, float cd_inv, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
     if (i >= N) return;
-    const float4 q = xv[((size_t)e * N + i) * 2];
+    const float4 q = st_x4(xv, (size_t)e * N + i);
     keys[(size_t)e * N + i] = ((uint32_t)e << GRID_CELL_BITS) | fine_cell((int)(q.x * cd_inv), (int)(q.y * cd_inv), (int)(q.z * cd_inv));
     vals[(size_t)e * N + i] = (uint32_t)i;
 }
-__global__ void k_fine_mark(int N, int E, const float4* __restrict__ xv, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ids,
+__global__ void k_fine_mark(int N, int E, const StateC xv, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ids,
                             int2* __restrict__ tab, float4* __restrict__ xs)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1701,7 +1708,7 @@ __global__ void k_fine_mark(int N, int E, const float4* __restrict__ xv, const u
     if (k == 0 || keys[g - 1] != key) tab[key].x = (int)g;
     if (k == N - 1 || keys[g + 1] != key) tab[key].y = (int)g + 1;
     const int j = (int)ids[g];
-    const float4 q = xv[((size_t)e * N + j) * 2];
+    const float4 q = st_x4(xv, (size_t)e * N + j);
     xs[g] = make_float4(q.x, q.y, q.z, __int_as_float(j));
 }
 __device__ __forceinline__ uint64_t cand_key(float4 qi, float4 qj, float cell_inv, int user_j)
@@ -1710,7 +1717,7 @@ __device__ __forceinline__ uint64_t cand_key(float4 qi, float4 qj, float cell_in
               dz = (int)(qj.z * cell_inv) - (int)(qi.z * cell_inv);
     return ((uint64_t)(uint32_t)(((dz + 1) * 3 + (dy + 1)) * 3 + (dx + 1)) << 32) | (uint32_t)user_j;
 }
-__global__ void k_candidates_fine(int N, int E, int words, int cap, const float4* __restrict__ xv, const int* __restrict__ masks,
+__global__ void k_candidates_fine(int N, int E, int words, int cap, const StateC xv, const int* __restrict__ masks,
                                   const int* __restrict__ perm, float cd, float cd_inv, float cell_inv, const int2* __restrict__ tab,
                                   const float4* __restrict__ xs, const uint32_t* __restrict__ bits, int* __restrict__ coll_idx,
                                   int* __restrict__ coll_num, int* __restrict__ max_count)
@@ -1719,7 +1726,7 @@ __global__ void k_candidates_fine(int N, int E, int words, int cap, const float4
     const int e = blockIdx.y;
     if (i >= N) return;
     const size_t eb = (size_t)e * N;
-    const float4 q = xv[(eb + i) * 2];
+    const float4 q = st_x4(xv, eb + i);
     const f3 x1 = xyz(q);
     const int mask1 = masks[i];
     const int fx = (int)(q.x * cd_inv), fy = (int)(q.y * cd_inv), fz = (int)(q.z * cd_inv);
@@ -1748,13 +1755,13 @@ __global__ void k_candidates_fine(int N, int E, int words, int cap, const float4
                     int pos = n; // insertion sort by key
                     while (pos > 0) {
                         const int jp = out[pos - 1];
-                        const float4 cp = xv[(eb + jp) * 2];
+                        const float4 cp = st_x4(xv, eb + jp);
                         if (cand_key(q, cp, cell_inv, perm[jp]) < key) break;
                         out[pos] = jp;
                         --pos;
                     }
                     out[pos] = j;
-                    if (n + 1 == cap) { const int jl = out[cap - 1]; worst = cand_key(q, xv[(eb + jl) * 2], cell_inv, perm[jl]); }
+                    if (n + 1 == cap) { const int jl = out[cap - 1]; worst = cand_key(q, st_x4(xv, eb + jl), cell_inv, perm[jl]); }
                 }
             }
     coll_num[eb + i] = min(cnt, cap);
@@ -1793,7 +1800,8 @@ struct R2SPhys {
     std::vector<int> h_radj_spring, h_radj_nbr, h_radj_self; // remote ELL slot -> spring / neighbour / owner
     std::vector<int> h_mesh_map, h_face_map;
     // device
-    float4* xv[2] = {nullptr, nullptr};
+    v2f* xv[2] = {nullptr, nullptr}; // ping-pong state, three 8-byte planes each (StateC / StateM)
+    StateM state(int b) const { return {xv[b], (size_t)E * N}; }
     int cur = 0;
     int *d_slice_off = nullptr, *d_slice_deg = nullptr, *d_rslice_off = nullptr, *d_rslice_deg = nullptr;
     unsigned short* d_adj_idx = nullptr;
@@ -1965,7 +1973,7 @@ int upload_stiffness(R2SPhys* h, const float* log_Y, hipStream_t s)
 }
 
 template <int B, int RCAP>
-void launch_substep_layout(const PhysDev& p, dim3 grid, const float4* in, float4* out, int step, int write_forces, bool with_self, int mesh,
+void launch_substep_layout(const PhysDev& p, dim3 grid, const StateC in, const StateM out, int step, int write_forces, bool with_self, int mesh,
                            hipStream_t s)
 {
 #define R2S_LAUNCH(SELF, MESH) hipLaunchKernelGGL((k_substep<B, RCAP, SELF, MESH>), grid, dim3(B), 0, s, p, in, out, step, write_forces)
@@ -1978,8 +1986,8 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
 {
     dim3 grid(8u * (unsigned)p.cb);
     const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
-    const float4* in = h->xv[in_buf];
-    float4* out = h->xv[in_buf ^ 1];
+    const StateC in = h->state(in_buf);
+    const StateM out = h->state(in_buf ^ 1);
     if (h->pb == 256) launch_substep_layout<256, 1024>(p, grid, in, out, step, write_forces, with_self, mesh, s);
     else launch_substep_layout<128, 768>(p, grid, in, out, step, write_forces, with_self, mesh, s);
     // What the fused kernel left unfinished: with something near a mesh (mesh_defer) ONE combined finishing kernel per substep —
@@ -2136,8 +2144,8 @@ int grid_sort(R2SPhys* h, hipStream_t s, const uint32_t** keys, const uint32_t**
     const float cell = h->prm.collision_dist * 5.0f;
     const float cell_inv = 1.0f / cell;
     dim3 grid((h->N + TPB - 1) / TPB, h->E);
-    if (fine) hipLaunchKernelGGL(k_fine_keys, grid, dim3(TPB), 0, s, h->N, h->E, h->xv[h->cur], 1.0f / h->prm.collision_dist, h->d_keys[0], h->d_ids[0]);
-    else hipLaunchKernelGGL(k_grid_keys, grid, dim3(TPB), 0, s, h->N, h->E, h->d_inv, h->xv[h->cur], cell_inv, h->d_keys[0], h->d_ids[0]);
+    if (fine) hipLaunchKernelGGL(k_fine_keys, grid, dim3(TPB), 0, s, h->N, h->E, h->state(h->cur), 1.0f / h->prm.collision_dist, h->d_keys[0], h->d_ids[0]);
+    else hipLaunchKernelGGL(k_grid_keys, grid, dim3(TPB), 0, s, h->N, h->E, h->d_inv, h->state(h->cur), cell_inv, h->d_keys[0], h->d_ids[0]);
     rocprim::double_buffer<uint32_t> dk(h->d_keys[0], h->d_keys[1]);
     rocprim::double_buffer<uint32_t> dv(h->d_ids[0], h->d_ids[1]);
     unsigned bits = GRID_CELL_BITS;
@@ -2339,19 +2347,23 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     }
     // ---- state ----
     for (int b = 0; b < 2; ++b) {
-        TRY(dev_alloc(&h->xv[b], (size_t)E * N * 2));
-        R2S_HIP_TRY(hipMemsetAsync(h->xv[b], 0, sizeof(float4) * (size_t)E * N * 2, s));
+        TRY(dev_alloc(&h->xv[b], (size_t)E * N * 3));
+        R2S_HIP_TRY(hipMemsetAsync(h->xv[b], 0, sizeof(v2f) * (size_t)E * N * 3, s));
     }
     {
-        std::vector<float4> pk((size_t)E * N * 2);
+        const size_t n = (size_t)E * N;
+        std::vector<float> pk(6 * n, 0.f); // three planes of (float, float)
         for (int e = 0; e < E; ++e)
             for (int u = 0; u < N; ++u) {
-                const size_t src = ((size_t)e * N + u) * 3, dst = ((size_t)e * N + h->h_inv[u]) * 2;
-                pk[dst] = make_float4(d->init_vertices[src], d->init_vertices[src + 1], d->init_vertices[src + 2], 0.f);
-                pk[dst + 1] = d->init_velocities ? make_float4(d->init_velocities[src], d->init_velocities[src + 1], d->init_velocities[src + 2], 0.f)
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                const size_t src = ((size_t)e * N + u) * 3, dst = (size_t)e * N + h->h_inv[u];
+                const float* x = d->init_vertices + src;
+                const float zero[3] = {0.f, 0.f, 0.f};
+                const float* v = d->init_velocities ? d->init_velocities + src : zero;
+                pk[2 * dst] = x[0]; pk[2 * dst + 1] = x[1];
+                pk[2 * (n + dst)] = x[2]; pk[2 * (n + dst) + 1] = v[2];
+                pk[2 * (2 * n + dst)] = v[0]; pk[2 * (2 * n + dst) + 1] = v[1];
             }
-        TRY(upload(h->xv[0], pk.data(), pk.size(), s));
+        TRY(upload((float*)h->xv[0], pk.data(), pk.size(), s));
     }
     h->cur = 0;
 
@@ -2677,7 +2689,7 @@ void r2s_phys_destroy(R2SPhys* h)
 int r2s_phys_set_state(R2SPhys* h, const float* x, const float* v, r2s_stream_t stream_)
 {
     if (!h) return R2S_ERR_INVALID;
-    hipLaunchKernelGGL(k_pack, dim3((h->N + 255) / 256, h->E), dim3(256), 0, (hipStream_t)stream_, h->N, h->E, h->d_inv, x, v, h->xv[h->cur]);
+    hipLaunchKernelGGL(k_pack, dim3((h->N + 255) / 256, h->E), dim3(256), 0, (hipStream_t)stream_, h->N, h->E, h->d_inv, x, v, h->state(h->cur));
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }
@@ -2685,7 +2697,7 @@ int r2s_phys_set_state(R2SPhys* h, const float* x, const float* v, r2s_stream_t 
 int r2s_phys_get_state(R2SPhys* h, float* x, float* v, r2s_stream_t stream_)
 {
     if (!h) return R2S_ERR_INVALID;
-    hipLaunchKernelGGL(k_unpack, dim3((h->N + 255) / 256, h->E), dim3(256), 0, (hipStream_t)stream_, h->N, h->E, h->d_inv, h->xv[h->cur], x, v);
+    hipLaunchKernelGGL(k_unpack, dim3((h->N + 255) / 256, h->E), dim3(256), 0, (hipStream_t)stream_, h->N, h->E, h->d_inv, h->state(h->cur), x, v);
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }
@@ -2700,7 +2712,7 @@ int r2s_phys_create_resting_case(R2SPhys* h, r2s_stream_t stream_)
     R2S_HIP_TRY(hipMemsetAsync(h->d_bits, 0, sizeof(uint32_t) * (size_t)h->E * h->N * h->words, s));
     const float r = h->prm.collision_dist * 5.0f;
     dim3 grid((h->N + TPB - 1) / TPB, h->E);
-    hipLaunchKernelGGL(k_build_resting, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->d_perm, h->d_inv, h->xv[h->cur], r, 1.0f / r, keys, ids, h->d_bits);
+    hipLaunchKernelGGL(k_build_resting, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->d_perm, h->d_inv, h->state(h->cur), r, 1.0f / r, keys, ids, h->d_bits);
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }
@@ -2717,12 +2729,12 @@ int r2s_phys_update_collision_graph(R2SPhys* h, r2s_stream_t stream_)
     dim3 grid((h->N + TPB - 1) / TPB, h->E);
     if (h->d_cell_tab) {
         const float cd = h->prm.collision_dist;
-        hipLaunchKernelGGL(k_fine_mark, grid, dim3(TPB), 0, s, h->N, h->E, h->xv[h->cur], keys, ids, h->d_cell_tab, h->d_cell_xs);
-        hipLaunchKernelGGL(k_candidates_fine, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->coll_cap, h->xv[h->cur], h->d_masks, h->d_perm, cd, 1.0f / cd,
+        hipLaunchKernelGGL(k_fine_mark, grid, dim3(TPB), 0, s, h->N, h->E, h->state(h->cur), keys, ids, h->d_cell_tab, h->d_cell_xs);
+        hipLaunchKernelGGL(k_candidates_fine, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->coll_cap, h->state(h->cur), h->d_masks, h->d_perm, cd, 1.0f / cd,
                            1.0f / r, h->d_cell_tab, h->d_cell_xs, h->d_bits, h->d_coll_idx, h->d_coll_num, h->d_max_count);
         hipLaunchKernelGGL(k_cell_clear, grid, dim3(TPB), 0, s, h->N, h->E, keys, h->d_cell_tab);
     } else {
-        hipLaunchKernelGGL(k_candidates, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->coll_cap, h->d_inv, h->xv[h->cur], h->d_masks, h->prm.collision_dist, r,
+        hipLaunchKernelGGL(k_candidates, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->coll_cap, h->d_inv, h->state(h->cur), h->d_masks, h->prm.collision_dist, r,
                            1.0f / r, keys, ids, h->d_bits, h->d_coll_idx, h->d_coll_num, h->d_max_count);
     }
     R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int), s));
