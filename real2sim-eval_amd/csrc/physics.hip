@@ -23,8 +23,9 @@
 //     v_before_collision[j]): particles that appear in a candidate list only PUBLISH their post-force velocity
 //     in the fused kernel and are finished by k_self_finish (second launch per substep, only captured into the
 //     graph flavour used while candidates exist).
-//   * State is ping-ponged between two buffers of three 8-byte planes [env][particle] (the LDS window's own
-//     layout: 24 B per particle, no padding); topology is shared by all environments and stays cache-resident.
+//   * State is ping-ponged between two buffers of 24-byte records [env][particle]{xy | (z, vz) | vxy} — the three
+//     8-byte words of the LDS window's planes, no padding, nothing to repack when staging; topology is shared by all
+//     environments and stays cache-resident.
 //   * The num_substeps launches are captured once per flavour in a hipGraph.
 //   * Resting pairs: per-environment N x N bitset instead of the reference's N x N byte matrix (:715).
 //   * Hash grid (wp.HashGrid 128^3, cell = 5 * collision_dist) for create_resting_case; the per-step candidate
@@ -203,17 +204,24 @@ __device__ __forceinline__ void closest_bary(f3 a, f3 b, f3 c, f3 q, float& u, f
     u = 1.f - vv - ww; v = vv; region = 0;
 }
 
-// Particle state of all environments: three planes of 8 bytes, [3][n_env * N] — xy | (z, vz) | vxy — which is the LDS window's
-// own layout (24 B per particle, no padding; the fused kernel stages a record with three 8-byte loads and three 8-byte LDS
-// writes, nothing to repack).
+// Particle state of all environments: 24 bytes per particle as three 8-byte words xy | (z, vz) | vxy — the words of the LDS
+// window's three planes, so the fused kernel stages a record with three 8-byte loads and three 8-byte LDS writes, nothing
+// to repack and no padding.  Kept as one 24-byte RECORD per particle ([n][3]), not as three planes ([3][n]): a halo gather
+// then touches one or two 64-byte sectors instead of three (counter passes: 49 vs 45 MB fetched per launch; measured
+// 21.5 vs 22.3 us per batched substep, against 22.3 for the 32-byte {x, v} float4 pairs of round 1).
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct StateC { const v2f* p; size_t n; };
 struct StateM { v2f* p; size_t n; operator StateC() const { return {p, n}; } };
-__device__ __forceinline__ f3 st_x(StateC s, size_t i) { const v2f a = s.p[i], b = s.p[s.n + i]; return mk(a.x, a.y, b.x); }
-__device__ __forceinline__ float4 st_x4(StateC s, size_t i) { const v2f a = s.p[i], b = s.p[s.n + i]; return make_float4(a.x, a.y, b.x, 0.f); }
+#ifdef R2S_STATE_PLANES // [3][n] planes
+__device__ __forceinline__ size_t st_at(size_t n, size_t i, int k) { return (size_t)k * n + i; }
+#else                    // [n][3]: one 24-byte record per particle
+__device__ __forceinline__ size_t st_at(size_t, size_t i, int k) { return 3 * i + (size_t)k; }
+#endif
+__device__ __forceinline__ f3 st_x(StateC s, size_t i) { const v2f a = s.p[st_at(s.n, i, 0)], b = s.p[st_at(s.n, i, 1)]; return mk(a.x, a.y, b.x); }
+__device__ __forceinline__ float4 st_x4(StateC s, size_t i) { const f3 x = st_x(s, i); return make_float4(x.x, x.y, x.z, 0.f); }
 __device__ __forceinline__ void st_store(StateM s, size_t i, f3 x, f3 v)
 {
-    s.p[i] = (v2f){x.x, x.y}; s.p[s.n + i] = (v2f){x.z, v.z}; s.p[2 * s.n + i] = (v2f){v.x, v.y};
+    s.p[st_at(s.n, i, 0)] = (v2f){x.x, x.y}; s.p[st_at(s.n, i, 1)] = (v2f){x.z, v.z}; s.p[st_at(s.n, i, 2)] = (v2f){v.x, v.y};
 }
 
 // -DR2S_PHASE_PROBE: wall-clock stamps of one finishing wavefront per particle (k_contact_finish), in program order
@@ -790,7 +798,7 @@ __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const StateC xv
     for (int n = 0; n < rdeg; ++n) {
         const int4 en = ra[n * SLICE];
         const size_t gi = env_base + (size_t)en.x;
-        const v2f jxy = xv.p[gi], jz = xv.p[xv.n + gi], jv = xv.p[2 * xv.n + gi];
+        const v2f jxy = xv.p[st_at(xv.n, gi, 0)], jz = xv.p[st_at(xv.n, gi, 1)], jv = xv.p[st_at(xv.n, gi, 2)];
         spring_term(jxy, jz.x, jv, jz.y, xi, vi, __int_as_float(en.y), __int_as_float(en.z), p.dashpot, fxy, fz);
     }
     return {fxy.x, fxy.y, fz};
@@ -1036,7 +1044,7 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const size_t g = eb + (size_t)min(part[k], p.N - 1);
-        if (part[k] < p.N) { qa[k] = xv_in.p[g]; qb[k] = xv_in.p[xv_in.n + g]; qc[k] = xv_in.p[2 * xv_in.n + g]; }
+        if (part[k] < p.N) { qa[k] = xv_in.p[st_at(xv_in.n, g, 0)]; qb[k] = xv_in.p[st_at(xv_in.n, g, 1)]; qc[k] = xv_in.p[st_at(xv_in.n, g, 2)]; }
         else { qa[k] = (v2f){0.f, 0.f}; qb[k] = qa[k]; qc[k] = qa[k]; }
     }
 #pragma unroll
@@ -1287,8 +1295,8 @@ __global__ void k_pack(int N, int E, const int* __restrict__ inv, const float* _
     if (u >= N) return;
     const size_t src = ((size_t)e * N + u) * 3, dst = (size_t)e * N + inv[u];
     float* f = (float*)xv.p; // x and v may be set separately: plane 1 holds one component of each
-    if (x) { xv.p[dst] = (v2f){x[src], x[src + 1]}; f[2 * (xv.n + dst)] = x[src + 2]; }
-    if (v) { xv.p[2 * xv.n + dst] = (v2f){v[src], v[src + 1]}; f[2 * (xv.n + dst) + 1] = v[src + 2]; }
+    if (x) { xv.p[st_at(xv.n, dst, 0)] = (v2f){x[src], x[src + 1]}; f[2 * st_at(xv.n, dst, 1)] = x[src + 2]; }
+    if (v) { xv.p[st_at(xv.n, dst, 2)] = (v2f){v[src], v[src + 1]}; f[2 * st_at(xv.n, dst, 1) + 1] = v[src + 2]; }
 }
 __global__ void k_unpack(int N, int E, const int* __restrict__ inv, const StateC xv, float* __restrict__ x, float* __restrict__ v)
 {
@@ -1296,9 +1304,9 @@ __global__ void k_unpack(int N, int E, const int* __restrict__ inv, const StateC
     const int e = blockIdx.y;
     if (u >= N) return;
     const size_t dst = ((size_t)e * N + u) * 3, src = (size_t)e * N + inv[u];
-    const v2f b = xv.p[xv.n + src];
-    if (x) { const v2f a = xv.p[src]; x[dst] = a.x; x[dst + 1] = a.y; x[dst + 2] = b.x; }
-    if (v) { const v2f c = xv.p[2 * xv.n + src]; v[dst] = c.x; v[dst + 1] = c.y; v[dst + 2] = b.y; }
+    const v2f b = xv.p[st_at(xv.n, src, 1)];
+    if (x) { const v2f a = xv.p[st_at(xv.n, src, 0)]; x[dst] = a.x; x[dst + 1] = a.y; x[dst + 2] = b.x; }
+    if (v) { const v2f c = xv.p[st_at(xv.n, src, 2)]; v[dst] = c.x; v[dst + 1] = c.y; v[dst + 2] = b.y; }
 }
 // candidate lists back to the caller's indexing (debug / parity taps)
 __global__ void k_lists_to_user(int N, int E, int cap, const int* __restrict__ perm, const int* __restrict__ num, const int* __restrict__ idx,
@@ -2359,9 +2367,16 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
                 const float* x = d->init_vertices + src;
                 const float zero[3] = {0.f, 0.f, 0.f};
                 const float* v = d->init_velocities ? d->init_velocities + src : zero;
-                pk[2 * dst] = x[0]; pk[2 * dst + 1] = x[1];
-                pk[2 * (n + dst)] = x[2]; pk[2 * (n + dst) + 1] = v[2];
-                pk[2 * (2 * n + dst)] = v[0]; pk[2 * (2 * n + dst) + 1] = v[1];
+                auto at = [&](int k) { // the device's st_at
+#ifdef R2S_STATE_PLANES
+                    return 2 * ((size_t)k * n + dst);
+#else
+                    return 2 * (3 * dst + (size_t)k);
+#endif
+                };
+                pk[at(0)] = x[0]; pk[at(0) + 1] = x[1];
+                pk[at(1)] = x[2]; pk[at(1) + 1] = v[2];
+                pk[at(2)] = v[0]; pk[at(2) + 1] = v[1];
             }
         TRY(upload((float*)h->xv[0], pk.data(), pk.size(), s));
     }

@@ -324,6 +324,46 @@ def test_large_meshes_that_are_not_welded_closed_manifolds_are_accepted_like_the
     assert close(h.x[0], o.x, 1e-5, what=f"{kind} large mesh vs oracle")
 
 
+def test_large_pusher_mesh_next_to_a_small_static_obstacle_vs_oracle():
+    """A scene that mixes both kinds of collision mesh: the ~12k-face pusher rod (box hierarchy in its rest frame, pseudonormal
+    sign) pressing the block against a small static box (12 faces: visited through the face table in the world frame, its
+    winding number summed exactly).  k_contact_finish answers both in one query per particle; the oracle brute-forces
+    every face.  Also checks the per-substep deferred-query counts the finishing kernel reports."""
+    import torch
+    from r2s_hip import synth
+    from util_physics import rigid_motion
+
+    n_sub = 16
+    ob = make_object("T", 1500, seed=21)
+    top = ob["points"][:, 2].max(); x_lo, x_hi = ob["points"][:, 0].min(), ob["points"][:, 0].max()
+    y_face = float(np.median(ob["points"][ob["points"][:, 0] < x_lo + 0.005, 1]))
+    rod = synth.cylinder_mesh((x_lo - 0.0052, y_face, top * 0.5 + 0.02), radius=0.005, length=0.2, n_seg=96, n_rings=60)
+    assert len(rod[1]) > 10000
+    y_back = float(np.median(ob["points"][ob["points"][:, 0] > x_hi - 0.005, 1]))
+    wall = synth.box_mesh((x_hi + 0.0105, y_back, top * 0.5), (0.02, 0.08, top))      # 0.5 mm behind the block's +x face
+    interp, centers, dv, om = rigid_motion(rod, n_sub, 5e-5, vel=(2.0, 0.0, 0.0), omega=(0.0, 0.0, 1.0))
+    kw = dict(dynamic_meshes=[rod], static_meshes=[wall], self_collision=False, use_pusher=True, collide_eef_fric=0.2)
+    ob["v0"] = np.zeros_like(ob["points"]); ob["v0"][:, 0] = 1.0                      # the block drifts into the wall
+    o = oracle_env(ob, num_substeps=n_sub, **kw)
+    h = hip_env(ob, num_substeps=n_sub, **kw)
+    o.set_mesh_interactive(interp, centers, dv, om)
+    t = lambda a: torch.from_numpy(a)[None].cuda()  # noqa: E731
+    h.set_mesh_interactive(t(interp), t(centers), t(dv), t(om))
+    o.step(); h.step()
+    fl = h.last_flavour()
+    assert fl["mesh_template"] == 2 and fl["deferred_mesh_queries"]
+    fo = o.collision_forces
+    n_rod = len(rod[1])
+    assert np.abs(fo[:n_rod]).max() > 0 and np.abs(fo[n_rod:]).max() > 0, "both the rod and the wall must be touched"
+    assert close(h.x[0], o.x, 1e-5, what="large rod + small wall vs oracle")
+    f = h.collision_forces()[0].cpu().numpy()
+    for name, sl in (("rod", slice(0, n_rod)), ("wall", slice(n_rod, None))):
+        tot_o, tot_h = fo[sl].sum(0), f[sl].sum(0)
+        assert np.allclose(tot_h, tot_o, rtol=2e-3, atol=np.abs(tot_o).max() * 2e-3), (name, tot_o, tot_h)
+    dc = h.deferred_counts()
+    assert dc.shape == (n_sub + 1,) and dc[-1] != 0 and dc[:-1].max() > 0 and dc[:-1].max() <= h.N
+
+
 def test_a_large_dynamic_mesh_that_deforms_is_reported_by_a_later_step():
     """The rigidity check of large dynamic meshes is read without blocking the stream (pinned word + event): the violation
     surfaces at the first step() after the check has landed, as R2S_ERR_INVALID."""

@@ -29,3 +29,9 @@ for mode in default chains1; do
   rm -rf $out/trace_$mode
 done
 unset R2S_CHAINS
+# the large-mesh finishing kernel (k_contact_finish<2>) in its own table: the pusher workload, second half of the window in contact
+timeout 400 rocprofv3 --kernel-trace --stats -d $out/trace_pusher -o bench -- python $R/bench.py --config T_pusher_32env --steps 6 --warmup 3 --no-cpu-baseline > $out/bench_trace_pusher.log 2>&1 || echo trace-failed
+db=$(find $out/trace_pusher -name "*.db" | head -1)
+python $R/tools/rocpd_stats.py $db $out/kernel_stats_pusher.md > /dev/null 2>&1 || echo stats-failed
+head -6 $out/kernel_stats_pusher.md | cut -c1-70,150-240
+rm -rf $out/trace_pusher
