@@ -2003,7 +2003,7 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
     // while candidates exist (mesh queries of the rare needy particle in place).
     if (mesh != 0 && (p.mesh_defer || mesh == 2)) {
         const bool small = mesh == 1 && h->nF <= 128; // every mesh small: the substep's triangles fit two per lane
-        const dim3 g(small ? 1024 : 512);             // 2048 wavefronts, grid-stride: workgroups of two (small) or four wavefronts
+        const dim3 g(small ? 1024 : 512);             // 2048 wavefronts (an idle launch costs the same ~2.5 us with 16 workgroups: it is the launch boundary), grid-stride: workgroups of two (small) or four wavefronts
 #define R2S_FIN(Q, S) hipLaunchKernelGGL((k_contact_finish<Q, S>), g, dim3(small ? 128 : 256), 0, s, p, in, out, step, write_forces)
         if (small) { if (with_self) R2S_FIN(3, true); else R2S_FIN(3, false); }
         else { if (with_self) R2S_FIN(2, true); else R2S_FIN(2, false); }
