@@ -364,6 +364,60 @@ def test_large_pusher_mesh_next_to_a_small_static_obstacle_vs_oracle():
     assert dc.shape == (n_sub + 1,) and dc[-1] != 0 and dc[:-1].max() > 0 and dc[:-1].max() <= h.N
 
 
+def test_more_listed_particles_than_finishing_workgroups_small_scene(monkeypatch):
+    """k_contact_finish walks its list with a grid-stride loop of whole workgroups (barriers inside): a substep that lists more
+    particles than the launch has workgroups (1024 for small scenes) must still finish every one of them, exactly once.  A
+    rope lying in an OPEN box (bottom removed: not a closed manifold, so the query's own 2 cm range is the early-out bound
+    and most of the rope is listed every substep), 8 identical environments, deferral forced; every environment against the
+    oracle."""
+    from r2s_hip import synth
+
+    monkeypatch.setenv("R2S_MESH_DEFER", "1")
+    n_sub, n_env = 10, 8
+    ob = make_object("rope", 800, seed=5, lift=0.0395)                                # lowest particles 0.5 mm above the box top
+    ob["v0"] = np.zeros_like(ob["points"]); ob["v0"][:, 2] = -0.5
+    c = ob["points"].mean(0)
+    v, f = synth.box_mesh((c[0], c[1], 0.02), (0.5, 0.08, 0.04))
+    f = f[[k for k in range(len(f)) if not (v[f[k], 2] < 0.001).all()]]          # drop the two bottom triangles
+    assert len(f) == 10
+    kw = dict(static_meshes=[(v, f)], self_collision=False)
+    o = oracle_env(ob, num_substeps=n_sub, **kw)
+    h = hip_env(ob, num_substeps=n_sub, n_env=n_env, **kw)
+    o.step(); h.step()
+    dc = h.deferred_counts()
+    assert dc[:-1].max() > 1024, dc[:-1].max()
+    assert np.abs(o.collision_forces).max() > 0
+    x = h.x.cpu().numpy()
+    for e in range(n_env):
+        assert close(x[e], o.x, ATOL, what=f"env {e}: {int(dc[:-1].max())} listed particles per substep")
+    fh = h.collision_forces().cpu().numpy()
+    assert np.allclose(fh[0], o.collision_forces, rtol=1e-3, atol=1e-1) and np.allclose(fh[-1], fh[0], rtol=1e-4, atol=1e-2)
+
+
+def test_more_listed_particles_than_finishing_workgroups_large_mesh():
+    """The same for the large-mesh finishing kernel (512 workgroups of four wavefronts): two T-blocks resting on a finely
+    tessellated static slab (2 688 faces, closed: box hierarchy + pseudonormals), every bottom particle inside the 1 mm margin."""
+    from r2s_hip import synth
+
+    n_sub, n_env = 8, 6
+    ob = make_object("T", 2229, seed=4)
+    ob["v0"] = np.zeros_like(ob["points"]); ob["v0"][:, 2] = -0.3
+    c = ob["points"].mean(0); z0 = ob["points"][:, 2].min()
+    slab = synth.cylinder_mesh((c[0], c[1], z0 - 0.0105), radius=0.3, length=0.02, n_seg=64, n_rings=20)   # top at z0 - 0.5 mm
+    assert len(slab[1]) > 2000
+    kw = dict(static_meshes=[slab], self_collision=False)
+    o = oracle_env(ob, num_substeps=n_sub, **kw)
+    h = hip_env(ob, num_substeps=n_sub, n_env=n_env, **kw)
+    o.step(); h.step()
+    assert h.last_flavour()["mesh_template"] == 2
+    dc = h.deferred_counts()
+    assert dc[:-1].max() > 512, dc[:-1].max()
+    assert np.abs(o.collision_forces).max() > 0
+    x = h.x.cpu().numpy()
+    for e in range(n_env):
+        assert close(x[e], o.x, ATOL, what=f"large slab, env {e}: {int(dc[:-1].max())} listed particles per substep")
+
+
 def test_a_large_dynamic_mesh_that_deforms_is_reported_by_a_later_step():
     """The rigidity check of large dynamic meshes is read without blocking the stream (pinned word + event): the violation
     surfaces at the first step() after the check has landed, as R2S_ERR_INVALID."""
