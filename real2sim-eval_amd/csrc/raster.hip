@@ -476,11 +476,9 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                                      atomicAdd(&g_comp_stats[2], hb == 0 ? 1ull : 0ull); atomicAdd(&g_comp_stats[3], (unsigned long long)__builtin_popcountll(ab)); }
                 }
 #endif
-                {   // "no lane hit" as a scalar test of the ballot (the i1 == 0 form compiles to v_cndmask + v_cmp)
-                    const unsigned long long hb = __builtin_amdgcn_ballot_w64(hit);
-                    if (((unsigned)hb | (unsigned)(hb >> 32)) == 0u) continue;
-                }
-                const float test_T = T * (1.f - alpha);
+                // No "nobody hit -> next instance" shortcut here: the ballot + scalar branch it needs in every iteration cost more than
+                // the blend instructions it saved in the 12 % of iterations without a hit (0.98 -> 0.80 ms without it, images identical).
+                const float test_T = T * (1.f - alpha);         // forward.cu:353 as written (T - alpha T is one instruction less, an ulp off, and 0.01 ms)
                 const bool keep = test_T >= 0.0001f;           // forward.cu:354: test_T < 0.0001f ends the pixel (one compare, not two)
                 const bool term = hit && !keep;
                 done = done || term;
