@@ -479,10 +479,10 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                 // No "nobody hit -> next instance" shortcut here: the ballot + scalar branch it needs in every iteration cost more than
                 // the blend instructions it saved in the 12 % of iterations without a hit (0.98 -> 0.80 ms without it, images identical).
                 const float test_T = T * (1.f - alpha);         // forward.cu:353 as written (T - alpha T is one instruction less, an ulp off, and 0.01 ms)
-                const bool keep = test_T >= 0.0001f;           // forward.cu:354: test_T < 0.0001f ends the pixel (one compare, not two)
-                const bool term = hit && !keep;
+                const bool ends = test_T < 0.0001f;            // forward.cu:354 ends the pixel; its complement is a mask operation, not a second
+                const bool term = hit && ends;                  // compare (">= 0.0001f" next to "!(>= 0.0001f)" compiled to two: NaN semantics)
                 done = done || term;
-                const bool blend = hit && keep;
+                const bool blend = hit != term;                 // = hit && !ends as a mask XOR (written with !ends the compiler compares again)
                 const float w = blend ? alpha * T : 0.0f;
                 C0 += c.y * w;
                 C1 += c.z * w;
