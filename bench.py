@@ -314,7 +314,7 @@ def main():
                                               "valu_busy_frac": pmc_comp.get("valu_busy_frac") if pmc_comp else None,
                                               "note": "VALU/exp-bound (≈115 flop per algorithmic byte, SURVEY.md §7): the north_star's >= 0.60 of HBM peak "
                                                       "is not reachable for this kernel at any instruction count above ~1/3 of the reference's per-pixel "
-                                                      "arithmetic; valu_busy_frac is the figure that says how close to its real bound it runs"}},
+                                                      "arithmetic; valu_busy_frac (VALU-active wave cycles per SIMD cycle of the kernel span; instructions of different waves overlap in the pipeline, so saturation reads slightly above 1) is the figure that says how close to its real bound it runs"}},
             "physics_ms_per_env_step": phys_ms, "skinning_ms_per_env_step": skin_ms,
             "task_success": {"envs_satisfying_predicate": int(records[:, 4].sum().item()), "of": total_envs,
                              "note": "frame-level success predicate of the scene's task evaluated on the device after the last step "
