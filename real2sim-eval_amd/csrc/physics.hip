@@ -1253,7 +1253,7 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
         const int n = *p.cand_count;
         for (int base = rb * gpb; base < n; base += gridDim.x * gpb) { // wave-uniform trip count
             const int t = base + grp;
-            if (t != g0) ci = p.cand_list[t < n ? t : 0];
+            if (t != g0 || t >= n) ci = p.cand_list[t < n ? t : 0]; // (the speculative entry of a slot past the count is stale or was never written: never index with it)
             const int e = ci.x & 0xfff, i = ci.y, cnt = ci.x >> 12;
             const size_t eb = (size_t)e * p.N;
             const bool act = t < n && e >= p.e0 && e < p.e0 + p.ne && p.cand_mark[eb + i] != step + 1; // not already done in part 1
@@ -2632,6 +2632,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     if (h->nF > 0) { // deferred mesh queries
         h->mesh_cap = std::max(4096, E * N); // a particle is listed at most once per substep: the list cannot overflow
         TRY(dev_alloc(&h->d_mesh_list, (size_t)8 * h->mesh_cap));
+        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_list, 0, sizeof(int2) * (size_t)8 * h->mesh_cap, s));
         TRY(dev_alloc(&h->d_mesh_cnt, (size_t)8 * (h->prm.num_substeps + 1)));
         TRY(dev_alloc(&h->d_vdef, (size_t)E * N));
         if (h->prm.self_collision) { TRY(dev_alloc(&h->d_cand_mark, (size_t)E * N)); R2S_HIP_TRY(hipMemsetAsync(h->d_cand_mark, 0, sizeof(int) * (size_t)E * N, s)); }
@@ -2644,6 +2645,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     if (h->prm.self_collision) {
         TRY(dev_alloc(&h->d_vbc, (size_t)E * N));
         TRY(dev_alloc(&h->d_cand_list, (size_t)E * N));
+        R2S_HIP_TRY(hipMemsetAsync(h->d_cand_list, 0, sizeof(int2) * (size_t)E * N, s));
         TRY(dev_alloc(&h->d_cand_count, 4));
         R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int) * 4, s));
         R2S_HIP_TRY(hipHostMalloc((void**)&h->h_cand_count, 64, hipHostMallocDefault));

@@ -297,9 +297,46 @@ class BatchedRollout:
         self.last_num_rendered = self.raster.forward(self._prepared, None, self.W, self.H)
         return self.out_color, self.out_depth
 
+    # ---- throughput mode for open-loop stretches (an action chunk, a replay): render(t) overlaps physics(t+1) ------------
+    def set_pipelined(self, on: bool):
+        """With ``on``, ``step`` enqueues skinning + rasterisation of env step t on a second stream and returns at once; the
+        physics of step t+1 only waits for the (short) skinning kernels, which are the readers of the particle state, so the
+        raster pipeline runs next to the next step's substeps.  The images of step t are complete after ``wait_render()``
+        (or any device synchronisation).  Same kernels on the same data: results are identical to the serial mode (tested).
+        Meaningful when the next action does not depend on this step's observation — inside an action chunk of the policy —
+        and therefore NOT what ``bench.py``'s ``value`` measures (that is the closed loop: observation before next action)."""
+        self._pipelined = bool(on)
+        if on and getattr(self, "_render_stream", None) is None:
+            self._render_stream = torch.cuda.Stream(device=self.device)
+        if not on:
+            self.wait_render()
+
+    def wait_render(self):
+        ev = getattr(self, "_render_done", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def _render_pipelined(self):
+        main = torch.cuda.current_stream(self.device)
+        rs = self._render_stream
+        ready = torch.cuda.Event()
+        ready.record(main)                       # physics(t) has written x
+        rs.wait_event(ready)
+        with torch.cuda.stream(rs):
+            self._update_means()
+            skinned = torch.cuda.Event()
+            skinned.record(rs)
+            if self._prepared is None:
+                self._prepared = self.raster.prepare(self._sets, self._frames)
+            self.last_num_rendered = self.raster.forward(self._prepared, None, self.W, self.H)
+            self._render_done = torch.cuda.Event()
+            self._render_done.record(rs)
+        main.wait_event(skinned)                 # the next step's state write-back must not overtake the skinning that reads x
+        return self.out_color, self.out_depth
+
     def step(self):
         self.physics_step()
-        out = self.render()
+        out = self._render_pipelined() if getattr(self, "_pipelined", False) else self.render()
         self.t += 1
         lg = self._log
         if lg is not None and lg["i"] < lg["n"]:
