@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--substeps", type=int, default=667)
     ap.add_argument("--schedule", default=None, help="grasp | lissajous (default: the scene's; see r2s_hip/rollout.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the throughput-mode comparison that follows the timed window")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--stub", action="store_true", help="CPU stand-in workload over gloo (launcher test)")
     ap.add_argument("--sink", default=None, help="directory: also run the observation sink (row f4) every step — packed 8-bit frames + state "
@@ -208,6 +209,31 @@ def main():
     n_success = int(ro.success_flags().sum().item())  # device-side task predicate (row f4); outside the timed region
     records = rdist.gather_records([ro.n_env, args.steps, elapsed * 1e3, float(ro.last_num_rendered), float(n_success)], dev)
     total_envs = int(records[:, 0].sum().item())
+
+    # throughput mode (outside the timed region, reported next to `value`, never as `value`): the rollout continues from the state
+    # the window ended in, first serially, then with the rasterisation of step t on a second stream next to the substeps of
+    # step t+1 (BatchedRollout.set_pipelined) — what an open-loop stretch (an action chunk) can run at
+    pipe_report = None
+    if not args.stub and not args.no_pipelined:
+        kp = max(4, min(args.steps, 10))
+        rates = []
+        for mode in (False, True):
+            ro.set_pipelined(mode)
+            for _ in range(2):
+                ro.step()
+            ro.wait_render()
+            torch.cuda.synchronize(dev)
+            t0p = time.perf_counter()
+            for _ in range(kp):
+                ro.step()
+            ro.wait_render()
+            torch.cuda.synchronize(dev)
+            rates.append(ro.n_env * kp / (time.perf_counter() - t0p))
+        ro.set_pipelined(False)
+        pipe_report = {"serial_env_steps_per_s": rates[0], "pipelined_env_steps_per_s": rates[1], "steps": kp,
+                       "note": "this rank, after the timed window, in the state the window ended in (contact): the same steps with the rasterisation of "
+                               "env step t on a second stream next to the substeps of step t+1; results are bit-identical (tested).  Valid when the "
+                               "next action does not depend on this step's observation (inside an action chunk); `value` above is the closed loop"}
 
     # cross-check for the roofline (untimed): the same env step captured as ONE kernel per batched substep, so that the
     # HIP-event time / 667 is a per-kernel duration that rocprofv3's per-kernel average can be compared with directly
@@ -322,6 +348,8 @@ def main():
         }
         if sink_report is not None:
             out["observation_sink"] = sink_report
+        if pipe_report is not None:
+            out["throughput_mode"] = pipe_report
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(ro, args.cpu_budget)
