@@ -1919,7 +1919,7 @@ namespace {
 template <typename T>
 int dev_alloc(T** p, size_t count)
 {
-    R2S_HIP_TRY(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+    R2S_HIP_TRY(r2s::dev_malloc((void**)p, sizeof(T) * (count ? count : 1)));
     return R2S_OK;
 }
 template <typename T>
@@ -2951,8 +2951,8 @@ int r2s_phys_collision_lists(R2SPhys* h, int32_t** number, int32_t** indices, in
     if (!h->prm.self_collision) { if (number) *number = h->d_coll_num; if (indices) *indices = nullptr; return R2S_OK; }
     // internal (Morton) indexing -> the caller's indexing, into side buffers (parity taps, not a hot path)
     if (!h->d_num_user) {
-        R2S_HIP_TRY(hipMalloc((void**)&h->d_num_user, sizeof(int) * (size_t)h->E * h->N));
-        R2S_HIP_TRY(hipMalloc((void**)&h->d_idx_user, sizeof(int) * (size_t)h->E * h->N * h->coll_cap));
+        R2S_HIP_TRY(r2s::dev_malloc((void**)&h->d_num_user, sizeof(int) * (size_t)h->E * h->N));
+        R2S_HIP_TRY(r2s::dev_malloc((void**)&h->d_idx_user, sizeof(int) * (size_t)h->E * h->N * h->coll_cap));
     }
     R2S_HIP_TRY(hipDeviceSynchronize());
     hipLaunchKernelGGL(k_lists_to_user, dim3((h->N + 255) / 256, h->E), dim3(256), 0, 0, h->N, h->E, h->coll_cap, h->d_perm, h->d_coll_num,

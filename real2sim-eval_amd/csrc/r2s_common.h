@@ -1,5 +1,6 @@
 // Shared host-side helpers of libr2s_hip (error capture, grow-only device buffers).
 #pragma once
+#include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -22,6 +23,17 @@ void set_last_error_msg(const char* msg);
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// hipMalloc for every device allocation of the library.  With R2S_POISON=1 in the environment (read once; a test facility) the new
+// memory is filled with 0xFF bytes — NaN as float, -1 as index — so that code which relies on fresh allocations being zero, or
+// reads entries it never wrote, fails loudly instead of working until freed memory is reused (tests/ run the GPU suite this way).
+inline hipError_t dev_malloc(void** p, size_t bytes)
+{
+    static const bool poison = [] { const char* e = getenv("R2S_POISON"); return e && e[0] && e[0] != '0'; }();
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && poison) e = hipMemset(*p, 0xFF, bytes);
+    return e;
+}
+
 // Grow-only device buffer (the role torch's resize_ plays for the reference's scratch tensors).
 struct DevBuf {
     char* p = nullptr;
@@ -36,7 +48,7 @@ struct DevBuf {
             if (e != hipSuccess) return e;
         }
         size_t want = align_up(bytes + bytes / 4, 1 << 20);
-        hipError_t e = hipMalloc((void**)&p, want);
+        hipError_t e = dev_malloc((void**)&p, want);
         if (e != hipSuccess) { p = nullptr; return e; }
         cap = want;
         return hipSuccess;

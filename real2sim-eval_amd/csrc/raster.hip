@@ -590,7 +590,7 @@ int ensure_frames(R2SRasterCtx* c, int n)
         c->d_frames = nullptr;
         c->h_frames = nullptr;
         int cap = n < 64 ? 64 : n;
-        R2S_HIP_TRY(hipMalloc((void**)&c->d_frames, sizeof(FrameDev) * cap));
+        R2S_HIP_TRY(r2s::dev_malloc((void**)&c->d_frames, sizeof(FrameDev) * cap));
         R2S_HIP_TRY(hipHostMalloc((void**)&c->h_frames, sizeof(FrameDev) * cap, hipHostMallocDefault));
         c->frames_cap = cap;
     }

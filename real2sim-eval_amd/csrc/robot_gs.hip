@@ -174,10 +174,10 @@ int r2s_robot_gs_create(int32_t n_links, const int32_t* link_listed, const doubl
     }
     auto fail = [&](int rc) { r2s_robot_gs_destroy(h); return rc; };
     const size_t n1 = std::max(n_gauss, 1);
-    if (hipMalloc((void**)&h->d_listed, sizeof(int) * n_links) != hipSuccess || hipMalloc((void**)&h->d_offset, sizeof(float) * 16 * n_links) != hipSuccess ||
-        hipMalloc((void**)&h->d_base_inv, sizeof(float) * 16 * n_links) != hipSuccess || hipMalloc((void**)&h->d_order, sizeof(int) * n1) != hipSuccess ||
-        hipMalloc((void**)&h->d_link, sizeof(int) * n1) != hipSuccess || hipMalloc((void**)&h->d_means, sizeof(float) * 3 * n1) != hipSuccess ||
-        hipMalloc((void**)&h->d_quats, sizeof(float4) * n1) != hipSuccess)
+    if (r2s::dev_malloc((void**)&h->d_listed, sizeof(int) * n_links) != hipSuccess || r2s::dev_malloc((void**)&h->d_offset, sizeof(float) * 16 * n_links) != hipSuccess ||
+        r2s::dev_malloc((void**)&h->d_base_inv, sizeof(float) * 16 * n_links) != hipSuccess || r2s::dev_malloc((void**)&h->d_order, sizeof(int) * n1) != hipSuccess ||
+        r2s::dev_malloc((void**)&h->d_link, sizeof(int) * n1) != hipSuccess || r2s::dev_malloc((void**)&h->d_means, sizeof(float) * 3 * n1) != hipSuccess ||
+        r2s::dev_malloc((void**)&h->d_quats, sizeof(float4) * n1) != hipSuccess)
         return fail(R2S_ERR_ALLOC);
     R2S_HIP_TRY(hipMemcpyAsync(h->d_listed, listed.data(), sizeof(int) * n_links, hipMemcpyHostToDevice, s));
     R2S_HIP_TRY(hipMemcpyAsync(h->d_offset, off32.data(), sizeof(float) * 16 * n_links, hipMemcpyHostToDevice, s));
@@ -210,7 +210,7 @@ int r2s_robot_gs_transform(R2SRobotGS* h, int32_t n_env, const float* link_pose,
     if (n_env > h->cap_env) {
         if (h->d_rec) (void)hipFree(h->d_rec);
         h->d_rec = nullptr; h->cap_env = 0;
-        R2S_HIP_TRY(hipMalloc((void**)&h->d_rec, sizeof(LinkRec) * (size_t)n_env * h->L));
+        R2S_HIP_TRY(r2s::dev_malloc((void**)&h->d_rec, sizeof(LinkRec) * (size_t)n_env * h->L));
         h->cap_env = n_env;
     }
     const int tot = n_env * h->L;

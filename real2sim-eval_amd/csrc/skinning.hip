@@ -181,14 +181,14 @@ int r2s_skin_create(int32_t n_bones, int32_t k_rel, const int32_t* relations, in
     if (!h) return R2S_ERR_ALLOC;
     h->N = n_bones; h->k_rel = k_rel; h->P = n_points; h->k_wgt = k_wgt;
     auto fail = [&](int rc) { r2s_skin_destroy(h); return rc; };
-    if (hipMalloc((void**)&h->d_rel, sizeof(int) * (size_t)n_bones * k_rel) != hipSuccess) return fail(R2S_ERR_ALLOC);
-    if (hipMalloc((void**)&h->d_widx, sizeof(int) * std::max<size_t>((size_t)n_points * k_wgt, 1)) != hipSuccess) return fail(R2S_ERR_ALLOC);
-    if (hipMalloc((void**)&h->d_w, sizeof(float) * std::max<size_t>((size_t)n_points * k_wgt, 1)) != hipSuccess) return fail(R2S_ERR_ALLOC);
+    if (r2s::dev_malloc((void**)&h->d_rel, sizeof(int) * (size_t)n_bones * k_rel) != hipSuccess) return fail(R2S_ERR_ALLOC);
+    if (r2s::dev_malloc((void**)&h->d_widx, sizeof(int) * std::max<size_t>((size_t)n_points * k_wgt, 1)) != hipSuccess) return fail(R2S_ERR_ALLOC);
+    if (r2s::dev_malloc((void**)&h->d_w, sizeof(float) * std::max<size_t>((size_t)n_points * k_wgt, 1)) != hipSuccess) return fail(R2S_ERR_ALLOC);
     R2S_HIP_TRY(hipMemcpyAsync(h->d_rel, relations, sizeof(int) * (size_t)n_bones * k_rel, hipMemcpyHostToDevice, s));
     std::vector<int> order(n_points), widx_t((size_t)n_points * k_wgt);
     std::vector<float> w_t((size_t)n_points * k_wgt);
     if (n_points > 0) {
-        if (hipMalloc((void**)&h->d_order, sizeof(int) * (size_t)n_points) != hipSuccess) return fail(R2S_ERR_ALLOC);
+        if (r2s::dev_malloc((void**)&h->d_order, sizeof(int) * (size_t)n_points) != hipSuccess) return fail(R2S_ERR_ALLOC);
         for (int i = 0; i < n_points; ++i) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weights_indices[(size_t)a * k_wgt] < weights_indices[(size_t)b * k_wgt]; });
         for (int t = 0; t < n_points; ++t)
@@ -231,8 +231,8 @@ int r2s_skin_interpolate_motions_strided(R2SSkin* h, int32_t n_env, const float*
         if (h->d_flag) (void)hipFree(h->d_flag);
         if (h->d_rot) (void)hipFree(h->d_rot);
         h->d_rec = nullptr; h->d_flag = nullptr; h->d_rot = nullptr; h->cap_env = 0;
-        R2S_HIP_TRY(hipMalloc((void**)&h->d_rec, sizeof(BoneRec) * (size_t)n_env * h->N));
-        R2S_HIP_TRY(hipMalloc((void**)&h->d_flag, sizeof(int) * (size_t)n_env));
+        R2S_HIP_TRY(r2s::dev_malloc((void**)&h->d_rec, sizeof(BoneRec) * (size_t)n_env * h->N));
+        R2S_HIP_TRY(r2s::dev_malloc((void**)&h->d_flag, sizeof(int) * (size_t)n_env));
         h->cap_env = n_env;
     }
     R2S_HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int) * (size_t)n_env, s));
@@ -248,7 +248,7 @@ int r2s_skin_debug(R2SSkin* h, const float** rotations, const int32_t** identity
 {
     if (!h || !h->d_rec) return R2S_ERR_INVALID;
     if (rotations) { // unpack the rotations of the records into a dense [cap_env, N, 9] array
-        if (!h->d_rot) R2S_HIP_TRY(hipMalloc((void**)&h->d_rot, sizeof(float) * 9 * (size_t)h->cap_env * h->N));
+        if (!h->d_rot) R2S_HIP_TRY(r2s::dev_malloc((void**)&h->d_rot, sizeof(float) * 9 * (size_t)h->cap_env * h->N));
         R2S_HIP_TRY(hipMemcpy2D(h->d_rot, sizeof(float) * 9, h->d_rec, sizeof(BoneRec), sizeof(float) * 9, (size_t)h->cap_env * h->N, hipMemcpyDeviceToDevice));
         *rotations = h->d_rot;
     }

@@ -182,3 +182,31 @@ def test_pipelined_rollout_is_identical_to_the_serial_one():
     assert np.array_equal(x0, x1)
     assert np.array_equal(c0, c1) and np.array_equal(d0, d1)
     assert c0.std() > 0
+
+
+def test_rollouts_with_poisoned_allocations_in_a_fresh_process():
+    """R2S_POISON=1 fills every device allocation of the library with 0xFF bytes (NaN / -1): code that relies on fresh memory
+    being zero, or reads list slots it never wrote, then fails at once instead of only after freed memory is reused (a stale
+    speculatively loaded candidate-list entry did exactly that in round 2: the second rollout of a process faulted).  Two
+    rollouts back to back, no synchronisation between the steps, gripper closing on the toy; run in a subprocess because the
+    switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os; sys.path[:0] = [os.path.join(%r, 'real2sim-eval_amd'), %r]\n"
+        "import torch, numpy as np\n"
+        "from r2s_hip.rollout import BatchedRollout\n"
+        "for k in range(2):\n"
+        "    ro = BatchedRollout('sloth_32env', n_env=3, num_substeps=60, seed=2, close_at=2, settle_steps=2)\n"
+        "    for t in range(6): ro.step()\n"
+        "    torch.cuda.synchronize()\n"
+        "    st = ro.contact_stats()\n"
+        "    assert st['self_collision_candidates'] > 0 and bool(torch.isfinite(ro.phys.x).all()) and bool(torch.isfinite(ro.out_color).all())\n"
+        "    del ro\n"
+        "print('POISON-OK')\n" % (root, root))
+    env = dict(os.environ, R2S_POISON="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "POISON-OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
