@@ -108,14 +108,10 @@ struct PhysDev {
     int n_mesh, n_dyn_mesh, nF, nV, n_dyn_pts;
     const int* faces;          // [nF,3] global vertex ids, in STORED order (large meshes: Morton-sorted clusters)
     const int* face_orig;      // [nF] stored face -> original (caller) face id
-    const int* face_mesh;      // [nF] stored face -> mesh index
     const int* mesh_map;       // [nF] by ORIGINAL face id
     const int* face_map;       // [nF] by ORIGINAL face id
     const int* mesh_face_off;  // [n_mesh+1]
     int n_cl, n_xf;            // face clusters; large dynamic meshes (one rigid transform each per env and substep)
-    const int* cl_f0;          // [n_cl] stored-face range of a cluster
-    const int* cl_f1;
-    const int* cl_mesh;        // [n_cl]
     const float* cl_box;       // [6][n_cl] rest-frame boxes (clusters of large meshes), component-major: one lane per cluster loads coalesced
     const int* mesh_kind;      // [n_mesh] bit 0: large (> 256 faces: clusters, wave-cooperative); bit 1: not a closed manifold (sign by
                                // exact winding number; closed large meshes use pseudonormals, small meshes always the winding number)
@@ -1855,7 +1851,7 @@ struct R2SPhys {
     char* d_sort_tmp = nullptr;
     size_t sort_bytes = 0;
     int *d_faces = nullptr, *d_mesh_map = nullptr, *d_face_map = nullptr, *d_mesh_face_off = nullptr, *d_mesh_vert_off = nullptr;
-    int *d_face_orig = nullptr, *d_face_mesh = nullptr, *d_cl_f0 = nullptr, *d_cl_f1 = nullptr, *d_cl_mesh = nullptr, *d_mesh_kind = nullptr,
+    int *d_face_orig = nullptr, *d_mesh_kind = nullptr,
         *d_mesh_xf = nullptr, *d_xf_mesh = nullptr, *d_xf_ref = nullptr;
     float *d_cl_box = nullptr, *d_xf = nullptr, *d_rest_pts = nullptr, *d_pnorm = nullptr, *d_xf_rest_box = nullptr, *d_tri_rest = nullptr;
     int4* d_cl_info = nullptr; int4* d_sup_info = nullptr; float* d_sup_box = nullptr; int* d_small_mesh = nullptr; int n_sup = 0, n_small = 0;
@@ -1904,8 +1900,8 @@ struct R2SPhys {
         p.mesh_list = d_mesh_list; p.mesh_cnt = d_mesh_cnt; p.mesh_cap = mesh_cap; p.mesh_defer = mesh_defer; p.vdef = d_vdef; p.cand_mark = d_cand_mark;
         p.n_mesh = n_mesh; p.n_dyn_mesh = n_dyn_mesh; p.nF = nF; p.nV = nV; p.n_dyn_pts = n_dyn_pts;
         p.faces = d_faces; p.mesh_map = d_mesh_map; p.face_map = d_face_map; p.mesh_face_off = d_mesh_face_off;
-        p.face_orig = d_face_orig; p.face_mesh = d_face_mesh; p.n_cl = n_cl; p.n_xf = n_xf; p.cl_f0 = d_cl_f0; p.cl_f1 = d_cl_f1;
-        p.cl_mesh = d_cl_mesh; p.cl_box = d_cl_box; p.mesh_kind = d_mesh_kind; p.mesh_xf = d_mesh_xf; p.xf_mesh = d_xf_mesh; p.xf = d_xf; p.rest_pts = d_rest_pts;
+        p.face_orig = d_face_orig; p.n_cl = n_cl; p.n_xf = n_xf;
+        p.cl_box = d_cl_box; p.mesh_kind = d_mesh_kind; p.mesh_xf = d_mesh_xf; p.xf_mesh = d_xf_mesh; p.xf = d_xf; p.rest_pts = d_rest_pts;
         p.pnorm = d_pnorm; p.tri_rest = d_tri_rest; p.cl_info = d_cl_info;
         p.n_sup = n_sup; p.n_small = n_small; p.sup_box = d_sup_box; p.sup_info = d_sup_info; p.small_mesh = d_small_mesh;
         p.mesh_pts = d_mesh_pts; p.interp_pts = d_interp; p.interp_center = d_center; p.dyn_vel = d_dyn_vel; p.dyn_omega = d_dyn_omega;
@@ -2531,16 +2527,15 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         }
         h->h_mesh_kind = mesh_kind; h->h_voff = voff; h->h_foff = foff; h->h_xf_mesh = xf_mesh; h->h_xf_ref = xf_ref;
         for (int m = 0; m < h->n_mesh; ++m) h->any_large = h->any_large || (mesh_kind[m] & 1);
-        TRY(dev_alloc(&h->d_face_orig, h->nF)); TRY(dev_alloc(&h->d_face_mesh, h->nF)); TRY(dev_alloc(&h->d_cl_f0, h->n_cl)); TRY(dev_alloc(&h->d_cl_f1, h->n_cl));
-        TRY(dev_alloc(&h->d_cl_mesh, h->n_cl)); TRY(dev_alloc(&h->d_cl_box, cl_box.size())); TRY(dev_alloc(&h->d_mesh_kind, h->n_mesh)); TRY(dev_alloc(&h->d_mesh_xf, h->n_mesh));
+        TRY(dev_alloc(&h->d_face_orig, h->nF));
+        TRY(dev_alloc(&h->d_cl_box, cl_box.size())); TRY(dev_alloc(&h->d_mesh_kind, h->n_mesh)); TRY(dev_alloc(&h->d_mesh_xf, h->n_mesh));
         TRY(dev_alloc(&h->d_rest_pts, 3 * (size_t)h->nV)); TRY(dev_alloc(&h->d_pnorm, pnorm.size()));
         TRY(dev_alloc(&h->d_xf_mesh, xf_mesh.size())); TRY(dev_alloc(&h->d_xf_ref, xf_ref.size())); TRY(dev_alloc(&h->d_xf_rest_box, xf_rest_box.size()));
         TRY(dev_alloc(&h->d_xf, (size_t)E * n_sub * std::max(1, h->n_xf) * 12)); TRY(dev_alloc(&h->d_rigid_err, 4));
         R2S_HIP_TRY(hipMemsetAsync(h->d_rigid_err, 0, 16, s));
         R2S_HIP_TRY(hipHostMalloc((void**)&h->h_rigid_err, 64, hipHostMallocDefault));
         *h->h_rigid_err = 0;
-        TRY(upload(h->d_face_orig, face_orig.data(), face_orig.size(), s)); TRY(upload(h->d_face_mesh, face_mesh.data(), face_mesh.size(), s));
-        TRY(upload(h->d_cl_f0, cl_f0.data(), cl_f0.size(), s)); TRY(upload(h->d_cl_f1, cl_f1.data(), cl_f1.size(), s)); TRY(upload(h->d_cl_mesh, cl_mesh.data(), cl_mesh.size(), s));
+        TRY(upload(h->d_face_orig, face_orig.data(), face_orig.size(), s));
         {
             std::vector<float> box_t(cl_box.size());
             for (int c = 0; c < h->n_cl; ++c)
@@ -2688,7 +2683,7 @@ void r2s_phys_destroy(R2SPhys* h)
     drop_graph(h);
     void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
                     h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_mesh_list, h->d_mesh_cnt, h->d_vdef, h->d_cand_mark, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
-                    h->d_faces, h->d_face_orig, h->d_face_mesh, h->d_cl_f0, h->d_cl_f1, h->d_cl_mesh, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
+                    h->d_faces, h->d_face_orig, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
                     h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_sup_info, h->d_sup_box, h->d_small_mesh, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
                     h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta, h->d_hit_cnt};
