@@ -182,6 +182,43 @@ def test_gripper_fingers_dynamic_mesh():
     assert np.abs(f - o.collision_forces).sum() < 0.3 * np.abs(o.collision_forces).sum()
 
 
+@pytest.mark.parametrize("defer", ["0", "1"], ids=["queries in place", "finishing kernel"])
+def test_small_meshes_with_more_than_128_faces_in_total(defer, monkeypatch):
+    """Every mesh small (<= 256 faces) but 176 faces in total: too many for the finishing kernel's triangles-in-registers
+    variant (128), so k_contact_finish answers through the face table (the small-mesh branch of the workgroup query) — two
+    closing fingers above the toy plus two static finger-sized posts it is pushed against; both flavours against the oracle."""
+    import torch
+    from r2s_hip import synth
+
+    monkeypatch.setenv("R2S_MESH_DEFER", defer)
+    n_sub = 100
+    ob = make_object("sloth", 500, seed=8)
+    c = ob["points"].mean(0)
+    top, x_hi = ob["points"][:, 2].max(), ob["points"][:, 0].max()
+    fl = synth.finger_mesh((c[0], c[1] - 0.02, top + 0.03))
+    fr = synth.finger_mesh((c[0], c[1] + 0.02, top + 0.03))
+    posts = [synth.finger_mesh((x_hi + 0.0105, c[1], top * z), size=(0.02, 0.06, 0.4 * top)) for z in (0.3, 0.7)]   # 0.5 mm behind the +x extremity
+    assert sum(len(m[1]) for m in (fl, fr, *posts)) > 128
+    interp, centers, dv, om = gripper_motion([fl, fr], n_sub, 5e-5, vel=(0.0, 0.0, -6.0), closing=1.0)
+    ob["v0"] = np.zeros_like(ob["points"]); ob["v0"][:, 0] = 1.0                       # drifting into the posts
+    kw = dict(dynamic_meshes=[fl, fr], static_meshes=posts, self_collision=False)
+    o = oracle_env(ob, num_substeps=n_sub, **kw)
+    h = hip_env(ob, num_substeps=n_sub, **kw)
+    o.set_mesh_interactive(interp, centers, dv, om)
+    t = lambda a: torch.from_numpy(a)[None].cuda()  # noqa: E731
+    h.set_mesh_interactive(t(interp), t(centers), t(dv), t(om))
+    o.step(); h.step()
+    fl_ = h.last_flavour()
+    assert fl_["mesh_template"] == 1 and fl_["deferred_mesh_queries"] == (defer == "1")
+    nd = len(fl[1]) + len(fr[1])
+    assert np.abs(o.collision_forces[:nd]).max() > 0 and np.abs(o.collision_forces[nd:]).max() > 0, "fingers and posts must both be touched"
+    assert close(h.x[0], o.x, ATOL, what=f"176 small faces, {'finishing kernel' if defer == '1' else 'in place'}")
+    f = h.collision_forces()[0].cpu().numpy()
+    for sl in (slice(0, nd), slice(nd, None)):
+        tot_o, tot_h = o.collision_forces[sl].sum(0), f[sl].sum(0)
+        assert np.allclose(tot_h, tot_o, rtol=2e-3, atol=np.abs(tot_o).max() * 2e-3), (tot_o, tot_h)
+
+
 def test_collision_forces_are_cleared_on_every_replay_of_the_step():
     """collision_forces holds the LAST substep's forces of the LAST step (the reference zeroes the accumulator in every
     substep): a second step without contact must read all zeros.  Regression for a captured memset that only cleared on
