@@ -219,6 +219,38 @@ def test_small_meshes_with_more_than_128_faces_in_total(defer, monkeypatch):
         assert np.allclose(tot_h, tot_o, rtol=2e-3, atol=np.abs(tot_o).max() * 2e-3), (tot_o, tot_h)
 
 
+def test_two_large_dynamic_meshes_finely_tessellated_fingers():
+    """Two dynamic meshes with more than 256 faces each (fingers re-tessellated to 320 triangles): both are large rigid meshes
+    with their own per-substep transform — the second one's is not the register-resident one of the query — and they are
+    gripper meshes (relative-velocity frame, 5 mm margin, re-query starting at the previous answer's cluster)."""
+    import torch
+    from r2s_hip import synth
+
+    n_sub = 100
+    ob = make_object("sloth", 500, seed=6)
+    c = ob["points"].mean(0)
+    top = ob["points"][:, 2].max()
+    fl = synth.finger_mesh((c[0], c[1] - 0.02, top + 0.03), n_faces=320)
+    fr = synth.finger_mesh((c[0], c[1] + 0.02, top + 0.03), n_faces=320)
+    assert len(fl[1]) > 256 and len(fr[1]) > 256
+    interp, centers, dv, om = gripper_motion([fl, fr], n_sub, 5e-5, vel=(0.0, 0.0, -6.0), closing=1.0)
+    kw = dict(dynamic_meshes=[fl, fr], self_collision=False)
+    o = oracle_env(ob, num_substeps=n_sub, **kw)
+    h = hip_env(ob, num_substeps=n_sub, **kw)
+    o.set_mesh_interactive(interp, centers, dv, om)
+    t = lambda a: torch.from_numpy(a)[None].cuda()  # noqa: E731
+    h.set_mesh_interactive(t(interp), t(centers), t(dv), t(om))
+    o.step(); h.step()
+    assert h.last_flavour()["mesh_template"] == 2
+    mm = h.mesh_map
+    assert np.abs(o.collision_forces[mm == 0]).max() > 0 and np.abs(o.collision_forces[mm == 1]).max() > 0, "both fingers must touch"
+    assert close(h.x[0], o.x, ATOL, what="two large dynamic (gripper) meshes vs oracle")
+    f = h.collision_forces()[0].cpu().numpy()
+    for m in (0, 1):
+        tot_o, tot_h = o.collision_forces[mm == m].sum(0), f[mm == m].sum(0)
+        assert np.allclose(tot_h, tot_o, rtol=2e-3, atol=np.abs(tot_o).max() * 2e-3), (m, tot_o, tot_h)
+
+
 def test_collision_forces_are_cleared_on_every_replay_of_the_step():
     """collision_forces holds the LAST substep's forces of the LAST step (the reference zeroes the accumulator in every
     substep): a second step without contact must read all zeros.  Regression for a captured memset that only cleared on
