@@ -251,6 +251,33 @@ def test_two_large_dynamic_meshes_finely_tessellated_fingers():
         assert np.allclose(tot_h, tot_o, rtol=2e-3, atol=np.abs(tot_o).max() * 2e-3), (m, tot_o, tot_h)
 
 
+def test_pusher_mesh_with_more_than_64_super_clusters():
+    """A 41k-face rod: more than 64 super-clusters (512 faces each), so the first level of the box hierarchy takes two passes
+    of one box per lane; against the oracle's brute force."""
+    import torch
+    from r2s_hip import synth
+    from util_physics import rigid_motion
+
+    n_sub = 10
+    ob = make_object("T", 1200, seed=15)
+    top = ob["points"][:, 2].max(); x_lo = ob["points"][:, 0].min()
+    y_face = float(np.median(ob["points"][ob["points"][:, 0] < x_lo + 0.005, 1]))
+    rod = synth.cylinder_mesh((x_lo - 0.0052, y_face, top * 0.5 + 0.02), radius=0.005, length=0.2, n_seg=128, n_rings=160)
+    assert len(rod[1]) > 64 * 512
+    interp, centers, dv, om = rigid_motion(rod, n_sub, 5e-5, vel=(2.0, 0.0, 0.0), omega=(0.0, 0.0, 2.0))
+    kw = dict(dynamic_meshes=[rod], self_collision=False, use_pusher=True, collide_eef_fric=0.2)
+    o = oracle_env(ob, num_substeps=n_sub, **kw)
+    h = hip_env(ob, num_substeps=n_sub, **kw)
+    o.set_mesh_interactive(interp, centers, dv, om)
+    t = lambda a: torch.from_numpy(a)[None].cuda()  # noqa: E731
+    h.set_mesh_interactive(t(interp), t(centers), t(dv), t(om))
+    o.step(); h.step()
+    assert np.abs(o.collision_forces).max() > 0, "the rod must touch the block in this scenario"
+    assert close(h.x[0], o.x, 1e-5, what="41k-face rod (two passes over the super-cluster boxes) vs oracle")
+    tot_o, tot_h = o.collision_forces.sum(0), h.collision_forces()[0].cpu().numpy().sum(0)
+    assert np.allclose(tot_h, tot_o, rtol=2e-3, atol=np.abs(tot_o).max() * 2e-3), (tot_o, tot_h)
+
+
 def test_collision_forces_are_cleared_on_every_replay_of_the_step():
     """collision_forces holds the LAST substep's forces of the LAST step (the reference zeroes the accumulator in every
     substep): a second step without contact must read all zeros.  Regression for a captured memset that only cleared on
