@@ -161,8 +161,9 @@ int r2s_phys_log_contacts(R2SPhys* h, int32_t* out3_dev, r2s_stream_t stream);
  * substep k of the last env step; out[num_substeps] != 0 if any particle was near a collision mesh.  HOST int32
  * [num_substeps + 1]; synchronises `stream`. */
 int r2s_phys_deferred_counts(R2SPhys* h, int32_t* out, r2s_stream_t stream);
-/* Which captured flavour the last r2s_phys_step ran: out[0] self-collision finishing kernel (0/1), out[1] mesh template
- * (0 none, 1 small meshes per lane, 2 large mesh wave-cooperative), out[2] deferred large-mesh queries (0/1), out[3] chains. */
+/* Which captured flavour the last r2s_phys_step ran: out[0] self-collision variant (0/1), out[1] mesh template (0 none,
+ * 1 every mesh small: the fused kernel answers the rare query itself unless out[2], 2 a large mesh is present: the fused
+ * kernel only lists), out[2] finishing kernel in the graph (0/1; always 1 with a large mesh), out[3] kernel chains. */
 int r2s_phys_last_flavour(R2SPhys* h, int32_t* out);
 /* Tuning (not part of the reference surface): chains > 0 overrides the number of concurrent kernel chains of the captured
  * env step (0 = default), mesh_defer 0/1 forces the deferred large-mesh-query flavour (-1 = automatic).  The environment
