@@ -1819,7 +1819,7 @@ struct R2SPhys {
     int* d_masks = nullptr;
     int *d_coll_num = nullptr, *d_coll_idx = nullptr, *d_max_count = nullptr;
     float4* d_vbc = nullptr;
-    int2* d_mesh_list = nullptr; int* d_mesh_cnt = nullptr; int mesh_cap = 0; // deferred mesh queries: [chains][cap], [chains][n_sub + 1]
+    int2* d_mesh_list = nullptr; int* d_mesh_cnt = nullptr; int mesh_cap = 0; // deferred mesh queries: [E * N] (a chain's slice starts at its first env), [chains][n_sub + 1]
     float4* d_vdef = nullptr;
     int* d_cand_mark = nullptr;
     int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false;
@@ -2031,7 +2031,8 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
     p.e0 = e0; p.ne = ne; p.cb = (h->nb * ne + 7) / 8;
     const int chain = chain_id;
     if (h->nF > 0) { // this chain's slice of the deferred-query list and counters ([n_sub] = the near-a-mesh count of the env step)
-        p.mesh_list = h->d_mesh_list + (size_t)chain * h->mesh_cap;
+        p.mesh_list = h->d_mesh_list + (size_t)e0 * h->N; // a chain lists only its own environments' particles: at most ne * N per substep
+        p.mesh_cap = ne * h->N;
         p.mesh_cnt = h->d_mesh_cnt + (size_t)chain * (h->prm.num_substeps + 1);
         hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((h->prm.num_substeps + 256) / 256)), dim3(256), 0, s, (float*)p.mesh_cnt, (size_t)h->prm.num_substeps + 1);
         if (with_self && p.mesh_defer) { // marks of the previous env step must not match this step's substep numbers
@@ -2625,9 +2626,9 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     TRY(dev_alloc(&h->d_max_count, 4));
     R2S_HIP_TRY(hipMemsetAsync(h->d_max_count, 0, sizeof(int) * 4, s));
     if (h->nF > 0) { // deferred mesh queries
-        h->mesh_cap = std::max(4096, E * N); // a particle is listed at most once per substep: the list cannot overflow
-        TRY(dev_alloc(&h->d_mesh_list, (size_t)8 * h->mesh_cap));
-        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_list, 0, sizeof(int2) * (size_t)8 * h->mesh_cap, s));
+        h->mesh_cap = E * N; // a particle is listed at most once per substep: the list cannot overflow
+        TRY(dev_alloc(&h->d_mesh_list, (size_t)h->mesh_cap));
+        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_list, 0, sizeof(int2) * (size_t)h->mesh_cap, s));
         TRY(dev_alloc(&h->d_mesh_cnt, (size_t)8 * (h->prm.num_substeps + 1)));
         TRY(dev_alloc(&h->d_vdef, (size_t)E * N));
         if (h->prm.self_collision) { TRY(dev_alloc(&h->d_cand_mark, (size_t)E * N)); R2S_HIP_TRY(hipMemsetAsync(h->d_cand_mark, 0, sizeof(int) * (size_t)E * N, s)); }
