@@ -44,12 +44,12 @@ def main():
                 ent["wave_cycles_waiting_frac"] = round(m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"], 4)
                 ent["wave_cycles_issue_stalled_frac"] = round(m.get("SQ_WAIT_INST_ANY", 0) / m["SQ_WAVE_CYCLES"], 4)
         out[key] = ent
-    res = {"note": "rocprofv3 --pmc passes (tools/profiling/pmc_r2.sh) over tools/profiling/pmc_run.py on one MI355X: sloth_32env, R2S_CHAINS=1 (a k_substep dispatch = "
+    res = {"note": "rocprofv3 --pmc passes (tools/profiling/pmc_r2.sh) over tools/profiling/pmc_run.py on one MI355X: " + os.environ.get("PMC_CONFIG", "sloth_32env") + ", R2S_CHAINS=1 (a k_substep dispatch = "
                    "one batched substep of all 32 envs), 2 free + 3 contact env steps.  hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                    "(FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md; the 512 MiB calibration copy of the same run is listed).  "
                    "valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 shader engines) — the counter sums the VALU-active cycles of every WAVE, and instructions of different waves overlap in the pipeline, so a saturated kernel reads slightly above 1 (k_composite: 1.14); lds_busy_frac = SQ_LDS_IDX_ACTIVE / 256 CUs "
                    "over the same span.",
-           "sloth_32env": out}
+           os.environ.get("PMC_CONFIG", "sloth_32env"): out}
     json.dump(res, open(os.path.join(root, "r2_pmc_summary.json"), "w"), indent=1)
     for k, e in out.items():
         print(k, {a: b for a, b in e.items() if a != "counters_mean_per_dispatch"})
