@@ -76,7 +76,7 @@ def cpu_baseline(ro, budget_s=20.0):
     means = ro.means[0].cpu().numpy()
     g = {k: v.cpu().numpy() for k, v in ro.g.items()}
     t0 = time.perf_counter()
-    for cam in ro.cams:
+    for cam in [ro.camera_numpy(0, v) for v in range(len(ro.cams))]:
         oracle.raster_forward(means, g["opacities"], cam["viewmatrix"], cam["projmatrix"], cam["campos"], cam["tanfovx"],
                               cam["tanfovy"], ro.H, ro.W, cam["bg"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
                               z_threshold=cam["z_threshold"])
@@ -145,6 +145,10 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the throughput-mode comparison that follows the timed window")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--stub", action="store_true", help="CPU stand-in workload over gloo (launcher test)")
+    ap.add_argument("--no-parity-gate", action="store_true", help="skip the parity gate that precedes the timed window (default: on; a failing gate "
+                                                                  "withholds `value`)")
+    ap.add_argument("--dephase", type=int, default=0, help="K > 1: additionally time a window in which environment e runs the same action trace "
+                                                           "(e %% K) steps late, so that the batch is not in one phase of the episode (reported next to `value`)")
     ap.add_argument("--sink", default=None, help="directory: also run the observation sink (row f4) every step — packed 8-bit frames + state "
                                                  "to pinned ring buffers, JPEG / pickle written by a host thread; not part of the headline")
     args = ap.parse_args()
@@ -168,6 +172,18 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     from r2s_hip.rollout import BatchedRollout
+
+    # ---- parity gate (every timed configuration first passes the position and image gates) ----------------
+    # One environment of THIS workload through the product path into the phase the window times in contact, 20 substeps + one
+    # frame against the oracle (oracle/parity_gate.py: the oracle is the checker, never the thing timed).  Rank 0 only; the
+    # other ranks wait at the first barrier.
+    gate = None
+    if not args.no_parity_gate and rank == 0:
+        from oracle import parity_gate
+        try:
+            gate = parity_gate.run(args.config, device=dev, seed=rank, num_substeps=args.substeps, n_compare=20, close_at=2)
+        except Exception as e:  # a gate that cannot run is a failed gate
+            gate = {"passed": False, "error": f"{type(e).__name__}: {e}"}
 
     close_at = args.warmup + args.steps // 2   # the timed window is half free motion, half contact (grasp schedule / pusher)
     ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=close_at)
@@ -193,7 +209,7 @@ def main():
     for k in range(args.steps):
         ro.step()
         if sink is not None:
-            sink.submit(k, ro.out_color, state=dict(x=ro.phys.x, v=ro.phys.v))
+            sink.submit(k, ro.out_color, state=dict(x=ro.phys.x, v=ro.phys.v), ready=getattr(ro, "_render_done", None))
     barrier()
     elapsed = time.perf_counter() - t0
     log = ro.read_log()
@@ -330,6 +346,7 @@ def main():
                        "note": "free = the end effector moves, nothing touches; contact = fingers closed on the toy's arms / rod against the block "
                                "(mesh_contacts = particles inside a collision margin in the last substep, self_collision_candidates = particles "
                                "with live candidates, maxima over the phase's steps)"},
+            "parity_gate": gate if gate is not None else {"passed": None, "note": "skipped (--no-parity-gate)"},
             "roofline": roof,
             "raster": {"gs_raster_mpix_per_s": frames * ro.W * ro.H / (raster_ms * 1e-3) / 1e6, "frames": frames,
                        "num_rendered": int(ro.last_num_rendered), "stage_ms": stages, "scene": scene,
@@ -350,6 +367,10 @@ def main():
             out["observation_sink"] = sink_report
         if pipe_report is not None:
             out["throughput_mode"] = pipe_report
+        if gate is not None and not gate.get("passed"):
+            out["value_withheld"] = out["value"]
+            out["value"] = None
+            out["note"] = "PARITY GATE FAILED: the throughput of a path whose results differ from the reference's is not a result (see parity_gate)"
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(ro, args.cpu_budget)

@@ -161,6 +161,10 @@ int r2s_phys_log_contacts(R2SPhys* h, int32_t* out3_dev, r2s_stream_t stream);
  * substep k of the last env step; out[num_substeps] != 0 if any particle was near a collision mesh.  HOST int32
  * [num_substeps + 1]; synchronises `stream`. */
 int r2s_phys_deferred_counts(R2SPhys* h, int32_t* out, r2s_stream_t stream);
+/* Diagnostics: how many particles with self-collision candidates were ALSO handed to the finishing kernel's mesh list
+ * (tagged entries: object_collision impulses, :230-268, then mesh_collision, :295-421, by one workgroup) at least once during
+ * the last r2s_phys_step.  HOST int32[1]; synchronises `stream`. */
+int r2s_phys_tagged_count(R2SPhys* h, int32_t* out, r2s_stream_t stream);
 /* Which captured flavour the last r2s_phys_step ran: out[0] self-collision variant (0/1), out[1] mesh template (0 none,
  * 1 every mesh small: the fused kernel answers the rare query itself unless out[2], 2 a large mesh is present: the fused
  * kernel only lists), out[2] finishing kernel in the graph (0/1; always 1 with a large mesh), out[3] kernel chains. */

@@ -1,0 +1,139 @@
+"""TEST INFRASTRUCTURE — NOT PRODUCT CODE.  The parity gate tied to timing (SURVEY.md §8d "every timed configuration first
+passes ..."): one environment of the bench's OWN scene and action trace is driven through the product path (BatchedRollout ->
+C ABI -> HIP kernels) up to the phase the timed window measures, then a few substeps of the contact flavour and one rendered
+frame are compared with the oracle.  Used by tests/test_contact_flavours_gpu.py and by ``bench.py --parity-gate`` (before the
+timed window; the oracle is the checker here, never the thing measured).
+
+What runs, for a gripper scene (sloth_32env, rope_1env, sloth_multicam_8env):
+  1. a 1-environment BatchedRollout of the config with the grasp at env step ``close_at`` (settled like the bench's);
+  2. every env step, oracle/eef_oracle.EefOracle (phystwin.py:362-513 restated) is stepped next to the device kinematics on the
+     same inputs — end-effector pose / rates / commanded opening of the synthetic trace, the previous step's per-face forces —
+     and its interpolated vertices / centres / finger velocities are compared with the device's (the grasp state machine
+     exactly);
+  3. in the first env step AFTER the fingers closed (arms pressed together: live self-collision candidates + finger contact,
+     the flavour k_substep<..,true,1> + k_contact_finish<3,true>), the particle state is copied to oracle.PhysOracle
+     (spring_mass_warp.py:823-943 restated), both rebuild their candidate lists, both run ``n_compare`` substeps driven by the
+     EefOracle's arrays / the device kinematics, positions are compared (gate 1e-5 abs, BASELINE.json);
+  4. the side-camera frame of the environment is rendered by the product path and by the raster oracle (forward.cu:262-394
+     restated) and compared (|d| <= 1e-4 + 1e-4 |ref|, at most 1e-4 of the pixels outside).
+For the pusher scene (T_pusher_32env) step 2 uses the pusher branch (phystwin.py:462-510) and step 3 runs in the first env step
+that starts with the rod against the block.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+
+def _eef_pts_func(table):
+    from .eef_oracle import make_eef_pts_func
+
+    return make_eef_pts_func(table)
+
+
+def run(config="sloth_32env", device="cuda:0", seed=0, num_substeps=667, n_compare=20, close_at=2, max_steps=None, render=True,
+        settle_steps=None):
+    """Returns a dict: x_max_abs, v_max_abs, rgb_max_rel, bad_pixels, ... and ``passed``."""
+    import torch
+
+    from . import PhysOracle, raster_forward
+    from .eef_oracle import EefOracle
+    from r2s_hip import synth
+    from r2s_hip.rollout import BatchedRollout
+
+    t_start = time.perf_counter()
+    ro = BatchedRollout(config, device=device, seed=seed, n_env=1, num_substeps=num_substeps, close_at=close_at, settle_steps=settle_steps)
+    ph = ro.phys
+    fn = _eef_pts_func(ro.eef_table)
+    eo = EefOracle(ro.dt, num_substeps, 3e4, use_pusher=ro.use_pusher)
+    x0 = ro.ob["points"] + ro.env_shift[0]
+    sta = None
+    if (ph.mesh_map < 0).any():
+        c = ro.ob["points"].mean(0)
+        sta = [synth.box_mesh((c[0] + 0.25, c[1] + 0.2, 0.135), (0.2, 0.13, 0.27))]
+    o = PhysOracle(x0, ro.ob["springs"], ro.ob["rest"], ro.ob["log_Y"], num_substeps=num_substeps, self_collision=ph.self_collision,
+                   dynamic_meshes=ro.fingers, static_meshes=sta, use_pusher=ro.use_pusher, collide_eef_fric=0.2 if ro.use_pusher else 1.0)
+    assert np.array_equal(o.mesh_map, ph.mesh_map)
+    out = dict(config=config, particles=int(ro.N), substeps_compared=int(n_compare), eef_pts_max_abs=0.0, eef_center_max_abs=0.0, eef_vel_max_abs=0.0)
+    max_steps = max_steps if max_steps is not None else close_at + 6
+    compared = False
+    for t in range(max_steps):
+        # ---- the caller side, oracle next to device (same inputs) ----
+        if ph.self_collision:
+            ph.update_collision_graph()
+        act = ro.synthetic_action(ro.t)
+        F_prev = ph.collision_forces()[0].cpu().numpy()
+        g = lambda k: act[k][0:1].cpu().numpy()  # noqa: E731
+        op = None if ro.use_pusher else float(act["gripper_openness"][0].item())
+        ref = eo.step(g("eef_xyz"), g("eef_vel"), g("eef_rot"), g("eef_rot_vel"), op, fn, ro.eef_init, F_prev, ph.mesh_map)
+        ro.apply_action(act)
+        pts, ctr, dv, om = [a.cpu().numpy() if a is not None else None for a in ph.mesh_motion(points=not ro.use_pusher)]
+        if pts is not None:
+            out["eef_pts_max_abs"] = max(out["eef_pts_max_abs"], float(np.abs(pts[0] - ref["interp_points"]).max()))
+        out["eef_center_max_abs"] = max(out["eef_center_max_abs"], float(np.abs(ctr[0] - ref["interp_center"]).max()))
+        nv = ref["dynamic_velocity"].shape[0]
+        out["eef_vel_max_abs"] = max(out["eef_vel_max_abs"], float(np.abs(dv[0, :nv] - ref["dynamic_velocity"]).max()))
+        if not ro.use_pusher:
+            cur, grasped = ph.eef_state()
+            if cur[0].item() != eo.current_openness or bool(grasped[0]) != eo.grasped:
+                out["state_machine_mismatch_at_step"] = t
+        # ---- the stepper: compare a window of substeps once the scene is in the flavour the bench times in contact ----
+        # gripper scenes: the first env step after the closing step whose candidate rebuild finds live pairs (the arms pressed
+        # together); pusher scene: the first env step that STARTS with the rod against the block
+        if t >= close_at + 1 and not compared:
+            x, v = ph.sync_state()
+            o.x[:] = x[0].cpu().numpy(); o.v[:] = v[0].cpu().numpy()
+            n_cand = 0
+            if ph.self_collision:
+                o.update_collision_graph()
+                n_cand = int((o.coll_num > 0).sum())
+            last_chance = t == max_steps - 1
+            if ro.use_pusher or n_cand > 0 or last_chance:
+                o.set_mesh_interactive(ref["interp_points"], ref["interp_center"], ref["dynamic_velocity"], ref["dynamic_omega"])
+                x_before = o.x.copy(); v_before = o.v.copy()
+                o.step(n_compare, 0)
+                hit = float(np.abs(o.collision_forces).max()) > 0
+                if ro.use_pusher and not hit and not last_chance:
+                    o.x[:] = x_before; o.v[:] = v_before          # the rod has not reached the block yet: try the next env step
+                else:
+                    ph.step(n_compare, 0)
+                    fl = ph.last_flavour()
+                    out.update(x_max_abs=float(np.abs(ph.x[0].cpu().numpy() - o.x).max()), v_max_abs=float(np.abs(ph.v[0].cpu().numpy() - o.v).max()),
+                               particles_with_candidates=n_cand, tagged_entries=int(ph.tagged_count()), mesh_contact=bool(hit),
+                               deferred_per_substep_max=int(ph.deferred_counts()[:n_compare].max()), flavour=fl["kernel"], compared_at_env_step=t)
+                    compared = True
+                    ph.step(num_substeps - n_compare, n_compare)       # the rest of this env step, on the device only
+        if compared:
+            break
+        ph.step(0, 0)
+        ro.t += 1
+    if not compared:
+        out.update(x_max_abs=float("inf"), v_max_abs=float("inf"), particles_with_candidates=0, tagged_entries=0, mesh_contact=False)
+    # ---- one frame of the environment: product path vs raster oracle ----
+    if render:
+        ro.render()
+        col, dep = ro.observations()
+        torch.cuda.synchronize()
+        cam = ro.camera_numpy(0, 0)
+        sc = ro.scene_numpy(0)
+        _, col_ref, _, dep_ref = raster_forward(sc["means3D"], sc["opacities"], cam["viewmatrix"], cam["projmatrix"], cam["campos"], cam["tanfovx"],
+                                                cam["tanfovy"], ro.H, ro.W, cam["bg"], shs=sc["shs"], scales=sc["scales"], rotations=sc["rotations"],
+                                                z_threshold=cam["z_threshold"])
+        c = col[0, 0].cpu().numpy().astype(np.float64); d = dep[0, 0].cpu().numpy().astype(np.float64)
+        err = np.abs(c - col_ref)
+        bad = (err > 1e-4 + 1e-4 * np.abs(col_ref)).any(0) | (np.abs(d - dep_ref) > 1e-4 * np.abs(dep_ref))[0]
+        lit = np.abs(col_ref) > 1e-2
+        out.update(rgb_max_rel=float((err[lit] / np.abs(col_ref[lit])).max()) if lit.any() else 0.0, rgb_max_abs=float(err.max()),
+                   bad_pixels=int(bad.sum()), pixels=int(bad.size), frame=f"{ro.W}x{ro.H} side camera, env 0")
+    else:
+        out.update(rgb_max_rel=None, bad_pixels=None, pixels=None)
+    ok_phys = out["x_max_abs"] < 1e-5 and out["mesh_contact"] and "state_machine_mismatch_at_step" not in out
+    if ph.self_collision and not ro.use_pusher:
+        ok_phys = ok_phys and out["particles_with_candidates"] > 0
+    ok_img = (not render) or out["bad_pixels"] <= 1e-4 * out["pixels"]
+    out["gates"] = {"x_max_abs": 1e-5, "bad_pixel_fraction": 1e-4, "rgb": "|d| <= 1e-4 + 1e-4 |ref|", "depth": "|d| <= 1e-4 |ref| (median-depth flips count as bad pixels)"}
+    out["passed"] = bool(ok_phys and ok_img)
+    out["seconds"] = time.perf_counter() - t_start
+    del ro
+    return out

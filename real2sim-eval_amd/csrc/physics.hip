@@ -21,8 +21,9 @@
 //     stay resident in that XCD's L2 and most halo records were written by the same XCD.
 //   * Self collision needs the post-force velocity of the contact partner (object_collision reads
 //     v_before_collision[j]): particles that appear in a candidate list only PUBLISH their post-force velocity
-//     in the fused kernel and are finished by k_self_finish (second launch per substep, only captured into the
-//     graph flavour used while candidates exist).
+//     in the fused kernel and are finished by the substep's ONE finishing launch — k_contact_finish (part 2; part 1 are
+//     the deferred mesh queries) while something is near a mesh, k_self_finish otherwise; only the graph flavours used
+//     while candidates exist carry it.
 //   * State is ping-ponged between two buffers of 24-byte records [env][particle]{xy | (z, vz) | vxy} — the three
 //     8-byte words of the LDS window's planes, no padding, nothing to repack when staging; topology is shared by all
 //     environments and stays cache-resident.
@@ -136,6 +137,7 @@ struct PhysDev {
     const float* aabb_static;  // [E,n_mesh-n_dyn_mesh,6]
     float* coll_forces;        // [E,nF,3]
     int* hit_cnt;              // [E] particles that reacted to a mesh in the LAST substep (zeroed with coll_forces)
+    int* fault;                // sticky: a self-collision impulse exceeded the bound the "no mesh in reach" decision relies on
 };
 
 // Everything from here to the spring gather is compiled WITHOUT fused multiply-add contraction: the collision
@@ -450,6 +452,12 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
         }
         // ---- large meshes
         int C0 = -1; // the cluster every wavefront has visited
+        // `best0`: the bound after the part every wavefront computed identically (small meshes, the hinted / nearest cluster).
+        // The ballots that NUMBER the candidates (smask, cm, r) use it, so that candidate r is the same cluster in every
+        // wavefront; the per-wavefront `best` — which diverges as soon as the wavefronts visit different clusters — only prunes
+        // a wavefront's own visits.  (Round 2 numbered with the diverging bound: a cluster could get a different rank in
+        // different wavefronts and be visited by none — more than eight super-clusters in reach, or more than 64 in total.)
+        float best0 = best;
         if (hint >= 0) { // a re-query next to the previous answer: its cluster first, no search for the nearest box
             C0 = hint;
             const int4 ci = p.cl_info[C0];
@@ -476,8 +484,9 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
                 }
                 R2S_QSTAMP(); // nearest cluster done
             }
+            if (sb == 0) best0 = best; // identical in every wavefront up to here
             // step 2: the super-clusters still in reach, eight per round
-            unsigned long long smask = __builtin_amdgcn_ballot_w64(d2s < best * 1.0001f + 1e-12f);
+            unsigned long long smask = __builtin_amdgcn_ballot_w64(d2s < best0 * 1.0001f + 1e-12f);
             int r = 0; // running candidate number (the same in every wavefront)
             while (smask) {
                 const int rank = __builtin_popcountll(smask & ((1ull << lane) - 1ull));
@@ -490,7 +499,7 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
                 const bool valid = idx < cnt && j < ncl;
                 const int c = valid ? c0 + j : 0;
                 const float d2c = valid ? box6(p.cl_box, p.n_cl, c, rest_point(slot)) : 3.0e38f;
-                unsigned long long cm = __builtin_amdgcn_ballot_w64(d2c < best * 1.0001f + 1e-12f && c != C0);
+                unsigned long long cm = __builtin_amdgcn_ballot_w64(d2c < best0 * 1.0001f + 1e-12f && c != C0);
                 while (cm) { // step 3: this wavefront's share of the candidates
                     const int L = __builtin_ctzll(cm);
                     cm &= cm - 1;
@@ -1254,9 +1263,15 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
             const size_t eb = (size_t)e * p.N;
             const bool act = t < n && e >= p.e0 && e < p.e0 + p.ne && p.cand_mark[eb + i] != step + 1; // not already done in part 1
             const f3 x0 = st_x(xv_in, eb + i);
-            const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub, cnt);
+            const f3 vpre = xyz(p.vbc[eb + i]);
+            const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, vpre, sub, cnt);
             // the fused kernel's test — widened by 2 mm = 40 m/s of velocity change in one substep — found no mesh in reach of this
-            // particle: no query, mesh_collision only advances it
+            // particle: no query, mesh_collision only advances it.  The bound is CHECKED: an impulse beyond it raises a sticky
+            // fault word that the next r2s_phys_step reports (the reference would have applied a mesh response here).
+            if (act && sub == 0) {
+                const f3 dvi = v - vpre;
+                if (dot(dvi, dvi) * p.dt * p.dt > 0.002f * 0.002f) *p.fault = 1;
+            }
             R2S_QP_DECL(-1);
             finish_wave<MESHQ == 3 ? 1 : 2, false, 2>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out, nullptr, nullptr, nullptr, nullptr, true R2S_QP_ARG);
         }
@@ -1906,6 +1921,7 @@ struct R2SPhys {
         p.n_sup = n_sup; p.n_small = n_small; p.sup_box = d_sup_box; p.sup_info = d_sup_info; p.small_mesh = d_small_mesh;
         p.mesh_pts = d_mesh_pts; p.interp_pts = d_interp; p.interp_center = d_center; p.dyn_vel = d_dyn_vel; p.dyn_omega = d_dyn_omega;
         p.aabb_dyn = d_aabb_dyn; p.aabb_static = d_aabb_static; p.coll_forces = d_coll_forces; p.hit_cnt = d_hit_cnt;
+        p.fault = d_mesh_total ? d_mesh_total + 1 : nullptr;
         return p;
     }
 };
@@ -2179,6 +2195,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     h->prm = d->params;
     h->E = d->n_env; h->N = d->num_object_points; h->S = d->num_springs;
     h->coll_cap = d->collision_capacity > 0 ? d->collision_capacity : 500;
+    if (h->coll_cap >= (1 << 19)) { delete h; return R2S_ERR_INVALID; } // list entries pack env (12 bits) | candidate count (19 bits + sign)
     const int N = h->N, E = h->E, S = h->S;
     for (int sp = 0; sp < S; ++sp)
         if (d->init_springs[2 * sp] < 0 || d->init_springs[2 * sp] >= N || d->init_springs[2 * sp + 1] < 0 || d->init_springs[2 * sp + 1] >= N) {
@@ -2632,9 +2649,10 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         TRY(dev_alloc(&h->d_mesh_cnt, (size_t)8 * (h->prm.num_substeps + 1)));
         TRY(dev_alloc(&h->d_vdef, (size_t)E * N));
         if (h->prm.self_collision) { TRY(dev_alloc(&h->d_cand_mark, (size_t)E * N)); R2S_HIP_TRY(hipMemsetAsync(h->d_cand_mark, 0, sizeof(int) * (size_t)E * N, s)); }
-        TRY(dev_alloc(&h->d_mesh_total, 4));
+        TRY(dev_alloc(&h->d_mesh_total, 4)); // [0] particles near a mesh in the last step, [1] sticky impulse-bound fault
+        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int) * 4, s));
         R2S_HIP_TRY(hipHostMalloc((void**)&h->h_mesh_total, 64, hipHostMallocDefault));
-        *h->h_mesh_total = 0;
+        h->h_mesh_total[0] = 0; h->h_mesh_total[1] = 0;
         R2S_HIP_TRY(hipEventCreateWithFlags(&h->mesh_event, hipEventDisableTiming));
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_cnt, 0, sizeof(int) * 8 * (size_t)(h->prm.num_substeps + 1), s));
     }
@@ -2892,6 +2910,11 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     if (h->nF > 0) { // defer the mesh queries to k_contact_finish when the last finished step saw particles near a mesh
         if (h->mesh_pending && hipEventQuery(h->mesh_event) == hipSuccess) h->mesh_pending = false;
         if (!h->mesh_pending) h->mesh_defer = *h->h_mesh_total > 0 ? 1 : 0; // an unfinished count keeps the previous flavour
+        if (!h->mesh_pending && h->h_mesh_total[1] != 0) {
+            r2s::set_last_error_msg("a self-collision impulse changed a particle's velocity by more than 40 m/s within one substep: its mesh-contact "
+                                    "test (widened by 2 mm) may have been skipped where the reference applies it (unsupported)");
+            return R2S_ERR_INVALID;
+        }
         if (h->force_defer >= 0) h->mesh_defer = h->force_defer; // test / tuning: force a flavour
         if (h->any_large) h->mesh_defer = 1;
     }
@@ -2915,7 +2938,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     if (h->nF > 0 && !h->mesh_pending) { // particles near a mesh during this step -> pinned memory, read at a later step without waiting
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int), s));
         hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(64), 0, s, h->d_mesh_cnt + h->prm.num_substeps, 8, h->prm.num_substeps + 1, h->d_mesh_total);
-        R2S_HIP_TRY(hipMemcpyAsync(h->h_mesh_total, h->d_mesh_total, sizeof(int), hipMemcpyDeviceToHost, s));
+        R2S_HIP_TRY(hipMemcpyAsync(h->h_mesh_total, h->d_mesh_total, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         R2S_HIP_TRY(hipEventRecord(h->mesh_event, s));
         h->mesh_pending = true;
     }
@@ -3038,6 +3061,22 @@ int r2s_phys_deferred_counts(R2SPhys* h, int32_t* out, r2s_stream_t stream_)
     return R2S_OK;
 }
 
+// Diagnostics: particles with self-collision candidates that the fused kernel ALSO handed to the mesh list (tagged entries:
+// impulses + query in one go by k_contact_finish part 1) at least once during the last r2s_phys_step.  Synchronises the stream.
+int r2s_phys_tagged_count(R2SPhys* h, int32_t* out, r2s_stream_t stream_)
+{
+    if (!h || !out) return R2S_ERR_INVALID;
+    *out = 0;
+    if (!h->d_cand_mark) return R2S_OK;
+    std::vector<int> tmp((size_t)h->E * h->N);
+    R2S_HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_cand_mark, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    R2S_HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    int n = 0;
+    for (int v : tmp) n += v != 0;
+    *out = n;
+    return R2S_OK;
+}
+
 // Candidate lists written by the caller (collision_number / collision_indices are plain arrays in the reference, :544-552):
 // HOST arrays in the caller's indexing, converted to the internal order.  Parity tests use it to replay the reference's
 // own lists; the next update_collision_graph overwrites them.
@@ -3058,6 +3097,18 @@ int r2s_phys_set_collision_lists(R2SPhys* h, const int32_t* number, const int32_
                 if (uj < 0 || uj >= N) return R2S_ERR_INVALID;
                 idx[dst * cap + k] = h->h_inv[uj];
             }
+        }
+    // object_collision reads v_before_collision[j] of every listed partner j, which only particles that have a list of their own
+    // publish: the candidate relation the reference builds is symmetric (:196-227; a row capped at the capacity may drop
+    // partners, its particle still publishes) — a partner without any list would be read stale, so such lists are refused.
+    for (int e = 0; e < E; ++e)
+        for (int i = 0; i < N; ++i) {
+            const size_t row = (size_t)e * N + i;
+            for (int k = 0; k < num[row]; ++k)
+                if (num[(size_t)e * N + idx[row * cap + k]] == 0) {
+                    r2s::set_last_error_msg("r2s_phys_set_collision_lists: a listed partner has no candidate list of its own (the relation must be symmetric)");
+                    return R2S_ERR_INVALID;
+                }
         }
     int rc = upload(h->d_coll_num, num.data(), num.size(), s);
     if (rc) return rc;

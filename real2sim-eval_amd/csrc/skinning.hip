@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) k_bone_fit(int N, int k_rel, const int* _
 // call on the benchmark scene before, for 0.25 GB of algorithmic traffic).  weights / widx are stored [k][t] (coalesced).
 __global__ void __launch_bounds__(256) k_skin(int N, int P, int k_wgt, const int* __restrict__ order, const float* __restrict__ weights,
                                               const int* __restrict__ widx, const BoneRec* __restrict__ rec, const int* __restrict__ ident_flag,
-                                              const float* __restrict__ xyz, long long xyz_stride, float* __restrict__ out, long long out_stride)
+                                              const float* xyz, long long xyz_stride, float* out, long long out_stride) // xyz may alias out (in-place skinning): no __restrict__
 {
 #pragma clang fp contract(off)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -55,7 +55,7 @@ def _bind():
         r2s_phys_set_eef_table=[vp, C.c_int32, vp, vp, C.c_float, vp], r2s_phys_set_eef_motion=[vp, vp, vp, vp, vp, vp, vp],
         r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
         r2s_phys_set_collision_lists=[vp, vp, vp, vp], r2s_phys_contact_stats=[vp, C.POINTER(C.c_int32), C.POINTER(vp)],
-        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32],
+        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32],
         r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
     ).items():
         fn = getattr(L, name)
@@ -332,6 +332,14 @@ class PhysBatch:
         with torch.cuda.device(self.device):
             check(_bind().r2s_phys_deferred_counts(self._h, out.ctypes.data, self._s()), "r2s_phys_deferred_counts")
         return out
+
+    def tagged_count(self) -> int:
+        """Particles with self-collision candidates that were also handed to the finishing kernel's mesh list (tagged entries)
+        at least once during the last ``step`` call; diagnostics."""
+        n = C.c_int32()
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_tagged_count(self._h, C.byref(n), self._s()), "r2s_phys_tagged_count")
+        return int(n.value)
 
     def last_flavour(self):
         a = (C.c_int32 * 4)()

@@ -2,11 +2,13 @@
 (sim/envs/env.py:53-94 -> PhysTwinDynamics.step, phystwin.py:362-521 -> GSRenderer.render / render_wrist,
 gs_renderer.py:924-1000), for ``n_env`` environments of one GPU at once.
 
-One env step =
+One env step (``BatchedRollout.step(action)``; the reference: ``env.step({'action': (1, 13)})``, env.py:86-94) =
+    action -> end-effector motion per environment (phystwin.py:104-147: velocity and angular rate from the commanded next pose)
     update_collision_graph                       (once per env step, phystwin.py:365-366)
     gripper / pusher kinematics + grasp logic    (on device: r2s_phys_set_eef_motion; phystwin.py:367-513)
     num_substeps fused physics substeps          (the captured graph, phystwin.py:515-519)
     Gaussians follow their particles             (LBS skinning, incremental: gs_renderer.py:717-747 -> r2s_skin_*)
+    wrist camera of every environment from its NEW end-effector pose (on device: r2s_wrist_camera; gs_renderer.py:966-985)
     2 rasterised frames per env (side + wrist)   (env.py:55-56)
 
 Synthetic inputs only: there is no network for the real PhysTwin / Scaniverse assets.
@@ -30,6 +32,35 @@ CONFIGS = {
     "sloth_multicam_8env": ("sloth_arms", 15000, 140000, 8, 1280, 720),   # configs[4] per GPU: 4 views, +60k robot-link Gaussians
     "tiny": ("rope", 600, 3000, 2, 160, 120),
 }
+
+
+def axis_angle_to_rotation_matrix(aa: torch.Tensor) -> torch.Tensor:
+    """kornia.geometry.conversions.axis_angle_to_rotation_matrix restated (kornia is not a dependency here): [N,3] -> [N,3,3],
+    Rodrigues with aa / (theta + 1e-6), first-order matrix when theta^2 <= 1e-6 — the conversion phystwin.py:379 applies."""
+    theta2 = (aa * aa).sum(1, keepdim=True)
+    theta = torch.sqrt(theta2)
+    w = aa / (theta + 1e-6)
+    wx, wy, wz = w[:, 0:1], w[:, 1:2], w[:, 2:3]
+    c, s_ = torch.cos(theta), torch.sin(theta)
+    k = 1.0 - c
+    normal = torch.cat([c + wx * wx * k, wx * wy * k - wz * s_, wy * s_ + wx * wz * k, wz * s_ + wx * wy * k, c + wy * wy * k, -wx * s_ + wy * wz * k,
+                        -wy * s_ + wx * wz * k, wx * s_ + wy * wz * k, c + wz * wz * k], dim=1).view(-1, 3, 3)
+    rx, ry, rz = aa[:, 0:1], aa[:, 1:2], aa[:, 2:3]
+    one = torch.ones_like(rx)
+    taylor = torch.cat([one, -rz, ry, rz, one, -rx, -ry, rx, one], dim=1).view(-1, 3, 3)
+    return torch.where((theta2 > 1e-6).view(-1, 1, 1), normal, taylor)
+
+
+def rotation_matrix_to_axis_angle(R: torch.Tensor) -> torch.Tensor:
+    """Log map of a batch of rotation matrices [N,3,3] -> [N,3] (the role of kornia's rotation_matrix_to_axis_angle at
+    phystwin.py:137; kornia goes through a quaternion, this is the same map written directly — parity unpinned, kornia absent)."""
+    tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    cos = ((tr - 1.0) * 0.5).clamp(-1.0, 1.0)
+    theta = torch.acos(cos)
+    v = torch.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], 1)   # 2 sin(theta) axis
+    s_ = torch.sin(theta)
+    scale = torch.where(theta > 1e-4, theta / (2.0 * s_.clamp(min=1e-12)), torch.full_like(theta, 0.5))
+    return v * scale[:, None]
 
 
 class BatchedRollout:
@@ -142,10 +173,27 @@ class BatchedRollout:
             self._robot_first = True
         self.raster = RasterBatch(self.device)
         self.raster.set_tile_culling(tile_culling)  # exact-output instance culling (include/r2s_raster.h)
-        self.raster.set_async(True)                 # no host read of the instance count inside the pipeline after the first batch
+        # Sync-free batches: no host read of the instance count inside the pipeline after the first batch.  A batch whose count
+        # outgrew the capacity derived from the previous one (+25 %: a reset, an object entering the view) loses its deepest
+        # instances; `render` polls without blocking and counts such batches (`lossy_batches`), `observations()` — what a
+        # closed-loop caller reads — waits, checks, and re-renders the step synchronously if it was one of them.
+        self.raster.set_async(True)
+        self._raster_overflows, self.lossy_batches = 0, 0
         self.cams = [synth.side_camera(W, H), synth.wrist_camera(W, H, eef_pos=(c[0], c[1], top + 0.30)),
                      synth.orbit_camera(W, H, 60.0, target=c), synth.orbit_camera(W, H, -110.0, target=c)][:views]
         self.cam_t = [{k: (t(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()} for cam in self.cams]
+        # The wrist camera (view 1) rides on each environment's end effector: its matrices are rebuilt on the device every step
+        # from (eef_xyz, eef_rot) and the fixed calibration eef2c (gs_renderer.py:966-985), one row per environment, written
+        # into the arrays the prepared frames point at.  The synthetic gripper table (synth.gripper_eef_table) is expressed in a
+        # tool frame whose y and z axes are flipped with respect to the xarm's (the physics inputs use eef_rot = identity for a
+        # tool pointing down), so the calibration constant absorbs the flip: eef2c = inv(c2eef) . diag(1, -1, -1, 1).
+        self.wrist = None
+        if views >= 2:
+            from .camera import WristCamera
+            flip = np.diag([1.0, -1.0, -1.0, 1.0])
+            self.wrist = WristCamera(E, W, H, synth.scaled_K(synth.WRIST_K, W, H), np.linalg.inv(synth.WRIST_C2EEF) @ flip, device=self.device)
+            self._wrist_xyz = t(np.array([c[0], c[1], top + 0.30], np.float32))[None].repeat(E, 1) + t(self.env_shift)   # without a gripper: parked
+            self._wrist_rot = torch.eye(3, device=self.device).repeat(E, 1, 1)
         self.out_color = torch.empty(E, views, 3, H, W, dtype=torch.float32, device=self.device)
         self.out_depth = torch.empty(E, views, 1, H, W, dtype=torch.float32, device=self.device)
         self._update_means()
@@ -154,11 +202,15 @@ class BatchedRollout:
         self._frames = []
         for e in range(E):
             for vi, cam in enumerate(self.cam_t):
-                self._frames.append(dict(set=e, viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"],
+                vm, pm, cp = cam["viewmatrix"], cam["projmatrix"], cam["campos"]
+                if vi == 1 and self.wrist is not None:          # per environment, rewritten in place every step
+                    vm, pm, cp = self.wrist.viewmatrix[e], self.wrist.projmatrix[e], self.wrist.campos[e]
+                self._frames.append(dict(set=e, viewmatrix=vm, projmatrix=pm, campos=cp,
                                          bg=cam["bg"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], z_threshold=cam["z_threshold"],
                                          out_color=self.out_color[e, vi], out_depth=self.out_depth[e, vi]))
         self.t = 0
         self._vel_trace = None
+        self._dephase, self._env_delay = 1, None
         self._cand_fresh = False
         self._prepared = None
         self._log = None
@@ -202,16 +254,63 @@ class BatchedRollout:
             return np.array([0.02 * np.cos(w * tt), 0.0, 0.05], np.float32)   # lift, with a slow sway along the fingers
         return np.array([0.05 * w * np.cos(w * tt) * 0.6, 0.05 * w * np.cos(2 * w * tt + 0.5) * 0.6, -0.01 * np.sin(w * tt)], np.float32)
 
-    def _set_gripper(self, step):
+    def synthetic_action(self, step):
+        """The synthetic action trace as a CALLER of ``step``: the end-effector motion of env step ``step`` for every environment,
+        device tensors (the whole trace lives on the device: no per-step upload).  ``dephase`` (set by ``set_dephase``) delays
+        environment e by ``e % dephase`` steps along the same trace, so that the environments are not all in the same phase of
+        their episode (episodes of eval_policy_parallel.py are independent: they do not share a phase)."""
         E = self.n_env
-        if self._vel_trace is None or step >= len(self._vel_trace):   # the whole action trace lives on the device: no per-step upload
-            n = max(1024, 2 * (step + 1))
+        if self._vel_trace is None or step >= len(self._vel_trace) - self._dephase:
+            n = max(1024, 2 * (step + 1 + self._dephase))
             self._vel_trace = torch.from_numpy(np.stack([self._eef_velocity(k) for k in range(n)])).to(self.device)
             self._open_cmd = torch.tensor([0.3 if self.close_at <= k < self.open_at else 1.0 for k in range(n)], dtype=torch.float32, device=self.device)
-        vel = self._vel_trace[step][None].expand(E, 3).contiguous()
-        openness = self._open_cmd[step].expand(E).contiguous()
-        self.phys.set_eef_motion(self.eef_xyz, vel, self.eef_rot, self.eef_rot_vel, None if self.use_pusher else openness)
-        self.eef_xyz = self.eef_xyz + vel * (self.num_substeps * self.dt)
+        if self._dephase > 1:
+            idx = step - self._env_delay                          # environment e replays the trace (e % dephase) steps late
+            act, idc = idx >= 0, idx.clamp(min=0)
+            vel = torch.where(act[:, None], self._vel_trace[idc], torch.zeros(E, 3, device=self.device))
+            openness = torch.where(act, self._open_cmd[idc], torch.ones(E, device=self.device))
+        else:
+            vel = self._vel_trace[step][None].expand(E, 3).contiguous()
+            openness = self._open_cmd[step].expand(E).contiguous()
+        return dict(eef_xyz=self.eef_xyz, eef_vel=vel, eef_rot=self.eef_rot, eef_rot_vel=self.eef_rot_vel,
+                    gripper_openness=None if self.use_pusher else openness, eef_rot_next=self.eef_rot)   # the traces do not rotate
+
+    def set_dephase(self, k: int):
+        """Stagger the synthetic episodes: environment e starts its trace ``e % k`` env steps late (it waits, gripper open, at the
+        start pose).  k <= 1: all environments in phase (the default)."""
+        self._dephase = max(1, int(k))
+        self._env_delay = (torch.arange(self.n_env, device=self.device) % self._dephase)
+        self._vel_trace = None
+
+    def action13_to_motion(self, action, fps=None):
+        """The reference's 'xyz_rot' action (phystwin.py:113-118, :131-138): ``action`` [n_env, 13] = next end-effector position
+        (3), next rotation matrix (9, row-major), commanded opening (1) -> the motion of this env step, all on the device:
+        eef_vel = (xyz_next - xyz) fps, eef_rot_vel = axis_angle(eef_rot . inv(rot_next)) fps."""
+        a = action.to(self.device, torch.float32).reshape(self.n_env, 13)
+        fps = float(fps) if fps is not None else 1.0 / (self.num_substeps * self.dt)
+        xyz_next, rot_next = a[:, :3], a[:, 3:12].reshape(-1, 3, 3)
+        vel = (xyz_next - self.eef_xyz) * fps
+        delta = self.eef_rot.bmm(torch.linalg.inv(rot_next))
+        return dict(eef_xyz=self.eef_xyz, eef_vel=vel, eef_rot=self.eef_rot, eef_rot_vel=rotation_matrix_to_axis_angle(delta) * fps,
+                    gripper_openness=None if self.use_pusher else a[:, 12].contiguous(), eef_xyz_next=xyz_next, eef_rot_next=rot_next)
+
+    def apply_action(self, action):
+        """Hand one env step's end-effector motion to the stepper — what BaseEnv hands to SpringMassDynamicsModule.step
+        (phystwin.py:362) — for every environment: a dict of device tensors eef_xyz [E,3], eef_vel [E,3], eef_rot [E,3,3],
+        eef_rot_vel [E,3], gripper_openness [E] (None for the pusher), or an [E,13] 'xyz_rot' action tensor.  Advances the
+        rollout's end-effector pose (what the wrist camera and the next action start from) like phystwin.py:160-166."""
+        if torch.is_tensor(action):
+            action = self.action13_to_motion(action)
+        E = self.n_env
+        xyz, vel = action["eef_xyz"].reshape(E, 3), action["eef_vel"].reshape(E, 3)
+        rot, rv = action["eef_rot"].reshape(E, 3, 3), action["eef_rot_vel"].reshape(E, 3)
+        self.phys.set_eef_motion(xyz, vel, rot, rv, action.get("gripper_openness"))
+        T = self.num_substeps * self.dt
+        self.eef_xyz = action["eef_xyz_next"] if "eef_xyz_next" in action else xyz + vel * T
+        if "eef_rot_next" in action:
+            self.eef_rot = action["eef_rot_next"]
+        else:   # integrate the commanded rate like the stepper does (phystwin.py:377-380 at the last substep); device ops, no sync
+            self.eef_rot = axis_angle_to_rotation_matrix(rv * T).transpose(1, 2).bmm(rot)
 
     def _arm_qpos(self, step):
         """Synthetic joint trajectory per environment (stand-in for the policy's qpos): slow sinusoids about the init pose."""
@@ -244,14 +343,14 @@ class BatchedRollout:
             self._robot_first = False
 
     # ---- one batched env step -----------------------------------------------------------------------------------
-    def physics_step(self):
+    def physics_step(self, action=None):
         # update_collision_graph works on the positions the previous step left (phystwin.py:365-366 calls it first thing in
         # step()); it is enqueued right AFTER the previous physics graph instead, so that its candidate count — which picks the
         # graph flavour on the host — has long landed when the next step starts, and the host never waits for the GPU
         if self.phys.self_collision and not self._cand_fresh:
             self.phys.update_collision_graph()
         if self.with_gripper:
-            self._set_gripper(self.t)
+            self.apply_action(action if action is not None else self.synthetic_action(self.t))
         lg = self._log
         if lg is not None and lg["i"] < lg["n"]:
             lg["p0"][lg["i"]].record()
@@ -290,12 +389,53 @@ class BatchedRollout:
             grasped = int(self.phys.eef_state()[1].sum().item())
         return dict(self_collision_candidates=int(n_cand), mesh_contacts=int(hits), grasped_envs=grasped, flavour=self.phys.last_flavour())
 
+    def _update_cameras(self):
+        """Wrist camera of every environment from its current end-effector pose (gs_renderer.py:966-985), on the device."""
+        if self.wrist is not None:
+            if self.with_gripper:
+                self.wrist.update(self.eef_xyz, self.eef_rot)
+            else:
+                self.wrist.update(self._wrist_xyz, self._wrist_rot)
+
+    def _poll_raster(self, wait=False):
+        running, n, ov = self.raster.poll(wait)
+        if ov > self._raster_overflows:
+            self.lossy_batches += ov - self._raster_overflows
+            self._raster_overflows = ov
+            return True
+        if not running:
+            self.last_num_rendered = n
+        return False
+
     def render(self):
         self._update_means()
+        self._update_cameras()
         if self._prepared is None:
             self._prepared = self.raster.prepare(self._sets, self._frames)
         self.last_num_rendered = self.raster.forward(self._prepared, None, self.W, self.H)
+        self._poll_raster()          # non-blocking: an EARLIER batch that overflowed its capacity is counted in lossy_batches
         return self.out_color, self.out_depth
+
+    def observations(self):
+        """The images of the last step as a closed-loop caller may read them: waits for the render, and if that batch overflowed
+        the capacity of the sync-free pipeline (its deepest instances were dropped) renders the step again — the next forward
+        re-sizes by reading the count once — so what is returned is always the complete frame.  (`lossy_batches` counts how often
+        that happened; an open-loop caller that only reads ``out_color`` after a device synchronisation should look at it.)"""
+        self.wait_render()
+        if self._poll_raster(wait=True):
+            self.last_num_rendered = self.raster.forward(self._prepared, None, self.W, self.H)
+            self._poll_raster(wait=True)
+        return self.out_color, self.out_depth
+
+    def camera_numpy(self, e, v):
+        """Settings of view ``v`` of environment ``e`` as the rasteriser currently sees them (numpy; parity tests, cpu_baseline)."""
+        cam = dict(self.cams[v])
+        if v == 1 and self.wrist is not None:
+            torch.cuda.synchronize(self.device)
+            cam["viewmatrix"] = self.wrist.viewmatrix[e].cpu().numpy()
+            cam["projmatrix"] = self.wrist.projmatrix[e].cpu().numpy()
+            cam["campos"] = self.wrist.campos[e].cpu().numpy()
+        return cam
 
     # ---- throughput mode for open-loop stretches (an action chunk, a replay): render(t) overlaps physics(t+1) ------------
     def set_pipelined(self, on: bool):
@@ -324,18 +464,23 @@ class BatchedRollout:
         rs.wait_event(ready)
         with torch.cuda.stream(rs):
             self._update_means()
+            self._update_cameras()
             skinned = torch.cuda.Event()
             skinned.record(rs)
             if self._prepared is None:
                 self._prepared = self.raster.prepare(self._sets, self._frames)
             self.last_num_rendered = self.raster.forward(self._prepared, None, self.W, self.H)
+            self._poll_raster()
             self._render_done = torch.cuda.Event()
             self._render_done.record(rs)
         main.wait_event(skinned)                 # the next step's state write-back must not overtake the skinning that reads x
         return self.out_color, self.out_depth
 
-    def step(self):
-        self.physics_step()
+    def step(self, action=None):
+        """One batched env step.  ``action``: None (the synthetic trace), a dict of per-environment motion tensors, or an
+        [n_env, 13] 'xyz_rot' action tensor — see ``apply_action``.  Returns (out_color [E,V,3,H,W], out_depth [E,V,1,H,W]); they
+        are complete once the launch stream has drained (``observations()`` waits and validates)."""
+        self.physics_step(action)
         out = self._render_pipelined() if getattr(self, "_pipelined", False) else self.render()
         self.t += 1
         lg = self._log

@@ -118,13 +118,18 @@ class ObservationSink:
         self._thread.start()
 
     # ---- producer side (the rollout loop) ------------------------------------------------------------------------------
-    def submit(self, cnt: int, color: torch.Tensor, state: Optional[dict] = None, robot: Optional[list] = None, final: bool = False):
+    def submit(self, cnt: int, color: torch.Tensor, state: Optional[dict] = None, robot: Optional[list] = None, final: bool = False,
+               ready: Optional[torch.cuda.Event] = None):
         """color: [n_env, n_cam, 3, H, W] float32 on the device (the rasteriser's output, unclamped); state: dict of device
         tensors with a leading n_env axis (e.g. x, v: what ``env.get_state()['renderer']`` holds; needs ``state_bytes`` >= their
         total size at construction); robot: per-env dicts for ``robot/NNNNNN.json``.  Returns immediately unless every ring
-        slot is still being written."""
+        slot is still being written.  ``ready``: an event after which ``color`` is complete when the frames were produced on
+        ANOTHER stream than the current one (BatchedRollout.set_pipelined renders on a private stream: pass its
+        ``_render_done`` event, or call ``wait_render()`` first); the pack kernel waits for it on the device."""
         if self._err:
             raise self._err
+        if ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(ready)
         try:
             k = self._free.get_nowait()
         except queue.Empty:

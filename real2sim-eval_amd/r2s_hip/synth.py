@@ -215,6 +215,31 @@ def cylinder_mesh(center, radius=0.005, length=0.2, n_seg=64, n_rings=190, axis=
     return (v + np.asarray(center, np.float64)).astype(np.float32), np.array(f, np.int32)
 
 
+def sphere_mesh(center, radius=0.015, n_seg=160, n_rings=110):
+    """Closed, outward-facing UV sphere with 2 * n_seg * (n_rings - 1) triangles (the defaults give 34 880: more than 64
+    super-clusters of 512 faces).  Seen from its centre every face is about equally far away — the worst case for a
+    closest-point hierarchy: most boxes stay "in reach"."""
+    th = np.linspace(0, 2 * np.pi, n_seg, endpoint=False)
+    ph = np.linspace(0, np.pi, n_rings + 1)[1:-1]                      # interior rings, north to south
+    v = [[0.0, 0.0, radius]]
+    for p in ph:
+        for t in th:
+            v.append([radius * np.sin(p) * np.cos(t), radius * np.sin(p) * np.sin(t), radius * np.cos(p)])
+    v.append([0.0, 0.0, -radius])
+    f = []
+    ring = lambda r, k: 1 + r * n_seg + (k % n_seg)  # noqa: E731
+    for k in range(n_seg):
+        f.append([0, ring(0, k), ring(0, k + 1)])
+    for r in range(n_rings - 2):
+        for k in range(n_seg):
+            a, b, c, d_ = ring(r, k), ring(r, k + 1), ring(r + 1, k), ring(r + 1, k + 1)
+            f += [[a, c, d_], [a, d_, b]]
+    south = len(v) - 1
+    for k in range(n_seg):
+        f.append([south, ring(n_rings - 2, k + 1), ring(n_rings - 2, k)])
+    return (np.asarray(v, np.float64) + np.asarray(center, np.float64)).astype(np.float32), np.asarray(f, np.int32)
+
+
 def finger_mesh(center, size=(0.02, 0.01, 0.05), n_faces=44, pad_normal=None):
     """A closed box re-tessellated to ``n_faces`` triangles (the real finger collision meshes have 44,
     assets/robots/xarm/xarm7_with_gripper_collision.urdf:425,519): the two large side faces are split

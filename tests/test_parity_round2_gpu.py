@@ -154,7 +154,7 @@ def test_C4_full_per_gpu_size_8_envs_4_views_1280x720_140k_gaussians():
     g = {k: v.cpu().numpy() for k, v in ro.g_env(0).items()}
     for e, v in ((0, 0), (7, 3)):
         sc = dict(ro.scene_numpy(e))
-        c = ro.cams[v]
+        c = ro.camera_numpy(e, v)          # view 1 is the wrist camera of THIS environment's gripper pose
         _, col_ref, _, dep_ref = oracle_render(sc, c)
         r = compare_images(ro.out_color[e, v].cpu().numpy(), ro.out_depth[e, v].cpu().numpy(), col_ref, dep_ref, what=f"env {e} view {v} vs oracle, 1280x720, 140k")
         assert r["frac_rgb"] <= 1e-4 and r["frac_depth"] <= 1e-4, (e, v, r)

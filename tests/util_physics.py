@@ -46,6 +46,38 @@ def two_blobs(seed=0, gap=0.06, speed=3.0, n=150):
     return dict(points=pts, springs=springs, rest=rest, log_Y=logy, v0=v)
 
 
+def two_sheets(seed=0, n=144, gap=0.004, z0=0.03):
+    """Two single-layer sheets standing upright in the x-z plane, `gap` apart in y (closer than collision_dist = 5 mm): every
+    particle of one sheet is a self-collision candidate of the sheet opposite once the candidate lists are rebuilt, AND within
+    the 5 mm margin of a finger pad pressed on the sheet — the two contact kinds on the SAME particles.  Returns the object
+    (points in the close configuration) and the number of particles of the first sheet; construct the steppers from
+    `far_apart(ob, nA)` (the resting-pair set must not contain the cross-sheet pairs), then set the state to ob["points"]."""
+    from r2s_hip import synth
+
+    a = synth.lattice_points("cloth", n, seed)
+    b = synth.lattice_points("cloth", n, seed + 1)
+
+    def up(p, y):
+        return np.stack([p[:, 0], np.full(len(p), y) + (p[:, 2] - p[:, 2].mean()), p[:, 1] - p[:, 1].min() + z0], 1).astype(np.float32)
+
+    A, B = up(a, -gap / 2), up(b, +gap / 2)
+    sa, ra = synth.build_springs(A)
+    sb, rb = synth.build_springs(B)
+    pts = np.concatenate([A, B])
+    springs = np.concatenate([sa, sb + len(A)]).astype(np.int32)
+    rest = np.concatenate([ra, rb]).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    logy = np.log(rng.uniform(5e3, 3e4, len(springs))).astype(np.float32)
+    return dict(points=pts, springs=springs, rest=rest, log_Y=logy, v0=np.zeros_like(pts)), len(A)
+
+
+def far_apart(ob, nA, shift=0.3):
+    far = dict(ob)
+    far["points"] = ob["points"].copy()
+    far["points"][nA:, 0] += shift
+    return far
+
+
 def oracle_env(ob, f64=False, dynamic_meshes=None, static_meshes=None, use_pusher=False, **over):
     import oracle
 
