@@ -57,6 +57,10 @@ def run(config="sloth_32env", device="cuda:0", seed=0, num_substeps=667, n_compa
     assert np.array_equal(o.mesh_map, ph.mesh_map)
     out = dict(config=config, particles=int(ro.N), substeps_compared=int(n_compare), eef_pts_max_abs=0.0, eef_center_max_abs=0.0, eef_vel_max_abs=0.0)
     max_steps = max_steps if max_steps is not None else close_at + 6
+    # "lissajous" traces (rope / T / tiny scenes: the gripper hovers above the object) never touch inside a short window: the
+    # gate then compares the flavour such a window times — free motion next to the gripper meshes — and does not ask for contact
+    expects_contact = ro.schedule in ("grasp", "push")
+    out["expects_contact"] = bool(expects_contact)
     compared = False
     for t in range(max_steps):
         # ---- the caller side, oracle next to device (same inputs) ----
@@ -89,7 +93,7 @@ def run(config="sloth_32env", device="cuda:0", seed=0, num_substeps=667, n_compa
                 o.update_collision_graph()
                 n_cand = int((o.coll_num > 0).sum())
             last_chance = t == max_steps - 1
-            if ro.use_pusher or n_cand > 0 or last_chance:
+            if ro.use_pusher or n_cand > 0 or last_chance or not expects_contact:
                 o.set_mesh_interactive(ref["interp_points"], ref["interp_center"], ref["dynamic_velocity"], ref["dynamic_omega"])
                 x_before = o.x.copy(); v_before = o.v.copy()
                 o.step(n_compare, 0)
@@ -128,9 +132,11 @@ def run(config="sloth_32env", device="cuda:0", seed=0, num_substeps=667, n_compa
                    bad_pixels=int(bad.sum()), pixels=int(bad.size), frame=f"{ro.W}x{ro.H} side camera, env 0")
     else:
         out.update(rgb_max_rel=None, bad_pixels=None, pixels=None)
-    ok_phys = out["x_max_abs"] < 1e-5 and out["mesh_contact"] and "state_machine_mismatch_at_step" not in out
-    if ph.self_collision and not ro.use_pusher:
-        ok_phys = ok_phys and out["particles_with_candidates"] > 0
+    ok_phys = out["x_max_abs"] < 1e-5 and "state_machine_mismatch_at_step" not in out
+    if expects_contact:
+        ok_phys = ok_phys and out["mesh_contact"]
+        if ph.self_collision and not ro.use_pusher:
+            ok_phys = ok_phys and out["particles_with_candidates"] > 0
     ok_img = (not render) or out["bad_pixels"] <= 1e-4 * out["pixels"]
     out["gates"] = {"x_max_abs": 1e-5, "bad_pixel_fraction": 1e-4, "rgb": "|d| <= 1e-4 + 1e-4 |ref|", "depth": "|d| <= 1e-4 |ref| (median-depth flips count as bad pixels)"}
     out["passed"] = bool(ok_phys and ok_img)
