@@ -732,8 +732,13 @@ __device__ __forceinline__ void spring_term(v2f xy, float zj, v2f vxy, float vzj
     const v2f dvxy = vxy - (v2f){vi.x, vi.y};
     const float dvz = vzj - vi.z;
     const float t = fmaf(dvxy.x, dxy.x, fmaf(dvxy.y, dxy.y, dvz * dz));
+#ifdef R2S_SC_ALG // (a L - k) r + c r^2 t  with  L r = |d|^2 r^2 = 1:  a - k r + (c r^2) t — one VALU instruction fewer per slot
+    (void)L;
+    const float sc = fmaf(dashpot * (rinv * rinv), t, fmaf(-k, rinv, a));
+#else
     const float mag = fmaf(dashpot * rinv, t, fmaf(a, L, -k));
     const float sc = mag * rinv;
+#endif
     fxy += dxy * sc;
     fz = fmaf(dz, sc, fz);
 }
@@ -1020,8 +1025,8 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int item = xcd * p.cb + q;
     if (q >= p.cb || item >= p.nb * p.ne) return; // whole workgroup
-    R2S_STAMP(0);
     const int b = item / p.ne, e = p.e0 + (item - b * p.ne);
+    R2S_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int i = b * B + tid;
@@ -1039,34 +1044,45 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
     // All loads of a thread are issued before its first LDS write: two dependent round trips (halo id, then state)
     // per workgroup instead of two per staging round.
     constexpr int K = (RCAP + B - 1) / B;
+    // R2S_STAGE_BATCH (tuning): staging rounds whose loads are in flight together.  Default: all K of them (two dependent round
+    // trips per workgroup); a smaller batch trades round trips for registers (the 64-VGPR build of the <320,1120> layout).
+#ifndef R2S_STAGE_BATCH
+#define R2S_STAGE_BATCH 0
+#endif
+    constexpr int KB = (R2S_STAGE_BATCH > 0 && R2S_STAGE_BATCH < K) ? R2S_STAGE_BATCH : K;
     const int h0 = p.halo_off[b], per_env = B + (p.halo_off[b + 1] - h0);
-    int part[K];
+    v2f own_a = {0.f, 0.f}, own_b = own_a, own_c = own_a; // this lane's own record (round 0)
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int r = tid + k * B;
-        part[k] = r < B ? i : (r < per_env ? p.halo_ids[h0 + r - B] : p.N);
-    }
-    v2f qa[K], qb[K], qc[K]; // xy | (z, vz) | vxy: the state planes are the window's planes
+    for (int k0 = 0; k0 < K; k0 += KB) {
+        int part[KB];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const size_t g = eb + (size_t)min(part[k], p.N - 1);
-        if (part[k] < p.N) { qa[k] = xv_in.p[st_at(xv_in.n, g, 0)]; qb[k] = xv_in.p[st_at(xv_in.n, g, 1)]; qc[k] = xv_in.p[st_at(xv_in.n, g, 2)]; }
-        else { qa[k] = (v2f){0.f, 0.f}; qb[k] = qa[k]; qc[k] = qa[k]; }
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int r = tid + k * B;
-        if (r < RCAP && part[k] < p.N) {
-            win_s[r] = qa[k];
-            win_s[RCAP + 1 + r] = qb[k];
-            win_s[2 * (RCAP + 1) + r] = qc[k];
+        for (int k = 0; k < KB; ++k) {
+            const int r = tid + (k0 + k) * B;
+            part[k] = (k0 + k >= K) ? p.N : (r < B ? i : (r < per_env ? p.halo_ids[h0 + r - B] : p.N));
         }
+        v2f qa[KB], qb[KB], qc[KB]; // xy | (z, vz) | vxy: the state planes are the window's planes
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const size_t g = eb + (size_t)min(part[k], p.N - 1);
+            if (part[k] < p.N) { qa[k] = xv_in.p[st_at(xv_in.n, g, 0)]; qb[k] = xv_in.p[st_at(xv_in.n, g, 1)]; qc[k] = xv_in.p[st_at(xv_in.n, g, 2)]; }
+            else { qa[k] = (v2f){0.f, 0.f}; qb[k] = qa[k]; qc[k] = qa[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int r = tid + (k0 + k) * B;
+            if (r < RCAP && part[k] < p.N) {
+                win_s[r] = qa[k];
+                win_s[RCAP + 1 + r] = qb[k];
+                win_s[2 * (RCAP + 1) + r] = qc[k];
+            }
+        }
+        if (k0 == 0) { own_a = qa[0]; own_b = qb[0]; own_c = qc[0]; }
     }
     __syncthreads();
     R2S_STAMP(1);
     // no early exit: lanes without a particle stay in the wavefront (the mesh queries at the end are wave-cooperative)
     // and simply compute on clamped indices without storing anything
-    const f3 x0 = mk(qa[0].x, qa[0].y, qb[0].x), v0 = mk(qc[0].x, qc[0].y, qb[0].y); // round 0 staged this lane's own record
+    const f3 x0 = mk(own_a.x, own_a.y, own_b.x), v0 = mk(own_c.x, own_c.y, own_b.y); // round 0 staged this lane's own record
     const float m1 = p.masses[ic];
 
     // eval_springs + update_vel_from_force
@@ -1111,8 +1127,11 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
 // (A <256,896> layout — 21.5 KB of LDS, 7 workgroups per CU, the fused kernel held to 72 VGPRs, so that only 96 instead of 352
 // of the benchmark's 1888 work items are left for a second round — was measured in round 2: 23.3 vs 22.1 us per substep with
 // two chains, 24.4 vs 24.8 with one.  More residency does not pay; the layouts stay <256,1024> and <128,768>.)
+#ifndef R2S_SUBSTEP_MIN_WAVES
+#define R2S_SUBSTEP_MIN_WAVES 1
+#endif
 template <int B, int RCAP, bool SELF, int MESH>
-__global__ void __launch_bounds__(B) k_substep(const PhysDev p, const StateC xv_in, const StateM xv_out, int step,
+__global__ void __launch_bounds__(B, R2S_SUBSTEP_MIN_WAVES) k_substep(const PhysDev p, const StateC xv_in, const StateM xv_out, int step,
                                                int write_forces)
 {
     substep_body<B, RCAP, SELF, MESH>(p, xv_in, xv_out, step, write_forces);
@@ -1853,10 +1872,13 @@ struct R2SPhys {
     int n_cand = 0;              // particles with candidates after the last update (host view)
     int chains() const // parallel kernel chains of the captured env step
     {
-        // two chains pay once a single kernel would not fit the chip in one go (6 workgroups per CU): 32 sloth envs = 1888
-        // workgroups: 23.5 / 21.3 / 22.4 / 23.2 us per substep for 1 / 2 / 3 / 4 chains; smaller batches lose (16 sloth envs
-        // 15.1 vs 16.8 us, 8 envs 10.7 vs 12.5 us, 32 T-block envs 10.3 vs 11.1 us for 1 vs 2 chains)
-        int c = (int64_t)nb * E >= 1536 ? 2 : 1;
+        // chains are separate graphs on separate streams (hardware queues; more than four lose: 26 / 42 us per substep with six).
+        // Measured per batched substep, free / contact (tools/profiling/variant_bench.py, round 3): 32 sloth envs (1888 work items)
+        // 1 chain 23.7 / 25.7, 2 chains 20.8 / 26.8, 4 chains 19.1 / 26.0 us; 8 sloth envs x 4 views (472 items) 10.6 / 17.3,
+        // 9.5 / 17.2, 10.6 / 19.3; 32 T-block envs with the 25k-face rod (288 items) 10.4 / 25.9, 10.5 / 24.4, 12.7 / 26.3.
+        const int64_t items = (int64_t)nb * E;
+        int c = items >= 1536 ? 4 : (items >= 256 ? 2 : 1);
+        c = std::min(c, E);
         if (chains_override > 0) c = std::max(1, std::min(chains_override, std::min(E, 8)));
         return c;
     }
@@ -1887,8 +1909,15 @@ struct R2SPhys {
     // [1] some do (fused kernel + self-collision finishing kernel per substep)
     // slot = defer * 4 + variant * 2 + start buffer: with an odd substep count (667) the state buffer flips every env step, so both
     // parities are kept instead of re-capturing 667 nodes per step
-    hipGraph_t graph[8] = {};
-    hipGraphExec_t graph_exec[8] = {};
+    // One graph per CHAIN and flavour, launched on the chain's own stream by r2s_phys_step (round 3; round 2 captured the chains as
+    // branches of ONE graph: the same kernels then ran 20.8 / 24.2 / 28.4 us per batched substep free / with an idle finishing
+    // launch / in contact, against 19.1 / 19.8 / 26.0 as separate graphs on four streams — a branch of a hipGraph is not a
+    // hardware queue of its own, a stream is).
+    static constexpr int MAX_CHAINS = 8;
+    hipGraph_t graph[MAX_CHAINS][8] = {};
+    hipGraphExec_t graph_exec[MAX_CHAINS][8] = {};
+    hipStream_t chain_stream[MAX_CHAINS] = {}; // [0] unused: chain 0 runs on the caller's stream
+    hipEvent_t chain_fork = nullptr, chain_join[MAX_CHAINS] = {};
     // timing
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -2003,18 +2032,34 @@ void launch_substep_layout(const PhysDev& p, dim3 grid, const StateC in, const S
 #undef R2S_LAUNCH
 }
 
-int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, hipStream_t s)
+// true when the env step's flavour carries k_contact_finish (deferred mesh queries + self-collision impulses in one launch)
+bool has_contact_finish(const R2SPhys* h, const PhysDev& p)
+{
+    const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
+    return mesh != 0 && (p.mesh_defer || mesh == 2);
+}
+
+void launch_fused(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, hipStream_t s)
 {
     dim3 grid(8u * (unsigned)p.cb);
     const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
     const StateC in = h->state(in_buf);
     const StateM out = h->state(in_buf ^ 1);
     if (h->pb == 256) launch_substep_layout<256, 1024>(p, grid, in, out, step, write_forces, with_self, mesh, s);
+    else if (h->pb == 320) launch_substep_layout<320, 1120>(p, grid, in, out, step, write_forces, with_self, mesh, s);
+    else if (h->pb == 384) launch_substep_layout<384, 1280>(p, grid, in, out, step, write_forces, with_self, mesh, s);
     else launch_substep_layout<128, 768>(p, grid, in, out, step, write_forces, with_self, mesh, s);
-    // What the fused kernel left unfinished: with something near a mesh (mesh_defer) ONE combined finishing kernel per substep —
-    // deferred mesh queries, one workgroup per particle, plus the self-collision impulses; otherwise only k_self_finish
-    // while candidates exist (mesh queries of the rare needy particle in place).
-    if (mesh != 0 && (p.mesh_defer || mesh == 2)) {
+}
+
+// What the fused kernel left unfinished: with something near a mesh (mesh_defer) ONE combined finishing kernel per substep —
+// deferred mesh queries, one workgroup per particle, plus the self-collision impulses; otherwise only k_self_finish
+// while candidates exist (mesh queries of the rare needy particle in place).
+void launch_finish(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, hipStream_t s)
+{
+    const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
+    const StateC in = h->state(in_buf);
+    const StateM out = h->state(in_buf ^ 1);
+    if (has_contact_finish(h, p)) {
         const bool small = mesh == 1 && h->nF <= 128; // every mesh small: the substep's triangles fit two per lane
         const dim3 g(small ? 1024 : 512);             // 2048 wavefronts (an idle launch costs the same ~2.5 us with 16 workgroups: it is the launch boundary), grid-stride: workgroups of two (small) or four wavefronts
 #define R2S_FIN(Q, S) hipLaunchKernelGGL((k_contact_finish<Q, S>), g, dim3(small ? 128 : 256), 0, s, p, in, out, step, write_forces)
@@ -2027,6 +2072,12 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
         if (mesh == 1) hipLaunchKernelGGL((k_self_finish<1>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
         else hipLaunchKernelGGL((k_self_finish<0>), dim3(blocks), dim3(256), 0, s, p, in, out, step, write_forces);
     }
+}
+
+int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, hipStream_t s)
+{
+    launch_fused(h, p, in_buf, step, write_forces, with_self, s);
+    launch_finish(h, p, in_buf, step, write_forces, with_self, s);
     return R2S_OK;
 }
 
@@ -2073,63 +2124,63 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
 
 void drop_graph(R2SPhys* h)
 {
-    for (int v = 0; v < 8; ++v) {
-        if (h->graph_exec[v]) (void)hipGraphExecDestroy(h->graph_exec[v]);
-        if (h->graph[v]) (void)hipGraphDestroy(h->graph[v]);
-        h->graph_exec[v] = nullptr; h->graph[v] = nullptr;
-    }
+    for (int c = 0; c < R2SPhys::MAX_CHAINS; ++c)
+        for (int v = 0; v < 8; ++v) {
+            if (h->graph_exec[c][v]) (void)hipGraphExecDestroy(h->graph_exec[c][v]);
+            if (h->graph[c][v]) (void)hipGraphDestroy(h->graph[c][v]);
+            h->graph_exec[c][v] = nullptr; h->graph[c][v] = nullptr;
+        }
 }
 
 void drop_graph_fwd(R2SPhys* h) { drop_graph(h); }
 
+// Environments are independent, so the env step runs as `chains` parallel kernel chains over disjoint environment ranges:
+// while one chain's workgroups stage their windows (memory phase, VALU idle) or sit in the launch gap between two substeps,
+// another chain's are in the gather (VALU phase), and one chain's finishing kernel runs next to the others' fused kernels.
+// Each chain is captured into its own graph.
 int capture_graph(R2SPhys* h, int variant, int start_buf)
 {
     const int slot = h->mesh_defer * 4 + variant * 2 + (start_buf & 1);
-    if (h->graph_exec[slot]) (void)hipGraphExecDestroy(h->graph_exec[slot]);
-    if (h->graph[slot]) (void)hipGraphDestroy(h->graph[slot]);
-    h->graph_exec[slot] = nullptr; h->graph[slot] = nullptr;
-    hipStream_t cs;
-    R2S_HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-    R2S_HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-    // Environments are independent, so the env step is captured as `chains` parallel kernel chains over disjoint
-    // environment ranges: while one chain's workgroups stage their windows (memory phase, VALU idle) or sit in the launch
-    // gap between two substeps, another chain's are in the gather (VALU phase).
     const int chains = h->chains();
-    int rc = R2S_OK;
-    std::vector<hipStream_t> side;
-    std::vector<hipEvent_t> evs;
-    hipEvent_t fork = nullptr;
-    if (chains > 1) {
-        R2S_HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-        R2S_HIP_TRY(hipEventRecord(fork, cs));
-    }
-    for (int c = 0; c < chains && rc == R2S_OK; ++c) {
+    for (int c = 0; c < chains; ++c) {
+        if (h->graph_exec[c][slot]) (void)hipGraphExecDestroy(h->graph_exec[c][slot]);
+        if (h->graph[c][slot]) (void)hipGraphDestroy(h->graph[c][slot]);
+        h->graph_exec[c][slot] = nullptr; h->graph[c][slot] = nullptr;
         const int e0 = (int)((int64_t)h->E * c / chains), e1 = (int)((int64_t)h->E * (c + 1) / chains);
-        hipStream_t st = cs;
-        if (c > 0) {
-            R2S_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            side.push_back(st);
-            R2S_HIP_TRY(hipStreamWaitEvent(st, fork, 0));
-        }
-        rc = enqueue_steps(h, 0, h->prm.num_substeps, start_buf, variant == 1, st, e0, e1 - e0, true, c);
-        if (c > 0 && rc == R2S_OK) {
-            hipEvent_t j;
-            R2S_HIP_TRY(hipEventCreateWithFlags(&j, hipEventDisableTiming));
-            evs.push_back(j);
-            R2S_HIP_TRY(hipEventRecord(j, st));
-            R2S_HIP_TRY(hipStreamWaitEvent(cs, j, 0));
-        }
+        hipStream_t cs;
+        R2S_HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        R2S_HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_steps(h, 0, h->prm.num_substeps, start_buf, variant == 1, cs, e0, e1 - e0, true, c);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(cs, &g);
+        (void)hipStreamDestroy(cs);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        R2S_HIP_TRY(e);
+        h->graph[c][slot] = g;
+        R2S_HIP_TRY(hipGraphInstantiate(&h->graph_exec[c][slot], g, nullptr, nullptr, 0));
     }
-    hipGraph_t g = nullptr;
-    hipError_t e = hipStreamEndCapture(cs, &g);
-    for (hipStream_t st : side) (void)hipStreamDestroy(st);
-    for (hipEvent_t j : evs) (void)hipEventDestroy(j);
-    if (fork) (void)hipEventDestroy(fork);
-    (void)hipStreamDestroy(cs);
-    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-    R2S_HIP_TRY(e);
-    h->graph[slot] = g;
-    R2S_HIP_TRY(hipGraphInstantiate(&h->graph_exec[slot], g, nullptr, nullptr, 0));
+    return R2S_OK;
+}
+
+// Launch the captured env step: chain 0 on the caller's stream, the others on the handle's own streams between a fork and a join.
+int launch_graphs(R2SPhys* h, int slot, hipStream_t s)
+{
+    const int chains = h->chains();
+    if (chains > 1) {
+        if (!h->chain_fork) R2S_HIP_TRY(hipEventCreateWithFlags(&h->chain_fork, hipEventDisableTiming));
+        R2S_HIP_TRY(hipEventRecord(h->chain_fork, s));
+    }
+    for (int c = 1; c < chains; ++c) {
+        if (!h->chain_stream[c]) {
+            R2S_HIP_TRY(hipStreamCreateWithFlags(&h->chain_stream[c], hipStreamNonBlocking));
+            R2S_HIP_TRY(hipEventCreateWithFlags(&h->chain_join[c], hipEventDisableTiming));
+        }
+        R2S_HIP_TRY(hipStreamWaitEvent(h->chain_stream[c], h->chain_fork, 0));
+        R2S_HIP_TRY(hipGraphLaunch(h->graph_exec[c][slot], h->chain_stream[c]));
+        R2S_HIP_TRY(hipEventRecord(h->chain_join[c], h->chain_stream[c]));
+    }
+    R2S_HIP_TRY(hipGraphLaunch(h->graph_exec[0][slot], s));
+    for (int c = 1; c < chains; ++c) R2S_HIP_TRY(hipStreamWaitEvent(s, h->chain_join[c], 0));
     return R2S_OK;
 }
 
@@ -2210,9 +2261,9 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     // layout: <256,1024> by default; measured against <128,768> on the 1-env rope, the 32-env T block (equal: those are
     // launch-latency bound) and the 32-env pusher scene (256 is 25 % faster).  R2S_LAYOUT=128|256 overrides.
     {
-        const int sizes[2] = {256, 128}, caps[2] = {1024, 768};
+        const int sizes[4] = {256, 128, 320, 384}, caps[4] = {1024, 768, 1120, 1280};
         int pick = 0;
-        if (const char* ev = getenv("R2S_LAYOUT")) { const int v = atoi(ev); for (int k = 0; k < 2; ++k) if (v == sizes[k]) pick = k; } // tuning knob
+        if (const char* ev = getenv("R2S_LAYOUT")) { const int v = atoi(ev); for (int k = 0; k < 4; ++k) if (v == sizes[k]) pick = k; } // tuning knob
         h->pb = sizes[pick]; h->rcap = caps[pick];
         // the remaining tuning knobs are also read here, ONCE per handle (r2s_phys_set_tuning changes them afterwards)
         if (const char* ev = getenv("R2S_CHAINS")) h->chains_override = atoi(ev);
@@ -2715,6 +2766,11 @@ void r2s_phys_destroy(R2SPhys* h)
     if (h->cand_event) (void)hipEventDestroy(h->cand_event);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->chain_fork) (void)hipEventDestroy(h->chain_fork);
+    for (int c = 0; c < R2SPhys::MAX_CHAINS; ++c) {
+        if (h->chain_join[c]) (void)hipEventDestroy(h->chain_join[c]);
+        if (h->chain_stream[c]) (void)hipStreamDestroy(h->chain_stream[c]);
+    }
     delete h;
 }
 
@@ -2923,13 +2979,14 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     if (use_graph) {
         // every flavour was captured at construction (capture_all); only set_params / set_tuning drop them
         const int slot = h->mesh_defer * 4 + variant * 2 + (h->cur & 1);
-        if (!h->graph_exec[slot]) {
+        if (!h->graph_exec[0][slot]) {
             const int keep = h->mesh_defer;
             int rc = capture_graph(h, variant, h->cur);
             h->mesh_defer = keep;
             if (rc) return rc;
         }
-        R2S_HIP_TRY(hipGraphLaunch(h->graph_exec[slot], s));
+        int rcl = launch_graphs(h, slot, s);
+        if (rcl) return rcl;
     } else {
         int rc = enqueue_steps(h, first_substep, n, h->cur, variant == 1, s);
         if (rc) return rc;
