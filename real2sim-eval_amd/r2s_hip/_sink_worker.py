@@ -52,6 +52,21 @@ def write_env(px, state, root, ext, encode, e, cnt, final, write_images, robot):
     return n
 
 
+def make_video(image_root, video_path, image_pattern="%06d.jpg", frame_rate=10, ffmpeg="ffmpeg"):
+    """The episode video of one camera: the reference's ``make_video`` (experiments/utils/ffmpeg.py:5-21, called per camera at the
+    end of an episode, experiments/eval_policy.py:261-267) — the same ``ffmpeg`` command line (libx264, yuv420p) over the frames
+    the sink wrote.  ffmpeg is an external program, as it is for the reference; returns False when it is not installed."""
+    import shutil
+    import subprocess
+
+    exe = shutil.which(ffmpeg)
+    if exe is None:
+        return False
+    r = subprocess.run([exe, "-y", "-hide_banner", "-loglevel", "error", "-framerate", str(frame_rate), "-i", os.path.join(str(image_root), image_pattern),
+                        "-c:v", "libx264", "-pix_fmt", "yuv420p", str(video_path)])
+    return r.returncode == 0
+
+
 def worker_main(job_q, done_q, shm_name, fmt):
     from multiprocessing import shared_memory
 
@@ -66,11 +81,14 @@ def worker_main(job_q, done_q, shm_name, fmt):
             if job is None:
                 return
             try:
+                if job[0] == "video":   # ("video", jid, image_root, video_path, pattern, frame_rate)
+                    done_q.put((job[1], int(make_video(*job[2:])), None))
+                    continue
                 (jid, px_off, V, H, W, state_desc, root, e, cnt, final, write_images, robot) = job
                 px = buf[px_off: px_off + V * H * W * 3].reshape(V, H, W, 3)
                 state = {name: np.ndarray(shape, np.dtype(dt), buffer=shm.buf, offset=off) for name, dt, shape, off in state_desc} or None
                 done_q.put((jid, write_env(px, state, root, fmt, encode, e, cnt, final, write_images, robot), None))
             except Exception as ex:  # reported to the main process, which raises it from submit() / close()
-                done_q.put((job[0], 0, repr(ex)))
+                done_q.put((job[1] if job[0] == "video" else job[0], 0, repr(ex)))
     finally:
         shm.close()

@@ -94,7 +94,7 @@ class ObservationSink:
         for k in range(self.slots):
             self._free.put(k)
         self._work: "queue.Queue" = queue.Queue()
-        self.stalls, self.frames_written, self.steps_written = 0, 0, 0
+        self.stalls, self.frames_written, self.steps_written, self.videos_written = 0, 0, 0, 0
         self._err = None
         for e in self.episode_ids:
             for c in range(self.V):
@@ -151,6 +151,17 @@ class ObservationSink:
         ev.record(torch.cuda.current_stream(self.device))
         self._work.put((k, ev, int(cnt), desc, robot, bool(final)))
 
+    def make_videos(self, frame_rate: int = 10):
+        """``vis_camera_C.mp4`` per episode and camera from the frames written so far — eval_policy.py:261-267 -> make_video
+        (experiments/utils/ffmpeg.py:5-21: ffmpeg, libx264, yuv420p), run by the worker processes after the frame queue has
+        drained.  Returns the number of videos written (0 when ffmpeg is not installed, or with the BMP fallback format)."""
+        self._work.put(("videos", int(frame_rate)))
+        self._videos_done = threading.Event()
+        self._videos_done.wait()
+        if self._err:
+            raise self._err
+        return self.videos_written
+
     def close(self):
         """Drain the queue, stop the dispatcher and the workers, release the ring."""
         self._work.put(None)
@@ -182,6 +193,13 @@ class ObservationSink:
                 item = self._work.get()
                 if item is None:
                     return
+                if item[0] == "videos":   # every frame submitted before this point has been written (the queue is FIFO)
+                    try:
+                        self.videos_written = self._write_videos(item[1], jid)
+                        jid += len(self.episode_ids) * self.V
+                    finally:
+                        self._videos_done.set()
+                    continue
                 k, ev, cnt, desc, robot, final = item
                 ev.synchronize()
                 base = k * self._slot_bytes
@@ -222,3 +240,25 @@ class ObservationSink:
         except Exception as e:  # surfaced by the next submit / close
             self._err = e
             self._free.put(0)
+
+    def _write_videos(self, frame_rate, jid0):
+        if self.ext != "jpg" or not self.write_images:
+            return 0
+        jobs = []
+        for e in self.episode_ids:
+            ep = os.path.join(self.root, f"episode_{e:04d}")
+            for c in range(self.V):
+                jobs.append(("video", jid0 + len(jobs), os.path.join(ep, f"camera_{c}", "rgb"), os.path.join(ep, f"vis_camera_{c}.mp4"), "%06d.jpg", frame_rate))
+        n = 0
+        if self._procs:
+            for j in jobs:
+                self._job_q.put(j)
+            for _ in jobs:
+                _, ok, err = self._done_q.get(timeout=600)
+                if err:
+                    raise RuntimeError(f"sink worker (video): {err}")
+                n += ok
+        else:
+            for j in jobs:
+                n += int(_sink_worker.make_video(*j[2:]))
+        return n

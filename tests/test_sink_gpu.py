@@ -78,3 +78,31 @@ def test_default_encoder_is_jpeg_when_pil_is_present(tmp_path):
     sink.close()
     im = np.asarray(Image.open(tmp_path / "j" / "episode_0000" / "camera_0" / "rgb" / "000000.jpg"))
     assert im.shape == (48, 64, 3) and im[..., 0].mean() > 240 and im[..., 1].mean() < 15 and im[..., 2].mean() < 15   # stored as RGB red
+
+
+@pytest.mark.parametrize("workers", [0, 2])
+def test_episode_videos_are_made_after_the_frames_have_drained(tmp_path, workers, monkeypatch):
+    """eval_policy.py:261-267: one vis_camera_C.mp4 per episode and camera through ffmpeg (experiments/utils/ffmpeg.py).  A
+    stand-in ffmpeg on PATH records how many frames exist when it is invoked: every submitted frame must have been written."""
+    import stat
+
+    import torch
+    from r2s_hip.sink import ObservationSink, default_format
+
+    if default_format() != "jpg":
+        pytest.skip("PIL not installed: BMP fallback has no video step")
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    fake = bindir / "ffmpeg"
+    fake.write_text("#!/bin/sh\nfor a in \"$@\"; do last=\"$a\"; case \"$prev\" in -i) src=\"$a\";; esac; prev=\"$a\"; done\nls \"$(dirname \"$src\")\" | wc -l > \"$last\"\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", f"{bindir}:{os.environ['PATH']}")
+    E, V = 2, 2
+    sink = ObservationSink(str(tmp_path), E, V, 24, 32, run_name="v", workers=workers, slots=2)
+    for cnt in range(6):
+        sink.submit(cnt, torch.rand(E, V, 3, 24, 32, device="cuda"))
+    assert sink.make_videos(frame_rate=10) == E * V
+    sink.close()
+    for e in range(E):
+        for c in range(V):
+            assert int((tmp_path / "v" / f"episode_{e:04d}" / f"vis_camera_{c}.mp4").read_text()) == 6
