@@ -147,8 +147,10 @@ def main():
     ap.add_argument("--stub", action="store_true", help="CPU stand-in workload over gloo (launcher test)")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the parity gate that precedes the timed window (default: on; a failing gate "
                                                                   "withholds `value`)")
-    ap.add_argument("--dephase", type=int, default=0, help="K > 1: additionally time a window in which environment e runs the same action trace "
-                                                           "(e %% K) steps late, so that the batch is not in one phase of the episode (reported next to `value`)")
+    ap.add_argument("--dephase", type=int, default=-1, help="after the timed window, time a second one in which environment e runs the same action trace "
+                                                            "(e %% K) steps late — the environments then close their grippers one after the other across the "
+                                                            "window instead of all at its middle (episodes of eval_policy_parallel.py do not share a phase); "
+                                                            "reported next to `value`, never as `value`.  -1: K = --steps (default), 0: skip")
     ap.add_argument("--sink", default=None, help="directory: also run the observation sink (row f4) every step — packed 8-bit frames + state "
                                                  "to pinned ring buffers, JPEG / pickle written by a host thread; not part of the headline")
     args = ap.parse_args()
@@ -213,6 +215,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     log = ro.read_log()
+    ro._poll_raster(wait=True)   # the sync-free raster pipeline: the count of the LAST batch, and how many batches of the window overflowed
     sink_report = None
     if sink is not None:
         t1 = time.perf_counter()
@@ -250,6 +253,31 @@ def main():
                        "note": "this rank, after the timed window, in the state the window ended in (contact): the same steps with the rasterisation of "
                                "env step t on a second stream next to the substeps of step t+1; results are bit-identical (tested).  Valid when the "
                                "next action does not depend on this step's observation (inside an action chunk); `value` above is the closed loop"}
+
+    # de-phased window (outside the timed region): same workload, same number of steps, the same half of the env-steps in
+    # contact — but the environments enter contact one after the other instead of together, so every step of the window runs
+    # the contact flavour for SOME environments (the graph flavour is picked per handle, not per environment)
+    dephase_report = None
+    K = args.steps if args.dephase < 0 else args.dephase
+    if K > 1 and not args.stub and ro.with_gripper and ro.schedule == "grasp":
+        ro2 = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=args.warmup)
+        ro2.set_dephase(K)
+        for _ in range(args.warmup):
+            ro2.step()
+        torch.cuda.synchronize(dev)
+        ro2.start_log(args.steps)
+        t0d = time.perf_counter()
+        for _ in range(args.steps):
+            ro2.step()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0d
+        lg2 = ro2.read_log()
+        dephase_report = {"env_steps_per_s": ro2.n_env * args.steps / el, "ms_per_step": el / args.steps * 1e3, "K": K,
+                          "substep_us_per_step": [round(m / args.substeps * 1e3, 2) for m in lg2["phys_ms"]], "grasped_envs_per_step": lg2["grasped"],
+                          "mesh_contacts_per_step": lg2["mesh_hits"],
+                          "note": "this rank; environment e closes its gripper at timed step (e % K): over the window the same share of env-steps is in "
+                                  "contact as in the synchronised window above (whose environments all close at its middle)"}
+        del ro2
 
     # cross-check for the roofline (untimed): the same env step captured as ONE kernel per batched substep, so that the
     # HIP-event time / 667 is a per-kernel duration that rocprofv3's per-kernel average can be compared with directly
@@ -350,6 +378,7 @@ def main():
             "roofline": roof,
             "raster": {"gs_raster_mpix_per_s": frames * ro.W * ro.H / (raster_ms * 1e-3) / 1e6, "frames": frames,
                        "num_rendered": int(ro.last_num_rendered), "stage_ms": stages, "scene": scene,
+                       "lossy_batches": int(ro.lossy_batches),   # sync-free batches whose instance count outgrew the capacity (must be 0)
                        "composite_roofline": {"bound": "hbm", "achieved": comp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": comp_gbs / HBM_PEAK_GBS, "algorithmic_bytes": comp_bytes,
                                               "traffic": pmc_comp["hbm_bytes_per_launch"] if pmc_comp and ro.n_env == 32 else None,
@@ -367,6 +396,9 @@ def main():
             out["observation_sink"] = sink_report
         if pipe_report is not None:
             out["throughput_mode"] = pipe_report
+        if dephase_report is not None:
+            dephase_report["vs_synchronised_window"] = dephase_report["env_steps_per_s"] / (ro.n_env * args.steps / elapsed) if world == 1 else None
+            out["dephased_window"] = dephase_report
         if gate is not None and not gate.get("passed"):
             out["value_withheld"] = out["value"]
             out["value"] = None

@@ -240,3 +240,137 @@ def color_correct_shs(shs, color_A, color_b):
     else:
         raise ValueError("color_A must have 9 (linear) or 18 (quadratic) entries")
     return np.concatenate(out, axis=1)
+
+
+# ---- scene assembly from files: GSRenderer.load_scaniverse (gs_renderer.py:333-714) ----------------------------------------
+def read_triangle_mesh(path):
+    """(vertices float64 [nv,3], triangles int32 [nf,3]) of a binary / ascii STL or a Wavefront OBJ — the role of
+    ``o3d.io.read_triangle_mesh`` at gs_renderer.py:358 (open3d is not a dependency here).  STL corners are kept as stored
+    (one vertex per corner: the stepper welds coincident vertices itself, r2s_phys_create)."""
+    path = str(path)
+    if path.lower().endswith(".obj"):
+        v, f = [], []
+        with open(path) as fh:
+            for line in fh:
+                t = line.split()
+                if not t:
+                    continue
+                if t[0] == "v":
+                    v.append([float(x) for x in t[1:4]])
+                elif t[0] == "f":
+                    idx = [int(x.split("/")[0]) for x in t[1:]]
+                    idx = [i - 1 if i > 0 else len(v) + i for i in idx]
+                    for k in range(1, len(idx) - 1):   # fan-triangulate polygons
+                        f.append([idx[0], idx[k], idx[k + 1]])
+        return np.asarray(v, np.float64).reshape(-1, 3), np.asarray(f, np.int32).reshape(-1, 3)
+    raw = open(path, "rb").read()
+    n = int(np.frombuffer(raw[80:84], "<u4")[0]) if len(raw) >= 84 else -1
+    if n >= 0 and len(raw) == 84 + 50 * n:            # binary STL: 80-byte header, count, 50-byte records
+        rec = np.frombuffer(raw[84:], dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), count=n)
+        return rec["v"].reshape(-1, 3).astype(np.float64), np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+    v = [[float(x) for x in line.split()[1:4]] for line in raw.decode("ascii", "replace").splitlines() if line.strip().startswith("vertex")]
+    return np.asarray(v, np.float64).reshape(-1, 3), np.arange(len(v), dtype=np.int32).reshape(-1, 3)
+
+
+def quats_to_rot_mats(q):
+    """Unit quaternions (w, x, y, z) [..., 4] -> rotation matrices (kornia's quaternion_to_rotation_matrix, which normalises first)."""
+    q = np.asarray(q, np.float64)
+    q = q / np.maximum(np.linalg.norm(q, axis=-1, keepdims=True), 1e-12)
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    return np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+                     np.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], -1),
+                     np.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)], -2)
+
+
+def _grid_pose(grid, idx):
+    """One entry of a grid randomisation (cfg.gs.*.grid_randomization: xy list, theta list in degrees, one_to_one):
+    (x, y, z = 0, angle in radians), gs_renderer.py:376-388 / :626-637."""
+    xy, theta = grid["xy"], grid["theta"]
+    if grid.get("one_to_one", False):
+        return float(xy[idx][0]), float(xy[idx][1]), 0.0, float(theta[idx]) * np.pi / 180.0
+    xi, ti = idx // len(theta), idx % len(theta)
+    return float(xy[xi][0]), float(xy[xi][1]), 0.0, float(theta[ti]) * np.pi / 180.0
+
+
+def _randomised_pose(pose, entry, randomize, use_grid, grid_index, rng, random_variables):
+    pose = np.array(pose, dtype=np.float64).reshape(4, 4).copy()
+    rand = None
+    if randomize and use_grid and entry.get("grid_randomization"):
+        rand = _grid_pose(entry["grid_randomization"], grid_index)
+    elif randomize and not use_grid:
+        tr, az = np.array(entry["translation_range"]), np.array(entry["azimuth_range"])
+        rand = (rng.uniform(tr[0], tr[1]), rng.uniform(tr[2], tr[3]), rng.uniform(tr[4], tr[5]), rng.uniform(az[0], az[1]) * np.pi / 180.0)
+    if rand is not None:
+        x, y, z, a = rand
+        pose[:3, 3] += np.array([x, y, z], dtype=np.float32)
+        rot_z = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=np.float32)
+        pose[:3, :3] = rot_z @ pose[:3, :3]
+        random_variables.append([x, y, z, a])
+    return pose
+
+
+def _splat_arrays(params, entry):
+    """means, shs [n,16,3] (colour-corrected when the entry has color_A / color_b), scales, raw quaternions, opacities of a
+    loaded splat file (gs_renderer.py:417-462, :543-590, :639-699)."""
+    shs = sh_colors_to_shs(np.asarray(params["sh_colors"], np.float32))
+    if "color_A" in entry:
+        shs = color_correct_shs(shs, entry["color_A"], entry["color_b"])
+    return (np.asarray(params["means3D"], np.float32), shs.astype(np.float32), np.exp(np.asarray(params["log_scales"], np.float32)),
+            np.asarray(params["unnorm_rotations"], np.float32), (1.0 / (1.0 + np.exp(-np.asarray(params["logit_opacities"], np.float32)))).astype(np.float32))
+
+
+def load_scaniverse(gs_cfg, randomize=False, index=None, rng=None):
+    """``GSRenderer.load_scaniverse`` (gs_renderer.py:333-714) without the renderer object: assemble the scene of one episode from
+    its files.  ``gs_cfg`` mirrors ``cfg.gs``: {'object': {'path', 'pose', ['color_A', 'color_b'], ['grid_randomization' |
+    'translation_range', 'azimuth_range']}, 'scene': {'table_splat_path', 'total_mask_path', ['color_A', 'color_b']}, 'meshes':
+    [{'name', 'mesh_path', 'splat_path', 'pose', ...}], 'use_grid_randomization': bool}.  Returns numpy arrays:
+      rendervar        object splats in the world frame: means3D posed by the (randomised) object pose, rotations =
+                       normalise(quat(pose_R . R(q))), scales, opacities, shs [n,16,3]                              (:592-648)
+      table_rendervar  table + robot scan as stored (rotations NOT normalised, like the reference keeps them)        (:650-714)
+      params_meshes    per static mesh: its splats (positions posed, rotations only normalised), and
+      meshes           its collision mesh (vertices posed, triangles)                                                (:354-501)
+      total_mask_full  link id of every table / robot splat (float32, the reference's dtype)                          (:503-505)
+      pose_obj, random_variables
+    The episode ``index`` is decoded like the reference: with grid randomisation the object takes index % n_object_rand and the
+    meshes share index // n_object_rand, peeled mesh by mesh (:343-352, :368-371)."""
+    rng = np.random.default_rng() if rng is None else rng
+    use_grid = bool(gs_cfg.get("use_grid_randomization", False))
+    obj_cfg, scene_cfg = gs_cfg["object"], gs_cfg["scene"]
+    params_obj = load_gaussians_ply(obj_cfg["path"])
+    params_table = load_gaussians_ply(scene_cfg["table_splat_path"])
+    true_index, true_index_mesh = index, None
+    if randomize and use_grid:
+        g = obj_cfg["grid_randomization"]
+        n_obj_rand = len(g["xy"]) if g.get("one_to_one", False) else len(g["xy"]) * len(g["theta"])
+        assert index is not None
+        true_index_mesh, true_index = index // n_obj_rand, index % n_obj_rand
+    random_variables, params_meshes, meshes = [], {}, {}
+    for m in gs_cfg.get("meshes", []):
+        gi = None
+        if randomize and use_grid and m.get("grid_randomization"):
+            g = m["grid_randomization"]
+            n_this = len(g["xy"]) if g.get("one_to_one", False) else len(g["xy"]) * len(g["theta"])
+            gi, true_index_mesh = true_index_mesh % n_this, true_index_mesh // n_this
+        pose = _randomised_pose(m["pose"], m, randomize, use_grid, gi, rng, random_variables)
+        pts, shs, scales, quats, opac = _splat_arrays(load_gaussians_ply(m["splat_path"]), m)
+        pts = pts @ pose[:3, :3].T + pose[:3, 3]
+        q = quats / np.maximum(np.linalg.norm(quats, axis=-1, keepdims=True), 1e-12)
+        params_meshes[m["name"]] = dict(means3D=pts.astype(np.float32), shs=shs, scales=scales, rotations=q.astype(np.float32), opacities=opac)
+        v, f = read_triangle_mesh(m["mesh_path"])
+        meshes[m["name"]] = ((v @ pose[:3, :3].T + pose[:3, 3]).astype(np.float32), f)
+    total_mask_full = np.load(scene_cfg["total_mask_path"]).astype(np.float32)
+    # object: posed by cfg.gs.object.pose (+ randomisation), rotations composed with the pose's rotation
+    pose_obj = _randomised_pose(obj_cfg["pose"], obj_cfg, randomize, use_grid, true_index, rng, random_variables).astype(np.float32)
+    pts, shs, scales, quats, opac = _splat_arrays(params_obj, obj_cfg)
+    qn = quats / np.maximum(np.linalg.norm(quats, axis=-1, keepdims=True), 1e-12)
+    rot = pose_obj[:3, :3].astype(np.float64) @ quats_to_rot_mats(qn)
+    q_world = rot_mats_to_quats(rot)
+    q_world = q_world / np.maximum(np.linalg.norm(q_world, axis=-1, keepdims=True), 1e-12)
+    rendervar = dict(means3D=(pts @ pose_obj[:3, :3].T + pose_obj[:3, 3]).astype(np.float32), shs=shs, scales=scales, rotations=q_world.astype(np.float32),
+                     opacities=opac)
+    tpts, tshs, tscales, tquats, topac = _splat_arrays(params_table, scene_cfg)
+    if len(total_mask_full) != len(tpts):
+        raise ValueError(f"total_mask has {len(total_mask_full)} entries, the table / robot scan {len(tpts)} splats")
+    table_rendervar = dict(means3D=tpts, shs=tshs, scales=tscales, rotations=tquats, opacities=topac)
+    return dict(rendervar=rendervar, table_rendervar=table_rendervar, params_meshes=params_meshes, meshes=meshes, total_mask_full=total_mask_full,
+                pose_obj=pose_obj, random_variables=random_variables)

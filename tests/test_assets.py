@@ -133,3 +133,87 @@ def test_sh_colour_correction_acts_on_the_rendered_colour():
     A2 = 0.1 * r.normal(size=(3, 3)).astype(np.float32)
     quad = assets.color_correct_shs(shs[:, :1], np.concatenate([A2, A], axis=1).reshape(-1), b)
     assert np.allclose(assets.C0 * quad[:, 0] + 0.5, (rgb ** 2) @ A2.T + rgb @ A.T + b, atol=1e-5)
+
+
+def _write_splat(path, n, seed):
+    from r2s_hip import assets
+
+    rng = np.random.default_rng(seed)
+    p = dict(means3D=rng.uniform(-0.05, 0.05, (n, 3)).astype(np.float32), sh_colors=rng.normal(0, 0.5, (n, 48)).astype(np.float32),
+             log_scales=rng.normal(np.log(0.004), 0.3, (n, 3)).astype(np.float32), unnorm_rotations=(rng.normal(size=(n, 4)) * 1.7).astype(np.float32),
+             logit_opacities=rng.normal(2, 1, (n, 1)).astype(np.float32))
+    assets.save_gaussians_ply(p, path)
+    return p
+
+
+def _write_binary_stl(path, v, f):
+    rec = np.zeros(len(f), dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]))
+    rec["v"] = v[f]
+    with open(path, "wb") as fh:
+        fh.write(b"\0" * 80 + np.uint32(len(f)).tobytes() + rec.tobytes())
+
+
+def scaniverse_scene(tmp_path, n_obj=300, n_tab=500, n_box=120):
+    """A synthetic scene directory laid out like cfg.gs points at (object splat, table + robot scan with its link mask, one
+    static mesh with its own splat), for tests of ``load_scaniverse`` and of the render path behind it."""
+    from r2s_hip import synth
+
+    po = _write_splat(tmp_path / "object.ply", n_obj, 1)
+    pt = _write_splat(tmp_path / "table.ply", n_tab, 2)
+    pb = _write_splat(tmp_path / "box.ply", n_box, 3)
+    mask = np.full(n_tab, -1, np.int32); mask[n_tab // 2:] = np.random.default_rng(4).integers(1, 9, n_tab - n_tab // 2)
+    np.save(tmp_path / "total_mask.npy", mask)
+    v, f = synth.box_mesh((0.0, 0.0, 0.05), (0.2, 0.1, 0.1))
+    _write_binary_stl(tmp_path / "box.stl", v, f)
+    th = np.deg2rad(30.0)
+    pose_obj = np.eye(4); pose_obj[:3, :3] = [[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]]; pose_obj[:3, 3] = (0.37, 0.05, 0.02)
+    pose_box = np.eye(4); pose_box[:3, 3] = (0.55, -0.1, 0.0)
+    cfg = dict(use_grid_randomization=True,
+               object=dict(path=str(tmp_path / "object.ply"), pose=pose_obj.reshape(-1).tolist(), color_A=np.diag([0.9, 1.0, 1.1]).reshape(-1).tolist(),
+                           color_b=[0.01, 0.0, -0.01], grid_randomization=dict(xy=[[0.0, 0.0], [0.02, -0.01], [-0.03, 0.02]], theta=[0.0, 45.0], one_to_one=False)),
+               scene=dict(table_splat_path=str(tmp_path / "table.ply"), total_mask_path=str(tmp_path / "total_mask.npy")),
+               meshes=[dict(name="box", mesh_path=str(tmp_path / "box.stl"), splat_path=str(tmp_path / "box.ply"), pose=pose_box.reshape(-1).tolist(),
+                            grid_randomization=dict(xy=[[0.0, 0.0], [0.05, 0.0]], theta=[0.0, 90.0], one_to_one=True))])
+    return cfg, dict(object=po, table=pt, box=pb, mask=mask, box_mesh=(v, f), pose_obj=pose_obj, pose_box=pose_box)
+
+
+def test_load_scaniverse_assembles_the_scene_like_the_reference(tmp_path):
+    """gs_renderer.py:333-714 restated (open3d / plyfile / kornia are absent, the function cannot be imported): poses, the
+    episode-index arithmetic of the grid randomisation, SH layout + colour correction, what is normalised and what is not."""
+    from scipy.spatial.transform import Rotation
+    from r2s_hip import assets
+
+    cfg, src = scaniverse_scene(tmp_path)
+    sc = assets.load_scaniverse(cfg)                                   # no randomisation: the configured poses
+    rv, tv = sc["rendervar"], sc["table_rendervar"]
+    assert rv["means3D"].shape == (300, 3) and rv["shs"].shape == (300, 16, 3) and tv["shs"].shape == (500, 16, 3)
+    R, t = src["pose_obj"][:3, :3], src["pose_obj"][:3, 3]
+    assert np.allclose(rv["means3D"], src["object"]["means3D"] @ R.T + t, atol=1e-6)
+    q = src["object"]["unnorm_rotations"].astype(np.float64); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    want = (Rotation.from_matrix(R) * Rotation.from_quat(q[:, [1, 2, 3, 0]])).as_matrix()           # scipy: (x, y, z, w)
+    got = Rotation.from_quat(rv["rotations"][:, [1, 2, 3, 0]]).as_matrix()
+    assert np.abs(got - want).max() < 2e-6 and np.allclose(np.linalg.norm(rv["rotations"], axis=1), 1.0, atol=1e-6)
+    assert np.allclose(rv["scales"], np.exp(src["object"]["log_scales"])) and np.allclose(rv["opacities"], 1 / (1 + np.exp(-src["object"]["logit_opacities"])), atol=1e-7)
+    shs0 = assets.sh_colors_to_shs(src["object"]["sh_colors"])
+    assert np.allclose(rv["shs"], assets.color_correct_shs(shs0, cfg["object"]["color_A"], cfg["object"]["color_b"]), atol=1e-6)
+    assert np.allclose(tv["rotations"], src["table"]["unnorm_rotations"]) and np.allclose(tv["shs"], assets.sh_colors_to_shs(src["table"]["sh_colors"]))   # as stored
+    assert sc["total_mask_full"].dtype == np.float32 and np.array_equal(sc["total_mask_full"], src["mask"].astype(np.float32))
+    bv, bf = sc["meshes"]["box"]
+    assert bf.shape == (12, 3) and np.allclose(bv, src["box_mesh"][0][src["box_mesh"][1]].reshape(-1, 3) + src["pose_box"][:3, 3], atol=1e-6)
+    pm = sc["params_meshes"]["box"]
+    assert np.allclose(pm["means3D"], src["box"]["means3D"] + src["pose_box"][:3, 3], atol=1e-6) and np.allclose(np.linalg.norm(pm["rotations"], axis=1), 1.0, atol=1e-6)
+    # episode index -> (mesh grid entry, object grid entry): object has 3 x 2 = 6 poses, the box 2 (one to one)
+    for index in (0, 5, 7, 11):
+        sc = assets.load_scaniverse(cfg, randomize=True, index=index)
+        oi, mi = index % 6, (index // 6) % 2
+        (bx, by, bz, ba), (ox, oy, oz, oa) = sc["random_variables"]
+        assert (bx, by) == ((0.0, 0.0), (0.05, 0.0))[mi] and np.isclose(ba, np.deg2rad((0.0, 90.0)[mi]))
+        assert (ox, oy) == tuple(cfg["object"]["grid_randomization"]["xy"][oi // 2]) and np.isclose(oa, np.deg2rad((0.0, 45.0)[oi % 2]))
+        Rz = Rotation.from_euler("z", oa).as_matrix()
+        assert np.allclose(sc["pose_obj"][:3, :3], Rz @ R, atol=1e-6) and np.allclose(sc["pose_obj"][:3, 3], t + np.array([ox, oy, 0.0]), atol=1e-6)
+    # the other mesh formats
+    v, f = src["box_mesh"]
+    with open(tmp_path / "box.obj", "w") as fh:
+        fh.write("".join(f"v {a} {b} {c}\n" for a, b, c in v) + "".join(f"f {a + 1} {b + 1} {c + 1}\n" for a, b, c in f))
+    vo, fo = assets.read_triangle_mesh(tmp_path / "box.obj")
+    assert np.allclose(vo, v) and np.array_equal(fo, f)
