@@ -30,18 +30,25 @@ for p in (ROOT, os.path.join(ROOT, "real2sim-eval_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = os.path.join("profiles", "r2_pmc_summary.json")
+PMC_FILE = os.path.join("profiles", "r3_pmc_summary.json")
 
 
 def pmc_summary(kernel, config):
     """Counter-derived figures of `kernel` from the committed rocprofv3 --pmc passes over THIS workload (profiles/, produced
-    by tools/profiling/refresh_profiles.sh; FETCH_SIZE x2 + WRITE_SIZE per the microarchitecture guide).  They are NOT
-    measured in this run — the JSON says so next to every number taken from here."""
+    by tools/profiling/pmc_r3.sh; FETCH_SIZE x2 + WRITE_SIZE per the microarchitecture guide).  They are NOT measured in this
+    run — the JSON says so next to every number taken from here — and the summary names the kernel sources it was collected
+    on (`source_sha16`, r2s_hip._lib.kernel_source_sha16): a summary of OTHER sources is labelled stale.
+    Returns (entry or None, provenance string)."""
     try:
+        from r2s_hip._lib import kernel_source_sha16
         d = json.load(open(os.path.join(ROOT, PMC_FILE)))
-        return d[config][kernel]
+        ent = d[config][kernel]
+        same = d.get("source_sha16") == kernel_source_sha16()
+        src = (f"{PMC_FILE} (rocprofv3 --pmc passes of this workload, committed; NOT measured in this run; collected on "
+               + ("these kernel sources" if same else "OTHER kernel sources: STALE") + f", git {d.get('git_head', '?')[:12]})")
+        return dict(ent, stale=not same), src
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(ro, budget_s=20.0):
@@ -112,7 +119,10 @@ def run_stub(args, rank, world):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    tc0 = time.perf_counter()
     ro = StubRollout(args.envs or 4, rank)
+    time.sleep(0.01 * (rank % 3))                      # ranks do not finish construction together
+    construct_s = time.perf_counter() - tc0
     for _ in range(args.warmup):
         ro.step()
     if world > 1:
@@ -123,11 +133,12 @@ def run_stub(args, rank, world):
     if world > 1:
         dist.barrier()
     elapsed = rdist.max_over_ranks(time.perf_counter() - t0, "cpu")
-    records = rdist.gather_records([ro.n_env, args.steps, elapsed * 1e3, float(rank), 0.0], "cpu")
+    records = rdist.gather_records([ro.n_env, args.steps, elapsed * 1e3, float(rank), 0.0, construct_s], "cpu")
     if rank == 0:
         print(json.dumps({"metric": "stub env-steps/s", "value": rdist.throughput(records, elapsed), "unit": "env-steps/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-                          "scaling": "weak", "data": "stub", "ranks_seen": int(records.shape[0]), "envs_total": int(records[:, 0].sum().item())}))
+                          "scaling": "weak", "data": "stub", "ranks_seen": int(records.shape[0]), "envs_total": int(records[:, 0].sum().item()),
+                          "construct_s_per_rank": [round(float(x), 4) for x in records[:, 5]]}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -188,7 +199,11 @@ def main():
             gate = {"passed": False, "error": f"{type(e).__name__}: {e}"}
 
     close_at = args.warmup + args.steps // 2   # the timed window is half free motion, half contact (grasp schedule / pusher)
+    tc0 = time.perf_counter()
     ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=close_at)
+
+    torch.cuda.synchronize(dev)
+    construct_s = time.perf_counter() - tc0            # scene synthesis, topology upload, graph capture of every flavour, settling
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -226,7 +241,7 @@ def main():
     # N > 1: slowest rank's time (MAX) and the metric all-gather of north_star — one fixed-size record per rank
     elapsed = rdist.max_over_ranks(elapsed, dev)
     n_success = int(ro.success_flags().sum().item())  # device-side task predicate (row f4); outside the timed region
-    records = rdist.gather_records([ro.n_env, args.steps, elapsed * 1e3, float(ro.last_num_rendered), float(n_success)], dev)
+    records = rdist.gather_records([ro.n_env, args.steps, elapsed * 1e3, float(ro.last_num_rendered), float(n_success), construct_s], dev)
     total_envs = int(records[:, 0].sum().item())
 
     # throughput mode (outside the timed region, reported next to `value`, never as `value`): the rollout continues from the state
@@ -343,13 +358,13 @@ def main():
                     "kernel_flavours": sorted({log["flavour"][i] for i in idx})}
 
         first_contact = ro.close_at - args.warmup  # index in the timed window of the step in which the fingers close / rod arrives
-        pmc_sub, pmc_comp = pmc_summary("k_substep", args.config), pmc_summary("k_composite", args.config)
-        src = f"{PMC_FILE} (rocprofv3 --pmc passes of this workload, committed; NOT measured in this run)"
+        (pmc_sub, src), (pmc_comp, _) = pmc_summary("k_substep", args.config), pmc_summary("k_composite", args.config)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_sub["hbm_bytes_per_launch"] if pmc_sub and ro.n_env == 32 and n_sub == 667 else None,
                 "traffic_source": src if pmc_sub else None,
                 "hbm_actual_frac": (pmc_sub["hbm_bytes_per_launch"] / t_kernel / 1e9 / HBM_PEAK_GBS) if pmc_sub and ro.n_env == 32 and n_sub == 667 else None,
                 "valu_busy_frac": pmc_sub.get("valu_busy_frac") if pmc_sub else None,
+                "counters_stale": pmc_sub.get("stale") if pmc_sub else None,
                 "kernel": "k_substep (fused spring gather + velocity + collisions + integrate)",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": t_kernel * 1e6, "launches": n_sub * args.steps,
                 "concurrent_chains": chains,
@@ -388,6 +403,7 @@ def main():
                                                       "is not reachable for this kernel at any instruction count above ~1/3 of the reference's per-pixel "
                                                       "arithmetic; valu_busy_frac (VALU-active wave cycles per SIMD cycle of the kernel span; instructions of different waves overlap in the pipeline, so saturation reads slightly above 1) is the figure that says how close to its real bound it runs"}},
             "physics_ms_per_env_step": phys_ms, "skinning_ms_per_env_step": skin_ms,
+            "construct_s_per_rank": [round(float(x), 3) for x in records[:, 5]],   # outside the timed region; every rank builds, captures and settles its own batch
             "task_success": {"envs_satisfying_predicate": int(records[:, 4].sum().item()), "of": total_envs,
                              "note": "frame-level success predicate of the scene's task evaluated on the device after the last step "
                                      "(synthetic action trace: not a policy result)"},

@@ -92,6 +92,22 @@ def lib() -> C.CDLL:
     return L
 
 
+def kernel_source_sha16() -> str:
+    """sha256[:16] over the kernel sources and C headers the library is built from (csrc/*.hip, csrc/*.h, include/*.h, sorted by
+    name).  Counter summaries under profiles/ carry it, so that bench.py can tell a summary collected on THESE kernels from a
+    stale one (the GPU box has no .git: a commit id cannot be read there)."""
+    import glob
+    import hashlib
+
+    root = os.path.dirname(_PKG_ROOT)
+    files = sorted(glob.glob(os.path.join(_PKG_ROOT, "csrc", "*.hip")) + glob.glob(os.path.join(_PKG_ROOT, "csrc", "*.h")) + glob.glob(os.path.join(root, "include", "*.h")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 class R2SError(RuntimeError):
     pass
 

@@ -101,3 +101,16 @@ def test_launch_command_shape():
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
     assert cmd[-5:] == ["bench.py", "--gpus", "8", "--config", "T_pusher_32env"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_8_stub_dry_run_of_the_round_end_scaling_launch():
+    """The driver's N = 8 launch, dry: `bench.py --gpus 8 --stub` self-launches eight ranks over gloo — rendezvous on 127.0.0.1,
+    barrier, MAX over ranks, the all-gather of one record per rank — and reports every rank's construction time, so that the
+    first real 8-GPU run has nothing left to discover but the number."""
+    rc, out, err = _run_bench(["--gpus", "8", "--stub", "--steps", "3", "--warmup", "1", "--envs", "32"], timeout=500)
+    assert rc == 0, err[-2000:]
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["envs_total"] == 256 and out["scaling"] == "weak"
+    assert len(out["construct_s_per_rank"]) == 8 and all(c >= 0 for c in out["construct_s_per_rank"])
+    # the slowest rank (rank 7 sleeps 8 x 2 ms per step) sets the time; whole-job value = 256 envs x steps / that time
+    assert out["value"] == pytest.approx(256 * 3 / (out["ms_per_step"] * 3e-3), rel=1e-6) and out["ms_per_step"] >= 16.0
