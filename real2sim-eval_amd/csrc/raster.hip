@@ -371,9 +371,10 @@ __global__ void __launch_bounds__(256) k_tile_len_keys(uint32_t n, const uint2* 
 
 // renderCUDA, forward.cu:262-394.  One workgroup per 16x16 tile; wavefront w owns the 8x8 quadrant
 // (w&1, w>>1) so that a whole-wave skip (all 64 pixels fail the alpha test) is likely for small splats.
-// The per-pixel arithmetic and its order (power -> alpha -> test_T -> colour -> median depth) follow
-// forward.cu:339-380 exactly; rgb and depth travel through LDS with the rest of the record instead of
-// being re-read from global memory inside the pixel loop (forward.cu:362).
+// The per-pixel sequence of DECISIONS (power -> alpha -> test_T stop -> colour -> median depth) is forward.cu:339-380's; the
+// arithmetic is not the reference's to the bit: the conic is pre-scaled by log2(e) once per staged instance, the quadratic is an
+// FMA chain and the exponential is v_exp_f32 (2^x) — parity is by tolerance.  rgb and depth travel through LDS
+// with the rest of the record instead of being re-read from global memory inside the pixel loop (forward.cu:362).
 #ifdef R2S_COMP_STATS // instrumented build (scratch/comp_stats.py): lane efficiency of the compositor
 __device__ unsigned long long g_comp_stats[4]; // wave iterations, hit lanes, iterations without a hit, lanes still alive
 extern "C" int r2s_raster_debug_comp_stats(unsigned long long* out, int reset)
@@ -411,19 +412,22 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
     // one 48-byte record per staged instance: (px, py, A, B) | (C, opacity, -, -) | (depth, r, g, b) — conic pre-scaled, see
     // below.  ONE address register serves the three broadcast reads (the instance index is scalar: every extra LDS address
     // is a v_mov), and (g, b) land in an even register pair, so the compiler's packed FMA needs no operand shuffles.
-    __shared__ float4 s_rec[TILE_THREADS * 3];
     // s_live[q][w]: which of the 64 instances staged by wavefront w can reach alpha >= 1/255 somewhere in quadrant q
     // (the same conservative bound as the tile culling, on the 8x8 pixel rectangle).  A quadrant's wavefront walks
     // only its set bits, so an instance costs nothing in the quadrants it cannot touch.
-    __shared__ unsigned long long s_live[4][4];
+    // (Round 3 measured the stage double-buffered — round i + 1 staged BEFORE round i is consumed, one barrier per round instead of
+    // two, so that a fast quadrant stages ahead while a slow one still blends: 25 KB of LDS, 6 instead of 8 wavefronts per SIMD,
+    // 1.14 vs 0.98 ms per 64 frames on the benchmark scene, images identical.  The barriers are not what the kernel waits for.)
+    constexpr int NBUF = 1;
+    __shared__ float4 s_rec[NBUF][TILE_THREADS * 3];
+    __shared__ unsigned long long s_live[NBUF][4][4];
 
     float T = 1.0f;
     uint32_t last_contributor = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
     float D = 15.0f; // forward.cu:309
 
-    for (int i = 0; i < rounds; ++i) {
-        if (__syncthreads_count(done) == TILE_THREADS) break;
+    auto stage = [&](int i, int buf) {
         const int progress = i * TILE_THREADS + tid;
         unsigned live4 = 0;
         if (progress < n) {
@@ -433,9 +437,9 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
             // conic pre-scaled once per staged instance: power * log2(e) = A dx^2 + B dx dy + C dy^2 with
             // A = -0.5 a log2e, B = -b log2e, C = -0.5 c log2e, so the pixel loop is 7 plain VALU ops + one v_exp_f32
             constexpr float LOG2E = 1.4426950408889634f;
-            s_rec[3 * tid] = make_float4(a.x, a.y, -0.5f * LOG2E * a.z, -LOG2E * a.w);
-            s_rec[3 * tid + 1] = make_float4(-0.5f * LOG2E * b.x, b.y, 0.f, 0.f);
-            s_rec[3 * tid + 2] = make_float4(b.z, b.w, c.x, c.y);
+            s_rec[buf][3 * tid] = make_float4(a.x, a.y, -0.5f * LOG2E * a.z, -LOG2E * a.w);
+            s_rec[buf][3 * tid + 1] = make_float4(-0.5f * LOG2E * b.x, b.y, 0.f, 0.f);
+            s_rec[buf][3 * tid + 2] = make_float4(b.z, b.w, c.x, c.y);
             const float lt = logf(1.0f / (255.0f * b.y));
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
@@ -447,20 +451,21 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const unsigned long long bal = __builtin_amdgcn_ballot_w64((live4 >> qd) & 1u);
-            if (lane == 0) s_live[qd][wave] = bal;
+            if (lane == 0) s_live[buf][qd][wave] = bal;
         }
-        __syncthreads();
+    };
+    auto consume = [&](int i, int buf) {
         const uint32_t base = (uint32_t)(i * TILE_THREADS);
         for (int sw = 0; sw < 4; ++sw) {
             if (__builtin_amdgcn_ballot_w64(!done) == 0) break; // whole quadrant finished (forward.cu:315 per block)
             // the live word is wave-uniform: keep it in SGPRs so the walk is s_ff1 / s_andn2 and a scalar branch
-            const unsigned long long lv = s_live[wave][sw];
+            const unsigned long long lv = s_live[buf][wave][sw];
             unsigned long long bits = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(lv >> 32)) << 32) |
                                       (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)lv);
             while (bits) {
                 const int j = sw * 64 + __builtin_ctzll(bits);
                 bits &= bits - 1;
-                const float4* rec = s_rec + 3 * j;
+                const float4* rec = s_rec[buf] + 3 * j;
                 const float4 a = rec[0];
                 const float2 b = make_float2(rec[1].x, rec[1].y);
                 const float4 c = rec[2]; // depth, r, g, b — issued with the other two reads (one address register, no second v_mov)
@@ -492,6 +497,12 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                 if (AUX) last_contributor = blend ? base + (uint32_t)j + 1u : last_contributor; // as forward.cu:335,380
             }
         }
+    };
+    for (int i = 0; i < rounds; ++i) {
+        if (__syncthreads_count(done) == TILE_THREADS) break;
+        stage(i, 0);
+        __syncthreads();
+        consume(i, 0);
     }
     if (inside) {
         const size_t pix = (size_t)W * py + px;
