@@ -151,6 +151,68 @@ __device__ __forceinline__ void sh_to_rgb(int idx, int deg, int M, const float* 
     }
 }
 
+// The candidate tiles of one Gaussian — its 3-sigma bounding rectangle in tiles, row-major like duplicateWithKeys walks them
+// (rasterizer_impl.cu:97-108) — counted (k_preprocess, exact-output culling) or emitted (k_emit_keys).  One lane per Gaussian
+// used to walk its own rectangle: with the wrist camera riding on the gripper a few splats close to the lens cover hundreds of
+// tiles, and every wavefront waited for the largest rectangle among its 64 Gaussians (k_preprocess 0.25 -> 0.73 ms, k_emit_keys
+// 0.32 -> 0.73 ms per 64 frames when the camera started to follow the gripper).  Now rectangles of up to RECT_SMALL_* tiles stay
+// per lane; the larger ones are taken ONE AT A TIME BY THE WHOLE WAVEFRONT, 64 candidate tiles per trip: the count is a ballot,
+// and the emitted run of a Gaussian is written with consecutive lanes at consecutive offsets (the per-lane walk scatters
+// 4-byte stores: 8x the payload in HBM traffic, profiles/r2_pmc_summary.json).  Order and content of the lists are unchanged.
+struct RectJob {
+    float mx, my, ca, cb, cc, lt;
+    uint32_t x0, y0, x1, y1; // empty (x1 == x0) for lanes without a visible Gaussian
+};
+// measured on the benchmark scene (64 frames, wrist cameras on the grippers), per-lane limit 2 / 6 / 12 / 24 / 40 / 64 / 100 tiles:
+// count 0.80 / 0.57 / 0.47 / 0.43 / 0.41 / 0.43 / 0.47 ms, emit 0.86 / 0.60 / 0.47 / 0.44 / 0.47 / 0.51 / 0.54 ms (all per lane: 0.73 / 0.73)
+constexpr uint32_t RECT_SMALL_COUNT = 40, RECT_SMALL_EMIT = 24;
+// EMIT = false: returns the number of candidate tiles that can contribute (every lane of the wavefront must call it).
+// EMIT = true: writes (tile key, value) of the surviving tiles from offset `off` on, clamped to `cap`; `test` = apply the culling
+// test (off in the reference-exact mode, where every tile of the rectangle is an instance).
+template <bool EMIT>
+__device__ __forceinline__ uint32_t rect_walk(const RectJob& j, int W, int H, uint32_t off, uint32_t cap, uint32_t tile_base, uint32_t val,
+                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx = 0, bool test = true)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t w = j.x1 - j.x0, n = w * (j.y1 - j.y0);
+    uint32_t count = 0;
+    const bool big = n > (EMIT ? RECT_SMALL_EMIT : RECT_SMALL_COUNT);
+    if (n > 0 && !big) {
+        for (uint32_t y = j.y0; y < j.y1; ++y)
+            for (uint32_t x = j.x0; x < j.x1; ++x) {
+                if (test && !tile_can_contribute(j.mx, j.my, j.ca, j.cb, j.cc, j.lt, (int)x, (int)y, W, H)) continue;
+                if (EMIT) { if (off < cap) { keys[off] = tile_base + y * (uint32_t)gx + x; vals[off] = val; } ++off; }
+                ++count;
+            }
+    }
+    unsigned long long m = __builtin_amdgcn_ballot_w64(big);
+    while (m) { // wave-uniform: one large rectangle per trip, all 64 lanes on it
+        const int L = __builtin_ctzll(m);
+        m &= m - 1;
+        auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); };
+        auto bu = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, L); };
+        const float mx = bf(j.mx), my = bf(j.my), ca = bf(j.ca), cb = bf(j.cb), cc = bf(j.cc), lt = bf(j.lt);
+        const uint32_t x0 = bu(j.x0), y0 = bu(j.y0), wL = bu(w), nL = bu(n);
+        uint32_t base = EMIT ? bu(off) : 0u;
+        const uint32_t tb = EMIT ? bu(tile_base) : 0u, vL = EMIT ? bu(val) : 0u;
+        uint32_t total = 0;
+        for (uint32_t t0 = 0; t0 < nL; t0 += 64) {
+            const uint32_t t = t0 + (uint32_t)lane;
+            const uint32_t ry = t / wL, rx = t - ry * wL;
+            const bool ok = t < nL && (!test || tile_can_contribute(mx, my, ca, cb, cc, lt, (int)(x0 + rx), (int)(y0 + ry), W, H));
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(ok);
+            if (EMIT) {
+                const uint32_t pos = base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                if (ok && pos < cap) { keys[pos] = tb + (y0 + ry) * (uint32_t)gx + (x0 + rx); vals[pos] = vL; }
+                base += (uint32_t)__builtin_popcountll(bal);
+            }
+            total += (uint32_t)__builtin_popcountll(bal);
+        }
+        if (lane == L) count = total;
+    }
+    return count;
+}
+
 // preprocessCUDA, forward.cu:156-257 with in_frustum (auxiliary.h:139-165), computeCov3D (forward.cu:118-152)
 // and computeCov2D (forward.cu:74-113) written out as scalar formulas in GLM's evaluation order.
 __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__ frames, int gx, int gy, int W, int H,
@@ -161,11 +223,13 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
 #pragma clang fp contract(off)
     const FrameDev& fr = frames[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= fr.P) return;
-    const size_t g = (size_t)fr.base + idx;
+    const bool valid = idx < fr.P; // no early return: the tile count of large splats below is wave-cooperative
+    const size_t g = (size_t)fr.base + (valid ? idx : 0);
     int radius_out = 0;
     uint32_t tiles = 0;
+    RectJob job = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}; // candidate tiles still to be tested (exact-output culling)
     do {
+        if (!valid) break;
         const float* vm = fr.view;
         const float* pm = fr.proj;
         const float p0 = fr.means3D[3 * idx], p1 = fr.means3D[3 * idx + 1], p2 = fr.means3D[3 * idx + 2];
@@ -261,14 +325,13 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
         geom[g] = rec;
         radius_out = (int)my_radius;
         tiles = (y1 - y0) * (x1 - x0);
-        if (cull) {
-            const float lt = logf(1.0f / (255.0f * fr.opac[idx]));
+        if (cull) { // a Gaussian whose every tile is culled keeps its radius (the reference reports it) but emits nothing
+            job = {pix, piy, ca, cb, cc, logf(1.0f / (255.0f * fr.opac[idx])), x0, y0, x1, y1};
             tiles = 0;
-            for (uint32_t y = y0; y < y1; ++y)
-                for (uint32_t x = x0; x < x1; ++x) tiles += tile_can_contribute(pix, piy, ca, cb, cc, lt, (int)x, (int)y, W, H) ? 1u : 0u;
-            // a Gaussian whose every tile was culled keeps its radius (the reference reports it) but emits nothing
         }
     } while (false);
+    if (cull) tiles = rect_walk<false>(job, W, H, 0u, 0u, 0u, 0u, nullptr, nullptr);
+    if (!valid) return;
     radii_all[g] = radius_out;
     if (fr.radii) fr.radii[idx] = radius_out;
     tiles_touched[g] = tiles;
@@ -303,24 +366,24 @@ __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ 
                                                    uint32_t* __restrict__ vals, int cull, uint32_t cap, int* __restrict__ overflow)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G) return;
-    if (i == G - 1 && offsets[i] > cap) *overflow = 1; // sync-free mode: the scratch was sized from an earlier batch and is too small
-    const uint32_t g = order[i];
-    const int r = radii_all[g];
-    if (r <= 0) return;
-    uint32_t off = (i == 0) ? 0u : offsets[i - 1];
-    const float4 q0 = geom[g].q0;
-    const float4 q1 = geom[g].q1;
-    uint32_t x0, y0, x1, y1;
-    tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
-    const uint32_t tile_base = (uint32_t)(gkeys[i] >> 32) * (uint32_t)(gx * gy);
-    const float lt = cull ? logf(1.0f / (255.0f * q1.y)) : 0.f;
-    for (uint32_t y = y0; y < y1; ++y)
-        for (uint32_t x = x0; x < x1; ++x) {
-            if (cull && !tile_can_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, lt, (int)x, (int)y, W, H)) continue;
-            if (off < cap) { keys[off] = tile_base + y * (uint32_t)gx + x; vals[off] = g; }
-            ++off;
+    const bool valid = i < G; // no early return: large rectangles are emitted by the whole wavefront (rect_walk)
+    if (valid && i == G - 1 && offsets[i] > cap) *overflow = 1; // sync-free mode: the scratch was sized from an earlier batch and is too small
+    RectJob job = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u};
+    uint32_t off = 0, tile_base = 0, g = 0;
+    if (valid) {
+        g = order[i];
+        const int r = radii_all[g];
+        if (r > 0) {
+            off = (i == 0) ? 0u : offsets[i - 1];
+            const float4 q0 = geom[g].q0;
+            const float4 q1 = geom[g].q1;
+            uint32_t x0, y0, x1, y1;
+            tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
+            tile_base = (uint32_t)(gkeys[i] >> 32) * (uint32_t)(gx * gy);
+            job = {q0.x, q0.y, q0.z, q0.w, q1.x, cull ? logf(1.0f / (255.0f * q1.y)) : 0.f, x0, y0, x1, y1};
         }
+    }
+    (void)rect_walk<true>(job, W, H, off, cap, tile_base, g, keys, vals, gx, cull != 0);
 }
 
 // identifyTileRanges, rasterizer_impl.cu:116-138.
