@@ -46,6 +46,13 @@ int r2s_skin_interpolate_motions(R2SSkin* h, int32_t n_env, const float* bones, 
 int r2s_skin_interpolate_motions_strided(R2SSkin* h, int32_t n_env, const float* bones, const float* motions, const float* xyz,
                                          int64_t xyz_env_stride, float* xyz_out, int64_t out_env_stride, r2s_stream_t stream);
 
+/* interpolate_motions(quat=...) (transform_utils.py:197-210; the simulator passes quat=None, offline tools rotate the splats):
+ * with the bone rotations of the LAST r2s_skin_interpolate_motions* call, quat_out = normalise(sum_j w_j q(R_bj)) (x) quat, the
+ * Hamilton product with the blended bone rotation first; q(R) is kornia's rotation_matrix_to_quaternion, normalised.  quat /
+ * quat_out: device [n_env, n_points, 4] (w, x, y, z) with the given environment strides in floats; may alias. */
+int r2s_skin_rotate_quats(R2SSkin* h, int32_t n_env, const float* quat, int64_t quat_env_stride, float* quat_out, int64_t out_env_stride,
+                          r2s_stream_t stream);
+
 /* Device pointer to the per-bone rotations of the last call, [n_env, n_bones, 9] row-major (parity taps), and the
  * per-environment "rank-deficient fit -> identity" flags [n_env]. */
 int r2s_skin_debug(R2SSkin* h, const float** rotations, const int32_t** identity_flags);

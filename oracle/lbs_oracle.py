@@ -62,3 +62,22 @@ def knn_weights(bones, pts, k=16):
     w = (1.0 / (dist + np.float32(1e-6))).astype(np.float32)
     w = w / w.sum(-1, keepdims=True)
     return w.astype(np.float32), idx.astype(np.int32)
+
+
+def rotate_quats(bones, motions, relations, quat, weights, weights_indices):
+    """The quat branch of interpolate_motions (transform_utils.py:197-210): bone rotations -> unit quaternions (kornia's
+    rotation_matrix_to_quaternion, restated in oracle/robot_oracle.py; third party: that conversion is not pinned), blended with
+    the skinning weights, normalised, composed with the splat's quaternion (blended rotation first)."""
+    from .robot_oracle import rotation_matrix_to_quaternion
+
+    R, _ = bone_rotations(bones, motions, relations)
+    bq = np.stack([np.asarray(rotation_matrix_to_quaternion(r), np.float32) for r in R.astype(np.float32)])
+    bq = bq / np.maximum(np.linalg.norm(bq, axis=-1, keepdims=True), 1e-12)
+    w = np.asarray(weights, np.float32)
+    q = (bq[np.asarray(weights_indices)] * w[:, :, None]).sum(1).astype(np.float32)
+    q = q / np.maximum(np.linalg.norm(q, axis=-1, keepdims=True), 1e-12)
+    p = np.asarray(quat, np.float32)
+    return np.stack([q[:, 0] * p[:, 0] - q[:, 1] * p[:, 1] - q[:, 2] * p[:, 2] - q[:, 3] * p[:, 3],
+                     q[:, 0] * p[:, 1] + q[:, 1] * p[:, 0] + q[:, 2] * p[:, 3] - q[:, 3] * p[:, 2],
+                     q[:, 0] * p[:, 2] - q[:, 1] * p[:, 3] + q[:, 2] * p[:, 0] + q[:, 3] * p[:, 1],
+                     q[:, 0] * p[:, 3] + q[:, 1] * p[:, 2] - q[:, 2] * p[:, 1] + q[:, 3] * p[:, 0]], -1).astype(np.float32)

@@ -715,8 +715,8 @@ __device__ __forceinline__ MeshHit mesh_query_regs(const TriRegs& t, f3 q, bool 
 // sqrt + three divides (the reference's own float atomics reorder sums far more than this perturbs them).
 #pragma clang fp contract(fast)
 
-// One neighbour, 19 VALU instructions: with d = xj - xi (NOT normalised), r = 1 / |d|, L = |d|, t = (vj - vi) . d
-//     F = [k (L / rest - 1) + c (dv . d r)] d r  =  [(a L - k) + (c r) t] r d,      a = k / rest (per slot, precomputed),
+// One neighbour, 18 VALU instructions: with d = xj - xi (NOT normalised), r = 1 / |d|, L = |d|, t = (vj - vi) . d
+//     F = [k (L / rest - 1) + c (dv . d r)] d r  =  [(a L - k) + (c r) t] r d  =  [a - k r + c r^2 t] d,      a = k / rest (per slot),
 // so the unit vector is never formed (3 multiplies), L / rest - 1 and the stiffness product fold into one FMA, and the
 // 1e-6 floor of the reference's normalisation (d / max(L, 1e-6), :84) becomes a 1e-30 seed of the squared length: padding
 // slots (d = 0, k = a = 0, dv = 0) contribute exactly 0 without a v_max, real springs (rest > 1e-4) never get near it.
@@ -728,17 +728,12 @@ __device__ __forceinline__ void spring_term(v2f xy, float zj, v2f vxy, float vzj
     const float dz = zj - xi.z;
     const float d2 = fmaf(dxy.x, dxy.x, fmaf(dxy.y, dxy.y, fmaf(dz, dz, 1e-30f)));
     const float rinv = __builtin_amdgcn_rsqf(d2);
-    const float L = d2 * rinv;
     const v2f dvxy = vxy - (v2f){vi.x, vi.y};
     const float dvz = vzj - vi.z;
     const float t = fmaf(dvxy.x, dxy.x, fmaf(dvxy.y, dxy.y, dvz * dz));
-#ifdef R2S_SC_ALG // (a L - k) r + c r^2 t  with  L r = |d|^2 r^2 = 1:  a - k r + (c r^2) t — one VALU instruction fewer per slot
-    (void)L;
+    // sc = [(a L - k) + (c r) t] r  with  L r = |d|^2 r^2 = 1:  a - k r + (c r^2) t — one VALU instruction fewer per slot than
+    // forming the magnitude first (round 3: 19.5 -> 19.2 us per batched substep; same rounding class: both cancel a against k r)
     const float sc = fmaf(dashpot * (rinv * rinv), t, fmaf(-k, rinv, a));
-#else
-    const float mag = fmaf(dashpot * rinv, t, fmaf(a, L, -k));
-    const float sc = mag * rinv;
-#endif
     fxy += dxy * sc;
     fz = fmaf(dz, sc, fz);
 }
@@ -1044,10 +1039,11 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
     // All loads of a thread are issued before its first LDS write: two dependent round trips (halo id, then state)
     // per workgroup instead of two per staging round.
     constexpr int K = (RCAP + B - 1) / B;
-    // R2S_STAGE_BATCH (tuning): staging rounds whose loads are in flight together.  Default: all K of them (two dependent round
-    // trips per workgroup); a smaller batch trades round trips for registers (the 64-VGPR build of the <320,1120> layout).
+    // R2S_STAGE_BATCH: staging rounds whose loads are in flight together.  All K of them (round 2) keep 28 staging registers live
+    // next to the prefetched adjacency group; two at a time leave the kernel at ~50 VGPRs outside the mesh code at the price of a
+    // second pair of dependent round trips per workgroup, which the other five resident workgroups hide.
 #ifndef R2S_STAGE_BATCH
-#define R2S_STAGE_BATCH 0
+#define R2S_STAGE_BATCH 2
 #endif
     constexpr int KB = (R2S_STAGE_BATCH > 0 && R2S_STAGE_BATCH < K) ? R2S_STAGE_BATCH : K;
     const int h0 = p.halo_off[b], per_env = B + (p.halo_off[b + 1] - h0);
@@ -1127,11 +1123,11 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
 // (A <256,896> layout — 21.5 KB of LDS, 7 workgroups per CU, the fused kernel held to 72 VGPRs, so that only 96 instead of 352
 // of the benchmark's 1888 work items are left for a second round — was measured in round 2: 23.3 vs 22.1 us per substep with
 // two chains, 24.4 vs 24.8 with one.  More residency does not pay; the layouts stay <256,1024> and <128,768>.)
-#ifndef R2S_SUBSTEP_MIN_WAVES
-#define R2S_SUBSTEP_MIN_WAVES 1
-#endif
+// <256,1024>: 24.6 KB of LDS allow six workgroups per CU; the register allocator is told so (84 -> 79 VGPRs, no spills: five ->
+// six wavefronts per SIMD).  On its own that is worth nothing measurable (19.8 vs 19.9 us), with the staging batch of two and the
+// shorter spring term 18.8 vs 19.5.
 template <int B, int RCAP, bool SELF, int MESH>
-__global__ void __launch_bounds__(B, R2S_SUBSTEP_MIN_WAVES) k_substep(const PhysDev p, const StateC xv_in, const StateM xv_out, int step,
+__global__ void __launch_bounds__(B, (B == 256 ? 6 : 1)) k_substep(const PhysDev p, const StateC xv_in, const StateM xv_out, int step,
                                                int write_forces)
 {
     substep_body<B, RCAP, SELF, MESH>(p, xv_in, xv_out, step, write_forces);
@@ -2045,8 +2041,6 @@ void launch_fused(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_
     const StateC in = h->state(in_buf);
     const StateM out = h->state(in_buf ^ 1);
     if (h->pb == 256) launch_substep_layout<256, 1024>(p, grid, in, out, step, write_forces, with_self, mesh, s);
-    else if (h->pb == 320) launch_substep_layout<320, 1120>(p, grid, in, out, step, write_forces, with_self, mesh, s);
-    else if (h->pb == 384) launch_substep_layout<384, 1280>(p, grid, in, out, step, write_forces, with_self, mesh, s);
     else launch_substep_layout<128, 768>(p, grid, in, out, step, write_forces, with_self, mesh, s);
 }
 
@@ -2272,9 +2266,12 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     // layout: <256,1024> by default; measured against <128,768> on the 1-env rope, the 32-env T block (equal: those are
     // launch-latency bound) and the 32-env pusher scene (256 is 25 % faster).  R2S_LAYOUT=128|256 overrides.
     {
-        const int sizes[4] = {256, 128, 320, 384}, caps[4] = {1024, 768, 1120, 1280};
+        // (<320,1120> and <384,1280> — layouts whose 1536 / 1280 work items of the 32-env benchmark are ALL resident at once in a
+        // 64-VGPR build: no second, half-empty round of workgroups — were measured in round 3: 23.5 / 23.6 us per batched substep
+        // against 20.8 for <256,1024> in the same run.  A single round is not faster; the layouts were removed again.)
+        const int sizes[2] = {256, 128}, caps[2] = {1024, 768};
         int pick = 0;
-        if (const char* ev = getenv("R2S_LAYOUT")) { const int v = atoi(ev); for (int k = 0; k < 4; ++k) if (v == sizes[k]) pick = k; } // tuning knob
+        if (const char* ev = getenv("R2S_LAYOUT")) { const int v = atoi(ev); for (int k = 0; k < 2; ++k) if (v == sizes[k]) pick = k; } // tuning knob
         h->pb = sizes[pick]; h->rcap = caps[pick];
         // the remaining tuning knobs are also read here, ONCE per handle (r2s_phys_set_tuning changes them afterwards)
         if (const char* ev = getenv("R2S_CHAINS")) h->chains_override = atoi(ev);

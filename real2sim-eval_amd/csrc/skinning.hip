@@ -156,6 +156,62 @@ __global__ void __launch_bounds__(256) k_skin(int N, int P, int k_wgt, const int
     out[eo] = ax; out[eo + 1] = ay; out[eo + 2] = az;
 }
 
+// interpolate_motions(quat=...), transform_utils.py:197-210: every bone's rotation as a unit quaternion
+// (kornia.geometry.conversions.rotation_matrix_to_quaternion — third party, restated like in robot_gs.hip: trace / largest-diagonal
+// branches, eps 1e-8, (w, x, y, z) — then normalised), blended per Gaussian with the skinning weights, normalised, and composed
+// with the Gaussian's own quaternion (Hamilton product, blended rotation first).
+__device__ __forceinline__ void rotmat_to_quat(const float* m, float q[4])
+{
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
+    const float trace = m00 + m11 + m22;
+    constexpr float eps = 1e-8f, tiny = 1.17549435e-38f;
+    auto sdiv = [&](float a, float b) { return a / fmaxf(b, tiny); }; // safe_zero_division
+    if (trace > 0.f) {
+        const float sq = sqrtf(trace + 1.0f + eps) * 2.0f;
+        q[0] = 0.25f * sq; q[1] = sdiv(m21 - m12, sq); q[2] = sdiv(m02 - m20, sq); q[3] = sdiv(m10 - m01, sq);
+    } else if (m00 > m11 && m00 > m22) {
+        const float sq = sqrtf(1.0f + m00 - m11 - m22 + eps) * 2.0f;
+        q[0] = sdiv(m21 - m12, sq); q[1] = 0.25f * sq; q[2] = sdiv(m01 + m10, sq); q[3] = sdiv(m02 + m20, sq);
+    } else if (m11 > m22) {
+        const float sq = sqrtf(1.0f + m11 - m00 - m22 + eps) * 2.0f;
+        q[0] = sdiv(m02 - m20, sq); q[1] = sdiv(m01 + m10, sq); q[2] = 0.25f * sq; q[3] = sdiv(m12 + m21, sq);
+    } else {
+        const float sq = sqrtf(1.0f + m22 - m00 - m11 + eps) * 2.0f;
+        q[0] = sdiv(m10 - m01, sq); q[1] = sdiv(m02 + m20, sq); q[2] = sdiv(m12 + m21, sq); q[3] = 0.25f * sq;
+    }
+    const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f); // F.normalize
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+
+__global__ void __launch_bounds__(256) k_skin_quat(int N, int P, int k_wgt, const int* __restrict__ order, const float* __restrict__ weights,
+                                                   const int* __restrict__ widx, const BoneRec* __restrict__ rec, const int* __restrict__ ident_flag,
+                                                   const float* quat, long long quat_stride, float* out, long long out_stride)
+{
+#pragma clang fp contract(off)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    if (t >= P) return;
+    const int pt = order[t];
+    const bool ident = ident_flag[e] != 0;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < k_wgt; ++k) {
+        const int j = widx[(size_t)k * P + t];
+        const float w = weights[(size_t)k * P + t];
+        float q[4] = {1.f, 0.f, 0.f, 0.f};
+        if (!ident) rotmat_to_quat(rec[(size_t)e * N + j].r, q);
+        for (int c = 0; c < 4; ++c) a[c] += q[c] * w;
+    }
+    const float n = fmaxf(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]), 1e-12f);
+    for (int c = 0; c < 4; ++c) a[c] /= n;
+    const float* q2 = quat + (size_t)e * quat_stride + (size_t)pt * 4;
+    const float b0 = q2[0], b1 = q2[1], b2 = q2[2], b3 = q2[3];
+    float* o = out + (size_t)e * out_stride + (size_t)pt * 4;
+    o[0] = a[0] * b0 - a[1] * b1 - a[2] * b2 - a[3] * b3;
+    o[1] = a[0] * b1 + a[1] * b0 + a[2] * b3 - a[3] * b2;
+    o[2] = a[0] * b2 - a[1] * b3 + a[2] * b0 + a[3] * b1;
+    o[3] = a[0] * b3 + a[1] * b2 - a[2] * b1 + a[3] * b0;
+}
+
 } // namespace
 
 struct R2SSkin {
@@ -240,6 +296,17 @@ int r2s_skin_interpolate_motions_strided(R2SSkin* h, int32_t n_env, const float*
     if (h->P > 0)
         hipLaunchKernelGGL(k_skin, dim3((h->P + 255) / 256, n_env), dim3(256), 0, s, h->N, h->P, h->k_wgt, h->d_order, h->d_w, h->d_widx, h->d_rec, h->d_flag, xyz,
                            (long long)xyz_env_stride, xyz_out, (long long)out_env_stride);
+    R2S_HIP_TRY(hipGetLastError());
+    return R2S_OK;
+}
+
+int r2s_skin_rotate_quats(R2SSkin* h, int32_t n_env, const float* quat, int64_t quat_env_stride, float* quat_out, int64_t out_env_stride,
+                          r2s_stream_t stream_)
+{
+    if (!h || n_env <= 0 || n_env > h->cap_env || !h->d_rec || (h->P > 0 && (!quat || !quat_out))) return R2S_ERR_INVALID;
+    if (h->P > 0)
+        hipLaunchKernelGGL(k_skin_quat, dim3((h->P + 255) / 256, n_env), dim3(256), 0, (hipStream_t)stream_, h->N, h->P, h->k_wgt, h->d_order, h->d_w, h->d_widx,
+                           h->d_rec, h->d_flag, quat, (long long)quat_env_stride, quat_out, (long long)out_env_stride);
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }

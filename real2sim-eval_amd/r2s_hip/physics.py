@@ -346,7 +346,7 @@ class PhysBatch:
         check(_bind().r2s_phys_last_flavour(self._h, a), "r2s_phys_last_flavour")
         rcap = self.layout_stats()["lds_bytes"] // 24
         return dict(self_collision_kernel=bool(a[0]), mesh_template=int(a[1]), deferred_mesh_queries=bool(a[2]), chains=int(a[3]),
-                    kernel=f"k_substep<{ {1024: 256, 1120: 320, 1280: 384}.get(rcap, 128) },{rcap},{'true' if a[0] else 'false'},{int(a[1])}>"
+                    kernel=f"k_substep<{256 if rcap >= 1024 else 128},{rcap},{'true' if a[0] else 'false'},{int(a[1])}>"
                            + (" + k_contact_finish" if a[2] else (" + k_self_finish" if a[0] else "")))
 
     def set_tuning(self, chains: int = 0, mesh_defer: int = -1):

@@ -31,6 +31,8 @@ def _bind():
         L.r2s_skin_interpolate_motions_strided.argtypes = [vp, i32, vp, vp, vp, C.c_int64, vp, C.c_int64, vp]
         L.r2s_skin_debug.restype = C.c_int
         L.r2s_skin_debug.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        L.r2s_skin_rotate_quats.restype = C.c_int
+        L.r2s_skin_rotate_quats.argtypes = [vp, i32, vp, C.c_int64, vp, C.c_int64, vp]
         _bound = True
     return L
 
@@ -87,6 +89,23 @@ class Skinning:
         with torch.cuda.device(self.device):
             check(_bind().r2s_skin_interpolate_motions_strided(self._h, E, b.data_ptr(), m.data_ptr(), x.data_ptr(), int(x.stride(0)), out.data_ptr(),
                                                                int(out.stride(0)), cur_stream(self.device)), "r2s_skin_interpolate_motions_strided")
+        return out[0] if single else out
+
+    def rotate_quats(self, quat, out=None):
+        """``interpolate_motions(quat=...)`` (transform_utils.py:197-210) with the bone rotations of the LAST ``interpolate_motions``
+        call: quat [n_env, n_points, 4] (or [n_points, 4]), (w, x, y, z) -> blended bone rotation (x) quat, same shape."""
+        single = quat.dim() == 2
+        q = quat.to(self.device, torch.float32)
+        q = q.reshape(-1, self.n_points, 4) if single else q
+        if not (q.stride(2) == 1 and q.stride(1) == 4):
+            q = q.contiguous()
+        E = q.shape[0]
+        if out is None:
+            out = torch.empty(E, self.n_points, 4, dtype=torch.float32, device=self.device)
+        assert out.shape == q.shape and out.stride(2) == 1 and out.stride(1) == 4 and out.dtype == torch.float32
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_skin_rotate_quats(self._h, E, q.data_ptr(), int(q.stride(0)), out.data_ptr(), int(out.stride(0)), cur_stream(self.device)),
+                  "r2s_skin_rotate_quats")
         return out[0] if single else out
 
     def debug(self, n_env=1):

@@ -33,12 +33,10 @@ def interpolate_motions(bones, motions, relations, xyz, rot=None, quat=None, wei
                         step='n/a'):
     """Drop-in for the reference's ``interpolate_motions`` (sim/utils/gs/transform_utils.py:58-212) as the simulator calls
     it (gs_renderer.py:738-747): returns ``(xyz_transformed, rot, weights)``.  The per-bone Kabsch fit and the blend run
-    as two HIP kernels (r2s_skin_interpolate_motions).  ``quat`` (rotating the Gaussians, never used by the simulator)
-    is not implemented."""
+    as two HIP kernels (r2s_skin_interpolate_motions).  With ``quat`` [n_particles, 4] the second return value is the splats'
+    rotated quaternions (:197-210, a third kernel); with ``quat=None`` (the simulator) it is ``rot`` passed through."""
     from r2s_hip.skinning import Skinning
 
-    if quat is not None:
-        raise NotImplementedError("interpolate_motions(quat=...) is outside the hot path: the simulator passes quat=None")
     cacheable = weights is not None and isinstance(relations, torch.Tensor)   # weights=None: recomputed from xyz / bones on every call
     if weights is None:  # sparsified weights over the 5 nearest bones, reference :166-174
         dist = torch.norm(xyz[:, None] - bones, dim=-1)
@@ -53,7 +51,8 @@ def interpolate_motions(bones, motions, relations, xyz, rot=None, quat=None, wei
     rel_t = relations if isinstance(relations, torch.Tensor) else torch.as_tensor(relations)
     if not cacheable:
         sk = Skinning(rel_t, weights, weights_indices, n_bones=bones.shape[0], device=xyz.device)
-        return sk.interpolate_motions(bones, motions, xyz), rot, weights
+        out = sk.interpolate_motions(bones, motions, xyz)
+        return out, (sk.rotate_quats(quat) if quat is not None else rot), weights
     # The uploaded topology is cached per (relations, weights, weights_indices) OBJECT: the renderer keeps these three
     # tensors for the lifetime of a scene (gs_renderer.py:195-211).  Identity is checked through weak references and the
     # tensors' version counters, so a freed tensor whose address is reused, or an in-place edit, can never hit a stale entry.
@@ -70,4 +69,5 @@ def interpolate_motions(bones, motions, relations, xyz, rot=None, quat=None, wei
         sk = Skinning(rel_t, weights, weights_indices, n_bones=bones.shape[0], device=xyz.device)
         _SKIN_CACHE[key] = (sk, tuple(weakref.ref(t) if t is not None else (lambda: None) for t in srcs),
                             tuple(t._version if t is not None else -1 for t in srcs))
-    return sk.interpolate_motions(bones, motions, xyz), rot, weights
+    out = sk.interpolate_motions(bones, motions, xyz)
+    return out, (sk.rotate_quats(quat) if quat is not None else rot), weights

@@ -22,12 +22,19 @@ REF = "/root/reference/sim/utils/gs/transform_utils.py"
 
 
 def load_reference():
-    for name in ("kornia", "diff_gaussian_rasterization"):
+    for name in ("kornia", "kornia.geometry", "kornia.geometry.conversions", "diff_gaussian_rasterization"):
         if name not in sys.modules:
             m = types.ModuleType(name)
             if name == "diff_gaussian_rasterization":
                 m.GaussianRasterizationSettings = object
             sys.modules[name] = m
+    # quat=... (the `lbs_quat` fixture only) calls kornia.geometry.conversions.rotation_matrix_to_quaternion (third party, absent):
+    # restated from kornia's published source in make_robot_gs_golden.py — that one conversion is NOT pinned by the fixture
+    from make_robot_gs_golden import kornia_rotation_matrix_to_quaternion
+    k = sys.modules["kornia"]
+    k.geometry = sys.modules["kornia.geometry"]
+    k.geometry.conversions = sys.modules["kornia.geometry.conversions"]
+    k.geometry.conversions.rotation_matrix_to_quaternion = kornia_rotation_matrix_to_quaternion
     spec = importlib.util.spec_from_file_location("ref_transform_utils", REF)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
@@ -78,6 +85,18 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"lbs_{name}.npz"), bones=bones, motions=mot, relations=rel.astype(np.int32), xyz=xyz,
                             weights=w.astype(np.float32), weights_indices=wi.astype(np.int32), xyz_out=out.numpy().astype(np.float32))
         print(name, "max |dx|", float(np.abs(out.numpy() - xyz).max()))
+    # the quat path (transform_utils.py:197-210): splats rotated by the blended bone rotations
+    bones, mot, rel, xyz, w, wi = case(5, 260, 1000, 8, 16, "smooth")
+    rng = np.random.default_rng(55)
+    quat = rng.normal(size=(len(xyz), 4)).astype(np.float32)
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    out, rot, _ = ref.interpolate_motions(bones=torch.from_numpy(bones), motions=torch.from_numpy(mot), relations=torch.from_numpy(rel),
+                                          xyz=torch.from_numpy(xyz), quat=torch.from_numpy(quat), weights=torch.from_numpy(w),
+                                          weights_indices=torch.from_numpy(wi), device="cpu")
+    np.savez_compressed(os.path.join(HERE, "lbs_quat.npz"), bones=bones, motions=mot, relations=rel.astype(np.int32), xyz=xyz, quat=quat,
+                        weights=w.astype(np.float32), weights_indices=wi.astype(np.int32), xyz_out=out.numpy().astype(np.float32),
+                        quat_out=rot.numpy().astype(np.float32))
+    print("quat: max |dq|", float(np.abs(rot.numpy() - quat).max()))
 
 
 if __name__ == "__main__":

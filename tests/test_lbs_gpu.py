@@ -107,3 +107,20 @@ def test_drop_in_cache_never_serves_a_stale_topology():
         out, _, wret = interpolate_motions(tb, tm, tr, torch.from_numpy(xyz).cuda(), weights=None)
         assert wret.shape == (P, 5)
         assert close(out, lbs_oracle.interpolate_motions(bones, mot, rel, xyz, w, wi), 5e-6), k
+
+
+def test_quat_branch_rotates_the_splats_like_the_reference_fixture():
+    """interpolate_motions(quat=...) through the drop-in: third kernel k_skin_quat, against lbs_quat.npz (made by the reference's
+    own function) and against the oracle on a batch."""
+    import torch
+    from oracle import lbs_oracle
+    from sim.utils.gs.transform_utils import interpolate_motions
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lbs_quat.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    xyz, rot, _ = interpolate_motions(t(g["bones"]), t(g["motions"]), t(g["relations"].astype(np.int64)), t(g["xyz"]), quat=t(g["quat"]),
+                                      weights=t(g["weights"]), weights_indices=t(g["weights_indices"].astype(np.int64)))
+    assert close(xyz, g["xyz_out"], 3e-6, what="quat fixture: positions")
+    assert close(rot, g["quat_out"], 3e-6, what="quat fixture: rotated quaternions vs reference")
+    ref = lbs_oracle.rotate_quats(g["bones"], g["motions"], g["relations"], g["quat"], g["weights"], g["weights_indices"])
+    assert close(rot, ref, 3e-6, what="quat fixture: vs oracle")
