@@ -1,7 +1,7 @@
 #!/bin/bash
 # Refresh the judged artefacts of a round (run on the GPU box through gpurun from the repository root):
 #   bench lines (headline as the driver runs it, the other workloads, the observation sink), kernel-trace stats of the bench
-#   command with the default two chains and with one chain (per-kernel durations do not overlap), the GPU test suite with the
+#   command with the default chains (four streams) and with one chain (per-kernel durations do not overlap), the GPU test suite with the
 #   parity log.  Counter passes: tools/profiling/pmc_r3.sh (separate call).  Copy what should be judged from gpurun_out/ to profiles/.
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/prof_r3; rm -rf $out; mkdir -p $out
 cd $R
@@ -22,15 +22,22 @@ PY
 cd /tmp && export TMPDIR=/tmp
 for mode in default chains1; do
   if [ $mode = chains1 ]; then export R2S_CHAINS=1; else unset R2S_CHAINS; fi
-  timeout 400 rocprofv3 --kernel-trace --stats -d $out/trace_$mode -o bench -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $out/bench_trace_$mode.log 2>&1 || echo trace-failed
+  timeout 400 rocprofv3 --kernel-trace --stats -d $out/trace_$mode -o bench -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-parity-gate --dephase 0 --no-pipelined > $out/bench_trace_$mode.log 2>&1 || echo trace-failed
   db=$(find $out/trace_$mode -name "*.db" | head -1)
   python $R/tools/rocpd_stats.py $db $out/kernel_stats_$mode.md > /dev/null 2>&1 || echo stats-failed
   head -9 $out/kernel_stats_$mode.md | cut -c1-70,150-240
   rm -rf $out/trace_$mode
 done
 unset R2S_CHAINS
+# configs[1]: one environment, 667 dependent launches per env step — kernel duration against launch period
+unset R2S_CHAINS
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/trace_rope -o bench -- python $R/bench.py --config rope_1env --steps 6 --warmup 3 --no-cpu-baseline --no-parity-gate --dephase 0 --no-pipelined > $out/bench_trace_rope.log 2>&1 || echo trace-failed
+db=$(find $out/trace_rope -name "*.db" | head -1)
+python $R/tools/rocpd_stats.py $db $out/kernel_stats_rope_1env.md > /dev/null 2>&1 || echo stats-failed
+head -5 $out/kernel_stats_rope_1env.md | cut -c1-70,150-240
+rm -rf $out/trace_rope
 # the large-mesh finishing kernel (k_contact_finish<2>) in its own table: the pusher workload, second half of the window in contact
-timeout 400 rocprofv3 --kernel-trace --stats -d $out/trace_pusher -o bench -- python $R/bench.py --config T_pusher_32env --steps 6 --warmup 3 --no-cpu-baseline > $out/bench_trace_pusher.log 2>&1 || echo trace-failed
+timeout 400 rocprofv3 --kernel-trace --stats -d $out/trace_pusher -o bench -- python $R/bench.py --config T_pusher_32env --steps 6 --warmup 3 --no-cpu-baseline --no-parity-gate --dephase 0 --no-pipelined > $out/bench_trace_pusher.log 2>&1 || echo trace-failed
 db=$(find $out/trace_pusher -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $db $out/kernel_stats_pusher.md > /dev/null 2>&1 || echo stats-failed
 head -6 $out/kernel_stats_pusher.md | cut -c1-70,150-240
