@@ -124,14 +124,19 @@ __global__ void __launch_bounds__(256) k_bone_fit(int N, int k_rel, const int* _
 // Thread t works on point order[t]: the points are walked sorted by their first bone, so that neighbouring lanes (and
 // neighbouring workgroups) gather the same few 64-byte bone records — caller order has no locality (2.2 GB fetched per
 // call on the benchmark scene before, for 0.25 GB of algorithmic traffic).  weights / widx are stored [k][t] (coalesced).
-__global__ void __launch_bounds__(256) k_skin(int N, int P, int k_wgt, const int* __restrict__ order, const float* __restrict__ weights,
+__global__ void __launch_bounds__(256) k_skin(int E, int N, int P, int k_wgt, const int* __restrict__ order, const float* __restrict__ weights,
                                               const int* __restrict__ widx, const BoneRec* __restrict__ rec, const int* __restrict__ ident_flag,
                                               const float* xyz, long long xyz_stride, float* out, long long out_stride) // xyz may alias out (in-place skinning): no __restrict__
 {
 #pragma clang fp contract(off)
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = blockIdx.y;
-    if (t >= P) return;
+    // Workgroup -> (environment, chunk of points) so that an environment is skinned by ONE XCD (linear workgroup id % 8 = XCD, a speed
+    // assumption only): its bone records (64 B x n_bones, ~1 MB) are gathered 16 times per Gaussian and then stay in that XCD's 4 MB L2.
+    // With the environment in blockIdx.y every XCD pulled every environment's records: 611 MB per call for 253 MB of algorithmic traffic.
+    const int chunks = (P + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int xcd = (int)(blockIdx.x & 7), q = (int)(blockIdx.x >> 3);
+    const int e = xcd + 8 * (q / chunks);
+    const int t = (q % chunks) * (int)blockDim.x + (int)threadIdx.x;
+    if (e >= E || t >= P) return;
     const int pt = order[t];
     const size_t ep = (size_t)e * xyz_stride + (size_t)pt * 3, eo = (size_t)e * out_stride + (size_t)pt * 3; // env strides in floats
     const float x = xyz[ep], y = xyz[ep + 1], z = xyz[ep + 2];
@@ -294,8 +299,8 @@ int r2s_skin_interpolate_motions_strided(R2SSkin* h, int32_t n_env, const float*
     R2S_HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int) * (size_t)n_env, s));
     hipLaunchKernelGGL(k_bone_fit, dim3((h->N + 255) / 256, n_env), dim3(256), 0, s, h->N, h->k_rel, h->d_rel, bones, motions, h->d_rec, h->d_flag);
     if (h->P > 0)
-        hipLaunchKernelGGL(k_skin, dim3((h->P + 255) / 256, n_env), dim3(256), 0, s, h->N, h->P, h->k_wgt, h->d_order, h->d_w, h->d_widx, h->d_rec, h->d_flag, xyz,
-                           (long long)xyz_env_stride, xyz_out, (long long)out_env_stride);
+        hipLaunchKernelGGL(k_skin, dim3((unsigned)(8 * ((h->P + 255) / 256) * ((n_env + 7) / 8))), dim3(256), 0, s, n_env, h->N, h->P, h->k_wgt, h->d_order, h->d_w,
+                           h->d_widx, h->d_rec, h->d_flag, xyz, (long long)xyz_env_stride, xyz_out, (long long)out_env_stride);
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }

@@ -11,7 +11,7 @@ LIB = os.path.join(ROOT, "real2sim-eval_amd", "libr2s_hip.so")
 
 def _declared():
     names = []
-    for h in ("r2s_raster.h", "r2s_physics.h", "r2s_skinning.h", "r2s_metrics.h", "r2s_robot.h", "r2s_obs.h"):
+    for h in ("r2s_raster.h", "r2s_physics.h", "r2s_skinning.h", "r2s_metrics.h", "r2s_robot.h", "r2s_obs.h", "r2s_camera.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names += re.findall(r"\b(r2s_[a-z0-9_]+)\s*\(", src)

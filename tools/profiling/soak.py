@@ -13,5 +13,5 @@ for k in range(n):
         torch.cuda.synchronize(); t1 = time.perf_counter()
         x = ro.phys.x
         print(f"step {k+1}: {ro.n_env*50/(t1-t0):8.1f} env-steps/s | finite {bool(torch.isfinite(x).all())} | z min {float(x[...,2].min()):+.4f} max |v| {float(ro.phys.v.abs().max()):.3f} "
-              f"| instances {ro.last_num_rendered} | mem {torch.cuda.memory_allocated()/2**20:.0f} MiB torch, {torch.cuda.mem_get_info()[0]/2**30:.1f} GiB free | success flags {int(ro.success_flags().sum())}")
+              f"| instances {ro.last_num_rendered} | mem {torch.cuda.memory_allocated()/2**20:.0f} MiB torch, {torch.cuda.mem_get_info()[0]/2**30:.1f} GiB free | success flags {int(ro.success_flags().sum())} | lossy raster batches {ro.lossy_batches}")
         t0 = time.perf_counter()
