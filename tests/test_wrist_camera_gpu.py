@@ -100,3 +100,44 @@ def test_step_takes_actions_dict_and_xyz_rot_tensor():
     assert torch.allclose(ctr[:, -1], xyz0 + d, atol=2e-6)                    # the stepper's eef centre at the last substep
     assert torch.allclose(om, -0.5 * m["eef_rot_vel"], atol=1e-6)             # dynamic_omega = -eef_rot_vel / 2 (phystwin.py:451)
     assert bool(torch.isfinite(a.phys.x).all())
+
+
+def test_observations_rerenders_a_sync_free_batch_that_overflowed():
+    """the sync-free raster pipeline sizes its binning scratch from the PREVIOUS batch (+25 % + 4096); a batch
+    that outgrows it loses its deepest instances.  The rollout must not hand such a frame to a closed-loop caller: the wrist cameras
+    jump from 4 cm above the rope (most of the scene is nearer than z_threshold = 5 cm and culled: ~11 k instances) to 1.5 m above it
+    (the whole table in view: ~20 k, beyond 11 k x 1.25 + 4096), `observations()` notices the overflow flag of that batch and renders
+    the step again; what it returns equals the oracle's frame."""
+    import torch
+    from r2s_hip.rollout import BatchedRollout
+
+    ro = BatchedRollout("tiny", num_substeps=10, seed=9, n_env=2)
+    rot = ro.eef_rot.clone()
+    top = float(ro.ob["points"][:, 2].max())
+    c = torch.from_numpy(ro.ob["points"].mean(0)).to(ro.device)
+
+    def action(z):
+        xyz_next = c[None].repeat(2, 1) + torch.from_numpy(ro.env_shift).to(ro.device)
+        xyz_next[:, 2] = z
+        return torch.cat([xyz_next, rot.reshape(2, 9), torch.ones(2, 1, device=ro.device)], 1)
+
+    counts = []
+    for _ in range(3):                       # lens inside the cull distance: few wrist instances; the capacity settles on this count
+        ro.step(action(top + 0.04))
+        ro.observations()
+        counts.append(ro.last_num_rendered)
+    assert ro.lossy_batches == 0
+    ro.step(action(top + 1.5))              # 1.5 m up: the whole scene in view
+    col, dep = ro.observations()
+    torch.cuda.synchronize()
+    counts.append(ro.last_num_rendered)
+    assert ro.lossy_batches >= 1, f"the scenario must overflow the capacity of the previous batch (instance counts {counts})"
+    for e in range(2):
+        cam = ro.camera_numpy(e, 1)
+        _, col_ref, _, dep_ref = oracle_render(ro.scene_numpy(e), cam)
+        r = compare_images(col[e, 1].cpu().numpy(), dep[e, 1].cpu().numpy(), col_ref, dep_ref, what=f"re-rendered overflow batch, env {e}")
+        assert r["frac_rgb"] <= 1e-3 and r["frac_depth"] <= 1e-3, (e, r, counts)
+    # and the pipeline recovers: the next batches are sized for the new count
+    ro.step(action(top + 1.5))
+    ro.observations()
+    assert ro.lossy_batches == 1, counts
