@@ -371,12 +371,12 @@ def main():
                 "single_chain_check": None if single_us is None else {
                     "avg_launch_us": single_us, "achieved": alg_bytes / (single_us * 1e-6) / 1e9, "frac": alg_bytes / (single_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                     "note": "same step with one kernel per batched substep (r2s_phys_set_tuning chains=1, measured after the timed region, "
-                            "in the contact state the window ended in): a per-kernel duration, comparable with profiles/r2_bench_kernel_stats_chains1.md"},
+                            "in the contact state the window ended in): a per-kernel duration, comparable with profiles/r3_bench_kernel_stats_chains1.md (that table is of the free + contact window, this figure of the contact state alone)"},
                 "note": f"frac is the SURVEY.md §8d contract figure: algorithmic bytes (16 S + 48 N per env) / avg launch time / 8 TB/s, averaged over "
                         f"the whole timed window (free + contact).  The topology (16 S) is shared by the {ro.n_env} envs and stays in L2, so the bytes that "
-                        "reach HBM are hbm_actual_frac of peak; valu_busy_frac = SQ_ACTIVE_INST_VALU share of the kernel span: the kernel is "
+                        "reach HBM are hbm_actual_frac of peak; valu_busy_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel span), the share of SIMD issue cycles spent on VALU instructions: the kernel is "
                         f"VALU-issue / latency bound, not HBM bound.  One 'launch' = one batched substep of all {ro.n_env} envs, issued as {chains} concurrent "
-                        "kernels over disjoint env ranges (per-kernel durations overlap); avg_launch_us = HIP-event time of the 667-substep graph / 667"}
+                        "kernels over disjoint env ranges, each chain its own captured graph on its own stream (per-kernel durations overlap); avg_launch_us = HIP-event time of the 667-substep step / 667"}
         out = {
             "metric": "sim env-steps/sec (phys+render) per node at 32 envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -401,7 +401,7 @@ def main():
                                               "valu_busy_frac": pmc_comp.get("valu_busy_frac") if pmc_comp else None,
                                               "note": "VALU/exp-bound (≈115 flop per algorithmic byte, SURVEY.md §7): the north_star's >= 0.60 of HBM peak "
                                                       "is not reachable for this kernel at any instruction count above ~1/3 of the reference's per-pixel "
-                                                      "arithmetic; valu_busy_frac (VALU-active wave cycles per SIMD cycle of the kernel span; instructions of different waves overlap in the pipeline, so saturation reads slightly above 1) is the figure that says how close to its real bound it runs"}},
+                                                      "arithmetic; valu_busy_frac (SQ_INSTS_VALU x 4 cycles over the SIMD cycles of the kernel span, at most 1) is the figure that says how close to its real bound it runs"}},
             "physics_ms_per_env_step": phys_ms, "skinning_ms_per_env_step": skin_ms,
             "construct_s_per_rank": [round(float(x), 3) for x in records[:, 5]],   # outside the timed region; every rank builds, captures and settles its own batch
             "task_success": {"envs_satisfying_predicate": int(records[:, 4].sum().item()), "of": total_envs,
