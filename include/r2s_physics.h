@@ -167,12 +167,21 @@ int r2s_phys_deferred_counts(R2SPhys* h, int32_t* out, r2s_stream_t stream);
 int r2s_phys_tagged_count(R2SPhys* h, int32_t* out, r2s_stream_t stream);
 /* Which captured flavour the last r2s_phys_step ran: out[0] self-collision variant (0/1), out[1] mesh template (0 none,
  * 1 every mesh small: the fused kernel answers the rare query itself unless out[2], 2 a large mesh is present: the fused
- * kernel only lists), out[2] finishing kernel in the graph (0/1; always 1 with a large mesh), out[3] kernel chains. */
+ * kernel only lists), out[2] finishing kernel in the graph (0/1; always 1 with a large mesh; 2 = the env step ran as ONE resident
+ * launch, see r2s_phys_set_resident), out[3] kernel chains. */
 int r2s_phys_last_flavour(R2SPhys* h, int32_t* out);
 /* Tuning (not part of the reference surface): chains > 0 overrides the number of concurrent kernel chains of the captured
  * env step (0 = default), mesh_defer 0/1 forces the deferred large-mesh-query flavour (-1 = automatic).  The environment
  * variables R2S_CHAINS / R2S_MESH_DEFER / R2S_LAYOUT / R2S_HALO_CAP are read ONCE, by r2s_phys_create. */
 int r2s_phys_set_tuning(R2SPhys* h, int chains, int mesh_defer);
+/* Small batches (at most 256 work items of 64 particles: one environment of the reference's own evaluation loop,
+ * eval_policy.py:180-240 -> phystwin.py:104-147 -> spring_mass_warp.py:723-726 `for i in range(num_substeps): step()`, up to a
+ * few) are laid out in 64-particle blocks, and the env step's free flavour (no self-collision candidates, nothing within reach of
+ * a collision mesh) runs as ONE launch that keeps the particles on the chip for all substeps (k_steps_resident: neighbouring
+ * blocks hand their halo over through tagged write-through records instead of kernel boundaries).  on = 0 runs every flavour
+ * with the per-substep kernels of the same layout (tests compare the two; R2S_RESIDENT=0 at create also keeps the large-batch
+ * layout).  Results of the two agree to the last bits (different summation order), not bit for bit. */
+int r2s_phys_set_resident(R2SPhys* h, int on);
 
 /* Layout report (DESIGN.md / bench.py): out[0] particle blocks, [1] largest halo (records), [2] ELL slots incl.
  * padding, [3] real neighbour slots (= 2 * active springs), [4] slots served by the global fallback instead of LDS,

@@ -70,6 +70,8 @@ struct PhysDev {
     int e0, ne;                // environments [e0, e0 + ne) handled by this launch (an env-step may run as parallel chains)
     const int* slice_off;      // [n_slices] first slot of a 64-particle slice (a multiple of 64 * GROUP)
     const int* slice_deg;      // [n_slices] slots per particle of the slice (a multiple of GROUP)
+    const int* slice_int;      // [n_slices] 64-particle layout only: the first slice_int slots (a multiple of GROUP) of every particle of the slice
+                               // point into the block's OWN records, the rest into its halo (else 0: neighbours in index order)
     // sliced ELL, 10 B per slot in three planes, GROUP-major: the 4 slots n = 4g..4g+3 of lane l of a slice sit together
     // at element (slice_off / 4 + g * 64 + l), so a group costs one 8-byte and two 16-byte coalesced loads per lane
     // (the adjacency stream is shared by every environment and is the largest L2 consumer of the kernel):
@@ -137,7 +139,9 @@ struct PhysDev {
     const float* aabb_static;  // [E,n_mesh-n_dyn_mesh,6]
     float* coll_forces;        // [E,nF,3]
     int* hit_cnt;              // [E] particles that reacted to a mesh in the LAST substep (zeroed with coll_forces)
-    int* fault;                // sticky: a self-collision impulse exceeded the bound the "no mesh in reach" decision relies on
+    int* fault;                // sticky: 1 = a self-collision impulse exceeded the bound the "no mesh in reach" decision relies on; 2 = a
+                               // hand-off of the resident stepper timed out
+    void* xch;                 // resident stepper: exchange array [E][2 buffers][3 planes][N] x 16 B {value, tag, value, tag}
 };
 
 // Everything from here to the spring gather is compiled WITHOUT fused multiply-add contraction: the collision
@@ -170,6 +174,15 @@ __device__ __forceinline__ f3 vel_update(const PhysDev& p, f3 v0, f3 f0, float m
 {
     const f3 grav = mk(0.f, 0.f, -9.8f) * m0 * p.rf;
     const f3 a = (f0 + grav) / m0;
+    const f3 v1 = v0 + a * p.dt;
+    return v1 * p.drag_factor;
+}
+
+// the resident stepper's form: the reciprocal mass is formed once per launch (1 ulp off the division above, like its force sum)
+__device__ __forceinline__ f3 vel_update_rcp(const PhysDev& p, f3 v0, f3 f0, float m0, float inv_m0)
+{
+    const f3 grav = mk(0.f, 0.f, -9.8f) * m0 * p.rf;
+    const f3 a = (f0 + grav) * inv_m0;
     const f3 v1 = v0 + a * p.dt;
     return v1 * p.drag_factor;
 }
@@ -757,12 +770,27 @@ struct AdjGroup {
     uint2 idx;     // 4 x u16 window byte offsets
     float4 k, a;   // stiffness, stiffness / rest length
 };
-__device__ __forceinline__ AdjGroup adj_load(const PhysDev& p, int t)
+// `row` is the group's first element and WAVE-UNIFORM (slice offset / 4 + group * 64, both scalar), `lane` the only per-lane part:
+// the three loads then use a scalar base with one loop-invariant 32-bit lane offset each, instead of a 64-bit per-lane address
+// computed with vector instructions for every group (round 3: 20 of the 148 VALU instructions of a two-group loop trip were that).
+__device__ __forceinline__ AdjGroup adj_load(const PhysDev& p, int row, int lane)
 {
+    // raw buffer loads: scalar resource + scalar element offset (`row`) + one 32-bit lane offset — buffer_load_dwordx2 / x4 ... offen.
+    // (Plain pointer arithmetic with a uniform base still compiled to a 64-bit vector add per load.)  Word 3 = 0x00020000: raw 32-bit
+    // data format of gfx9; the range check (num_records) is off the table: offsets are built from the handle's own tables.
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)p.adj_idx, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)p.adj_k, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.adj_ir, 0, 0x7fffffff, 0x00020000);
+    const v2u i2 = __builtin_amdgcn_raw_buffer_load_b64(ri, (unsigned)lane * 8u, row * 8, 0);
+    const v4f k4 = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)lane * 16u, row * 16, 0);
+    const v4f a4 = __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)lane * 16u, row * 16, 0);
     AdjGroup g;
-    g.idx = p.adj_idx[t]; g.k = p.adj_k[t]; g.a = p.adj_ir[t];
+    g.idx = make_uint2(i2.x, i2.y); g.k = make_float4(k4.x, k4.y, k4.z, k4.w); g.a = make_float4(a4.x, a4.y, a4.z, a4.w);
     return g;
 }
+
 template <int RCAP>
 __device__ __forceinline__ void spring_group(const PhysDev& p, const AdjGroup& g, const __attribute__((address_space(3))) char* win, f3 xi,
                                              f3 vi, v2f& fxy, float& fz)
@@ -783,16 +811,16 @@ __device__ __forceinline__ void spring_group(const PhysDev& p, const AdjGroup& g
 template <int RCAP>
 __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const StateC xv,
                                                const __attribute__((address_space(3))) char* win, size_t env_base, int sl, int ln, f3 xi,
-                                               f3 vi, int gbase, int ngroups, AdjGroup g0)
+                                               f3 vi, int srow, int ngroups, AdjGroup g0)
 {
     v2f fxy = {0.f, 0.f};
     float fz = 0.f;
     AdjGroup a = g0, b = g0;
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) { // ngroups is wave-uniform (one slice per wavefront): scalar branches
-        b = adj_load(p, gbase + (g + 1) * SLICE);
+        b = adj_load(p, srow + (g + 1) * SLICE, ln);
         spring_group<RCAP>(p, a, win, xi, vi, fxy, fz);
-        a = adj_load(p, gbase + min(g + 2, ngroups - 1) * SLICE); // unconditional (the last trip re-reads a group it will not use): no
+        a = adj_load(p, srow + min(g + 2, ngroups - 1) * SLICE, ln); // unconditional (the last trip re-reads a group it will not use): no
                                                                   // branch inside the loop body (guarded: 24.0 vs 22.8 us with one chain)
         spring_group<RCAP>(p, b, win, xi, vi, fxy, fz);
     }
@@ -817,6 +845,10 @@ __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const StateC xv
 // distance to the mesh is at least its distance to the AABB: if that is >= the margin for every mesh, nothing can happen and
 // the query is skipped.  Meshes that are not closed manifolds (checked at construction) only get the query's own 2 cm range
 // as the bound.  `pad` widens the test (particles whose velocity is not final yet); `near` = within NEAR_PAD of a margin.
+__device__ __forceinline__ float mesh_margin(const PhysDev& p, int m)
+{
+    return (p.mesh_kind[m] & 2) ? MESH_MAX_DIST : ((m < p.n_dyn_mesh && !p.use_pusher) ? 0.005f : 0.001f);
+}
 __device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 next_x, float pad, bool& near)
 {
     bool need = false;
@@ -824,12 +856,34 @@ __device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 
     for (int m = 0; m < p.n_mesh; ++m) {
         const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
                                            : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
-        const float mg = ((p.mesh_kind[m] & 2) ? MESH_MAX_DIST : ((m < p.n_dyn_mesh && !p.use_pusher) ? 0.005f : 0.001f)) + pad;
+        const float mg = mesh_margin(p, m) + pad;
         const float d2 = box_dist2(next_x, bb);
         need = need || d2 < mg * mg * 1.0001f;
         near = near || d2 < (mg + NEAR_PAD) * (mg + NEAR_PAD);
     }
     return need;
+}
+
+// The resident stepper's side channel into finish_wave: the finished state coming back, and boxes for the mesh early-out — per mesh
+// (meshes beyond RES_MAX_MESH share the last box) the union of its world boxes over all substeps of the launch, and the union of
+// those.  A particle farther from a union than margin + NEAR_PAD is neither within reach of nor near that mesh at any substep
+// (every box lies inside its union, so its distance is at least the union's): when no lane of the wavefront is inside that range of
+// the total union, and then of any mesh's, the per-substep tests — and the loads of the substep's boxes, two dependent round trips
+// in the critical path of every substep — are skipped; otherwise the exact tests run as in k_substep.
+constexpr int RES_MAX_MESH = 4;
+struct ResidentIO {
+    f3 x, v;                      // out: the particle's new state
+    float ubox[6], ur2;           // in: union of everything; (largest margin + NEAR_PAD)^2, widened by 1e-4 relative
+    float mbox[RES_MAX_MESH][6];  // in: union over the substeps per mesh
+    float mr2[RES_MAX_MESH];      // in: (its margin + NEAR_PAD)^2, widened (0 for unused slots: never in range)
+};
+__device__ __forceinline__ bool resident_in_range(const ResidentIO& io, f3 next_x, bool fin)
+{
+    if (__builtin_amdgcn_ballot_w64(fin && box_dist2(next_x, io.ubox) < io.ur2) == 0ull) return false;
+    bool any = false;
+#pragma unroll
+    for (int m = 0; m < RES_MAX_MESH; ++m) any = any || box_dist2(next_x, io.mbox[m]) < io.mr2[m];
+    return __builtin_amdgcn_ballot_w64(fin && any) != 0ull;
 }
 
 // ---- everything after the velocity update: mesh collision, ground, store ------------------------------------
@@ -848,9 +902,11 @@ __device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 
 // NEED: 0 = decide by the exact early-out; 1 = query without testing (the fused kernel already found the particle in reach of a
 // mesh: saves the finishing kernel one dependent round trip for the boxes); 2 = never query (the fused kernel's WIDENED test
 // found nothing in reach: mesh_collision then only advances the position, :321 / :420)
-template <int MESH, bool MAIN = false, int NEED = 0>
+// KEEP (the resident stepper): every lane with `fin` also returns its new state in keep->x / keep->v and only stores it when
+// xv_out.p is set (the launch's last substep); the mesh boxes of the early-out come from *keep.
+template <int MESH, bool MAIN = false, int NEED = 0, bool KEEP = false>
 __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v, bool fin,
-                                            const StateM xv_out, const TriRegs* tr, QShare* qs, int* qpar, const Xf* xf0, bool store R2S_QP_PARAM)
+                                            const StateM xv_out, const TriRegs* tr, QShare* qs, int* qpar, const Xf* xf0, bool store, ResidentIO* keep R2S_QP_PARAM)
 {
     f3 x = x0;
     // mesh_collision, :295-421 — advances x by v*dt for EVERY particle (:321, :420)
@@ -858,6 +914,9 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         f3 vin = v;
         f3 next_x = x0 + vin * p.dt;
         f3 next_v = vin;
+        bool in_range = true;
+        if (KEEP) in_range = resident_in_range(*keep, next_x, fin); // wave-uniform
+      if (in_range) {
         bool need = false, near = false;
         if (NEED == 1) need = fin;
         else if (NEED == 0 && fin) need = mesh_need(p, e, step, next_x, 0.f, near);
@@ -961,12 +1020,13 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
             atomicAdd(cf3 + 2, fo.z);
             atomicAdd(p.hit_cnt + e, 1);
         }
+      }
         x = next_x;
         v = next_v;
     }
 
     // integrate_ground_collision, :424-474
-    if (fin && store) {
+    if (fin && (store || KEEP)) {
         const f3 normal = mk(0.f, 0.f, 1.f) * p.rf;
         const float x_z = x.z, v_z = v.z;
         const float next_x_z = (x_z + v_z * p.dt) * p.rf;
@@ -986,7 +1046,8 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
             toi = 0.f;
         }
         const f3 xn = x + v * toi + v1 * (p.dt - toi);
-        st_store(xv_out, eb + i, xn, v1);
+        if (store && (!KEEP || xv_out.p != nullptr)) st_store(xv_out, eb + i, xn, v1);
+        if (KEEP) { keep->x = xn; keep->v = v1; }
     }
 }
 
@@ -1030,11 +1091,11 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
     const int ic = min(i, p.N - 1);
     // first adjacency group of this wavefront's slice: in flight while the LDS window is staged
     const int sl = __builtin_amdgcn_readfirstlane(ic / SLICE);
-    const int gbase = __builtin_amdgcn_readfirstlane(p.slice_off[sl] / GROUP) + lane;
+    const int srow = __builtin_amdgcn_readfirstlane(p.slice_off[sl] / GROUP); // wave-uniform
     const int ngroups = __builtin_amdgcn_readfirstlane(p.slice_deg[sl] / GROUP);
     AdjGroup g0;
     g0.idx = make_uint2(0u, 0u); g0.k = make_float4(0.f, 0.f, 0.f, 0.f); g0.a = g0.k;
-    if (ngroups > 0) g0 = adj_load(p, gbase);
+    if (ngroups > 0) g0 = adj_load(p, srow, lane);
     // stage the block's own records (record r < B is particle b*B + r) and its halo (record B + k is halo particle k).
     // All loads of a thread are issued before its first LDS write: two dependent round trips (halo id, then state)
     // per workgroup instead of two per staging round.
@@ -1083,7 +1144,7 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
 
     // eval_springs + update_vel_from_force
     const __attribute__((address_space(3))) char* win = (const __attribute__((address_space(3))) char*)win_s;
-    f3 v = vel_update(p, v0, spring_force_lds<RCAP>(p, xv_in, win, eb, sl, lane, x0, v0, gbase, ngroups, g0), m1);
+    f3 v = vel_update(p, v0, spring_force_lds<RCAP>(p, xv_in, win, eb, sl, lane, x0, v0, srow, ngroups, g0), m1);
 #ifdef R2S_PHASE_PROBE
     if (v.x == 1.2345e33f) return; // keep the stamp after the gather
 #endif
@@ -1116,7 +1177,7 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
         }
     }
     R2S_QP_DECL(-1);
-    finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out, nullptr, nullptr, nullptr, nullptr, true R2S_QP_ARG);
+    finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
     R2S_STAMP(3);
 }
 
@@ -1132,6 +1193,298 @@ __global__ void __launch_bounds__(B, (B == 256 ? 6 : 1)) k_substep(const PhysDev
 {
     substep_body<B, RCAP, SELF, MESH>(p, xv_in, xv_out, step, write_forces);
 }
+// ---- the resident stepper: every substep of an env step in ONE launch (small batches) ---------------------------
+// A batch whose (block, env) work items are all on the chip at once — one environment of the reference's own evaluation loop
+// (eval_policy.py drives ONE simulator), up to a few — is bound by latency, not by throughput: k_substep for the 8 k-particle
+// rope is 7.0 us per launch in a 7.6 us launch period for 0.15 us of arithmetic (profiles/r3_bench_kernel_stats_rope_1env.md):
+// two dependent staging round trips, one wavefront walking a particle's ~35 slots alone, the finishing code, the kernel
+// boundary.  This kernel keeps the env step on the chip instead:
+//   * one workgroup = ONE 64-particle ELL slice x FOUR wavefronts; wavefront w evaluates groups w, w+4, ... of every particle of
+//     the slice (its <= RES_NGR adjacency groups live in registers for the whole launch: no adjacency stream at all), the four
+//     partial forces meet in LDS and are added in a fixed order; every wavefront then finishes the particle redundantly (same
+//     inputs, same instructions, same result — nothing to broadcast), wavefront 0 owns the side effects;
+//   * own particles stay in registers and in the block's LDS window from substep to substep; only the HALO crosses workgroups:
+//     after a substep wavefront q publishes plane q of its 64 records as 16-byte {value, tag, value, tag} write-through stores
+//     (sc1) into a double-buffered exchange array, and the neighbours poll exactly the records of their halo list until both tags
+//     read the substep's number — the data is the flag (cdna_hip_programming.md, Guideline 16 R2: no fence, no flag, no grid
+//     barrier: a workgroup only ever waits for the blocks it shares springs with).  Two buffers are enough: a block publishes
+//     version v+1 (overwriting v-1) only after it has read version v of every neighbour, and a neighbour publishes v only after
+//     it has read v-1 of this block (halo lists are symmetric: they follow the springs);
+//   * tags are substep numbers within the launch (1 ..), the exchange array is zeroed by a kernel node ahead of every launch;
+//     polls are bounded (RES_SPIN_LIMIT passes, then the sticky fault word and out: never a hang).
+// Used for the flavour "no particle has self-collision candidates, nothing within reach of a mesh" (in-place queries for the
+// rare needy particle, like k_substep without p.mesh_defer); every other flavour runs the per-substep kernels of the same
+// <64, 512> layout.  Results differ from k_substep's in the last bit (four partial sums instead of one running sum).
+constexpr int RES_THREADS = 512;                // eight wavefronts: two per SIMD, so that one's LDS and dependent-issue latency is the other's issue slot
+constexpr int RES_NG = 2;                       // interior and halo adjacency groups a wavefront keeps in registers (each: every 4th group of the slice)
+constexpr unsigned RES_SPIN_LIMIT = 1u << 21;   // poll passes before a workgroup gives up (each >= one L2 round trip: seconds)
+constexpr int RES_AUX_SC1 = 16;                 // buffer-instruction cache policy: sc1 = agent scope (write-through store, L1-bypassing load)
+#ifndef R2S_RES_AUXLD
+#define R2S_RES_AUXLD (16 | (int)0x80000000)
+#endif
+#ifndef R2S_RES_PRE
+#define R2S_RES_PRE 0
+#endif
+constexpr int RES_AUX_LOAD = R2S_RES_AUXLD;     // poll loads: sc1 + the compiler-side volatile bit (= sc0 sc1 in the instruction)
+constexpr int RES_PRE = R2S_RES_PRE;            // interior groups evaluated BEFORE the first poll pass is issued
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// NG groups back to back, no branch in between: the LDS reads of a later group are scheduled under the arithmetic of an earlier one
+// (a wavefront is alone on its SIMD here: whatever latency the instruction stream exposes is paid in full)
+struct GroupRecs { v2f xy[GROUP], zz[GROUP], vv[GROUP]; };
+template <int RCAP>
+__device__ __forceinline__ void group_read(const AdjGroup& g, const __attribute__((address_space(3))) char* win, GroupRecs& r)
+{
+    typedef __attribute__((address_space(3))) const v2f lds_f2;
+    const unsigned off[GROUP] = {g.idx.x & 0xffffu, g.idx.x >> 16, g.idx.y & 0xffffu, g.idx.y >> 16};
+#pragma unroll
+    for (int u = 0; u < GROUP; ++u) {
+        r.xy[u] = *(lds_f2*)(win + off[u]);
+        r.zz[u] = *(lds_f2*)(win + off[u] + PLANE1<RCAP>());
+        r.vv[u] = *(lds_f2*)(win + off[u] + PLANE2<RCAP>());
+    }
+}
+__device__ __forceinline__ void group_eval(const PhysDev& p, const AdjGroup& g, const GroupRecs& r, f3 xi, f3 vi, v2f& fxy, float& fz)
+{
+    const float k[GROUP] = {g.k.x, g.k.y, g.k.z, g.k.w};
+    const float a[GROUP] = {g.a.x, g.a.y, g.a.z, g.a.w};
+#pragma unroll
+    for (int u = 0; u < GROUP; ++u) spring_term(r.xy[u], r.zz[u].x, r.vv[u], r.zz[u].y, xi, vi, k[u], a[u], p.dashpot, fxy, fz);
+}
+// The compiler's own schedule of spring_group waits for each slot's three reads and then runs that slot's dependent chain (fine with
+// six wavefronts per SIMD to switch to, 180 cycles per slot for a lone one); here the records of group j + 1 are read before group j is
+// evaluated, and scheduling barriers keep the two from being sunk back together.
+template <int RCAP, int NG>
+__device__ __forceinline__ void spring_groups(const PhysDev& p, const AdjGroup* g, const __attribute__((address_space(3))) char* win, f3 xi, f3 vi,
+                                              v2f& fxy, float& fz)
+{
+    GroupRecs r[2];
+    group_read<RCAP>(g[0], win, r[0]);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        if (j + 1 < NG) group_read<RCAP>(g[j + 1], win, r[(j + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        group_eval(p, g[j], r[j & 1], xi, vi, fxy, fz);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int RCAP>
+__device__ __forceinline__ void spring_groups_n(const PhysDev& p, int n, const AdjGroup* g, const __attribute__((address_space(3))) char* win, f3 xi,
+                                                f3 vi, v2f& fxy, float& fz)
+{
+    static_assert(RES_NG == 2, "one case per count");
+    if (n == 2) spring_groups<RCAP, 2>(p, g, win, xi, vi, fxy, fz);
+    else if (n == 1) spring_groups<RCAP, 1>(p, g, win, xi, vi, fxy, fz);
+}
+
+template <int RCAP, int MESH>
+__global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev p, const StateC xv_in, const StateM xv_out, int first, int n_steps)
+{
+    static_assert(MESH != 2, "large meshes always defer their queries to k_contact_finish");
+    constexpr int B = SLICE, NW = RES_THREADS / 64;
+    constexpr int KT = ((RCAP - B) * 3 + RES_THREADS - 1) / RES_THREADS; // hand-off tasks (halo record, plane) per lane
+    typedef __attribute__((address_space(3))) v2f lds_v2f;
+    __shared__ __attribute__((aligned(16))) v2f win_s[3 * (RCAP + 1)]; // planes xy | (z, vz) | vxy like the fused substep's window
+    __shared__ float part_s[NW][3][B];
+    __shared__ volatile int fail_s;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int item = xcd * p.cb + q;      // XCD c owns a contiguous run of blocks: most hand-offs stay inside one L2
+    if (q >= p.cb || item >= p.nb * p.ne) return;
+    const int b = item / p.ne, e = p.e0 + (item - b * p.ne);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = b * B + lane;
+    const bool valid = i < p.N;
+    const int ic = min(i, p.N - 1);
+    const size_t eb = (size_t)e * p.N;
+    const unsigned xe = (unsigned)e * 6u * (unsigned)p.N, xb = 3u * (unsigned)p.N * 16u; // exchange array: [env][buffer][plane][particle] x 16 B
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, 0x7fffffff, 0x00020000);
+    __attribute__((address_space(3))) char* win_w = (__attribute__((address_space(3))) char*)win_s;
+    const __attribute__((address_space(3))) char* win = win_w;
+    const bool finisher = wave < 3; // wavefronts 0..2 (alone on their SIMDs while the others wait) finish the particle; wavefront q publishes plane q
+
+    // ---- once per launch: hand-off tasks, window of substep 0 from the state arrays, adjacency into registers ----
+    const int h0 = p.halo_off[b], nh = p.halo_off[b + 1] - h0, nt = 3 * nh;
+    unsigned t_off[KT], t_lds[KT], pend0 = 0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int t = tid + RES_THREADS * k;
+        t_off[k] = 0; t_lds[k] = 0;
+        if (t < nt) {
+            const int pl = t / nh, r = t - pl * nh;
+            const int hid = p.halo_ids[h0 + r];
+            t_off[k] = (xe + (unsigned)pl * (unsigned)p.N + (unsigned)hid) * 16u;
+            t_lds[k] = (unsigned)(pl * (RCAP + 1) + B + r) * 8u;
+            pend0 |= 1u << k;
+            win_s[pl * (RCAP + 1) + B + r] = xv_in.p[st_at(xv_in.n, eb + (size_t)hid, pl)];
+        }
+    }
+    if (wave < 3) win_s[wave * (RCAP + 1) + lane] = xv_in.p[st_at(xv_in.n, eb + (size_t)ic, wave)];
+    // group g of the slice belongs to wavefront g % NW; groups [0, gi) only touch the block's own records, [gi, ng) its halo
+    const int srow = __builtin_amdgcn_readfirstlane(p.slice_off[b] / GROUP);
+    const int ng = __builtin_amdgcn_readfirstlane(p.slice_deg[b] / GROUP), gi = __builtin_amdgcn_readfirstlane(p.slice_int[b] / GROUP);
+    const int n_own = gi > wave ? (gi - wave + NW - 1) / NW : 0;            // this wavefront's interior groups: wave, wave + NW, ... < gi
+    const int n_all = ng > wave ? (ng - wave + NW - 1) / NW : 0, n_halo = n_all - n_own;
+    AdjGroup ag_own[RES_NG], ag_halo[RES_NG];
+#pragma unroll
+    for (int j = 0; j < RES_NG; ++j) {
+        ag_own[j].idx = make_uint2(0u, 0u); ag_own[j].k = make_float4(0.f, 0.f, 0.f, 0.f); ag_own[j].a = ag_own[j].k;
+        ag_halo[j] = ag_own[j];
+        if (j < n_own) ag_own[j] = adj_load(p, srow + (wave + NW * j) * SLICE, lane);
+        if (j < n_halo) ag_halo[j] = adj_load(p, srow + (wave + NW * (n_own + j)) * SLICE, lane);
+    }
+    const float m1 = p.masses[ic];
+    if (tid == 0) fail_s = 0;
+    const float inv_m1 = 1.0f / m1;
+    ResidentIO io;
+    io.x = mk(0.f, 0.f, 0.f); io.v = io.x;
+    io.ur2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) io.ubox[c] = c < 3 ? 3e38f : -3e38f;
+#pragma unroll
+    for (int m = 0; m < RES_MAX_MESH; ++m) {
+        io.mr2[m] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) io.mbox[m][c] = io.ubox[c];
+    }
+    if (MESH) { // unions of the mesh boxes over the launch's substeps (once per launch: a few loads per lane, a reduction through LDS)
+        const int n_static = p.n_mesh - p.n_dyn_mesh, n_box = n_steps * p.n_dyn_mesh + n_static;
+        for (int t = tid; t < n_box; t += RES_THREADS) {
+            const int m = t < n_static ? p.n_dyn_mesh + t : (t - n_static) % p.n_dyn_mesh, slot = min(m, RES_MAX_MESH - 1);
+            const float* bb = t < n_static ? p.aabb_static + ((size_t)e * n_static + t) * 6
+                                           : p.aabb_dyn + (((size_t)e * p.n_sub + first) * p.n_dyn_mesh + (t - n_static)) * 6;
+#pragma unroll
+            for (int mm = 0; mm < RES_MAX_MESH; ++mm)
+                if (mm == slot)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { io.mbox[mm][c] = fminf(io.mbox[mm][c], bb[c]); io.mbox[mm][3 + c] = fmaxf(io.mbox[mm][3 + c], bb[3 + c]); }
+        }
+        __shared__ float ub_s[NW][RES_MAX_MESH][6];
+#pragma unroll
+        for (int m = 0; m < RES_MAX_MESH; ++m)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                float u = io.mbox[m][c];
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float other = __shfl_xor(u, o, 64);
+                    u = c < 3 ? fminf(u, other) : fmaxf(u, other);
+                }
+                if (lane == 0) ub_s[wave][m][c] = u;
+            }
+        __syncthreads();
+        float mgmax = 0.f;
+#pragma unroll
+        for (int m = 0; m < RES_MAX_MESH; ++m) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                float u = ub_s[0][m][c];
+                for (int w = 1; w < NW; ++w) u = c < 3 ? fminf(u, ub_s[w][m][c]) : fmaxf(u, ub_s[w][m][c]);
+                io.mbox[m][c] = u;
+                io.ubox[c] = c < 3 ? fminf(io.ubox[c], u) : fmaxf(io.ubox[c], u);
+            }
+            float mg = 0.f;
+            for (int mm = m; mm < p.n_mesh; mm += (m == RES_MAX_MESH - 1 ? 1 : p.n_mesh)) mg = fmaxf(mg, mesh_margin(p, mm)); // slot m: mesh m (the last slot: every mesh from it on)
+            if (m < p.n_mesh) { const float r = mg + NEAR_PAD; io.mr2[m] = r * r * 1.0001f; mgmax = fmaxf(mgmax, mg); }
+        }
+        const float r = mgmax + NEAR_PAD;
+        io.ur2 = r * r * 1.0001f;
+    }
+#ifdef R2S_PHASE_PROBE // wall clock (100 MHz) spent per phase by wavefront 0, summed over the launch: own gather + poll | halo gather + reduce | finish | publish; [4] poll passes
+    long long pr_acc[5] = {0, 0, 0, 0, 0}, pr_t = (long long)wall_clock64();
+#define R2S_RSTAMP(kk) do { const long long now_ = (long long)wall_clock64(); pr_acc[kk] += now_ - pr_t; pr_t = now_; } while (0)
+#else
+#define R2S_RSTAMP(kk) do { } while (0)
+#endif
+
+    for (int k = 0; k < n_steps; ++k) {
+        const int step = first + k;
+        const bool last = k == n_steps - 1;
+        __syncthreads(); // A: the block's own records of version k are in the window (k = 0: its halo too)
+        const v2f oa = win_s[lane], ob = win_s[RCAP + 1 + lane], oc = win_s[2 * (RCAP + 1) + lane];
+        const f3 x0 = mk(oa.x, oa.y, ob.x), v0 = mk(oc.x, oc.y, ob.y);
+
+        // the halo of version k (the state after k substeps of this launch) from buffer k & 1: the first pass is issued here, the
+        // interior springs are evaluated under its round trip
+        const unsigned bofs = (unsigned)(k & 1) * xb;
+        unsigned pend = k > 0 ? pend0 : 0u;
+        v4u d[KT];
+        v2f fxy = {0.f, 0.f};
+        float fz = 0.f;
+        const int n_pre = min(n_own, RES_PRE);
+        if (RES_PRE > 0) spring_groups_n<RCAP>(p, n_pre, ag_own, win, x0, v0, fxy, fz);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk)
+            if (pend & (1u << kk)) d[kk] = __builtin_amdgcn_raw_buffer_load_b128(rx, t_off[kk] + bofs, 0, RES_AUX_LOAD);
+        asm volatile("" ::: "memory");
+        spring_groups_n<RCAP>(p, n_own - n_pre, ag_own + RES_PRE, win, x0, v0, fxy, fz);
+
+        for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk)
+                if ((pend & (1u << kk)) && d[kk].y == (unsigned)k && d[kk].w == (unsigned)k) {
+                    *(lds_v2f*)(win_w + t_lds[kk]) = (v2f){__uint_as_float(d[kk].x), __uint_as_float(d[kk].z)};
+                    pend &= ~(1u << kk);
+                }
+#ifdef R2S_PHASE_PROBE
+            ++pr_acc[4];
+#endif
+            if (__builtin_amdgcn_ballot_w64(pend != 0) == 0ull) break;
+            if (spins >= RES_SPIN_LIMIT) {
+                if (lane == 0) { if (p.fault) *p.fault = 2; fail_s = 1; }
+                break;
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk)
+                if (pend & (1u << kk)) d[kk] = __builtin_amdgcn_raw_buffer_load_b128(rx, t_off[kk] + bofs, 0, RES_AUX_LOAD);
+        }
+        __syncthreads(); // B: the halo records are in the window
+        if (fail_s) break;
+        R2S_RSTAMP(0);
+
+        spring_groups_n<RCAP>(p, n_halo, ag_halo, win, x0, v0, fxy, fz);
+        part_s[wave][0][lane] = fxy.x; part_s[wave][1][lane] = fxy.y; part_s[wave][2][lane] = fz;
+        __syncthreads(); // C
+        if (finisher) {
+            f3 f;
+            f.x = (((part_s[0][0][lane] + part_s[1][0][lane]) + (part_s[2][0][lane] + part_s[3][0][lane])) + ((part_s[4][0][lane] + part_s[5][0][lane]) + (part_s[6][0][lane] + part_s[7][0][lane])));
+            f.y = (((part_s[0][1][lane] + part_s[1][1][lane]) + (part_s[2][1][lane] + part_s[3][1][lane])) + ((part_s[4][1][lane] + part_s[5][1][lane]) + (part_s[6][1][lane] + part_s[7][1][lane])));
+            f.z = (((part_s[0][2][lane] + part_s[1][2][lane]) + (part_s[2][2][lane] + part_s[3][2][lane])) + ((part_s[4][2][lane] + part_s[5][2][lane]) + (part_s[6][2][lane] + part_s[7][2][lane])));
+#ifdef R2S_PHASE_PROBE
+            if (f.x == 1.2345e33f) return;
+#endif
+            R2S_RSTAMP(1);
+
+            // update_vel_from_force, mesh_collision, integrate_ground_collision — the same in the three finishing wavefronts; wavefront 0
+            // stores / accumulates
+            const f3 v = vel_update_rcp(p, v0, f, m1, inv_m1);
+            StateM out = xv_out;
+            if (!last) out.p = nullptr;
+            io.x = x0; io.v = v0;
+            R2S_QP_DECL(-1);
+            finish_wave<MESH, MESH != 0, 0, true>(p, e, i, eb, step, last ? 1 : 0, x0, v, valid, out, nullptr, nullptr, nullptr, nullptr, wave == 0, &io R2S_QP_ARG);
+#ifdef R2S_PHASE_PROBE
+            if (io.x.x == 1.2345e33f) return;
+#endif
+            R2S_RSTAMP(2);
+
+            if (!last) { // publish version k + 1 (plane `wave`) and refresh the block's own records in the window
+                const float va = wave == 0 ? io.x.x : (wave == 1 ? io.x.z : io.v.x), vb = wave == 0 ? io.x.y : (wave == 1 ? io.v.z : io.v.y);
+                if (valid) {
+                    const unsigned tag = (unsigned)(k + 1);
+                    const v4u w = {__float_as_uint(va), tag, __float_as_uint(vb), tag};
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rx, (xe + (unsigned)wave * (unsigned)p.N + (unsigned)i) * 16u + (unsigned)((k + 1) & 1) * xb, 0, RES_AUX_SC1);
+                }
+                win_s[wave * (RCAP + 1) + lane] = (v2f){va, vb};
+            }
+            R2S_RSTAMP(3);
+        }
+    }
+#ifdef R2S_PHASE_PROBE
+    if (tid == 0 && item < 8192 / 2) { for (int kk = 0; kk < 4; ++kk) g_phase_probe[item * 8 + kk] = pr_acc[kk]; g_phase_probe[item * 8 + 4] = pr_acc[4]; }
+#endif
+}
+
 // object_collision for ONE particle by a whole wavefront / a group of lanes: the lanes stride over its candidates (up to 500,
 // each a dependent gather of the partner's position and published velocity), `G` = lanes per particle (a power of two).
 template <int G>
@@ -1196,7 +1549,7 @@ __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const Stat
         const f3 x0 = st_x(xv_in, eb + i);
         const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub, cnt);
         R2S_QP_DECL(-1);
-        finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out, nullptr, nullptr, nullptr, nullptr, true R2S_QP_ARG);
+        finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
     }
 }
 
@@ -1254,7 +1607,7 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
         if (lane == 0 && qp.wave >= 0 && qp.wave < 1024) g_query_probe[qp.wave * 32 + 31] = probe_entry;
 #endif
         R2S_QSTAMP(); // entry loaded, x0 / v (and the impulses) done
-        finish_wave<MESHQ, false, 1>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr, &qshare, &qpar, &X0, wave == 0 R2S_QP_ARG);
+        finish_wave<MESHQ, false, 1>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr, &qshare, &qpar, &X0, wave == 0, nullptr R2S_QP_ARG);
         R2S_QSTAMP(); // stored
     }
     if (WITH_SELF) {
@@ -1288,7 +1641,7 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
                 if (dot(dvi, dvi) * p.dt * p.dt > 0.002f * 0.002f) *p.fault = 1;
             }
             R2S_QP_DECL(-1);
-            finish_wave<MESHQ == 3 ? 1 : 2, false, 2>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out, nullptr, nullptr, nullptr, nullptr, true R2S_QP_ARG);
+            finish_wave<MESHQ == 3 ? 1 : 2, false, 2>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
         }
 #ifdef R2S_PHASE_PROBE
         if (lane == 0 && gw < 1024 && step == p.n_sub - 2) g_query_probe[gw * 32 + 29] = (long long)wall_clock64();
@@ -1831,14 +2184,14 @@ struct R2SPhys {
     std::vector<int> h_adj_nbr;    // ELL slot -> neighbour particle (internal id)
     std::vector<int> h_adj_self;   // ELL slot -> owning particle (internal id; padding target)
     std::vector<int> h_adj_loc;    // ELL slot -> LDS record of the neighbour in the owner's block, or ~global id
-    std::vector<int> h_perm, h_inv, h_slice_off, h_slice_deg, h_rslice_off, h_rslice_deg;
+    std::vector<int> h_perm, h_inv, h_slice_off, h_slice_deg, h_rslice_off, h_rslice_deg, h_slice_int;
     std::vector<int> h_radj_spring, h_radj_nbr, h_radj_self; // remote ELL slot -> spring / neighbour / owner
     std::vector<int> h_mesh_map, h_face_map;
     // device
     v2f* xv[2] = {nullptr, nullptr}; // ping-pong state, three 8-byte planes each (StateC / StateM)
     StateM state(int b) const { return {xv[b], (size_t)E * N}; }
     int cur = 0;
-    int *d_slice_off = nullptr, *d_slice_deg = nullptr, *d_rslice_off = nullptr, *d_rslice_deg = nullptr;
+    int *d_slice_off = nullptr, *d_slice_deg = nullptr, *d_rslice_off = nullptr, *d_rslice_deg = nullptr, *d_slice_int = nullptr;
     unsigned short* d_adj_idx = nullptr;
     float *d_adj_k = nullptr, *d_adj_ir = nullptr;
     int4* d_radj = nullptr;
@@ -1853,6 +2206,9 @@ struct R2SPhys {
     float4* d_vdef = nullptr;
     int* d_cand_mark = nullptr;
     int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false;
+    void* d_xch = nullptr;    // resident stepper: exchange array (96 B per particle)
+    bool resident_ok = false; // the handle can run the env step as ONE resident launch (k_steps_resident) in its free flavour
+    int resident_pref = 1;    // R2S_RESIDENT=0 / r2s_phys_set_tuning: never pick the 64-particle layout / the resident launch
     int chains_override = 0;  // > 0: tuning override of chains() (R2S_CHAINS at create, r2s_phys_set_tuning later)
     int force_defer = -1;     // >= 0: force the deferred-query flavour on / off (tests, tuning)
     int last_flavour[4] = {0, 0, 0, 1}; // of the last step: self-collision variant, mesh template, deferred queries, chains
@@ -1874,6 +2230,7 @@ struct R2SPhys {
         // 9.5 / 17.2, 10.6 / 19.3; 32 T-block envs with the 25k-face rod (288 items) 10.4 / 25.9, 10.5 / 24.4, 12.7 / 26.3.
         const int64_t items = (int64_t)nb * E;
         int c = items >= 1536 ? 4 : (items >= 256 ? 2 : 1);
+        if (pb == 64) c = 1; // small batches (the resident layout): one chain
         c = std::min(c, E);
         if (chains_override > 0) c = std::max(1, std::min(chains_override, std::min(E, 8)));
         return c;
@@ -1924,7 +2281,7 @@ struct R2SPhys {
         PhysDev p{};
         p.N = N; p.E = E; p.n_sub = prm.num_substeps;
         p.nb = nb; p.cb = cb; p.e0 = 0; p.ne = E;
-        p.slice_off = d_slice_off; p.slice_deg = d_slice_deg; p.adj_idx = (const uint2*)d_adj_idx; p.adj_k = (const float4*)d_adj_k; p.adj_ir = (const float4*)d_adj_ir; p.rslice_off = d_rslice_off; p.rslice_deg = d_rslice_deg; p.radj = d_radj;
+        p.slice_off = d_slice_off; p.slice_deg = d_slice_deg; p.slice_int = d_slice_int; p.adj_idx = (const uint2*)d_adj_idx; p.adj_k = (const float4*)d_adj_k; p.adj_ir = (const float4*)d_adj_ir; p.rslice_off = d_rslice_off; p.rslice_deg = d_rslice_deg; p.radj = d_radj;
         p.halo_off = d_halo_off; p.halo_ids = d_halo_ids; p.perm = d_perm; p.inv = d_inv;
         p.masses = d_masses; p.masks = d_masks;
         p.dt = prm.dt; p.dashpot = prm.dashpot_damping; p.drag_factor = expf(-prm.dt * prm.drag_damping);
@@ -1946,6 +2303,7 @@ struct R2SPhys {
         p.mesh_pts = d_mesh_pts; p.interp_pts = d_interp; p.interp_center = d_center; p.dyn_vel = d_dyn_vel; p.dyn_omega = d_dyn_omega;
         p.aabb_dyn = d_aabb_dyn; p.aabb_static = d_aabb_static; p.coll_forces = d_coll_forces; p.hit_cnt = d_hit_cnt;
         p.fault = d_mesh_total ? d_mesh_total + 1 : nullptr;
+        p.xch = d_xch;
         return p;
     }
 };
@@ -2041,7 +2399,8 @@ void launch_fused(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_
     const StateC in = h->state(in_buf);
     const StateM out = h->state(in_buf ^ 1);
     if (h->pb == 256) launch_substep_layout<256, 1024>(p, grid, in, out, step, write_forces, with_self, mesh, s);
-    else launch_substep_layout<128, 768>(p, grid, in, out, step, write_forces, with_self, mesh, s);
+    else if (h->pb == 128) launch_substep_layout<128, 768>(p, grid, in, out, step, write_forces, with_self, mesh, s);
+    else launch_substep_layout<64, 512>(p, grid, in, out, step, write_forces, with_self, mesh, s);
 }
 
 // What the fused kernel left unfinished: with something near a mesh (mesh_defer) ONE combined finishing kernel per substep —
@@ -2084,6 +2443,14 @@ __global__ void k_zero_f32(float* __restrict__ p, size_t n)
     if (i < n) p[i] = 0.f;
 }
 
+// The env step's flavour that runs as one resident launch: no particle with self-collision candidates, nothing near a mesh.
+bool resident_flavour(const R2SPhys* h, bool with_self, int mesh_defer)
+{
+    return h->resident_ok && h->resident_pref != 0 && !with_self && !(h->nF > 0 && mesh_defer);
+}
+constexpr int RES_MAX_ITEMS = 256; // (block, env) work items of a resident launch: one 256-thread workgroup per CU (one wavefront per SIMD: the
+                                   // register file of a SIMD is one wavefront's, 8 adjacency groups live in it), all on the chip at once
+
 int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, hipStream_t s, int e0 = 0, int ne = -1, bool zero_forces = true, int chain_id = 0)
 {
     PhysDev p = h->dev();
@@ -2099,6 +2466,28 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
             const size_t cnt = (size_t)ne * h->N;
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (float*)(h->d_cand_mark + (size_t)e0 * h->N), cnt);
         }
+    }
+    if (resident_flavour(h, with_self, p.mesh_defer)) {
+        // one launch for all n substeps: the final state goes to the OTHER buffer whatever n is (a late workgroup may still be reading
+        // its substep-0 window from the input buffer while an early one stores its last substep) — r2s_phys_step flips accordingly
+        if (h->nF > 0 && zero_forces) {
+            const size_t cnt = 3 * (size_t)ne * h->nF;
+            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->d_coll_forces + 3 * (size_t)e0 * h->nF, cnt);
+            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, (float*)(h->d_hit_cnt + e0), (size_t)ne);
+        }
+        const size_t words = (size_t)24 * ne * h->N; // this chain's environments: 2 buffers x 3 planes x 16 B per particle
+        hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_xch + (size_t)24 * e0 * h->N, words);
+        const dim3 grid(8u * (unsigned)p.cb);
+        const StateC in = h->state(start_buf);
+        const StateM out = h->state(start_buf ^ 1);
+#ifdef R2S_RES_NOMESH // timing experiment only: the mesh code compiled out
+        const bool with_mesh = false;
+#else
+        const bool with_mesh = h->nF > 0;
+#endif
+        if (with_mesh) hipLaunchKernelGGL((k_steps_resident<512, 1>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n);
+        else hipLaunchKernelGGL((k_steps_resident<512, 0>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n);
+        return R2S_OK;
     }
     int buf = start_buf;
     for (int k = 0; k < n; ++k) {
@@ -2269,9 +2658,13 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         // (<320,1120> and <384,1280> — layouts whose 1536 / 1280 work items of the 32-env benchmark are ALL resident at once in a
         // 64-VGPR build: no second, half-empty round of workgroups — were measured in round 3: 23.5 / 23.6 us per batched substep
         // against 20.8 for <256,1024> in the same run.  A single round is not faster; the layouts were removed again.)
-        const int sizes[2] = {256, 128}, caps[2] = {1024, 768};
+        // <64,512>: batches small enough to be resident at once (RES_MAX_ITEMS work items of 64 particles) — the layout of the resident
+        // stepper (k_steps_resident); the per-substep kernels of the contact flavours run on it as one-wavefront workgroups.
+        const int sizes[3] = {256, 128, 64}, caps[3] = {1024, 768, 512};
         int pick = 0;
-        if (const char* ev = getenv("R2S_LAYOUT")) { const int v = atoi(ev); for (int k = 0; k < 2; ++k) if (v == sizes[k]) pick = k; } // tuning knob
+        if (const char* ev = getenv("R2S_RESIDENT")) h->resident_pref = atoi(ev) != 0;
+        if (h->resident_pref && (int64_t)((h->N + 63) / 64) * h->E <= RES_MAX_ITEMS) pick = 2;
+        if (const char* ev = getenv("R2S_LAYOUT")) { const int v = atoi(ev); for (int k = 0; k < 3; ++k) if (v == sizes[k]) pick = k; } // tuning knob
         h->pb = sizes[pick]; h->rcap = caps[pick];
         // the remaining tuning knobs are also read here, ONCE per handle (r2s_phys_set_tuning changes them afterwards)
         if (const char* ev = getenv("R2S_CHAINS")) h->chains_override = atoi(ev);
@@ -2369,6 +2762,27 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             }
         for (size_t k = 0; k < hl.size(); ++k) slot_of[hl[k]] = -1;
     }
+    // 64-particle layout (a block IS a slice): every particle's list starts with its neighbours inside the block, padded to the slice's
+    // largest interior count (whole groups), then the halo neighbours — the resident stepper evaluates the interior groups while the
+    // neighbouring blocks' halo records are still on their way (k_steps_resident).  Padding entries carry spring -1 like the ELL's own.
+    h->h_slice_int.assign(h->n_slices, 0);
+    if (PB == SL)
+        for (int b = 0; b < h->nb; ++b) {
+            int imax = 0;
+            for (int i = b * PB; i < std::min(N, (b + 1) * PB); ++i) {
+                std::stable_partition(loc[i].begin(), loc[i].end(), [&](const std::array<int, 3>& a) { return a[2] < PB; });
+                int ni = 0;
+                for (auto& a : loc[i]) ni += a[2] < PB;
+                imax = std::max(imax, ni);
+            }
+            imax = (imax + GROUP - 1) / GROUP * GROUP;
+            h->h_slice_int[b] = imax;
+            for (int i = b * PB; i < std::min(N, (b + 1) * PB); ++i) {
+                int ni = 0;
+                for (auto& a : loc[i]) ni += a[2] < PB;
+                loc[i].insert(loc[i].begin() + ni, (size_t)(imax - ni), std::array<int, 3>{i, -1, i % PB});
+            }
+        }
     // (A bank-aware slot order — every lane takes, per slot, the neighbour whose record falls on the least-used LDS bank pair of
     // its half-wave — was measured in round 1 with fused reads and again in round 2 with plain ds_read_b64: 22.2 vs 22.1 us per
     // substep.  LDS bank conflicts are not what bounds the gather; the adjacency stays in index order.)
@@ -2410,6 +2824,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     TRY(dev_alloc(&h->d_halo_off, halo_off.size())); TRY(dev_alloc(&h->d_halo_ids, halo_ids.size()));
     TRY(upload(h->d_halo_off, halo_off.data(), halo_off.size(), s)); TRY(upload(h->d_halo_ids, halo_ids.data(), halo_ids.size(), s));
     TRY(upload(h->d_slice_off, h->h_slice_off.data(), h->h_slice_off.size(), s)); TRY(upload(h->d_slice_deg, h->h_slice_deg.data(), h->h_slice_deg.size(), s));
+    TRY(dev_alloc(&h->d_slice_int, h->n_slices)); TRY(upload(h->d_slice_int, h->h_slice_int.data(), h->h_slice_int.size(), s));
     TRY(upload(h->d_rslice_off, h->h_rslice_off.data(), h->h_rslice_off.size(), s)); TRY(upload(h->d_rslice_deg, h->h_rslice_deg.data(), h->h_rslice_deg.size(), s));
     TRY(dev_alloc(&h->d_masses, N)); TRY(dev_alloc(&h->d_masks, N));
     {
@@ -2708,12 +3123,27 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         TRY(dev_alloc(&h->d_mesh_cnt, (size_t)8 * (h->prm.num_substeps + 1)));
         TRY(dev_alloc(&h->d_vdef, (size_t)E * N));
         if (h->prm.self_collision) { TRY(dev_alloc(&h->d_cand_mark, (size_t)E * N)); R2S_HIP_TRY(hipMemsetAsync(h->d_cand_mark, 0, sizeof(int) * (size_t)E * N, s)); }
-        TRY(dev_alloc(&h->d_mesh_total, 4)); // [0] particles near a mesh in the last step, [1] sticky impulse-bound fault
-        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int) * 4, s));
-        R2S_HIP_TRY(hipHostMalloc((void**)&h->h_mesh_total, 64, hipHostMallocDefault));
-        h->h_mesh_total[0] = 0; h->h_mesh_total[1] = 0;
-        R2S_HIP_TRY(hipEventCreateWithFlags(&h->mesh_event, hipEventDisableTiming));
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_cnt, 0, sizeof(int) * 8 * (size_t)(h->prm.num_substeps + 1), s));
+    }
+    TRY(dev_alloc(&h->d_mesh_total, 4)); // [0] particles near a mesh in the last step, [1] sticky fault word (PhysDev::fault)
+    R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int) * 4, s));
+    R2S_HIP_TRY(hipHostMalloc((void**)&h->h_mesh_total, 64, hipHostMallocDefault));
+    h->h_mesh_total[0] = 0; h->h_mesh_total[1] = 0;
+    R2S_HIP_TRY(hipEventCreateWithFlags(&h->mesh_event, hipEventDisableTiming));
+    {
+        // the resident launch needs: the 64-particle layout, every neighbour inside the block's window (a remote neighbour would be read
+        // from the state arrays, which a resident launch only touches at its two ends), no large mesh (its queries are workgroup-cooperative
+        // and always deferred), and all work items on the chip at once
+        bool remote = false;
+        for (int t = 0; t < h->rell_len && !remote; ++t) remote = h->h_radj_spring[t] >= 0;
+        bool fits = true; // a wavefront keeps at most RES_NG interior and RES_NG halo groups of a slice in registers (every fourth group each)
+        for (int sl = 0; sl < h->n_slices && h->pb == 64; ++sl)
+            fits = fits && h->h_slice_int[sl] <= (RES_THREADS / 64) * RES_NG * GROUP && h->h_slice_deg[sl] - h->h_slice_int[sl] <= (RES_THREADS / 64) * RES_NG * GROUP;
+        h->resident_ok = h->pb == 64 && !remote && fits && !h->any_large && (int64_t)h->nb * E <= RES_MAX_ITEMS;
+        if (h->resident_ok) {
+            TRY(dev_alloc((char**)&h->d_xch, (size_t)96 * E * N));
+            R2S_HIP_TRY(hipMemsetAsync(h->d_xch, 0, (size_t)96 * E * N, s));
+        }
     }
     if (h->prm.self_collision) {
         TRY(dev_alloc(&h->d_vbc, (size_t)E * N));
@@ -2759,12 +3189,12 @@ void r2s_phys_destroy(R2SPhys* h)
     if (!h) return;
     (void)hipDeviceSynchronize();
     drop_graph(h);
-    void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
+    void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_slice_int, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
                     h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_mesh_list, h->d_mesh_cnt, h->d_vdef, h->d_cand_mark, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
                     h->d_faces, h->d_face_orig, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
                     h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_sup_info, h->d_sup_box, h->d_small_mesh, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
-                    h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta, h->d_hit_cnt};
+                    h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta, h->d_hit_cnt, h->d_xch};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_cand_count) (void)hipHostFree(h->h_cand_count);
     if (h->h_mesh_total) (void)hipHostFree(h->h_mesh_total);
@@ -2969,19 +3399,25 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         }
     }
     const int variant = (h->prm.self_collision && h->n_cand > 0) ? 1 : 0;
-    if (h->nF > 0) { // defer the mesh queries to k_contact_finish when the last finished step saw particles near a mesh
-        if (h->mesh_pending && hipEventQuery(h->mesh_event) == hipSuccess) h->mesh_pending = false;
-        if (!h->mesh_pending) h->mesh_defer = *h->h_mesh_total > 0 ? 1 : 0; // an unfinished count keeps the previous flavour
-        if (!h->mesh_pending && h->h_mesh_total[1] != 0) {
+    if (h->mesh_pending && hipEventQuery(h->mesh_event) == hipSuccess) h->mesh_pending = false;
+    if (!h->mesh_pending && h->h_mesh_total[1] != 0) { // the sticky fault word of an earlier step
+        if (h->h_mesh_total[1] == 2)
+            r2s::set_last_error_msg("resident stepper: a workgroup waited for a neighbour block's substep beyond the poll limit (the launch was not "
+                                    "resident at once, or the device is shared with a kernel that never ends); the state is invalid");
+        else
             r2s::set_last_error_msg("a self-collision impulse changed a particle's velocity by more than 40 m/s within one substep: its mesh-contact "
                                     "test (widened by 2 mm) may have been skipped where the reference applies it (unsupported)");
-            return R2S_ERR_INVALID;
-        }
+        return R2S_ERR_INVALID;
+    }
+    if (h->nF > 0) { // defer the mesh queries to k_contact_finish when the last finished step saw particles near a mesh
+        if (!h->mesh_pending) h->mesh_defer = *h->h_mesh_total > 0 ? 1 : 0; // an unfinished count keeps the previous flavour
         if (h->force_defer >= 0) h->mesh_defer = h->force_defer; // test / tuning: force a flavour
         if (h->any_large) h->mesh_defer = 1;
     }
     h->last_flavour[0] = variant; h->last_flavour[1] = h->nF > 0 ? (h->any_large ? 2 : 1) : 0; h->last_flavour[2] = h->mesh_defer;
     h->last_flavour[3] = use_graph ? h->chains() : 1;
+    const bool resident = resident_flavour(h, variant == 1, h->mesh_defer);
+    if (resident) h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)
     if (use_graph) {
         // every flavour was captured at construction (capture_all); only set_params / set_tuning drop them
         const int slot = h->mesh_defer * 4 + variant * 2 + (h->cur & 1);
@@ -2997,10 +3433,10 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         int rc = enqueue_steps(h, first_substep, n, h->cur, variant == 1, s);
         if (rc) return rc;
     }
-    h->cur ^= (n & 1);
-    if (h->nF > 0 && !h->mesh_pending) { // particles near a mesh during this step -> pinned memory, read at a later step without waiting
+    h->cur ^= resident ? 1 : (n & 1);
+    if ((h->nF > 0 || h->resident_ok) && !h->mesh_pending) { // particles near a mesh during this step (+ the fault word) -> pinned memory, read at a later step without waiting
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(64), 0, s, h->d_mesh_cnt + h->prm.num_substeps, 8, h->prm.num_substeps + 1, h->d_mesh_total);
+        if (h->nF > 0) hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(64), 0, s, h->d_mesh_cnt + h->prm.num_substeps, 8, h->prm.num_substeps + 1, h->d_mesh_total);
         R2S_HIP_TRY(hipMemcpyAsync(h->h_mesh_total, h->d_mesh_total, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         R2S_HIP_TRY(hipEventRecord(h->mesh_event, s));
         h->mesh_pending = true;
@@ -3078,6 +3514,14 @@ int r2s_phys_set_tuning(R2SPhys* h, int chains, int mesh_defer)
     if (!h) return R2S_ERR_INVALID;
     h->chains_override = chains > 0 ? chains : 0;
     h->force_defer = mesh_defer < 0 ? -1 : (mesh_defer != 0);
+    drop_graph(h);
+    return R2S_OK;
+}
+
+int r2s_phys_set_resident(R2SPhys* h, int on)
+{
+    if (!h) return R2S_ERR_INVALID;
+    h->resident_pref = on != 0;
     drop_graph(h);
     return R2S_OK;
 }

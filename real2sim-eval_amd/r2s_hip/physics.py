@@ -55,7 +55,7 @@ def _bind():
         r2s_phys_set_eef_table=[vp, C.c_int32, vp, vp, C.c_float, vp], r2s_phys_set_eef_motion=[vp, vp, vp, vp, vp, vp, vp],
         r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
         r2s_phys_set_collision_lists=[vp, vp, vp, vp], r2s_phys_contact_stats=[vp, C.POINTER(C.c_int32), C.POINTER(vp)],
-        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32],
+        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32], r2s_phys_set_resident=[vp, i32],
         r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
     ).items():
         fn = getattr(L, name)
@@ -345,12 +345,20 @@ class PhysBatch:
         a = (C.c_int32 * 4)()
         check(_bind().r2s_phys_last_flavour(self._h, a), "r2s_phys_last_flavour")
         rcap = self.layout_stats()["lds_bytes"] // 24
-        return dict(self_collision_kernel=bool(a[0]), mesh_template=int(a[1]), deferred_mesh_queries=bool(a[2]), chains=int(a[3]),
-                    kernel=f"k_substep<{256 if rcap >= 1024 else 128},{rcap},{'true' if a[0] else 'false'},{int(a[1])}>"
+        if a[2] == 2:       # the env step as one resident launch (small batches, free flavour)
+            return dict(self_collision_kernel=False, mesh_template=int(a[1]), deferred_mesh_queries=False, chains=1, resident=True,
+                        kernel=f"k_steps_resident<{rcap},{int(a[1])}>")
+        return dict(self_collision_kernel=bool(a[0]), mesh_template=int(a[1]), deferred_mesh_queries=bool(a[2]), chains=int(a[3]), resident=False,
+                    kernel=f"k_substep<{ {1024: 256, 768: 128}.get(rcap, 64)},{rcap},{'true' if a[0] else 'false'},{int(a[1])}>"
                            + (" + k_contact_finish" if a[2] else (" + k_self_finish" if a[0] else "")))
 
     def set_tuning(self, chains: int = 0, mesh_defer: int = -1):
         check(_bind().r2s_phys_set_tuning(self._h, int(chains), int(mesh_defer)), "r2s_phys_set_tuning")
+
+    def set_resident(self, on: bool):
+        """Small batches only (r2s_physics.h): run the env step's free flavour as one resident launch (default) or, off, with
+        the per-substep kernels of the same 64-particle layout."""
+        check(_bind().r2s_phys_set_resident(self._h, int(bool(on))), "r2s_phys_set_resident")
 
     def collision_max_count(self) -> int:
         m = C.c_int32()

@@ -204,7 +204,7 @@ def test_bench_scene_one_env_20_substeps_in_the_grasp_vs_oracle_driven_through_e
     assert r["passed"], r
 
 
-def test_T_pusher_32_envs_batch_independence_determinism_and_gate():
+def test_T_pusher_32_envs_batch_independence_determinism_and_gate(monkeypatch):
     """configs[3] at its per-GPU size: 32 environments, the ~25k-face rod against the T block, self-collision rebuild on (its
     real settings).  (1) the parity gate of that scene (one environment vs PhysOracle + EefOracle's pusher branch, in contact);
     (2) two runs of the 32-environment batch are bit-identical; (3) environment 0 of the batch equals a 1-environment run of the
@@ -229,6 +229,11 @@ def test_T_pusher_32_envs_batch_independence_determinism_and_gate():
     xb, cb, _, _ = run(32)
     assert st["mesh_contacts"] > 0 and st["flavour"]["mesh_template"] == 2
     assert np.array_equal(xa, xb) and np.array_equal(ca, cb), "two runs of the same batch must be bit-identical"
+    # a 1-environment handle is laid out in 64-particle blocks (the resident stepper's layout: neighbours in another order, the same
+    # sums to the last bits); with the large-batch layout forced it must reproduce environment 0 of the batch bit for bit
+    x1, c1, _, _ = run(1)
+    assert np.abs(xa[0] - x1[0]).max() < 2e-6, np.abs(xa[0] - x1[0]).max()
+    monkeypatch.setenv("R2S_RESIDENT", "0")
     x1, c1, _, _ = run(1)
     assert np.array_equal(xa[0], x1[0]), np.abs(xa[0] - x1[0]).max()
     moved = np.abs(xa - x_init).max(axis=(1, 2))

@@ -1,0 +1,142 @@
+"""The resident stepper (k_steps_resident, physics.hip): small batches — one environment of the reference's own evaluation
+loop (eval_policy.py:180-240 -> phystwin.py:104-147 -> spring_mass_warp.py:723-726, `for i in range(num_substeps): step()`),
+up to a few — run all substeps of an env step in ONE launch whose workgroups hand their halo particles to each other through
+tagged write-through records.  Checked against the oracle, against the per-substep kernels of the same handle, for determinism,
+for ragged sizes / several environments / partial steps, with moving fingers hovering and touching, and next to a second stream
+that keeps the chip busy."""
+import numpy as np
+import pytest
+
+from util_parity import record
+from util_physics import gripper_motion, hip_env, make_object, oracle_env
+
+pytestmark = pytest.mark.gpu
+
+
+def _falling(shape, n, seed, lift=0.0005):
+    ob = make_object(shape, n, seed=seed)
+    ob["points"][:, 2] += lift - ob["points"][:, 2].min()      # lowest particle `lift` above the ground
+    ob["v0"] = np.zeros_like(ob["points"])
+    ob["v0"][:, 2] = -0.3
+    return ob
+
+
+@pytest.mark.parametrize("shape,n,n_env,n_sub", [("rope", 600, 1, 201), ("sloth", 3000, 3, 120), ("T", 2229, 2, 100), ("rope", 70, 1, 64)],
+                         ids=["rope 1 env odd substeps", "sloth 3 envs", "T 2 envs even substeps", "two blocks, one ragged"])
+def test_resident_launch_vs_oracle_and_vs_the_per_substep_kernels(shape, n, n_env, n_sub):
+    """Free flight onto the ground (spring forces, drag, ground contact): the env step as one resident launch against the oracle
+    (1e-5, BASELINE.json) and against the same handle running the per-substep kernels of the same layout (set_resident(False));
+    the two differ by summation order only."""
+    ob = _falling(shape, n, seed=3)
+    kw = dict(num_substeps=n_sub, self_collision=False)
+    o = oracle_env(ob, **kw)
+    h = hip_env(ob, n_env=n_env, **kw)
+    g = hip_env(ob, n_env=n_env, **kw)
+    g.set_resident(False)
+    st = h.layout_stats()
+    assert st["lds_bytes"] == 512 * 24 and st["fallback_slots"] == 0, st
+    for _ in range(3):
+        o.step(); h.step(); g.step()
+    fl, fg = h.last_flavour(), g.last_flavour()
+    assert fl["resident"] and fl["kernel"].startswith("k_steps_resident<512,"), fl
+    assert not fg["resident"] and fg["kernel"].startswith("k_substep<64,512,"), fg
+    x, xg = h.x.cpu().numpy(), g.x.cpu().numpy()
+    err_o = float(np.abs(x - o.x[None]).max())
+    err_g = float(np.abs(x - xg).max())
+    record(f"resident stepper, {shape} {n} x {n_env} envs, {3 * n_sub} substeps", x_max_abs_vs_oracle=err_o, x_max_abs_vs_per_substep_kernels=err_g, tol=1e-5)
+    assert err_o < 1e-5 and err_g < 2e-6, (err_o, err_g)
+    assert np.abs(h.v.cpu().numpy() - g.v.cpu().numpy()).max() < 1e-3
+    assert np.array_equal(x, np.repeat(x[0:1], n_env, 0)), "environments with identical inputs must agree bit for bit"
+    assert o.v[:, 2].max() > -0.2, "the scenario must reach the ground (free fall alone leaves every particle faster than -0.3 m/s)"
+
+
+def test_resident_launch_is_deterministic_and_partial_steps_compose():
+    """Two handles, same inputs: bit-identical states.  And step(n, first) pieces — each its own resident launch, final state
+    always in the OTHER buffer whatever the parity of n — compose to the full step bit for bit."""
+    ob = _falling("sloth", 3000, seed=5)
+    kw = dict(num_substeps=90, self_collision=False)
+    a, b, c = (hip_env(ob, n_env=2, **kw) for _ in range(3))
+    for _ in range(2):
+        a.step(); b.step()
+        c.step(20, 0); c.step(31, 20); c.step(39, 51)
+    assert a.last_flavour()["resident"] and c.last_flavour()["resident"]
+    xa, xb, xc = a.x.cpu().numpy(), b.x.cpu().numpy(), c.x.cpu().numpy()
+    assert np.array_equal(xa, xb) and np.array_equal(a.v.cpu().numpy(), b.v.cpu().numpy())
+    assert np.array_equal(xa, xc) and np.array_equal(a.v.cpu().numpy(), c.v.cpu().numpy())
+
+
+def test_resident_launch_with_fingers_hovering_then_touching():
+    """Moving finger meshes: while they hover beyond margin + 3 cm the union-box early-out skips every per-mesh test; when they
+    come down the in-range wavefronts run the exact tests and the in-place queries inside the resident launch (the first env step
+    in reach: the host only switches to the deferred flavour one step later).  Both against the oracle, forces included."""
+    import torch
+    from r2s_hip import synth
+
+    n_sub = 120
+    ob = make_object("sloth", 500, seed=6)
+    c = ob["points"].mean(0)
+    top = ob["points"][:, 2].max()
+    kw = dict(self_collision=False, num_substeps=n_sub)
+
+    def run(height, vel, expect_contact):
+        fl = synth.finger_mesh((c[0], c[1] - 0.02, top + height))
+        fr = synth.finger_mesh((c[0], c[1] + 0.02, top + height))
+        interp, centers, dv, om = gripper_motion([fl, fr], n_sub, 5e-5, vel=vel, closing=1.0 if expect_contact else 0.0)
+        o = oracle_env(ob, dynamic_meshes=[fl, fr], **kw)
+        h = hip_env(ob, dynamic_meshes=[fl, fr], **kw)
+        o.set_mesh_interactive(interp, centers, dv, om)
+        h.set_mesh_interactive(torch.from_numpy(interp)[None].cuda(), torch.from_numpy(centers)[None].cuda(),
+                               torch.from_numpy(dv)[None].cuda(), torch.from_numpy(om)[None].cuda())
+        o.step(); h.step()
+        assert h.last_flavour()["resident"], h.last_flavour()
+        x = h.x[0].cpu().numpy()
+        f = h.collision_forces()[0].cpu().numpy()
+        hit = float(np.abs(o.collision_forces).max()) > 0
+        assert hit == expect_contact
+        assert np.abs(x - o.x).max() < 1e-5, np.abs(x - o.x).max()
+        for m in (0, 1):
+            tot_o, tot_h = o.collision_forces[h.mesh_map == m].sum(0), f[h.mesh_map == m].sum(0)
+            assert np.allclose(tot_h, tot_o, rtol=1e-3, atol=max(np.abs(tot_o).max() * 1e-3, 1e-6)), (m, tot_o, tot_h)
+        return float(np.abs(x - o.x).max()), int(h.deferred_counts()[n_sub])
+
+    e_far, near_far = run(0.09, (0.0, 0.0, -0.5), False)      # 9 cm up, 3 mm down per step: never within margin + NEAR_PAD
+    assert near_far == 0
+    e_hit, near_hit = run(0.03, (0.0, 0.0, -6.0), True)       # the scenario of test_gripper_fingers_dynamic_mesh
+    assert near_hit != 0, "particles near the fingers must be reported (the host picks the next step's flavour from it)"
+    record("resident stepper with finger meshes (hovering / in-place queries)", x_max_abs_hover=e_far, x_max_abs_contact=e_hit, tol=1e-5)
+
+
+def test_resident_launch_next_to_a_busy_second_stream():
+    """Hand-offs under load: a second stream keeps every CU streaming through HBM while the resident launches run (uneven
+    arrival of the workgroups, loaded memory queues).  The states must equal the quiet run bit for bit."""
+    import torch
+
+    ob = _falling("sloth", 3000, seed=7)
+    kw = dict(num_substeps=150, self_collision=False)
+    quiet, busy = hip_env(ob, n_env=3, **kw), hip_env(ob, n_env=3, **kw)
+    for _ in range(3):
+        quiet.step()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")      # 1 GiB
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                big.mul_(1.0001)
+        busy.step()
+    torch.cuda.synchronize()
+    assert busy.last_flavour()["resident"]
+    assert np.array_equal(quiet.x.cpu().numpy(), busy.x.cpu().numpy()) and np.array_equal(quiet.v.cpu().numpy(), busy.v.cpu().numpy())
+
+
+def test_large_batches_and_forced_layouts_keep_the_per_substep_path(monkeypatch):
+    """More work items than the chip holds at once (or R2S_RESIDENT=0): the large-batch layout and one kernel per substep."""
+    ob = _falling("sloth", 3000, seed=9)
+    kw = dict(num_substeps=40, self_collision=False)
+    h = hip_env(ob, n_env=9, **kw)           # 47 blocks of 64 x 9 envs > 256 work items
+    h.step()
+    assert not h.last_flavour()["resident"] and h.layout_stats()["lds_bytes"] == 1024 * 24
+    monkeypatch.setenv("R2S_RESIDENT", "0")
+    g = hip_env(ob, n_env=1, **kw)
+    g.step()
+    assert not g.last_flavour()["resident"] and g.layout_stats()["lds_bytes"] == 1024 * 24
