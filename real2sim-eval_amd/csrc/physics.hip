@@ -1106,7 +1106,12 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
 #ifndef R2S_STAGE_BATCH
 #define R2S_STAGE_BATCH 2
 #endif
-    constexpr int KB = (R2S_STAGE_BATCH > 0 && R2S_STAGE_BATCH < K) ? R2S_STAGE_BATCH : K;
+#ifndef R2S_STAGE64
+#define R2S_STAGE64 2
+#endif
+    // (one-wavefront workgroups of the small-batch layout: all K rounds in flight at once was measured and changes nothing, 9.8 vs 9.5 us —
+    // that kernel is bound by the lone wavefront walking all of a particle's slots)
+    constexpr int KB = B == 64 ? (R2S_STAGE64 < K ? R2S_STAGE64 : K) : ((R2S_STAGE_BATCH > 0 && R2S_STAGE_BATCH < K) ? R2S_STAGE_BATCH : K);
     const int h0 = p.halo_off[b], per_env = B + (p.halo_off[b + 1] - h0);
     v2f own_a = {0.f, 0.f}, own_b = own_a, own_c = own_a; // this lane's own record (round 0)
 #pragma unroll
@@ -1223,7 +1228,10 @@ constexpr int RES_AUX_SC1 = 16;                 // buffer-instruction cache poli
 #define R2S_RES_AUXLD (16 | (int)0x80000000)
 #endif
 #ifndef R2S_RES_PRE
-#define R2S_RES_PRE 0
+#define R2S_RES_PRE 2
+#endif
+#ifndef R2S_RES_DELAY
+#define R2S_RES_DELAY 0
 #endif
 constexpr int RES_AUX_LOAD = R2S_RES_AUXLD;     // poll loads: sc1 + the compiler-side volatile bit (= sc0 sc1 in the instruction)
 constexpr int RES_PRE = R2S_RES_PRE;            // interior groups evaluated BEFORE the first poll pass is issued
@@ -1285,7 +1293,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     constexpr int KT = ((RCAP - B) * 3 + RES_THREADS - 1) / RES_THREADS; // hand-off tasks (halo record, plane) per lane
     typedef __attribute__((address_space(3))) v2f lds_v2f;
     __shared__ __attribute__((aligned(16))) v2f win_s[3 * (RCAP + 1)]; // planes xy | (z, vz) | vxy like the fused substep's window
-    __shared__ float part_s[NW][3][B];
+    __shared__ float4 part_s[NW][B]; // partial forces of the eight wavefronts: one 16-byte write per lane, eight 16-byte reads per finishing lane
     __shared__ volatile int fail_s;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int item = xcd * p.cb + q;      // XCD c owns a contiguous run of blocks: most hand-offs stay inside one L2
@@ -1412,11 +1420,12 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
         const int n_pre = min(n_own, RES_PRE);
         if (RES_PRE > 0) spring_groups_n<RCAP>(p, n_pre, ag_own, win, x0, v0, fxy, fz);
         asm volatile("" ::: "memory");
+        if (R2S_RES_DELAY > 0 && k > 0) __builtin_amdgcn_s_sleep(R2S_RES_DELAY);
 #pragma unroll
         for (int kk = 0; kk < KT; ++kk)
             if (pend & (1u << kk)) d[kk] = __builtin_amdgcn_raw_buffer_load_b128(rx, t_off[kk] + bofs, 0, RES_AUX_LOAD);
         asm volatile("" ::: "memory");
-        spring_groups_n<RCAP>(p, n_own - n_pre, ag_own + RES_PRE, win, x0, v0, fxy, fz);
+        if (RES_PRE < RES_NG) spring_groups_n<RCAP>(p, n_own - n_pre, ag_own + (RES_PRE < RES_NG ? RES_PRE : 0), win, x0, v0, fxy, fz);
 
         for (unsigned spins = 0;; ++spins) {
 #pragma unroll
@@ -1443,13 +1452,19 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
         R2S_RSTAMP(0);
 
         spring_groups_n<RCAP>(p, n_halo, ag_halo, win, x0, v0, fxy, fz);
-        part_s[wave][0][lane] = fxy.x; part_s[wave][1][lane] = fxy.y; part_s[wave][2][lane] = fz;
+        part_s[wave][lane] = make_float4(fxy.x, fxy.y, fz, 0.f);
         __syncthreads(); // C
         if (finisher) {
             f3 f;
-            f.x = (((part_s[0][0][lane] + part_s[1][0][lane]) + (part_s[2][0][lane] + part_s[3][0][lane])) + ((part_s[4][0][lane] + part_s[5][0][lane]) + (part_s[6][0][lane] + part_s[7][0][lane])));
-            f.y = (((part_s[0][1][lane] + part_s[1][1][lane]) + (part_s[2][1][lane] + part_s[3][1][lane])) + ((part_s[4][1][lane] + part_s[5][1][lane]) + (part_s[6][1][lane] + part_s[7][1][lane])));
-            f.z = (((part_s[0][2][lane] + part_s[1][2][lane]) + (part_s[2][2][lane] + part_s[3][2][lane])) + ((part_s[4][2][lane] + part_s[5][2][lane]) + (part_s[6][2][lane] + part_s[7][2][lane])));
+            {
+                static_assert(NW == 8, "the fixed summation tree below");
+                float4 q[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) q[w] = part_s[w][lane];
+                f.x = ((q[0].x + q[1].x) + (q[2].x + q[3].x)) + ((q[4].x + q[5].x) + (q[6].x + q[7].x));
+                f.y = ((q[0].y + q[1].y) + (q[2].y + q[3].y)) + ((q[4].y + q[5].y) + (q[6].y + q[7].y));
+                f.z = ((q[0].z + q[1].z) + (q[2].z + q[3].z)) + ((q[4].z + q[5].z) + (q[6].z + q[7].z));
+            }
 #ifdef R2S_PHASE_PROBE
             if (f.x == 1.2345e33f) return;
 #endif

@@ -525,13 +525,18 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
             const unsigned long long lv = s_live[buf][wave][sw];
             unsigned long long bits = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(lv >> 32)) << 32) |
                                       (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)lv);
-            while (bits) {
-                const int j = sw * 64 + __builtin_ctzll(bits);
-                bits &= bits - 1;
+            // The walk is software-pipelined by hand, two register sets alternating: the three LDS reads of the NEXT live instance are
+            // issued before the current one is blended.  With eight wavefronts per SIMD (the 32-environment batches) other wavefronts
+            // cover the ~100 cycles between a record's reads and its first use; a single environment's frames leave the deepest tile's
+            // wavefronts alone on their SIMDs, and the serial read -> blend -> read chain WAS the kernel: 0.53 ms for two frames whose
+            // longest list has 3 326 instances.
+            auto fetch = [&](int j, float4& a, float2& b, float4& c) {
                 const float4* rec = s_rec[buf] + 3 * j;
-                const float4 a = rec[0];
-                const float2 b = make_float2(rec[1].x, rec[1].y);
-                const float4 c = rec[2]; // depth, r, g, b — issued with the other two reads (one address register, no second v_mov)
+                a = rec[0];
+                b = make_float2(rec[1].x, rec[1].y);
+                c = rec[2]; // depth, r, g, b — issued with the other two reads (one address register, no second v_mov)
+            };
+            auto blend_one = [&](const float4 a, const float2 b, const float4 c, const int j) {
                 const float dx = a.x - pfx, dy = a.y - pfy;
                 const float power = fmaf(dx, fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy); // = log2(e) * forward.cu:342's power
                 const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
@@ -558,6 +563,23 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                 D = (blend && T > 0.5f && test_T < 0.5f) ? c.x : D;
                 T = blend ? test_T : T;
                 if (AUX) last_contributor = blend ? base + (uint32_t)j + 1u : last_contributor; // as forward.cu:335,380
+            };
+            if (bits) {
+                int j0 = sw * 64 + __builtin_ctzll(bits), j1 = 0;
+                bits &= bits - 1;
+                float4 a0, c0, a1, c1;
+                float2 b0, b1;
+                fetch(j0, a0, b0, c0);
+                for (;;) {
+                    const bool more = bits != 0;
+                    if (more) { j1 = sw * 64 + __builtin_ctzll(bits); bits &= bits - 1; fetch(j1, a1, b1, c1); }
+                    blend_one(a0, b0, c0, j0);
+                    if (!more) break;
+                    const bool more2 = bits != 0;
+                    if (more2) { j0 = sw * 64 + __builtin_ctzll(bits); bits &= bits - 1; fetch(j0, a0, b0, c0); }
+                    blend_one(a1, b1, c1, j1);
+                    if (!more2) break;
+                }
             }
         }
     };

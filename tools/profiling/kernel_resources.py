@@ -18,5 +18,5 @@ for l in out.splitlines():
             rows[cur][k] = int(m.group(1))
 for k, v in rows.items():
     name = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "").split("(")[0]
-    if any(s in name for s in ("k_substep", "contact_finish", "self_finish", "k_composite", "k_persist")):
+    if any(s in name for s in ("k_substep", "contact_finish", "self_finish", "k_composite", "k_steps_resident", "k_emit", "k_preprocess")):
         print(f"{name:60s} {v}")
