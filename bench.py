@@ -306,6 +306,17 @@ def main():
         ms1, k1 = ro.phys.last_step_ms()
         single_us = ms1 / max(k1, 1) * 1e3
         ro.phys.set_tuning(chains=0)
+    # small batches: the same env step with the per-substep kernels of the same layout instead of the resident launch (untimed)
+    per_substep_us = None
+    if ro.phys.last_flavour().get("resident"):
+        ro.phys.set_resident(False)
+        for _ in range(3):
+            ro.physics_step()
+        torch.cuda.synchronize(dev)
+        ms1, k1 = ro.phys.last_step_ms()
+        per_substep_us = {"avg_launch_us": ms1 / max(k1, 1) * 1e3, "kernel": ro.phys.last_flavour()["kernel"],
+                          "note": "r2s_phys_set_resident(0): one launch per substep, measured after the timed region"}
+        ro.phys.set_resident(True)
     ro.phys.set_timing(False)
 
     # stage timing of the raster pipeline (separate, untimed pass)
@@ -357,6 +368,7 @@ def main():
                     "grasped_envs": int(max(log["grasped"][i] for i in idx)),
                     "kernel_flavours": sorted({log["flavour"][i] for i in idx})}
 
+        resident_steps = sum("k_steps_resident" in f for f in log["flavour"])   # env steps of the window that ran as one resident launch
         first_contact = ro.close_at - args.warmup  # index in the timed window of the step in which the fingers close / rod arrives
         (pmc_sub, src), (pmc_comp, _) = pmc_summary("k_substep", args.config), pmc_summary("k_composite", args.config)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -365,8 +377,10 @@ def main():
                 "hbm_actual_frac": (pmc_sub["hbm_bytes_per_launch"] / t_kernel / 1e9 / HBM_PEAK_GBS) if pmc_sub and ro.n_env == 32 and n_sub == 667 else None,
                 "valu_busy_frac": pmc_sub.get("valu_busy_frac") if pmc_sub else None,
                 "counters_stale": pmc_sub.get("stale") if pmc_sub else None,
-                "kernel": "k_substep (fused spring gather + velocity + collisions + integrate)",
+                "kernel": ("k_steps_resident (small batch: all substeps of an env step in ONE launch; the figures below are per substep of it)" if resident_steps == args.steps
+                           else "k_substep (fused spring gather + velocity + collisions + integrate)"),
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": t_kernel * 1e6, "launches": n_sub * args.steps,
+                "resident_env_steps": resident_steps, "per_substep_kernels_check": per_substep_us,
                 "concurrent_chains": chains,
                 "single_chain_check": None if single_us is None else {
                     "avg_launch_us": single_us, "achieved": alg_bytes / (single_us * 1e-6) / 1e9, "frac": alg_bytes / (single_us * 1e-6) / 1e9 / HBM_PEAK_GBS,

@@ -872,17 +872,17 @@ __device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 
 // in the critical path of every substep — are skipped; otherwise the exact tests run as in k_substep.
 constexpr int RES_MAX_MESH = 4;
 struct ResidentIO {
-    f3 x, v;                      // out: the particle's new state
-    float ubox[6], ur2;           // in: union of everything; (largest margin + NEAR_PAD)^2, widened by 1e-4 relative
-    float mbox[RES_MAX_MESH][6];  // in: union over the substeps per mesh
-    float mr2[RES_MAX_MESH];      // in: (its margin + NEAR_PAD)^2, widened (0 for unused slots: never in range)
+    f3 x, v;               // out: the particle's new state
+    const float* boxes;    // in (LDS, wave-uniform values — 35 registers per lane if they lived there): [0..5] union of everything, [6] (largest
+                           // margin + NEAR_PAD)^2 widened by 1e-4 relative; then per mesh slot m at 8 + 8 m: [0..5] its union over the substeps,
+                           // [6] (its margin + NEAR_PAD)^2, widened (0 for unused slots: never in range)
 };
 __device__ __forceinline__ bool resident_in_range(const ResidentIO& io, f3 next_x, bool fin)
 {
-    if (__builtin_amdgcn_ballot_w64(fin && box_dist2(next_x, io.ubox) < io.ur2) == 0ull) return false;
+    if (__builtin_amdgcn_ballot_w64(fin && box_dist2(next_x, io.boxes) < io.boxes[6]) == 0ull) return false;
     bool any = false;
 #pragma unroll
-    for (int m = 0; m < RES_MAX_MESH; ++m) any = any || box_dist2(next_x, io.mbox[m]) < io.mr2[m];
+    for (int m = 0; m < RES_MAX_MESH; ++m) any = any || box_dist2(next_x, io.boxes + 8 + 8 * m) < io.boxes[8 + 8 * m + 6];
     return __builtin_amdgcn_ballot_w64(fin && any) != 0ull;
 }
 
@@ -915,7 +915,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         f3 next_x = x0 + vin * p.dt;
         f3 next_v = vin;
         bool in_range = true;
-        if (KEEP) in_range = resident_in_range(*keep, next_x, fin); // wave-uniform
+        if (KEEP && keep->boxes) in_range = resident_in_range(*keep, next_x, fin); // wave-uniform (a single-substep launch carries no unions)
       if (in_range) {
         bool need = false, near = false;
         if (NEED == 1) need = fin;
@@ -1252,6 +1252,9 @@ __device__ __forceinline__ void group_read(const AdjGroup& g, const __attribute_
         r.vv[u] = *(lds_f2*)(win + off[u] + PLANE2<RCAP>());
     }
 }
+// (Evaluating the four slots of a group stage by stage behind scheduling barriers — four independent instructions between an
+// instruction and its consumer instead of one slot's dependent chain after the other — was measured and changes nothing: 2.37 vs 2.36 us
+// per substep.  With two wavefronts per SIMD the chain latency is covered; what a substep waits for is the hand-off.)
 __device__ __forceinline__ void group_eval(const PhysDev& p, const AdjGroup& g, const GroupRecs& r, f3 xi, f3 vi, v2f& fxy, float& fz)
 {
     const float k[GROUP] = {g.k.x, g.k.y, g.k.z, g.k.w};
@@ -1285,10 +1288,14 @@ __device__ __forceinline__ void spring_groups_n(const PhysDev& p, int n, const A
     else if (n == 1) spring_groups<RCAP, 1>(p, g, win, xi, vi, fxy, fz);
 }
 
-template <int RCAP, int MESH>
-__global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev p, const StateC xv_in, const StateM xv_out, int first, int n_steps)
+// The same kernel is the small-batch layout's PER-SUBSTEP kernel (n_steps = 1: no hand-off at all, the window comes from the state
+// arrays, wavefront 0 alone finishes and owns every side effect): the contact flavours — deferred mesh queries, self-collision
+// candidates (SELF; only ever with n_steps = 1) — keep their finishing kernels and a launch per substep, but a block's springs are
+// still shared by eight wavefronts instead of walked by one (k_substep<64,512,..>: 8.0 us per substep of the rope, this: see DESIGN §4).
+template <int RCAP, bool SELF, int MESH>
+__global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev p, const StateC xv_in, const StateM xv_out, int first, int n_steps,
+                                                                    int write_forces_last)
 {
-    static_assert(MESH != 2, "large meshes always defer their queries to k_contact_finish");
     constexpr int B = SLICE, NW = RES_THREADS / 64;
     constexpr int KT = ((RCAP - B) * 3 + RES_THREADS - 1) / RES_THREADS; // hand-off tasks (halo record, plane) per lane
     typedef __attribute__((address_space(3))) v2f lds_v2f;
@@ -1308,7 +1315,9 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, 0x7fffffff, 0x00020000);
     __attribute__((address_space(3))) char* win_w = (__attribute__((address_space(3))) char*)win_s;
     const __attribute__((address_space(3))) char* win = win_w;
-    const bool finisher = wave < 3; // wavefronts 0..2 (alone on their SIMDs while the others wait) finish the particle; wavefront q publishes plane q
+    // wavefronts 0..2 (alone on their SIMDs while the others wait) finish the particle, wavefront q publishes plane q; a single substep
+    // publishes nothing: wavefront 0 alone
+    const bool finisher = wave < (n_steps == 1 ? 1 : 3);
 
     // ---- once per launch: hand-off tasks, window of substep 0 from the state arrays, adjacency into registers ----
     const int h0 = p.halo_off[b], nh = p.halo_off[b + 1] - h0, nt = 3 * nh;
@@ -1345,16 +1354,14 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     const float inv_m1 = 1.0f / m1;
     ResidentIO io;
     io.x = mk(0.f, 0.f, 0.f); io.v = io.x;
-    io.ur2 = 0.f;
+    __shared__ float box_s[8 * (1 + RES_MAX_MESH)];
+    io.boxes = (MESH && n_steps > 1) ? box_s : nullptr;
+    if (MESH && n_steps > 1) { // unions of the mesh boxes over the launch's substeps (once per launch: a few loads per lane, a reduction through LDS)
+        float mb[RES_MAX_MESH][6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) io.ubox[c] = c < 3 ? 3e38f : -3e38f;
+        for (int m = 0; m < RES_MAX_MESH; ++m)
 #pragma unroll
-    for (int m = 0; m < RES_MAX_MESH; ++m) {
-        io.mr2[m] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) io.mbox[m][c] = io.ubox[c];
-    }
-    if (MESH) { // unions of the mesh boxes over the launch's substeps (once per launch: a few loads per lane, a reduction through LDS)
+            for (int c = 0; c < 6; ++c) mb[m][c] = c < 3 ? 3e38f : -3e38f;
         const int n_static = p.n_mesh - p.n_dyn_mesh, n_box = n_steps * p.n_dyn_mesh + n_static;
         for (int t = tid; t < n_box; t += RES_THREADS) {
             const int m = t < n_static ? p.n_dyn_mesh + t : (t - n_static) % p.n_dyn_mesh, slot = min(m, RES_MAX_MESH - 1);
@@ -1364,14 +1371,14 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             for (int mm = 0; mm < RES_MAX_MESH; ++mm)
                 if (mm == slot)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { io.mbox[mm][c] = fminf(io.mbox[mm][c], bb[c]); io.mbox[mm][3 + c] = fmaxf(io.mbox[mm][3 + c], bb[3 + c]); }
+                    for (int c = 0; c < 3; ++c) { mb[mm][c] = fminf(mb[mm][c], bb[c]); mb[mm][3 + c] = fmaxf(mb[mm][3 + c], bb[3 + c]); }
         }
         __shared__ float ub_s[NW][RES_MAX_MESH][6];
 #pragma unroll
         for (int m = 0; m < RES_MAX_MESH; ++m)
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                float u = io.mbox[m][c];
+                float u = mb[m][c];
                 for (int o = 32; o > 0; o >>= 1) {
                     const float other = __shfl_xor(u, o, 64);
                     u = c < 3 ? fminf(u, other) : fmaxf(u, other);
@@ -1379,22 +1386,26 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                 if (lane == 0) ub_s[wave][m][c] = u;
             }
         __syncthreads();
-        float mgmax = 0.f;
-#pragma unroll
-        for (int m = 0; m < RES_MAX_MESH; ++m) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                float u = ub_s[0][m][c];
-                for (int w = 1; w < NW; ++w) u = c < 3 ? fminf(u, ub_s[w][m][c]) : fmaxf(u, ub_s[w][m][c]);
-                io.mbox[m][c] = u;
-                io.ubox[c] = c < 3 ? fminf(io.ubox[c], u) : fmaxf(io.ubox[c], u);
+        if (tid == 0) {
+            float ub[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f}, mgmax = 0.f;
+            for (int m = 0; m < RES_MAX_MESH; ++m) {
+                for (int c = 0; c < 6; ++c) {
+                    float u = ub_s[0][m][c];
+                    for (int w = 1; w < NW; ++w) u = c < 3 ? fminf(u, ub_s[w][m][c]) : fmaxf(u, ub_s[w][m][c]);
+                    box_s[8 + 8 * m + c] = u;
+                    ub[c] = c < 3 ? fminf(ub[c], u) : fmaxf(ub[c], u);
+                }
+                float mg = 0.f;
+                for (int mm = m; mm < p.n_mesh; mm += (m == RES_MAX_MESH - 1 ? 1 : p.n_mesh)) mg = fmaxf(mg, mesh_margin(p, mm)); // slot m: mesh m (the last slot: every mesh from it on)
+                const float r = mg + NEAR_PAD;
+                box_s[8 + 8 * m + 6] = m < p.n_mesh ? r * r * 1.0001f : 0.f;
+                if (m < p.n_mesh) mgmax = fmaxf(mgmax, mg);
             }
-            float mg = 0.f;
-            for (int mm = m; mm < p.n_mesh; mm += (m == RES_MAX_MESH - 1 ? 1 : p.n_mesh)) mg = fmaxf(mg, mesh_margin(p, mm)); // slot m: mesh m (the last slot: every mesh from it on)
-            if (m < p.n_mesh) { const float r = mg + NEAR_PAD; io.mr2[m] = r * r * 1.0001f; mgmax = fmaxf(mgmax, mg); }
+            for (int c = 0; c < 6; ++c) box_s[c] = ub[c];
+            const float r = mgmax + NEAR_PAD;
+            box_s[6] = r * r * 1.0001f;
         }
-        const float r = mgmax + NEAR_PAD;
-        io.ur2 = r * r * 1.0001f;
+        // visible to the finishing wavefronts after barrier A of the first substep
     }
 #ifdef R2S_PHASE_PROBE // wall clock (100 MHz) spent per phase by wavefront 0, summed over the launch: own gather + poll | halo gather + reduce | finish | publish; [4] poll passes
     long long pr_acc[5] = {0, 0, 0, 0, 0}, pr_t = (long long)wall_clock64();
@@ -1476,8 +1487,28 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             StateM out = xv_out;
             if (!last) out.p = nullptr;
             io.x = x0; io.v = v0;
+            bool fin = valid;
+            if (SELF) { // as in substep_body: particles with candidates publish v_before_collision and are finished by k_self_finish / k_contact_finish
+                const int ncand = valid ? p.coll_num[eb + i] : 0;
+                if (ncand > 0) {
+                    p.vbc[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
+                    fin = false;
+                    if (MESH != 0 && (p.mesh_defer || MESH == 2)) {
+                        bool near;
+                        if (mesh_need(p, e, step, x0 + v * p.dt, 0.002f, near)) {
+                            const int slot = atomicAdd(p.mesh_cnt + step, 1);
+                            if (slot < p.mesh_cap) {
+                                p.mesh_list[slot] = make_int2(e | (ncand << 12), i | (int)0x80000000);
+                                p.cand_mark[eb + i] = step + 1;
+                            }
+                        }
+                        const unsigned long long nm = __builtin_amdgcn_ballot_w64(near);
+                        if (nm && lane == __builtin_ctzll(nm)) p.mesh_cnt[p.n_sub] = 1;
+                    }
+                }
+            }
             R2S_QP_DECL(-1);
-            finish_wave<MESH, MESH != 0, 0, true>(p, e, i, eb, step, last ? 1 : 0, x0, v, valid, out, nullptr, nullptr, nullptr, nullptr, wave == 0, &io R2S_QP_ARG);
+            finish_wave<MESH, MESH != 0, 0, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, v, fin, out, nullptr, nullptr, nullptr, nullptr, wave == 0, &io R2S_QP_ARG);
 #ifdef R2S_PHASE_PROBE
             if (io.x.x == 1.2345e33f) return;
 #endif
@@ -2222,6 +2253,7 @@ struct R2SPhys {
     int* d_cand_mark = nullptr;
     int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false;
     void* d_xch = nullptr;    // resident stepper: exchange array (96 B per particle)
+    bool split_ok = false;    // 64-particle layout whose slices fit k_steps_resident's registers (no remote neighbours, <= 64 interior / halo slots)
     bool resident_ok = false; // the handle can run the env step as ONE resident launch (k_steps_resident) in its free flavour
     int resident_pref = 1;    // R2S_RESIDENT=0 / r2s_phys_set_tuning: never pick the 64-particle layout / the resident launch
     int chains_override = 0;  // > 0: tuning override of chains() (R2S_CHAINS at create, r2s_phys_set_tuning later)
@@ -2415,7 +2447,13 @@ void launch_fused(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_
     const StateM out = h->state(in_buf ^ 1);
     if (h->pb == 256) launch_substep_layout<256, 1024>(p, grid, in, out, step, write_forces, with_self, mesh, s);
     else if (h->pb == 128) launch_substep_layout<128, 768>(p, grid, in, out, step, write_forces, with_self, mesh, s);
-    else launch_substep_layout<64, 512>(p, grid, in, out, step, write_forces, with_self, mesh, s);
+    else if (!h->split_ok) launch_substep_layout<64, 512>(p, grid, in, out, step, write_forces, with_self, mesh, s);
+    else { // small-batch layout: eight wavefronts per 64-particle block (k_steps_resident with one substep)
+#define R2S_LAUNCH64(SELF, MESH) hipLaunchKernelGGL((k_steps_resident<512, SELF, MESH>), grid, dim3(RES_THREADS), 0, s, p, in, out, step, 1, write_forces)
+        if (with_self) { if (mesh == 2) R2S_LAUNCH64(true, 2); else if (mesh == 1) R2S_LAUNCH64(true, 1); else R2S_LAUNCH64(true, 0); }
+        else { if (mesh == 2) R2S_LAUNCH64(false, 2); else if (mesh == 1) R2S_LAUNCH64(false, 1); else R2S_LAUNCH64(false, 0); }
+#undef R2S_LAUNCH64
+    }
 }
 
 // What the fused kernel left unfinished: with something near a mesh (mesh_defer) ONE combined finishing kernel per substep —
@@ -2500,8 +2538,8 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
 #else
         const bool with_mesh = h->nF > 0;
 #endif
-        if (with_mesh) hipLaunchKernelGGL((k_steps_resident<512, 1>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n);
-        else hipLaunchKernelGGL((k_steps_resident<512, 0>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n);
+        if (with_mesh) hipLaunchKernelGGL((k_steps_resident<512, false, 1>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
+        else hipLaunchKernelGGL((k_steps_resident<512, false, 0>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
         return R2S_OK;
     }
     int buf = start_buf;
@@ -3154,7 +3192,8 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         bool fits = true; // a wavefront keeps at most RES_NG interior and RES_NG halo groups of a slice in registers (every fourth group each)
         for (int sl = 0; sl < h->n_slices && h->pb == 64; ++sl)
             fits = fits && h->h_slice_int[sl] <= (RES_THREADS / 64) * RES_NG * GROUP && h->h_slice_deg[sl] - h->h_slice_int[sl] <= (RES_THREADS / 64) * RES_NG * GROUP;
-        h->resident_ok = h->pb == 64 && !remote && fits && !h->any_large && (int64_t)h->nb * E <= RES_MAX_ITEMS;
+        h->split_ok = h->pb == 64 && !remote && fits;
+        h->resident_ok = h->split_ok && !h->any_large && (int64_t)h->nb * E <= RES_MAX_ITEMS;
         if (h->resident_ok) {
             TRY(dev_alloc((char**)&h->d_xch, (size_t)96 * E * N));
             R2S_HIP_TRY(hipMemsetAsync(h->d_xch, 0, (size_t)96 * E * N, s));
