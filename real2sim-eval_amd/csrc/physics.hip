@@ -1409,6 +1409,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     }
 #ifdef R2S_PHASE_PROBE // wall clock (100 MHz) spent per phase by wavefront 0, summed over the launch: own gather + poll | halo gather + reduce | finish | publish; [4] poll passes
     long long pr_acc[5] = {0, 0, 0, 0, 0}, pr_t = (long long)wall_clock64();
+    const long long pr_w0 = pr_t, pr_c0 = (long long)__builtin_readcyclecounter(); // shader clock = cycles / wall ticks x 100 MHz
 #define R2S_RSTAMP(kk) do { const long long now_ = (long long)wall_clock64(); pr_acc[kk] += now_ - pr_t; pr_t = now_; } while (0)
 #else
 #define R2S_RSTAMP(kk) do { } while (0)
@@ -1527,7 +1528,12 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
         }
     }
 #ifdef R2S_PHASE_PROBE
-    if (tid == 0 && item < 8192 / 2) { for (int kk = 0; kk < 4; ++kk) g_phase_probe[item * 8 + kk] = pr_acc[kk]; g_phase_probe[item * 8 + 4] = pr_acc[4]; }
+    if (tid == 0 && item < 8192 / 2) {
+        for (int kk = 0; kk < 4; ++kk) g_phase_probe[item * 8 + kk] = pr_acc[kk];
+        g_phase_probe[item * 8 + 4] = pr_acc[4];
+        g_phase_probe[item * 8 + 5] = (long long)__builtin_readcyclecounter() - pr_c0;
+        g_phase_probe[item * 8 + 6] = (long long)wall_clock64() - pr_w0;
+    }
 #endif
 }
 

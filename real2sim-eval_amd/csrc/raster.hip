@@ -529,7 +529,10 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
             // issued before the current one is blended.  With eight wavefronts per SIMD (the 32-environment batches) other wavefronts
             // cover the ~100 cycles between a record's reads and its first use; a single environment's frames leave the deepest tile's
             // wavefronts alone on their SIMDs, and the serial read -> blend -> read chain WAS the kernel: 0.53 ms for two frames whose
-            // longest list has 3 326 instances.
+            // longest list has 3 326 instances (0.54 -> 0.47 ms; 0.92 -> 0.89 ms per 64 frames of the benchmark).  (Taking the live instances in
+            // PAIRS on top — the two alphas computed side by side behind scheduling barriers, then the two blends in list order, bit-identical
+            // images, 18 more registers, a variant for batches under 4096 tiles — was measured too: 0.466 -> 0.453 ms.  The lone wavefront issues
+            // ~one instruction per 8 cycles whatever the order: 22 VALU + 15 SALU per instance with mask results crossing between the two.)
             auto fetch = [&](int j, float4& a, float2& b, float4& c) {
                 const float4* rec = s_rec[buf] + 3 * j;
                 a = rec[0];

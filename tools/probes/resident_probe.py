@@ -23,3 +23,4 @@ a = np.array(buf, dtype=np.int64).reshape(n, 8).astype(np.float64)
 us = a[:, :4] * 0.01 / 667
 print("per substep, us: poll %.2f  gather+reduce %.2f  finish %.2f  publish %.2f   (mean over %d workgroups); poll passes per substep %.2f" % (*us.mean(0), n, a[:, 4].mean() / 666))
 print("max over workgroups:", us.max(0), "min:", us.min(0))
+print("shader clock over the launch: %.0f MHz (cycle counter / 100 MHz wall clock)" % (a[:, 5].sum() / a[:, 6].sum() * 100))
