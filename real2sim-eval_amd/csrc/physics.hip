@@ -49,6 +49,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -2616,6 +2617,43 @@ hipStream_t chain_side_stream(int c)
     return pool[dev][c];
 }
 
+// Resident launches of one device run one after the other, whatever handle and stream they come from: a launch needs ALL its
+// workgroups on the chip at once (one per CU: the kernel's registers leave room for one 512-thread workgroup per CU), and two of them
+// dispatched side by side from two hardware queues can each hold part of the chip while waiting for workgroups that no longer fit —
+// both would spin into their poll limit.  Each launch waits for the event of the previous one and records its own (same process only:
+// two PROCESSES stepping small batches on one GPU can still collide; the poll limit then turns the collision into an error return).
+struct ResidentGate {
+    std::mutex mu;
+    hipEvent_t last[16] = {};
+    bool recorded[16] = {};
+};
+ResidentGate& resident_gate() { static ResidentGate g; return g; }
+int resident_enter(hipStream_t s, int* dev_out)
+{
+    int dev = 0;
+    R2S_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return R2S_ERR_INVALID;
+    ResidentGate& g = resident_gate();
+    g.mu.lock(); // held until resident_leave: wait + launch + record must not interleave with another thread's
+    if (g.recorded[dev]) {
+        const hipError_t e = hipStreamWaitEvent(s, g.last[dev], 0);
+        if (e != hipSuccess) { g.mu.unlock(); R2S_HIP_TRY(e); }
+    }
+    *dev_out = dev;
+    return R2S_OK;
+}
+int resident_leave(hipStream_t s, int dev)
+{
+    ResidentGate& g = resident_gate();
+    hipError_t e = hipSuccess;
+    if (!g.last[dev]) e = hipEventCreateWithFlags(&g.last[dev], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(g.last[dev], s);
+    if (e == hipSuccess) g.recorded[dev] = true;
+    g.mu.unlock();
+    R2S_HIP_TRY(e);
+    return R2S_OK;
+}
+
 // Launch the captured env step: chain 0 on the caller's stream, the others on the device's side streams between a fork and a join.
 int launch_graphs(R2SPhys* h, int slot, hipStream_t s)
 {
@@ -3478,6 +3516,9 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     h->last_flavour[3] = use_graph ? h->chains() : 1;
     const bool resident = resident_flavour(h, variant == 1, h->mesh_defer);
     if (resident) h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)
+    int gate_dev = -1;
+    if (resident) { int rcg = resident_enter(s, &gate_dev); if (rcg) return rcg; }
+    struct GateLeave { hipStream_t s; int dev; ~GateLeave() { if (dev >= 0) (void)resident_leave(s, dev); } } gate_leave{s, gate_dev};
     if (use_graph) {
         // every flavour was captured at construction (capture_all); only set_params / set_tuning drop them
         const int slot = h->mesh_defer * 4 + variant * 2 + (h->cur & 1);

@@ -129,6 +129,40 @@ def test_resident_launch_next_to_a_busy_second_stream():
     assert np.array_equal(quiet.x.cpu().numpy(), busy.x.cpu().numpy()) and np.array_equal(quiet.v.cpu().numpy(), busy.v.cpu().numpy())
 
 
+def test_two_handles_on_two_streams_do_not_starve_each_other():
+    """A resident launch needs all its workgroups on the chip at once, one per CU; two handles stepping on two streams — 141 + 141
+    workgroups on 256 CUs — would each hold part of the chip and spin for workgroups that no longer fit.  The library runs the
+    resident launches of a device one after the other (event chain across handles): both rollouts finish and equal their solo runs."""
+    import torch
+
+    ob = _falling("sloth", 3000, seed=11)
+    kw = dict(num_substeps=100, self_collision=False)
+    solo = hip_env(ob, n_env=3, **kw)
+    for _ in range(4):
+        solo.step()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        a = hip_env(ob, n_env=3, **kw)
+    with torch.cuda.stream(s2):
+        b = hip_env(ob, n_env=3, **kw)
+    torch.cuda.synchronize()
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            a.step(sync_state=False)
+        with torch.cuda.stream(s2):
+            b.step(sync_state=False)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        xa = a.sync_state()[0].cpu().numpy()
+    with torch.cuda.stream(s2):
+        xb = b.sync_state()[0].cpu().numpy()
+    assert a.last_flavour()["resident"] and b.last_flavour()["resident"]
+    xs = solo.x.cpu().numpy()
+    assert np.array_equal(xa, xs) and np.array_equal(xb, xs)
+    a.step(); b.step()          # the sticky fault word of a timed-out hand-off would make these raise
+
+
 def test_large_batches_and_forced_layouts_keep_the_per_substep_path(monkeypatch):
     """More work items than the chip holds at once (or R2S_RESIDENT=0): the large-batch layout and one kernel per substep."""
     ob = _falling("sloth", 3000, seed=9)
