@@ -319,7 +319,9 @@ def main():
         ro.phys.set_resident(True)
     ro.phys.set_timing(False)
 
-    # stage timing of the raster pipeline (separate, untimed pass)
+    # stage timing of the raster pipeline (separate, untimed pass; drained first: the candidate rebuild of the last physics step runs
+    # on its own stream and would otherwise sit inside the stage events)
+    torch.cuda.synchronize(dev)
     ro.raster.set_timing(True)
     ro.render()
     torch.cuda.synchronize(dev)

@@ -359,31 +359,72 @@ __global__ void __launch_bounds__(256) k_gather_tiles(uint32_t G, const uint32_t
 }
 
 // duplicateWithKeys, rasterizer_impl.cu:70-111, walking the Gaussians in (frame, depth) order; key = frame-extended tile id.
+// Large rectangles (> RECT_SMALL_EMIT tiles) are walked by a whole wavefront.  Big batches (QUEUE = false): in place, by the wavefront
+// that owns them — 80 k wavefronts, a few large rectangles each.  Small batches (one environment's frames: a few hundred wavefronts on a
+// thousand SIMDs): a wavefront whose 64 Gaussians include many screen-filling splats IS the kernel (0.10 ms for 160 k instances), so
+// k_emit_keys only QUEUES them and k_emit_big drains the queue, one rectangle per wavefront, over the whole chip (0.057 ms).  Where an
+// instance lands is fixed by the scan of the tile counts, so the drain order does not matter.  (The queue for big batches too: 2.0 - 2.6
+// ms instead of 0.40 for the 64-frame benchmark batch — several 100 k appends through one counter, even one atomic per wavefront.)
+struct EmitJob { RectJob job; uint32_t off, tile_base, g; };
+__device__ __forceinline__ EmitJob emit_job(uint32_t i, int gx, int gy, const uint64_t* __restrict__ gkeys, const uint32_t* __restrict__ order,
+                                            const int* __restrict__ radii_all, const GeomRec* __restrict__ geom,
+                                            const uint32_t* __restrict__ offsets, int cull)
+{
+    EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
+    e.g = order[i];
+    const int r = radii_all[e.g];
+    if (r > 0) {
+        e.off = (i == 0) ? 0u : offsets[i - 1];
+        const float4 q0 = geom[e.g].q0;
+        const float4 q1 = geom[e.g].q1;
+        uint32_t x0, y0, x1, y1;
+        tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
+        e.tile_base = (uint32_t)(gkeys[i] >> 32) * (uint32_t)(gx * gy);
+        e.job = {q0.x, q0.y, q0.z, q0.w, q1.x, cull ? logf(1.0f / (255.0f * q1.y)) : 0.f, x0, y0, x1, y1};
+    }
+    return e;
+}
+template <bool QUEUE>
 __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ frames, uint32_t G, int gx, int gy, int W, int H,
                                                    const uint64_t* __restrict__ gkeys, const uint32_t* __restrict__ order,
                                                    const int* __restrict__ radii_all, const GeomRec* __restrict__ geom,
                                                    const uint32_t* __restrict__ offsets, uint32_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals, int cull, uint32_t cap, int* __restrict__ overflow)
+                                                   uint32_t* __restrict__ vals, int cull, uint32_t cap, int* __restrict__ overflow,
+                                                   uint32_t* __restrict__ big_q, int* __restrict__ big_n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i < G; // no early return: large rectangles are emitted by the whole wavefront (rect_walk)
+    const bool valid = i < G;
     if (valid && i == G - 1 && offsets[i] > cap) *overflow = 1; // sync-free mode: the scratch was sized from an earlier batch and is too small
-    RectJob job = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u};
-    uint32_t off = 0, tile_base = 0, g = 0;
-    if (valid) {
-        g = order[i];
-        const int r = radii_all[g];
-        if (r > 0) {
-            off = (i == 0) ? 0u : offsets[i - 1];
-            const float4 q0 = geom[g].q0;
-            const float4 q1 = geom[g].q1;
-            uint32_t x0, y0, x1, y1;
-            tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
-            tile_base = (uint32_t)(gkeys[i] >> 32) * (uint32_t)(gx * gy);
-            job = {q0.x, q0.y, q0.z, q0.w, q1.x, cull ? logf(1.0f / (255.0f * q1.y)) : 0.f, x0, y0, x1, y1};
+    EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
+    if (valid) e = emit_job(i, gx, gy, gkeys, order, radii_all, geom, offsets, cull);
+    const bool big = QUEUE && (e.job.x1 - e.job.x0) * (e.job.y1 - e.job.y0) > RECT_SMALL_EMIT;
+    const unsigned long long bm = __builtin_amdgcn_ballot_w64(big);
+    if (QUEUE && bm) { // one atomic per wavefront
+        const int lane = (int)(threadIdx.x & 63), leader = __builtin_ctzll(bm);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(big_n, __builtin_popcountll(bm));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if (big) {
+            big_q[base + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = i;
+            e.job.x1 = e.job.x0; // nothing left for this lane here
         }
     }
-    (void)rect_walk<true>(job, W, H, off, cap, tile_base, g, keys, vals, gx, cull != 0);
+    (void)rect_walk<true>(e.job, W, H, e.off, cap, e.tile_base, e.g, keys, vals, gx, cull != 0);
+}
+__global__ void __launch_bounds__(256) k_emit_big(uint32_t G, int gx, int gy, int W, int H, const uint64_t* __restrict__ gkeys,
+                                                  const uint32_t* __restrict__ order, const int* __restrict__ radii_all,
+                                                  const GeomRec* __restrict__ geom, const uint32_t* __restrict__ offsets,
+                                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int cull, uint32_t cap,
+                                                  const uint32_t* __restrict__ big_q, const int* __restrict__ big_n)
+{
+    const int n = *big_n;
+    const int lane = (int)(threadIdx.x & 63);
+    const int waves = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int q = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); q < n; q += waves) { // wave-uniform: one rectangle per trip
+        EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
+        if (lane == 0) e = emit_job(big_q[q], gx, gy, gkeys, order, radii_all, geom, offsets, cull); // rect_walk broadcasts lane 0's rectangle
+        (void)rect_walk<true>(e.job, W, H, e.off, cap, e.tile_base, e.g, keys, vals, gx, cull != 0);
+    }
 }
 
 // identifyTileRanges, rasterizer_impl.cu:116-138.
@@ -755,19 +796,19 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         rocprim::double_buffer<uint32_t> dv((uint32_t*)nullptr, (uint32_t*)nullptr);
         R2S_HIP_TRY(rocprim::radix_sort_pairs<GaussSortConfig>(nullptr, gsort_bytes, dk, dv, G ? G : 1, 0u, 32u + fbits, stream));
     }
-    float* depths; int* radii_all; GeomRec* geom; uint32_t* tiles_touched; uint32_t* tiles_sorted; uint32_t* offsets; char* scan_tmp; int* err_flag;
+    float* depths; int* radii_all; GeomRec* geom; uint32_t* tiles_touched; uint32_t* tiles_sorted; uint32_t* offsets; char* scan_tmp; int* err_flag; uint32_t* big_q;
     uint64_t *gkeys_a, *gkeys_b; uint32_t *gvals_a, *gvals_b; char* gsort_tmp;
     {
         r2s::Carver sz(nullptr);
         sz.take<float>(G); sz.take<int>(G); sz.take<GeomRec>(G); sz.take<uint32_t>(G); sz.take<uint32_t>(G); sz.take<uint32_t>(G);
-        sz.take<char>(scan_bytes); sz.take<int>(4);
+        sz.take<char>(scan_bytes); sz.take<int>(4); sz.take<uint32_t>(G);
         sz.take<uint64_t>(G); sz.take<uint64_t>(G); sz.take<uint32_t>(G); sz.take<uint32_t>(G); sz.take<char>(gsort_bytes);
         char* p = c->scratch(0, sz.bytes());
         if (!p) return R2S_ERR_ALLOC;
         r2s::Carver cv(p);
         depths = cv.take<float>(G); radii_all = cv.take<int>(G); geom = cv.take<GeomRec>(G);
         tiles_touched = cv.take<uint32_t>(G); tiles_sorted = cv.take<uint32_t>(G); offsets = cv.take<uint32_t>(G);
-        scan_tmp = cv.take<char>(scan_bytes); err_flag = cv.take<int>(4);
+        scan_tmp = cv.take<char>(scan_bytes); err_flag = cv.take<int>(4); big_q = cv.take<uint32_t>(G);
         gkeys_a = cv.take<uint64_t>(G); gkeys_b = cv.take<uint64_t>(G); gvals_a = cv.take<uint32_t>(G); gvals_b = cv.take<uint32_t>(G);
         gsort_tmp = cv.take<char>(gsort_bytes);
     }
@@ -866,8 +907,14 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
 
         if (sync_free) // instances this batch does not produce: sentinel keys that sort behind every (frame, tile)
             hipLaunchKernelGGL(k_fill_sentinel, dim3((cap + 255) / 256), dim3(256), 0, stream, offsets + (G - 1), cap, (uint32_t)F * (uint32_t)tiles, keys_a);
-        hipLaunchKernelGGL(k_emit_keys, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
-                           order, radii_all, geom, offsets, keys_a, vals_a, c->cull, cap, err_flag + 1);
+        if (G <= (size_t)1 << 18) { // small batch: large rectangles through the queue (see k_emit_keys)
+            hipLaunchKernelGGL(k_emit_keys<true>, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
+                               order, radii_all, geom, offsets, keys_a, vals_a, c->cull, cap, err_flag + 1, big_q, err_flag + 2);
+            hipLaunchKernelGGL(k_emit_big, dim3(1024), dim3(256), 0, stream, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
+                               order, radii_all, geom, offsets, keys_a, vals_a, c->cull, cap, big_q, err_flag + 2);
+        } else
+            hipLaunchKernelGGL(k_emit_keys<false>, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
+                               order, radii_all, geom, offsets, keys_a, vals_a, c->cull, cap, err_flag + 1, big_q, err_flag + 2);
         mark(3);
         rocprim::double_buffer<uint32_t> dkey(keys_a, keys_b);
         rocprim::double_buffer<uint32_t> dval(vals_a, vals_b);

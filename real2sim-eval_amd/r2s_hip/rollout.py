@@ -349,6 +349,10 @@ class BatchedRollout:
         # graph flavour on the host — has long landed when the next step starts, and the host never waits for the GPU
         if self.phys.self_collision and not self._cand_fresh:
             self.phys.update_collision_graph()
+        ev = getattr(self, "_cand_done", None)
+        if ev is not None:                                  # the rebuild enqueued next to the previous step's rendering (below)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._cand_done = None
         if self.with_gripper:
             self.apply_action(action if action is not None else self.synthetic_action(self.t))
         lg = self._log
@@ -360,7 +364,19 @@ class BatchedRollout:
             self.phys.log_contacts(lg["counts"][lg["i"]])
             lg["flavour"].append(self.phys.last_flavour()["kernel"] + f" x{self.phys.last_flavour()['chains']} chains")
         if self.phys.self_collision:
-            self.phys.update_collision_graph()
+            # ... on a second stream: the rebuild (spatial sort + candidate lists: 0.1 ms for one environment, 0.3 ms for 32) only reads the
+            # state this step left, like the skinning + rasterisation that follow on the launch stream, and nothing before the next
+            # step's substeps needs its result — so the two run side by side instead of one after the other
+            main = torch.cuda.current_stream(self.device)
+            if getattr(self, "_cand_stream", None) is None:
+                self._cand_stream = torch.cuda.Stream(device=self.device)
+            stepped = torch.cuda.Event()
+            stepped.record(main)
+            self._cand_stream.wait_event(stepped)
+            with torch.cuda.stream(self._cand_stream):
+                self.phys.update_collision_graph()
+                self._cand_done = torch.cuda.Event()
+                self._cand_done.record(self._cand_stream)
             self._cand_fresh = True
 
     # ---- per-step log of a timed window: stamps on the launch stream + contact counters kept on the device ------------
