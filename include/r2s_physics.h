@@ -182,6 +182,12 @@ int r2s_phys_set_tuning(R2SPhys* h, int chains, int mesh_defer);
  * with the per-substep kernels of the same layout (tests compare the two; R2S_RESIDENT=0 at create also keeps the large-batch
  * layout).  Results of the two agree to the last bits (different summation order), not bit for bit. */
 int r2s_phys_set_resident(R2SPhys* h, int on);
+/* The device's pooled side stream k (1 .. 7) — the streams the library launches the kernel chains 1.. of an env step on; created on
+ * first use, shared by every handle of the current device, never destroyed.  For callers that want work of their own next to the
+ * launch stream BETWEEN env steps (the rollout runs update_collision_graph there while the launch stream renders): a stream of the
+ * caller's own would be one more hardware queue, and with more streams than queues the chains of the next step share one and
+ * serialise (measured: 10.2 -> 12.2 us per batched substep on the 32-environment T-block scene). */
+int r2s_phys_side_stream(int32_t k, r2s_stream_t* out);
 
 /* Layout report (DESIGN.md / bench.py): out[0] particle blocks, [1] largest halo (records), [2] ELL slots incl.
  * padding, [3] real neighbour slots (= 2 * active springs), [4] slots served by the global fallback instead of LDS,

@@ -140,8 +140,8 @@ struct PhysDev {
     const float* aabb_static;  // [E,n_mesh-n_dyn_mesh,6]
     float* coll_forces;        // [E,nF,3]
     int* hit_cnt;              // [E] particles that reacted to a mesh in the LAST substep (zeroed with coll_forces)
-    int* fault;                // sticky: 1 = a self-collision impulse exceeded the bound the "no mesh in reach" decision relies on; 2 = a
-                               // hand-off of the resident stepper timed out
+    int* fault;                // [0] sticky: 1 = a self-collision impulse exceeded the bound the "no mesh in reach" decision relies on; 2 = a
+                               // hand-off of the resident stepper timed out; [1] a particle needed a mesh query since the host last looked
     void* xch;                 // resident stepper: exchange array [E][2 buffers][3 planes][N] x 16 B {value, tag, value, tag}
 };
 
@@ -872,6 +872,12 @@ __device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 
 // the total union, and then of any mesh's, the per-substep tests — and the loads of the substep's boxes, two dependent round trips
 // in the critical path of every substep — are skipped; otherwise the exact tests run as in k_substep.
 constexpr int RES_MAX_MESH = 4;
+// Reach of the early-out beyond a mesh's margin.  Small batches pick their flavour from "a query was NEEDED" (a particle inside a margin),
+// not from "something is NEAR" (margin + 3 cm), so a resident launch only has to find the particles inside a margin exactly; with the
+// 3 cm of the large-batch rule every block under a hovering gripper ran the exact per-substep tests (two dependent loads in the
+// finishing code) and paced the whole chain: 2.7 instead of 2.3 us per substep.  The "near" flag of a resident launch is therefore only
+// raised from within this reach.
+constexpr float RES_RANGE_PAD = 0.002f;
 struct ResidentIO {
     f3 x, v;               // out: the particle's new state
     const float* boxes;    // in (LDS, wave-uniform values — 35 registers per lane if they lived there): [0..5] union of everything, [6] (largest
@@ -928,6 +934,10 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
             // 1.5 - 2 us per substep in the pusher and grasp scenes)
             const unsigned long long nm = __builtin_amdgcn_ballot_w64(near);
             if (nm && (int)(threadIdx.x & 63) == __builtin_ctzll(nm)) p.mesh_cnt[p.n_sub] = 1;
+            // "a query was needed" (a particle inside a margin's reach), sticky until the host has read it: what small batches pick the
+            // next step's flavour from (r2s_phys_step) — their free flavour is the resident launch, worth keeping while the gripper merely hovers
+            const unsigned long long qm = __builtin_amdgcn_ballot_w64(need);
+            if (qm && (int)(threadIdx.x & 63) == __builtin_ctzll(qm)) p.fault[1] = 1;
             if (need && (p.mesh_defer || MESH == 2)) { // large scenes always defer: the fused kernel carries no query code
                 const int slot = atomicAdd(p.mesh_cnt + step, 1);
                 if (slot < p.mesh_cap) {
@@ -1171,6 +1181,7 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
                 // Such a particle goes to the mesh list TAGGED: k_contact_finish applies its impulses and queries in one go.
                 bool near;
                 if (mesh_need(p, e, step, x0 + v * p.dt, 0.002f, near)) {
+                    p.fault[1] = 1;
                     const int slot = atomicAdd(p.mesh_cnt + step, 1);
                     if (slot < p.mesh_cap) {
                         p.mesh_list[slot] = make_int2(e | (ncand << 12), i | (int)0x80000000);
@@ -1398,12 +1409,12 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                 }
                 float mg = 0.f;
                 for (int mm = m; mm < p.n_mesh; mm += (m == RES_MAX_MESH - 1 ? 1 : p.n_mesh)) mg = fmaxf(mg, mesh_margin(p, mm)); // slot m: mesh m (the last slot: every mesh from it on)
-                const float r = mg + NEAR_PAD;
+                const float r = mg + RES_RANGE_PAD;
                 box_s[8 + 8 * m + 6] = m < p.n_mesh ? r * r * 1.0001f : 0.f;
                 if (m < p.n_mesh) mgmax = fmaxf(mgmax, mg);
             }
             for (int c = 0; c < 6; ++c) box_s[c] = ub[c];
-            const float r = mgmax + NEAR_PAD;
+            const float r = mgmax + RES_RANGE_PAD;
             box_s[6] = r * r * 1.0001f;
         }
         // visible to the finishing wavefronts after barrier A of the first substep
@@ -1498,6 +1509,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                     if (MESH != 0 && (p.mesh_defer || MESH == 2)) {
                         bool near;
                         if (mesh_need(p, e, step, x0 + v * p.dt, 0.002f, near)) {
+                            p.fault[1] = 1;
                             const int slot = atomicAdd(p.mesh_cnt + step, 1);
                             if (slot < p.mesh_cap) {
                                 p.mesh_list[slot] = make_int2(e | (ncand << 12), i | (int)0x80000000);
@@ -3222,10 +3234,10 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         if (h->prm.self_collision) { TRY(dev_alloc(&h->d_cand_mark, (size_t)E * N)); R2S_HIP_TRY(hipMemsetAsync(h->d_cand_mark, 0, sizeof(int) * (size_t)E * N, s)); }
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_cnt, 0, sizeof(int) * 8 * (size_t)(h->prm.num_substeps + 1), s));
     }
-    TRY(dev_alloc(&h->d_mesh_total, 4)); // [0] particles near a mesh in the last step, [1] sticky fault word (PhysDev::fault)
+    TRY(dev_alloc(&h->d_mesh_total, 4)); // [0] particles near a mesh in the last step, [1] sticky fault word (PhysDev::fault), [2] a mesh query was needed
     R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int) * 4, s));
     R2S_HIP_TRY(hipHostMalloc((void**)&h->h_mesh_total, 64, hipHostMallocDefault));
-    h->h_mesh_total[0] = 0; h->h_mesh_total[1] = 0;
+    h->h_mesh_total[0] = 0; h->h_mesh_total[1] = 0; h->h_mesh_total[2] = 0;
     R2S_HIP_TRY(hipEventCreateWithFlags(&h->mesh_event, hipEventDisableTiming));
     {
         // the resident launch needs: the 64-particle layout, every neighbour inside the block's window (a remote neighbour would be read
@@ -3508,7 +3520,11 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         return R2S_ERR_INVALID;
     }
     if (h->nF > 0) { // defer the mesh queries to k_contact_finish when the last finished step saw particles near a mesh
-        if (!h->mesh_pending) h->mesh_defer = *h->h_mesh_total > 0 ? 1 : 0; // an unfinished count keeps the previous flavour
+        // an unfinished count keeps the previous flavour.  Large batches defer as soon as anything is NEAR a mesh (an idle finishing launch
+        // costs them ~0.7 us per substep, an in-place query in the fused kernel up to 190); small batches only once a query was NEEDED:
+        // their free flavour is the resident launch (2.3 vs 7.2 us per substep for the rope), and a gripper hovering within 3 cm is free
+        // motion — the step in which the first particle enters a margin pays for its in-place queries once
+        if (!h->mesh_pending) h->mesh_defer = (h->resident_ok && h->resident_pref ? h->h_mesh_total[2] : h->h_mesh_total[0]) > 0 ? 1 : 0;
         if (h->force_defer >= 0) h->mesh_defer = h->force_defer; // test / tuning: force a flavour
         if (h->any_large) h->mesh_defer = 1;
     }
@@ -3538,7 +3554,8 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     if ((h->nF > 0 || h->resident_ok) && !h->mesh_pending) { // particles near a mesh during this step (+ the fault word) -> pinned memory, read at a later step without waiting
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int), s));
         if (h->nF > 0) hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(64), 0, s, h->d_mesh_cnt + h->prm.num_substeps, 8, h->prm.num_substeps + 1, h->d_mesh_total);
-        R2S_HIP_TRY(hipMemcpyAsync(h->h_mesh_total, h->d_mesh_total, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        R2S_HIP_TRY(hipMemcpyAsync(h->h_mesh_total, h->d_mesh_total, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total + 2, 0, sizeof(int), s)); // "a query was needed": counted from here on
         R2S_HIP_TRY(hipEventRecord(h->mesh_event, s));
         h->mesh_pending = true;
     }
@@ -3616,6 +3633,15 @@ int r2s_phys_set_tuning(R2SPhys* h, int chains, int mesh_defer)
     h->chains_override = chains > 0 ? chains : 0;
     h->force_defer = mesh_defer < 0 ? -1 : (mesh_defer != 0);
     drop_graph(h);
+    return R2S_OK;
+}
+
+int r2s_phys_side_stream(int32_t k, r2s_stream_t* out)
+{
+    if (!out || k < 1 || k >= R2SPhys::MAX_CHAINS) return R2S_ERR_INVALID;
+    hipStream_t s = chain_side_stream(k);
+    if (!s) return R2S_ERR_HIP;
+    *out = (r2s_stream_t)s;
     return R2S_OK;
 }
 

@@ -55,7 +55,7 @@ def _bind():
         r2s_phys_set_eef_table=[vp, C.c_int32, vp, vp, C.c_float, vp], r2s_phys_set_eef_motion=[vp, vp, vp, vp, vp, vp, vp],
         r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
         r2s_phys_set_collision_lists=[vp, vp, vp, vp], r2s_phys_contact_stats=[vp, C.POINTER(C.c_int32), C.POINTER(vp)],
-        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32], r2s_phys_set_resident=[vp, i32],
+        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32], r2s_phys_set_resident=[vp, i32], r2s_phys_side_stream=[i32, C.POINTER(vp)],
         r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
     ).items():
         fn = getattr(L, name)
@@ -354,6 +354,14 @@ class PhysBatch:
 
     def set_tuning(self, chains: int = 0, mesh_defer: int = -1):
         check(_bind().r2s_phys_set_tuning(self._h, int(chains), int(mesh_defer)), "r2s_phys_set_tuning")
+
+    def side_stream(self, k: int = 1):
+        """The device's pooled side stream k as a torch stream (r2s_physics.h: one of the streams the env step's kernel chains run on;
+        idle between env steps)."""
+        p = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_side_stream(int(k), C.byref(p)), "r2s_phys_side_stream")
+        return torch.cuda.ExternalStream(p.value, device=self.device)
 
     def set_resident(self, on: bool):
         """Small batches only (r2s_physics.h): run the env step's free flavour as one resident launch (default) or, off, with

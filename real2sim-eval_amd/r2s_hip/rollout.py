@@ -15,6 +15,8 @@ Synthetic inputs only: there is no network for the real PhysTwi
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -367,9 +369,14 @@ class BatchedRollout:
             # ... on a second stream: the rebuild (spatial sort + candidate lists: 0.1 ms for one environment, 0.3 ms for 32) only reads the
             # state this step left, like the skinning + rasterisation that follow on the launch stream, and nothing before the next
             # step's substeps needs its result — so the two run side by side instead of one after the other
+            if os.environ.get("R2S_CAND_STREAM", "1") == "0":     # knob: rebuild on the launch stream, before the rendering
+                self.phys.update_collision_graph()
+                self._cand_fresh = True
+                return
             main = torch.cuda.current_stream(self.device)
             if getattr(self, "_cand_stream", None) is None:
-                self._cand_stream = torch.cuda.Stream(device=self.device)
+                self._cand_stream = self.phys.side_stream(1)   # a pooled stream of the library, idle between env steps: a stream of our own
+                                                               # would be one more hardware queue, and the next step's chains would share one
             stepped = torch.cuda.Event()
             stepped.record(main)
             self._cand_stream.wait_event(stepped)
