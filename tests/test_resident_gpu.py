@@ -66,9 +66,10 @@ def test_resident_launch_is_deterministic_and_partial_steps_compose():
 
 
 def test_resident_launch_with_fingers_hovering_then_touching():
-    """Moving finger meshes: while they hover beyond margin + 3 cm the union-box early-out skips every per-mesh test; when they
-    come down the in-range wavefronts run the exact tests and the in-place queries inside the resident launch (the first env step
-    in reach: the host only switches to the deferred flavour one step later).  Both against the oracle, forces included."""
+    """Moving finger meshes: while they hover the union-box early-out skips every per-mesh test and the batch stays on the resident
+    launch (small batches defer once a query was NEEDED, not when something is merely near); when the fingers come down the
+    wavefronts in reach run the exact tests and the in-place queries inside the resident launch (the first env step in reach: the
+    host switches to the deferred flavour one step later).  All against the oracle, forces included."""
     import torch
     from r2s_hip import synth
 
@@ -97,12 +98,17 @@ def test_resident_launch_with_fingers_hovering_then_touching():
         for m in (0, 1):
             tot_o, tot_h = o.collision_forces[h.mesh_map == m].sum(0), f[h.mesh_map == m].sum(0)
             assert np.allclose(tot_h, tot_o, rtol=1e-3, atol=max(np.abs(tot_o).max() * 1e-3, 1e-6)), (m, tot_o, tot_h)
-        return float(np.abs(x - o.x).max()), int(h.deferred_counts()[n_sub])
+        near = int(h.deferred_counts()[n_sub])
+        h.step()                                               # the flavour of THIS step follows from what the previous one saw
+        return float(np.abs(x - o.x).max()), near, h.last_flavour()
 
-    e_far, near_far = run(0.09, (0.0, 0.0, -0.5), False)      # 9 cm up, 3 mm down per step: never within margin + NEAR_PAD
-    assert near_far == 0
-    e_hit, near_hit = run(0.03, (0.0, 0.0, -6.0), True)       # the scenario of test_gripper_fingers_dynamic_mesh
-    assert near_hit != 0, "particles near the fingers must be reported (the host picks the next step's flavour from it)"
+    e_far, near_far, fl = run(0.09, (0.0, 0.0, -0.5), False)  # 9 cm up, 3 mm down per step
+    assert near_far == 0 and fl["resident"]
+    e_hov, _, fl = run(0.02, (0.0, 0.0, -0.05), False)        # hovering 2 cm above the toy: "near" for a large batch, free motion for a small one
+    assert fl["resident"], "a small batch stays on the resident launch while no particle needs a mesh query"
+    e_hit, near_hit, fl = run(0.03, (0.0, 0.0, -6.0), True)   # the scenario of test_gripper_fingers_dynamic_mesh
+    assert near_hit != 0, "particles inside a margin must be reported"
+    assert not fl["resident"] and fl["deferred_mesh_queries"], "after a step that needed queries the next one runs the deferred flavour"
     record("resident stepper with finger meshes (hovering / in-place queries)", x_max_abs_hover=e_far, x_max_abs_contact=e_hit, tol=1e-5)
 
 
