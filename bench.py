@@ -310,12 +310,15 @@ def main():
     per_substep_us = None
     if ro.phys.last_flavour().get("resident"):
         ro.phys.set_resident(False)
-        for _ in range(3):
+        best = None
+        for _ in range(6):                        # the first steps capture their graph flavour (both parities of the state buffer): best of six
             ro.physics_step()
-        torch.cuda.synchronize(dev)
-        ms1, k1 = ro.phys.last_step_ms()
-        per_substep_us = {"avg_launch_us": ms1 / max(k1, 1) * 1e3, "kernel": ro.phys.last_flavour()["kernel"],
-                          "note": "r2s_phys_set_resident(0): one launch per substep, measured after the timed region"}
+            torch.cuda.synchronize(dev)
+            ms1, k1 = ro.phys.last_step_ms()
+            best = ms1 / max(k1, 1) * 1e3 if best is None else min(best, ms1 / max(k1, 1) * 1e3)
+        per_substep_us = {"avg_launch_us": best, "kernel": ro.phys.last_flavour()["kernel"],
+                          "note": "r2s_phys_set_resident(0): one launch per substep (large batches' flavour rule: deferred queries while anything is "
+                                  "within 3 cm of a mesh), best of six env steps after the timed region"}
         ro.phys.set_resident(True)
     ro.phys.set_timing(False)
 

@@ -165,7 +165,8 @@ int r2s_phys_deferred_counts(R2SPhys* h, int32_t* out, r2s_stream_t stream);
  * (tagged entries: object_collision impulses, :230-268, then mesh_collision, :295-421, by one workgroup) at least once during
  * the last r2s_phys_step.  HOST int32[1]; synchronises `stream`. */
 int r2s_phys_tagged_count(R2SPhys* h, int32_t* out, r2s_stream_t stream);
-/* Which captured flavour the last r2s_phys_step ran: out[0] self-collision variant (0/1), out[1] mesh template (0 none,
+/* Which captured flavour the last r2s_phys_step ran: out[0] bit 0 self-collision variant, bit 1 the handle's per-substep kernel is
+ * k_steps_resident with one substep (small-batch layout), out[1] mesh template (0 none,
  * 1 every mesh small: the fused kernel answers the rare query itself unless out[2], 2 a large mesh is present: the fused
  * kernel only lists), out[2] finishing kernel in the graph (0/1; always 1 with a large mesh; 2 = the env step ran as ONE resident
  * launch, see r2s_phys_set_resident), out[3] kernel chains. */

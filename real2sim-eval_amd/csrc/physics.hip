@@ -867,7 +867,7 @@ __device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 
 
 // The resident stepper's side channel into finish_wave: the finished state coming back, and boxes for the mesh early-out — per mesh
 // (meshes beyond RES_MAX_MESH share the last box) the union of its world boxes over all substeps of the launch, and the union of
-// those.  A particle farther from a union than margin + NEAR_PAD is neither within reach of nor near that mesh at any substep
+// those.  A particle farther from a union than margin + RES_RANGE_PAD is not within reach of that mesh at any substep
 // (every box lies inside its union, so its distance is at least the union's): when no lane of the wavefront is inside that range of
 // the total union, and then of any mesh's, the per-substep tests — and the loads of the substep's boxes, two dependent round trips
 // in the critical path of every substep — are skipped; otherwise the exact tests run as in k_substep.
@@ -881,8 +881,8 @@ constexpr float RES_RANGE_PAD = 0.002f;
 struct ResidentIO {
     f3 x, v;               // out: the particle's new state
     const float* boxes;    // in (LDS, wave-uniform values — 35 registers per lane if they lived there): [0..5] union of everything, [6] (largest
-                           // margin + NEAR_PAD)^2 widened by 1e-4 relative; then per mesh slot m at 8 + 8 m: [0..5] its union over the substeps,
-                           // [6] (its margin + NEAR_PAD)^2, widened (0 for unused slots: never in range)
+                           // margin + RES_RANGE_PAD)^2 widened by 1e-4 relative; then per mesh slot m at 8 + 8 m: [0..5] its union over the substeps,
+                           // [6] (its margin + RES_RANGE_PAD)^2, widened (0 for unused slots: never in range)
 };
 __device__ __forceinline__ bool resident_in_range(const ResidentIO& io, f3 next_x, bool fin)
 {
@@ -1216,24 +1216,28 @@ __global__ void __launch_bounds__(B, (B == 256 ? 6 : 1)) k_substep(const PhysDev
 // rope is 7.0 us per launch in a 7.6 us launch period for 0.15 us of arithmetic (profiles/r3_bench_kernel_stats_rope_1env.md):
 // two dependent staging round trips, one wavefront walking a particle's ~35 slots alone, the finishing code, the kernel
 // boundary.  This kernel keeps the env step on the chip instead:
-//   * one workgroup = ONE 64-particle ELL slice x FOUR wavefronts; wavefront w evaluates groups w, w+4, ... of every particle of
-//     the slice (its <= RES_NGR adjacency groups live in registers for the whole launch: no adjacency stream at all), the four
-//     partial forces meet in LDS and are added in a fixed order; every wavefront then finishes the particle redundantly (same
-//     inputs, same instructions, same result — nothing to broadcast), wavefront 0 owns the side effects;
-//   * own particles stay in registers and in the block's LDS window from substep to substep; only the HALO crosses workgroups:
-//     after a substep wavefront q publishes plane q of its 64 records as 16-byte {value, tag, value, tag} write-through stores
-//     (sc1) into a double-buffered exchange array, and the neighbours poll exactly the records of their halo list until both tags
-//     read the substep's number — the data is the flag (cdna_hip_programming.md, Guideline 16 R2: no fence, no flag, no grid
-//     barrier: a workgroup only ever waits for the blocks it shares springs with).  Two buffers are enough: a block publishes
-//     version v+1 (overwriting v-1) only after it has read version v of every neighbour, and a neighbour publishes v only after
-//     it has read v-1 of this block (halo lists are symmetric: they follow the springs);
+//   * one workgroup = ONE 64-particle ELL slice x EIGHT wavefronts (two per SIMD: one's LDS / dependent-issue latency is the other's issue
+//     slot); wavefront w evaluates groups w, w+8, ... of every particle of the slice (its <= RES_NG interior and RES_NG halo adjacency
+//     groups live in registers for the whole launch: no adjacency stream at all), the eight partial forces meet in LDS and are added in
+//     a fixed tree; wavefronts 0..2 then finish the particle redundantly (same inputs, same instructions, same result), wavefront 0
+//     owns the side effects, wavefront q publishes plane q;
+//   * own particles stay in the block's LDS window from substep to substep; only the HALO crosses workgroups: after a substep the three
+//     planes of the block's 64 records go out as 16-byte {value, tag, value, tag} write-through stores (sc1) into a double-buffered
+//     exchange array, and the neighbours poll exactly the records of their halo list until both tags read the substep's number — the
+//     data is the flag (cdna_hip_programming.md, Guideline 16 R2: no fence, no flag, no grid barrier: a workgroup only ever waits for
+//     the blocks it shares springs with).  Two buffers are enough: a block publishes version v+1 (overwriting v-1) only after it has
+//     read version v of every neighbour, and a neighbour publishes v only after it has read v-1 of this block (halo lists are
+//     symmetric: they follow the springs);
+//   * the 64-particle layout lists a particle's neighbours inside the block first: those groups are evaluated while the neighbours'
+//     records are still on their way, the poll follows, then the halo groups;
 //   * tags are substep numbers within the launch (1 ..), the exchange array is zeroed by a kernel node ahead of every launch;
-//     polls are bounded (RES_SPIN_LIMIT passes, then the sticky fault word and out: never a hang).
-// Used for the flavour "no particle has self-collision candidates, nothing within reach of a mesh" (in-place queries for the
-// rare needy particle, like k_substep without p.mesh_defer); every other flavour runs the per-substep kernels of the same
-// <64, 512> layout.  Results differ from k_substep's in the last bit (four partial sums instead of one running sum).
+//     polls are bounded (RES_SPIN_LIMIT passes, then the sticky fault word and out: never a hang); launches of one device are
+//     serialised across handles (resident_enter): a launch needs all its workgroups on the chip at once, one per CU.
+// Used for the flavour "no particle has self-collision candidates, no mesh query was needed in the last step" (in-place queries for
+// the first particle that enters a margin, like k_substep without p.mesh_defer); every other flavour runs this kernel with ONE substep
+// per launch (below).  Results differ from k_substep's in the last bits (eight partial sums, reciprocal mass).
 constexpr int RES_THREADS = 512;                // eight wavefronts: two per SIMD, so that one's LDS and dependent-issue latency is the other's issue slot
-constexpr int RES_NG = 2;                       // interior and halo adjacency groups a wavefront keeps in registers (each: every 4th group of the slice)
+constexpr int RES_NG = 2;                       // interior and halo adjacency groups a wavefront keeps in registers (each: every 8th group of the slice)
 constexpr unsigned RES_SPIN_LIMIT = 1u << 21;   // poll passes before a workgroup gives up (each >= one L2 round trip: seconds)
 constexpr int RES_AUX_SC1 = 16;                 // buffer-instruction cache policy: sc1 = agent scope (write-through store, L1-bypassing load)
 #ifndef R2S_RES_AUXLD
@@ -3528,7 +3532,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         if (h->force_defer >= 0) h->mesh_defer = h->force_defer; // test / tuning: force a flavour
         if (h->any_large) h->mesh_defer = 1;
     }
-    h->last_flavour[0] = variant; h->last_flavour[1] = h->nF > 0 ? (h->any_large ? 2 : 1) : 0; h->last_flavour[2] = h->mesh_defer;
+    h->last_flavour[0] = variant | (h->split_ok ? 2 : 0); h->last_flavour[1] = h->nF > 0 ? (h->any_large ? 2 : 1) : 0; h->last_flavour[2] = h->mesh_defer;
     h->last_flavour[3] = use_graph ? h->chains() : 1;
     const bool resident = resident_flavour(h, variant == 1, h->mesh_defer);
     if (resident) h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)

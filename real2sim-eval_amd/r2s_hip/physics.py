@@ -347,10 +347,12 @@ class PhysBatch:
         rcap = self.layout_stats()["lds_bytes"] // 24
         if a[2] == 2:       # the env step as one resident launch (small batches, free flavour)
             return dict(self_collision_kernel=False, mesh_template=int(a[1]), deferred_mesh_queries=False, chains=1, resident=True,
-                        kernel=f"k_steps_resident<{rcap},{int(a[1])}>")
-        return dict(self_collision_kernel=bool(a[0]), mesh_template=int(a[1]), deferred_mesh_queries=bool(a[2]), chains=int(a[3]), resident=False,
-                    kernel=f"k_substep<{ {1024: 256, 768: 128}.get(rcap, 64)},{rcap},{'true' if a[0] else 'false'},{int(a[1])}>"
-                           + (" + k_contact_finish" if a[2] else (" + k_self_finish" if a[0] else "")))
+                        kernel=f"k_steps_resident<{rcap},false,{int(a[1])}>")
+        sc, split = bool(a[0] & 1), bool(a[0] & 2)
+        return dict(self_collision_kernel=sc, mesh_template=int(a[1]), deferred_mesh_queries=bool(a[2]), chains=int(a[3]), resident=False,
+                    kernel=(f"k_steps_resident<{rcap},{'true' if sc else 'false'},{int(a[1])}> x 1 substep" if split else
+                            f"k_substep<{ {1024: 256, 768: 128}.get(rcap, 64)},{rcap},{'true' if sc else 'false'},{int(a[1])}>")
+                           + (" + k_contact_finish" if a[2] else (" + k_self_finish" if sc else "")))
 
     def set_tuning(self, chains: int = 0, mesh_defer: int = -1):
         check(_bind().r2s_phys_set_tuning(self._h, int(chains), int(mesh_defer)), "r2s_phys_set_tuning")
