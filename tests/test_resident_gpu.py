@@ -50,6 +50,46 @@ def test_resident_launch_vs_oracle_and_vs_the_per_substep_kernels(shape, n, n_en
     assert o.v[:, 2].max() > -0.2, "the scenario must reach the ground (free fall alone leaves every particle faster than -0.3 m/s)"
 
 
+def test_environments_with_different_states_and_a_stiffness_update_between_steps():
+    """Environments of one resident launch are independent: three environments of the same object with different initial velocities
+    and heights, each against its OWN oracle run (identical environments would hide an indexing slip between the per-environment
+    slices of the exchange array).  Between two env steps the stiffness is replaced (set_spring_Y: the adjacency the launch keeps in
+    registers is reloaded by the next launch)."""
+    from r2s_hip.physics import PhysBatch
+    from util_physics import DEFAULTS
+
+    ob = _falling("sloth", 3000, seed=13)
+    E, n_sub = 3, 100
+    x0 = np.repeat(ob["points"][None], E, 0).copy()
+    v0 = np.zeros_like(x0)
+    for e in range(E):
+        x0[e, :, 2] += 0.0004 * e
+        v0[e, :, 2] = -0.2 - 0.15 * e
+        v0[e, :, 0] = 0.05 * (e - 1)
+    kw = dict(DEFAULTS, num_substeps=n_sub, self_collision=False)
+    h = PhysBatch(init_vertices=x0, init_springs=ob["springs"], init_rest_lengths=ob["rest"], init_masses=np.ones(len(ob["points"]), np.float32),
+                  init_spring_Y=ob["log_Y"], init_velocities=v0, **kw)
+    oracles = []
+    for e in range(E):
+        oe = dict(ob, points=x0[e], v0=v0[e])
+        oracles.append(oracle_env(oe, num_substeps=n_sub, self_collision=False))
+    logy2 = (ob["log_Y"] + np.log(0.6)).astype(np.float32)
+    for k in range(3):
+        if k == 2:
+            h.set_spring_Y(logy2)
+            for o in oracles:
+                o.log_Y[:] = logy2            # the oracle reads its stiffness array every substep
+        h.step()
+        for o in oracles:
+            o.step()
+    assert h.last_flavour()["resident"]
+    x = h.x.cpu().numpy()
+    errs = [float(np.abs(x[e] - oracles[e].x).max()) for e in range(E)]
+    record("resident stepper, 3 different environments + stiffness update", x_max_abs_per_env=max(errs), tol=1e-5)
+    assert max(errs) < 1e-5, errs
+    assert np.abs(x[0] - x[2]).max() > 1e-3, "the environments must actually differ"
+
+
 def test_resident_launch_is_deterministic_and_partial_steps_compose():
     """Two handles, same inputs: bit-identical states.  And step(n, first) pieces — each its own resident launch, final state
     always in the OTHER buffer whatever the parity of n — compose to the full step bit for bit."""
