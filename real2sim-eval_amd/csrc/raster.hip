@@ -479,6 +479,9 @@ __global__ void __launch_bounds__(256) k_tile_len_keys(uint32_t n, const uint2* 
 // arithmetic is not the reference's to the bit: the conic is pre-scaled by log2(e) once per staged instance, the quadratic is an
 // FMA chain and the exponential is v_exp_f32 (2^x) — parity is by tolerance.  rgb and depth travel through LDS
 // with the rest of the record instead of being re-read from global memory inside the pixel loop (forward.cu:362).
+#if defined(R2S_COMP_STATS) && !defined(R2S_COMP_CXX)
+#define R2S_COMP_CXX // the lane statistics are taken inside the C++ form of the blend
+#endif
 #ifdef R2S_COMP_STATS // instrumented build (scratch/comp_stats.py): lane efficiency of the compositor
 __device__ unsigned long long g_comp_stats[4]; // wave iterations, hit lanes, iterations without a hit, lanes still alive
 extern "C" int r2s_raster_debug_comp_stats(unsigned long long* out, int reset)
@@ -508,6 +511,9 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
     const bool inside = px < W && py < H;
     const float pfx = (float)px, pfy = (float)py;
     bool done = !inside;
+#ifndef R2S_COMP_CXX
+    unsigned done_i = inside ? 0u : 1u; // the asm blend keeps the flag in a VGPR (its conditions live in EXEC, not in SGPR masks)
+#endif
 
     const uint2 range = ranges[ft];
     const int n = (int)(range.y - range.x);
@@ -561,6 +567,9 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
     auto consume = [&](int i, int buf) {
         const uint32_t base = (uint32_t)(i * TILE_THREADS);
         for (int sw = 0; sw < 4; ++sw) {
+#ifndef R2S_COMP_CXX
+            done = done_i != 0;
+#endif
             if (__builtin_amdgcn_ballot_w64(!done) == 0) break; // whole quadrant finished (forward.cu:315 per block)
             // the live word is wave-uniform: keep it in SGPRs so the walk is s_ff1 / s_andn2 and a scalar branch
             const unsigned long long lv = s_live[buf][wave][sw];
@@ -580,6 +589,69 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                 b = make_float2(rec[1].x, rec[1].y);
                 c = rec[2]; // depth, r, g, b — issued with the other two reads (one address register, no second v_mov)
             };
+#ifndef R2S_COMP_CXX
+            // The blend with its predicates in EXEC (round 3; -DR2S_COMP_CXX builds the C++ form below instead, which is the specification:
+            // forward.cu:339-380's sequence of decisions).  v_cmpx narrows the active lanes — pixel not done -> power <= 0 -> alpha >= 1/255 ->
+            // not ending —, the arithmetic runs on the lanes left, and the state of every other lane is simply not touched: instead of the
+            // compiler's three compares into SGPR masks, six scalar mask operations and four selects per instance, whose VALU -> SALU -> VALU
+            // hand-overs a lone wavefront pays in full.  Operation for operation the arithmetic of the C++ form (same products, same FMAs,
+            // same operand values; (C1, C2) as two FMAs instead of one packed FMA), so the images are bit-identical (sha256 of the benchmark
+            // batch and of the single-environment frames compared between the two builds).  0.88 -> 0.76 ms per 64 frames, 0.47 -> 0.37 ms
+            // for one environment's two frames.
+#define R2S_BLEND_ASM(EXTRA)                                                                                                            \
+                    "s_mov_b64 %[sv], exec\n\t"                                                                                           \
+                    "v_cmpx_eq_u32_e32 0, %[done]\n\t"                                                                                    \
+                    "v_sub_f32_e32 %[t0], %[ax], %[pfx]\n\t"                                                                              \
+                    "v_sub_f32_e32 %[t1], %[ay], %[pfy]\n\t"                                                                              \
+                    "v_mul_f32_e32 %[t2], %[aw], %[t1]\n\t"                                                                               \
+                    "v_mul_f32_e32 %[t3], %[t1], %[bx]\n\t"                                                                               \
+                    "v_fmac_f32_e32 %[t2], %[az], %[t0]\n\t"                                                                              \
+                    "v_mul_f32_e32 %[t3], %[t1], %[t3]\n\t"                                                                               \
+                    "v_fmac_f32_e32 %[t3], %[t0], %[t2]\n\t" /* power (x log2 e) */                                                        \
+                    "v_cmpx_nlt_f32_e32 0, %[t3]\n\t"        /* keep !(power > 0) */                                                       \
+                    "v_exp_f32_e32 %[t2], %[t3]\n\t"                                                                                      \
+                    "s_nop 1\n\t"                            /* trans result -> non-trans consumer */                                      \
+                    "v_mul_f32_e32 %[t2], %[by], %[t2]\n\t"                                                                               \
+                    "v_min_f32_e32 %[t2], 0x3f7d70a4, %[t2]\n\t" /* alpha = min(0.99, opacity * e) */                                     \
+                    "v_cmpx_ngt_f32_e32 0x3b808081, %[t2]\n\t"   /* keep !(alpha < 1/255) */                                              \
+                    "v_sub_f32_e32 %[t3], 1.0, %[t2]\n\t"                                                                                 \
+                    "v_mul_f32_e32 %[t3], %[T], %[t3]\n\t"       /* test_T = T * (1 - alpha) */                                           \
+                    "v_cmp_gt_f32_e32 vcc, 0x38d1b717, %[t3]\n\t" /* ends: test_T < 1e-4 */                                               \
+                    "v_cndmask_b32_e64 %[done], %[done], 1, vcc\n\t"                                                                      \
+                    "v_cmpx_ngt_f32_e32 0x38d1b717, %[t3]\n\t"   /* keep the lanes that blend */                                          \
+                    "v_mul_f32_e32 %[t2], %[T], %[t2]\n\t"       /* w = alpha * T */                                                      \
+                    "v_fmac_f32_e32 %[C0], %[cy], %[t2]\n\t"                                                                              \
+                    "v_fmac_f32_e32 %[C1], %[cz], %[t2]\n\t"                                                                              \
+                    "v_fmac_f32_e32 %[C2], %[cw], %[t2]\n\t"                                                                              \
+                    "v_cmp_lt_f32_e32 vcc, 0.5, %[T]\n\t"        /* T > 0.5 */                                                            \
+                    "v_cmp_gt_f32_e64 %[s2], 0.5, %[t3]\n\t"     /* test_T < 0.5 */                                                       \
+                    "s_and_b64 vcc, vcc, %[s2]\n\t"                                                                                       \
+                    "v_cndmask_b32_e32 %[D], %[D], %[cx], vcc\n\t" /* median depth: the blend that crosses T = 0.5 */                     \
+                    "v_mov_b32_e32 %[T], %[t3]\n\t"                                                                                       \
+                    EXTRA                                                                                                                  \
+                    "s_mov_b64 exec, %[sv]"
+            auto blend_one = [&](const float4 a, const float2 b, const float4 c, const int j) {
+                float t0, t1, t2, t3;
+                unsigned long long sv, s2;
+                if (AUX) {
+                    const uint32_t jid = base + (uint32_t)j + 1u; // as forward.cu:335,380
+                    asm volatile(R2S_BLEND_ASM("v_mov_b32_e32 %[last], %[jid]\n\t")
+                                 : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sv] "=&s"(sv), [s2] "=&s"(s2), [done] "+v"(done_i),
+                                   [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [D] "+v"(D), [last] "+v"(last_contributor)
+                                 : [ax] "v"(a.x), [ay] "v"(a.y), [az] "v"(a.z), [aw] "v"(a.w), [bx] "v"(b.x), [by] "v"(b.y), [cx] "v"(c.x), [cy] "v"(c.y),
+                                   [cz] "v"(c.z), [cw] "v"(c.w), [pfx] "v"(pfx), [pfy] "v"(pfy), [jid] "s"(jid)
+                                 : "vcc");
+                } else {
+                    asm volatile(R2S_BLEND_ASM("")
+                                 : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sv] "=&s"(sv), [s2] "=&s"(s2), [done] "+v"(done_i),
+                                   [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [D] "+v"(D)
+                                 : [ax] "v"(a.x), [ay] "v"(a.y), [az] "v"(a.z), [aw] "v"(a.w), [bx] "v"(b.x), [by] "v"(b.y), [cx] "v"(c.x), [cy] "v"(c.y),
+                                   [cz] "v"(c.z), [cw] "v"(c.w), [pfx] "v"(pfx), [pfy] "v"(pfy)
+                                 : "vcc");
+                }
+            };
+#undef R2S_BLEND_ASM
+#else
             auto blend_one = [&](const float4 a, const float2 b, const float4 c, const int j) {
                 const float dx = a.x - pfx, dy = a.y - pfy;
                 const float power = fmaf(dx, fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy); // = log2(e) * forward.cu:342's power
@@ -608,6 +680,7 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                 T = blend ? test_T : T;
                 if (AUX) last_contributor = blend ? base + (uint32_t)j + 1u : last_contributor; // as forward.cu:335,380
             };
+#endif
             if (bits) {
                 int j0 = sw * 64 + __builtin_ctzll(bits), j1 = 0;
                 bits &= bits - 1;
@@ -615,12 +688,20 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                 float2 b0, b1;
                 fetch(j0, a0, b0, c0);
                 for (;;) {
+                    // the next record is fetched UNCONDITIONALLY (record 0 of the word again when the walk is over): a fetch inside a branch
+                    // leaves the wait in front of the blend with "everything outstanding" on the merged path, i.e. no prefetch at all
                     const bool more = bits != 0;
-                    if (more) { j1 = sw * 64 + __builtin_ctzll(bits); bits &= bits - 1; fetch(j1, a1, b1, c1); }
+                    j1 = sw * 64 + (more ? __builtin_ctzll(bits) : 0);
+                    bits &= bits - 1;
+                    fetch(j1, a1, b1, c1);
+                    __builtin_amdgcn_sched_barrier(0); // the reads of the next record stay IN FRONT of this record's blend
                     blend_one(a0, b0, c0, j0);
                     if (!more) break;
                     const bool more2 = bits != 0;
-                    if (more2) { j0 = sw * 64 + __builtin_ctzll(bits); bits &= bits - 1; fetch(j0, a0, b0, c0); }
+                    j0 = sw * 64 + (more2 ? __builtin_ctzll(bits) : 0);
+                    bits &= bits - 1;
+                    fetch(j0, a0, b0, c0);
+                    __builtin_amdgcn_sched_barrier(0);
                     blend_one(a1, b1, c1, j1);
                     if (!more2) break;
                 }
@@ -628,6 +709,9 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
         }
     };
     for (int i = 0; i < rounds; ++i) {
+#ifndef R2S_COMP_CXX
+        done = done_i != 0;
+#endif
         if (__syncthreads_count(done) == TILE_THREADS) break;
         stage(i, 0);
         __syncthreads();
