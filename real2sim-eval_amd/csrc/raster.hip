@@ -608,9 +608,9 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
                     "v_fmac_f32_e32 %[t2], %[az], %[t0]\n\t"                                                                              \
                     "v_mul_f32_e32 %[t3], %[t1], %[t3]\n\t"                                                                               \
                     "v_fmac_f32_e32 %[t3], %[t0], %[t2]\n\t" /* power (x log2 e) */                                                        \
-                    "v_cmpx_nlt_f32_e32 0, %[t3]\n\t"        /* keep !(power > 0) */                                                       \
                     "v_exp_f32_e32 %[t2], %[t3]\n\t"                                                                                      \
-                    "s_nop 1\n\t"                            /* trans result -> non-trans consumer */                                      \
+                    "v_cmpx_nlt_f32_e32 0, %[t3]\n\t"        /* keep !(power > 0); also the wait state a trans result needs before a */    \
+                    "s_nop 0\n\t"                            /* non-trans consumer (lanes it drops computed an exponential nobody reads) */ \
                     "v_mul_f32_e32 %[t2], %[by], %[t2]\n\t"                                                                               \
                     "v_min_f32_e32 %[t2], 0x3f7d70a4, %[t2]\n\t" /* alpha = min(0.99, opacity * e) */                                     \
                     "v_cmpx_ngt_f32_e32 0x3b808081, %[t2]\n\t"   /* keep !(alpha < 1/255) */                                              \
