@@ -82,7 +82,10 @@ __device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int
 // positive-definite quadratic in d = mean - pixel; its maximum over the tile's pixel RECTANGLE (a superset of the pixel
 // lattice) is attained at the mean if that is inside, else on one of the two rectangle edges facing the mean.  The
 // instance is dropped only if that bound is 1 % below the threshold, so float rounding can never drop a live instance.
-__device__ __forceinline__ bool rect_can_contribute(float mx, float my, float ca, float cb, float cc, float log_thresh, float x_lo,
+// rdy = -cb / cc and rdx = -cb / ca (the unconstrained minimiser's slope along an edge) are formed ONCE per Gaussian by the caller: two IEEE
+// divisions per candidate tile were a third of this test's instructions, and the test is what k_preprocess and k_emit_keys are bound by.
+// (The bound is conservative with 0.01 of slack in the log domain; how its arithmetic rounds never changes a pixel.)
+__device__ __forceinline__ bool rect_can_contribute(float mx, float my, float ca, float cb, float cc, float rdy, float rdx, float log_thresh, float x_lo,
                                                     float x_hi, float y_lo, float y_hi)
 {
     const bool in_x = mx >= x_lo && mx <= x_hi, in_y = my >= y_lo && my <= y_hi;
@@ -90,23 +93,23 @@ __device__ __forceinline__ bool rect_can_contribute(float mx, float my, float ca
     float qmin = 3.0e38f;
     if (!in_x) { // vertical edge facing the mean: dx fixed, minimise over dy = my - y, y in [y_lo, y_hi]
         const float dx = mx - (mx < x_lo ? x_lo : x_hi);
-        const float dy_free = -cb * dx / cc;
+        const float dy_free = rdy * dx;
         const float dy = fminf(fmaxf(dy_free, my - y_hi), my - y_lo);
         qmin = fminf(qmin, ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy);
     }
     if (!in_y) {
         const float dy = my - (my < y_lo ? y_lo : y_hi);
-        const float dx_free = -cb * dy / ca;
+        const float dx_free = rdx * dy;
         const float dx = fminf(fmaxf(dx_free, mx - x_hi), mx - x_lo);
         qmin = fminf(qmin, ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy);
     }
     return !(-0.5f * qmin < log_thresh - 0.01f); // NaN-safe: anything odd keeps the instance
 }
 
-__device__ __forceinline__ bool tile_can_contribute(float mx, float my, float ca, float cb, float cc, float log_thresh, int tx, int ty,
+__device__ __forceinline__ bool tile_can_contribute(float mx, float my, float ca, float cb, float cc, float rdy, float rdx, float log_thresh, int tx, int ty,
                                                     int W, int H)
 {
-    return rect_can_contribute(mx, my, ca, cb, cc, log_thresh, (float)(tx * TILE), (float)min(tx * TILE + TILE - 1, W - 1),
+    return rect_can_contribute(mx, my, ca, cb, cc, rdy, rdx, log_thresh, (float)(tx * TILE), (float)min(tx * TILE + TILE - 1, W - 1),
                                (float)(ty * TILE), (float)min(ty * TILE + TILE - 1, H - 1));
 }
 
@@ -160,7 +163,7 @@ __device__ __forceinline__ void sh_to_rgb(int idx, int deg, int M, const float* 
 // and the emitted run of a Gaussian is written with consecutive lanes at consecutive offsets (the per-lane walk scatters
 // 4-byte stores: 8x the payload in HBM traffic, profiles/r2_pmc_summary.json).  Order and content of the lists are unchanged.
 struct RectJob {
-    float mx, my, ca, cb, cc, lt;
+    float mx, my, ca, cb, cc, lt, rdy, rdx; // rdy = -cb / cc, rdx = -cb / ca
     uint32_t x0, y0, x1, y1; // empty (x1 == x0) for lanes without a visible Gaussian
 };
 // measured on the benchmark scene (64 frames, wrist cameras on the grippers), per-lane limit 2 / 6 / 12 / 24 / 40 / 64 / 100 tiles:
@@ -180,7 +183,7 @@ __device__ __forceinline__ uint32_t rect_walk(const RectJob& j, int W, int H, ui
     if (n > 0 && !big) {
         for (uint32_t y = j.y0; y < j.y1; ++y)
             for (uint32_t x = j.x0; x < j.x1; ++x) {
-                if (test && !tile_can_contribute(j.mx, j.my, j.ca, j.cb, j.cc, j.lt, (int)x, (int)y, W, H)) continue;
+                if (test && !tile_can_contribute(j.mx, j.my, j.ca, j.cb, j.cc, j.rdy, j.rdx, j.lt, (int)x, (int)y, W, H)) continue;
                 if (EMIT) { if (off < cap) { keys[off] = tile_base + y * (uint32_t)gx + x; vals[off] = val; } ++off; }
                 ++count;
             }
@@ -191,7 +194,7 @@ __device__ __forceinline__ uint32_t rect_walk(const RectJob& j, int W, int H, ui
         m &= m - 1;
         auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); };
         auto bu = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, L); };
-        const float mx = bf(j.mx), my = bf(j.my), ca = bf(j.ca), cb = bf(j.cb), cc = bf(j.cc), lt = bf(j.lt);
+        const float mx = bf(j.mx), my = bf(j.my), ca = bf(j.ca), cb = bf(j.cb), cc = bf(j.cc), lt = bf(j.lt), rdy = bf(j.rdy), rdx = bf(j.rdx);
         const uint32_t x0 = bu(j.x0), y0 = bu(j.y0), wL = bu(w), nL = bu(n);
         uint32_t base = EMIT ? bu(off) : 0u;
         const uint32_t tb = EMIT ? bu(tile_base) : 0u, vL = EMIT ? bu(val) : 0u;
@@ -199,7 +202,7 @@ __device__ __forceinline__ uint32_t rect_walk(const RectJob& j, int W, int H, ui
         for (uint32_t t0 = 0; t0 < nL; t0 += 64) {
             const uint32_t t = t0 + (uint32_t)lane;
             const uint32_t ry = t / wL, rx = t - ry * wL;
-            const bool ok = t < nL && (!test || tile_can_contribute(mx, my, ca, cb, cc, lt, (int)(x0 + rx), (int)(y0 + ry), W, H));
+            const bool ok = t < nL && (!test || tile_can_contribute(mx, my, ca, cb, cc, rdy, rdx, lt, (int)(x0 + rx), (int)(y0 + ry), W, H));
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(ok);
             if (EMIT) {
                 const uint32_t pos = base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
     const size_t g = (size_t)fr.base + (valid ? idx : 0);
     int radius_out = 0;
     uint32_t tiles = 0;
-    RectJob job = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}; // candidate tiles still to be tested (exact-output culling)
+    RectJob job = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}; // candidate tiles still to be tested (exact-output culling)
     do {
         if (!valid) break;
         const float* vm = fr.view;
@@ -326,7 +329,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
         radius_out = (int)my_radius;
         tiles = (y1 - y0) * (x1 - x0);
         if (cull) { // a Gaussian whose every tile is culled keeps its radius (the reference reports it) but emits nothing
-            job = {pix, piy, ca, cb, cc, logf(1.0f / (255.0f * fr.opac[idx])), x0, y0, x1, y1};
+            job = {pix, piy, ca, cb, cc, logf(1.0f / (255.0f * fr.opac[idx])), -cb / cc, -cb / ca, x0, y0, x1, y1};
             tiles = 0;
         }
     } while (false);
@@ -370,7 +373,7 @@ __device__ __forceinline__ EmitJob emit_job(uint32_t i, int gx, int gy, const ui
                                             const int* __restrict__ radii_all, const GeomRec* __restrict__ geom,
                                             const uint32_t* __restrict__ offsets, int cull)
 {
-    EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
+    EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
     e.g = order[i];
     const int r = radii_all[e.g];
     if (r > 0) {
@@ -380,7 +383,7 @@ __device__ __forceinline__ EmitJob emit_job(uint32_t i, int gx, int gy, const ui
         uint32_t x0, y0, x1, y1;
         tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
         e.tile_base = (uint32_t)(gkeys[i] >> 32) * (uint32_t)(gx * gy);
-        e.job = {q0.x, q0.y, q0.z, q0.w, q1.x, cull ? logf(1.0f / (255.0f * q1.y)) : 0.f, x0, y0, x1, y1};
+        e.job = {q0.x, q0.y, q0.z, q0.w, q1.x, cull ? logf(1.0f / (255.0f * q1.y)) : 0.f, -q0.w / q1.x, -q0.w / q0.z, x0, y0, x1, y1};
     }
     return e;
 }
@@ -395,7 +398,7 @@ __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < G;
     if (valid && i == G - 1 && offsets[i] > cap) *overflow = 1; // sync-free mode: the scratch was sized from an earlier batch and is too small
-    EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
+    EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
     if (valid) e = emit_job(i, gx, gy, gkeys, order, radii_all, geom, offsets, cull);
     const bool big = QUEUE && (e.job.x1 - e.job.x0) * (e.job.y1 - e.job.y0) > RECT_SMALL_EMIT;
     const unsigned long long bm = __builtin_amdgcn_ballot_w64(big);
@@ -421,7 +424,7 @@ __global__ void __launch_bounds__(256) k_emit_big(uint32_t G, int gx, int gy, in
     const int lane = (int)(threadIdx.x & 63);
     const int waves = (int)(gridDim.x * (blockDim.x >> 6));
     for (int q = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); q < n; q += waves) { // wave-uniform: one rectangle per trip
-        EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
+        EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
         if (lane == 0) e = emit_job(big_q[q], gx, gy, gkeys, order, radii_all, geom, offsets, cull); // rect_walk broadcasts lane 0's rectangle
         (void)rect_walk<true>(e.job, W, H, e.off, cap, e.tile_base, e.g, keys, vals, gx, cull != 0);
     }
@@ -550,11 +553,11 @@ __global__ void __launch_bounds__(TILE_THREADS) k_composite(const FrameDev* __re
             s_rec[buf][3 * tid] = make_float4(a.x, a.y, -0.5f * LOG2E * a.z, -LOG2E * a.w);
             s_rec[buf][3 * tid + 1] = make_float4(-0.5f * LOG2E * b.x, b.y, 0.f, 0.f);
             s_rec[buf][3 * tid + 2] = make_float4(b.z, b.w, c.x, c.y);
-            const float lt = logf(1.0f / (255.0f * b.y));
+            const float lt = logf(1.0f / (255.0f * b.y)), rdy = -a.w / b.x, rdx = -a.w / a.z;
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const float x_lo = (float)(tx * TILE + (qd & 1) * 8), y_lo = (float)(ty * TILE + (qd >> 1) * 8);
-                live4 |= rect_can_contribute(a.x, a.y, a.z, a.w, b.x, lt, x_lo, fminf(x_lo + 7.f, (float)(W - 1)), y_lo,
+                live4 |= rect_can_contribute(a.x, a.y, a.z, a.w, b.x, rdy, rdx, lt, x_lo, fminf(x_lo + 7.f, (float)(W - 1)), y_lo,
                                              fminf(y_lo + 7.f, (float)(H - 1))) ? (1u << qd) : 0u;
             }
         }
