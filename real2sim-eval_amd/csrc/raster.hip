@@ -216,6 +216,83 @@ __device__ __forceinline__ uint32_t rect_walk(const RectJob& j, int W, int H, ui
     return count;
 }
 
+// The candidate tiles of a wavefront's 64 Gaussians, FLATTENED (round 3, late): rect_walk gives every Gaussian to one lane (or, the large
+// ones, to the whole wavefront one after the other), so a wavefront runs as many trips as its largest small rectangle has tiles while
+// most lanes idle — the counters put k_emit_keys at 215 M wavefront instructions for 37 M candidate tiles, nine times what the tiles
+// need.  Here the 64 rectangles are laid end to end (prefix sum of their tile counts, parameters parked in the wavefront's LDS slice),
+// and trip t hands candidate 64 t + lane to lane `lane`: a binary search of the prefix array names its Gaussian, the test runs on all 64
+// lanes, and the passing tiles of a Gaussian find their rank from a ballot plus the running count of earlier trips.  Counts and emitted
+// lists are the ones rect_walk produces (tile order inside a Gaussian is row-major either way).
+struct WalkShared {      // one per wavefront
+    uint32_t pre[64];    // inclusive prefix of the candidate counts
+    float4 p0[64];       // mx, my, ca, cb
+    float4 p1[64];       // cc, lt, rdy, rdx
+    uint4 p2[64];        // x0, y0, w, first output slot (emit)
+    uint2 p3[64];        // tile_base, value (emit)
+    uint32_t cnt[64];    // passing tiles so far
+};
+template <bool EMIT>
+__device__ __forceinline__ uint32_t rect_walk_flat(WalkShared& ws, const RectJob& j, int W, int H, uint32_t off, uint32_t cap, uint32_t tile_base,
+                                                   uint32_t val, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx, bool test)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t w = j.x1 - j.x0, n = w * (j.y1 - j.y0);
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    ws.pre[lane] = incl;
+    ws.p0[lane] = make_float4(j.mx, j.my, j.ca, j.cb);
+    ws.p1[lane] = make_float4(j.cc, j.lt, j.rdy, j.rdx);
+    ws.p2[lane] = make_uint4(j.x0, j.y0, w, off);
+    if (EMIT) ws.p3[lane] = make_uint2(tile_base, val);
+    ws.cnt[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    for (uint32_t t0 = 0; t0 < total; t0 += 64) { // wave-uniform
+        const uint32_t c = t0 + (uint32_t)lane;
+        const bool active = c < total;
+        int lo = 0, hi = 63; // the Gaussian of candidate c: the first lane whose inclusive prefix exceeds c
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int mid = (lo + hi) >> 1;
+            if (ws.pre[mid] > c) hi = mid; else lo = mid + 1;
+        }
+        const int g = min(lo, 63);
+        const uint32_t start = g > 0 ? ws.pre[g - 1] : 0u;
+        const float4 q0 = ws.p0[g], q1 = ws.p1[g];
+        const uint4 q2 = ws.p2[g];
+        const uint32_t k = c - start; // the k-th candidate tile of Gaussian g, row-major in its rectangle
+        const uint32_t ry = (uint32_t)(((float)k + 0.5f) * (1.0f / (float)max(q2.z, 1u))), rx = k - ry * q2.z; // k < 2^11, w <= 2^7: exact
+        const bool ok = active && (!test || tile_can_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, q1.z, q1.w, q1.y, (int)(q2.x + rx), (int)(q2.y + ry), W, H));
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(ok);
+        // this Gaussian's candidates of this trip sit in lanes [seg, seg_end)
+        const int seg = (int)max((int)start - (int)t0, 0), seg_end = (int)min(ws.pre[g] - t0, 64u);
+        const unsigned long long upto = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const unsigned long long from = (seg == 0) ? ~0ull : ~(~0ull >> (64 - seg));
+        const uint32_t before = ws.cnt[g]; // passing tiles of g in earlier trips (read by every lane before any lane of this trip adds)
+        __builtin_amdgcn_wave_barrier();
+        if (EMIT) {
+            const uint32_t pos = q2.w + before + (uint32_t)__builtin_popcountll(bal & upto & from);
+            if (ok && pos < cap) {
+                const uint2 q3 = ws.p3[g];
+                keys[pos] = q3.x + (q2.y + ry) * (uint32_t)gx + (q2.x + rx);
+                vals[pos] = q3.y;
+            }
+        }
+        if (active && lane == seg_end - 1) { // the last lane of the segment books the segment's passing tiles
+            const unsigned long long segmask = from & ((seg_end == 64) ? ~0ull : (~0ull >> (64 - seg_end)));
+            ws.cnt[g] = before + (uint32_t)__builtin_popcountll(bal & segmask);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return ws.cnt[lane];
+}
+
 // preprocessCUDA, forward.cu:156-257 with in_frustum (auxiliary.h:139-165), computeCov3D (forward.cu:118-152)
 // and computeCov2D (forward.cu:74-113) written out as scalar formulas in GLM's evaluation order.
 __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__ frames, int gx, int gy, int W, int H,
@@ -333,7 +410,8 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
             tiles = 0;
         }
     } while (false);
-    if (cull) tiles = rect_walk<false>(job, W, H, 0u, 0u, 0u, 0u, nullptr, nullptr);
+    __shared__ WalkShared ws_s[4];
+    if (cull) tiles = rect_walk_flat<false>(ws_s[threadIdx.x >> 6], job, W, H, 0u, 0u, 0u, 0u, nullptr, nullptr, 0, true);
     if (!valid) return;
     radii_all[g] = radius_out;
     if (fr.radii) fr.radii[idx] = radius_out;
@@ -412,7 +490,8 @@ __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ 
             e.job.x1 = e.job.x0; // nothing left for this lane here
         }
     }
-    (void)rect_walk<true>(e.job, W, H, e.off, cap, e.tile_base, e.g, keys, vals, gx, cull != 0);
+    __shared__ WalkShared ws_s[4];
+    (void)rect_walk_flat<true>(ws_s[threadIdx.x >> 6], e.job, W, H, e.off, cap, e.tile_base, e.g, keys, vals, gx, cull != 0);
 }
 __global__ void __launch_bounds__(256) k_emit_big(uint32_t G, int gx, int gy, int W, int H, const uint64_t* __restrict__ gkeys,
                                                   const uint32_t* __restrict__ order, const int* __restrict__ radii_all,
