@@ -126,7 +126,7 @@ int64_t r2s_raster_forward_batch(
 /* Sync-free mode (off by default).  The reference reads the instance count back between the scan and the key emission
  * (a blocking cudaMemcpy, rasterizer_impl.cu:284) to size its binning buffer; r2s_raster_forward_batch normally does the
  * same once per batch.  With this mode on, only the FIRST batch does: later batches size the binning scratch from the last
- * known count + 25 %, pad the sort with sentinel keys, take the count on the device where a kernel needs it, and return
+ * known count + 12.5 % (+ 4096), pad the sort with sentinel keys, take the count on the device where a kernel needs it, and return
  * without touching the host — the return value is then the most recent count the host has seen (an earlier batch's).
  * r2s_raster_ctx_poll(ctx, wait, &num_rendered, &overflows) looks at the last batch without blocking (wait = 0: returns 1
  * while it is still running) or blocking (wait = 1): its count, the number of batches so far whose capacity was too small

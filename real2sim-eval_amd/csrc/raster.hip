@@ -1011,8 +1011,12 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         if ((int)(c->h_read[1] & 0xFFFFFFFFull) != 0) c->late_error = R2S_ERR_PREFILTERED;
         if ((int)(c->h_read[2] & 0xFFFFFFFFull) != 0) { c->overflows++; c->L_cap = 0; sync_free = false; }
         else if (c->L_cap > 0) {
-            const uint64_t want = (uint64_t)c->last_L + c->last_L / 4 + 4096;
-            if (want > c->L_cap || want < c->L_cap / 2) c->L_cap = (uint32_t)std::min<uint64_t>(want, 0xFFFFFFF0ull); // follow the scene
+            // follow the scene BOTH ways, one batch late: everything behind the emission (sentinel fill, tile sort, ranges) runs over the
+            // capacity, not over the count, so slack is paid for on every step — 12.5 % + 4096 (a rollout's count moves by a percent or two
+            // per step; a bigger jump is an overflow: reported, and the closed loop renders that step again).  Growing-only with 25 % of
+            // slack had the tile sort work on 1.25 x the PEAK count of the episode.
+            const uint64_t want = (uint64_t)c->last_L + c->last_L / 8 + 4096;
+            c->L_cap = (uint32_t)std::min<uint64_t>(want, 0xFFFFFFF0ull);
         }
     }
     mark(0);
@@ -1042,7 +1046,7 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
             L = (uint32_t)(c->h_read[0] & 0xFFFFFFFFull);
             if ((int)(c->h_read[1] & 0xFFFFFFFFull) != 0) return R2S_ERR_PREFILTERED;
             c->last_L = L;
-            if (c->async_mode) c->L_cap = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 4 + 4096, 0xFFFFFFF0ull); // first call of the mode
+            if (c->async_mode) c->L_cap = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 8 + 4096, 0xFFFFFFF0ull); // first call of the mode
         }
     } else {
         mark(1); mark(2);

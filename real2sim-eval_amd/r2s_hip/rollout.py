@@ -176,7 +176,7 @@ class BatchedRollout:
         self.raster = RasterBatch(self.device)
         self.raster.set_tile_culling(tile_culling)  # exact-output instance culling (include/r2s_raster.h)
         # Sync-free batches: no host read of the instance count inside the pipeline after the first batch.  A batch whose count
-        # outgrew the capacity derived from the previous one (+25 %: a reset, an object entering the view) loses its deepest
+        # outgrew the capacity derived from the previous one (+12.5 %: a reset, an object entering the view) loses its deepest
         # instances; `render` polls without blocking and counts such batches (`lossy_batches`), `observations()` — what a
         # closed-loop caller reads — waits, checks, and re-renders the step synchronously if it was one of them.
         self.raster.set_async(True)

@@ -103,10 +103,10 @@ def test_step_takes_actions_dict_and_xyz_rot_tensor():
 
 
 def test_observations_rerenders_a_sync_free_batch_that_overflowed():
-    """the sync-free raster pipeline sizes its binning scratch from the PREVIOUS batch (+25 % + 4096); a batch
+    """the sync-free raster pipeline sizes its binning scratch from the PREVIOUS batch (+12.5 % + 4096); a batch
     that outgrows it loses its deepest instances.  The rollout must not hand such a frame to a closed-loop caller: the wrist cameras
     jump from 4 cm above the rope (most of the scene is nearer than z_threshold = 5 cm and culled: ~11 k instances) to 1.5 m above it
-    (the whole table in view: ~20 k, beyond 11 k x 1.25 + 4096), `observations()` notices the overflow flag of that batch and renders
+    (the whole table in view: ~20 k, beyond 11 k x 1.125 + 4096), `observations()` notices the overflow flag of that batch and renders
     the step again; what it returns equals the oracle's frame."""
     import torch
     from r2s_hip.rollout import BatchedRollout
