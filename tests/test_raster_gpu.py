@@ -8,6 +8,7 @@ stay below 1e-4 of all pixels (SURVEY.md §8d "Parity gates")."""
 import numpy as np
 import pytest
 
+from util_parity import record
 from util_raster import compare_images, hip_render, oracle_render, scene_and_camera
 
 pytestmark = pytest.mark.gpu
@@ -55,6 +56,42 @@ def test_num_rendered_and_intermediates_exact():
     same_depth = np.array_equal(d["depths"].numpy()[vis].view(np.uint32), dbg["depths"][vis].view(np.uint32))
     if same_depth:
         assert np.array_equal(d["point_list"].numpy().astype(np.uint32), dbg["point_list"])
+
+
+def test_backward_auxiliaries_final_T_and_n_contrib_vs_oracle():
+    """The compositor variant that also writes final_T / n_contrib (forward.cu:335, :380, :386-388; only on request): with the
+    tile culling off the tile lists are the reference's, so n_contrib — the position of a pixel's last blended instance in its tile
+    list — must equal the oracle's exactly, final_T to float tolerance, and colour / depth must be the bits of the plain variant."""
+    import torch
+    from r2s_hip.raster import RasterBatch
+
+    sc, c = scene_and_camera(6000, 320, 240, 11)
+    _, col_ref, _, dep_ref, dbg = oracle_render(sc, c, debug=True)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    H, W = c["image_height"], c["image_width"]
+    outs = []
+    for aux in (False, True):
+        rb = RasterBatch(dev)
+        rb.set_tile_culling(False)
+        s = rb.make_set(t(sc["means3D"]), t(sc["opacities"]), shs=t(sc["shs"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]))
+        out_c = torch.empty(3, H, W, device=dev); out_d = torch.empty(1, H, W, device=dev)
+        fT = torch.full((1, H, W), -1.0, device=dev); nC = torch.full((1, H, W), -1, dtype=torch.int32, device=dev)
+        if aux:
+            rb.set_aux(fT, nC)
+        fr = dict(set=0, viewmatrix=t(c["viewmatrix"]), projmatrix=t(c["projmatrix"]), campos=t(c["campos"]), bg=t(c["bg"]),
+                  tanfovx=c["tanfovx"], tanfovy=c["tanfovy"], z_threshold=c["z_threshold"], out_color=out_c, out_depth=out_d)
+        rb.forward([s], [fr], W, H)
+        torch.cuda.synchronize()
+        outs.append((out_c.cpu().numpy(), out_d.cpu().numpy(), fT.cpu().numpy()[0], nC.cpu().numpy()[0]))
+    (c0, d0, _, _), (c1, d1, fT, nC) = outs
+    assert np.array_equal(c0, c1) and np.array_equal(d0, d1), "the auxiliary outputs must not change a pixel"
+    n_ref, T_ref = np.asarray(dbg["n_contrib"]).astype(np.int64), np.asarray(dbg["final_T"])
+    agree = float((nC == n_ref).mean())
+    record("final_T / n_contrib vs oracle", n_contrib_agree_frac=agree, final_T_max_abs=float(np.abs(fT - T_ref)[nC == n_ref].max()), tol=1e-4)
+    assert agree >= 1.0 - 5e-4, agree      # a threshold decision (alpha < 1/255, T < 1e-4) can flip on a float-rounded alpha at a few pixels
+    assert np.abs(fT - T_ref)[nC == n_ref].max() < 1e-4
+    assert (nC >= 0).all() and (fT >= 0).all()
 
 
 def test_p_zero_returns_zero_images():
