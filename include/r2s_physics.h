@@ -125,7 +125,13 @@ int r2s_phys_mesh_motion(R2SPhys* h, float** interp_points, float** interp_cente
 
 /* step (:823-943) / wp.capture_launch(graph) (phystwin.py:515-519).  n_substeps <= 0 or
  * == params.num_substeps replays the captured graph; any other count runs substeps
- * [first_substep, first_substep + n_substeps) eagerly (they index the interpolated mesh motion). */
+ * [first_substep, first_substep + n_substeps) eagerly (they index the interpolated mesh motion).
+ * Errors (R2S_ERR_INVALID + r2s_last_error): two conditions the kernels detect are reported by the first r2s_phys_step AFTER
+ * the step in which they occurred has finished on the device (a word copied to pinned memory, read without waiting) — (1) a
+ * self-collision impulse changed a particle's velocity by more than 40 m/s in one substep, so the "no mesh within reach"
+ * decision taken before the impulse (test widened by 2 mm) may have skipped a mesh response the reference applies; (2) a
+ * workgroup of the resident small-batch launch waited for its neighbour beyond the poll limit (see r2s_phys_set_resident).
+ * The word is sticky — every later r2s_phys_step fails — until r2s_phys_set_state hands in a new state. */
 int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t stream);
 
 /* collision_forces (:690-695): device pointer to [n_env, n_faces, 3]; holds the LAST substep's

@@ -1254,7 +1254,7 @@ constexpr int RES_PRE = R2S_RES_PRE;            // interior groups evaluated BEF
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // NG groups back to back, no branch in between: the LDS reads of a later group are scheduled under the arithmetic of an earlier one
-// (a wavefront is alone on its SIMD here: whatever latency the instruction stream exposes is paid in full)
+// (two wavefronts share a SIMD here, six in the fused substep: most of the latency the instruction stream exposes is paid)
 struct GroupRecs { v2f xy[GROUP], zz[GROUP], vv[GROUP]; };
 template <int RCAP>
 __device__ __forceinline__ void group_read(const AdjGroup& g, const __attribute__((address_space(3))) char* win, GroupRecs& r)
@@ -2275,7 +2275,7 @@ struct R2SPhys {
     int2* d_mesh_list = nullptr; int* d_mesh_cnt = nullptr; int mesh_cap = 0; // deferred mesh queries: [E * N] (a chain's slice starts at its first env), [chains][n_sub + 1]
     float4* d_vdef = nullptr;
     int* d_cand_mark = nullptr;
-    int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false;
+    int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false, fault_stale = false;
     void* d_xch = nullptr;    // resident stepper: exchange array (96 B per particle)
     bool split_ok = false;    // 64-particle layout whose slices fit k_steps_resident's registers (no remote neighbours, <= 64 interior / halo slots)
     bool resident_ok = false; // the handle can run the env step as ONE resident launch (k_steps_resident) in its free flavour
@@ -2525,8 +2525,8 @@ bool resident_flavour(const R2SPhys* h, bool with_self, int mesh_defer)
 {
     return h->resident_ok && h->resident_pref != 0 && !with_self && !(h->nF > 0 && mesh_defer);
 }
-constexpr int RES_MAX_ITEMS = 256; // (block, env) work items of a resident launch: one 256-thread workgroup per CU (one wavefront per SIMD: the
-                                   // register file of a SIMD is one wavefront's, 8 adjacency groups live in it), all on the chip at once
+constexpr int RES_MAX_ITEMS = 256; // (block, env) work items of a resident launch: one 512-thread workgroup per CU (two wavefronts per SIMD, each
+                                   // with its 2 + 2 adjacency groups in registers), all on the chip at once
 
 int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, hipStream_t s, int e0 = 0, int ne = -1, bool zero_forces = true, int chain_id = 0)
 {
@@ -2604,7 +2604,7 @@ int capture_graph(R2SPhys* h, int variant, int start_buf)
         const int e0 = (int)((int64_t)h->E * c / chains), e1 = (int)((int64_t)h->E * (c + 1) / chains);
         hipStream_t cs;
         R2S_HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        R2S_HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        if (const hipError_t eb = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal); eb != hipSuccess) { (void)hipStreamDestroy(cs); R2S_HIP_TRY(eb); }
         const int rc = enqueue_steps(h, 0, h->prm.num_substeps, start_buf, variant == 1, cs, e0, e1 - e0, true, c);
         hipGraph_t g = nullptr;
         const hipError_t e = hipStreamEndCapture(cs, &g);
@@ -3246,7 +3246,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         // and always deferred), and all work items on the chip at once
         bool remote = false;
         for (int t = 0; t < h->rell_len && !remote; ++t) remote = h->h_radj_spring[t] >= 0;
-        bool fits = true; // a wavefront keeps at most RES_NG interior and RES_NG halo groups of a slice in registers (every fourth group each)
+        bool fits = true; // a wavefront keeps at most RES_NG interior and RES_NG halo groups of a slice in registers (every eighth group each)
         for (int sl = 0; sl < h->n_slices && h->pb == 64; ++sl)
             fits = fits && h->h_slice_int[sl] <= (RES_THREADS / 64) * RES_NG * GROUP && h->h_slice_deg[sl] - h->h_slice_int[sl] <= (RES_THREADS / 64) * RES_NG * GROUP;
         h->split_ok = h->pb == 64 && !remote && fits;
@@ -3329,6 +3329,12 @@ int r2s_phys_set_state(R2SPhys* h, const float* x, const float* v, r2s_stream_t 
     if (!h) return R2S_ERR_INVALID;
     hipLaunchKernelGGL(k_pack, dim3((h->N + 255) / 256, h->E), dim3(256), 0, (hipStream_t)stream_, h->N, h->E, h->d_inv, x, v, h->state(h->cur));
     R2S_HIP_TRY(hipGetLastError());
+    // A fault word (r2s_phys_step) says "the state is invalid": a state set by the caller makes the handle usable again.
+    if (h->d_mesh_total) {
+        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total + 1, 0, sizeof(int), (hipStream_t)stream_));
+        if (h->mesh_pending) h->fault_stale = true; // a copy still in flight may carry the old word: dropped when it lands
+        else h->h_mesh_total[1] = 0;
+    }
     return R2S_OK;
 }
 
@@ -3491,6 +3497,7 @@ int r2s_phys_mesh_motion(R2SPhys* h, float** interp_points, float** interp_cente
 int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t stream_)
 {
     if (!h) return R2S_ERR_INVALID;
+    r2s::set_last_error_msg(""); // an R2S_ERR_INVALID of this call with a message carries THIS call's reason
     hipStream_t s = (hipStream_t)stream_;
     const int full = h->prm.num_substeps;
     const bool use_graph = (n_substeps <= 0 || n_substeps == full) && first_substep == 0;
@@ -3513,7 +3520,10 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         }
     }
     const int variant = (h->prm.self_collision && h->n_cand > 0) ? 1 : 0;
-    if (h->mesh_pending && hipEventQuery(h->mesh_event) == hipSuccess) h->mesh_pending = false;
+    if (h->mesh_pending && hipEventQuery(h->mesh_event) == hipSuccess) {
+        h->mesh_pending = false;
+        if (h->fault_stale) { h->h_mesh_total[1] = 0; h->fault_stale = false; } // the copy was in flight when set_state cleared the word
+    }
     if (!h->mesh_pending && h->h_mesh_total[1] != 0) { // the sticky fault word of an earlier step
         if (h->h_mesh_total[1] == 2)
             r2s::set_last_error_msg("resident stepper: a workgroup waited for a neighbour block's substep beyond the poll limit (the launch was not "

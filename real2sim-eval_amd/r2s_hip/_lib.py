@@ -117,9 +117,10 @@ _ERR = {-1: "invalid argument", -2: "HIP runtime error", -3: "scratch allocation
         -5: "more than 2^32-1 Gaussian/tile instances"}
 
 
-def check(rc: int, what: str) -> int:
+def check(rc: int, what: str, reason: bool = False) -> int:
+    """``reason``: the entry point clears the library's message on entry, so an 'invalid' return with a message says why."""
     if rc < 0:
-        detail = lib().r2s_last_error().decode() if rc == -2 else ""
+        detail = lib().r2s_last_error().decode() if rc == -2 or (reason and rc == -1) else ""
         raise R2SError(f"{what}: {_ERR.get(int(rc), 'error %d' % rc)} {detail}".strip())
     return int(rc)
 

@@ -269,7 +269,7 @@ class PhysBatch:
 
     def step(self, n_substeps: int = 0, first_substep: int = 0, sync_state: bool = True):
         with torch.cuda.device(self.device):
-            check(_bind().r2s_phys_step(self._h, int(n_substeps), int(first_substep), self._s()), "r2s_phys_step")
+            check(_bind().r2s_phys_step(self._h, int(n_substeps), int(first_substep), self._s()), "r2s_phys_step", reason=True)
         if sync_state:
             self.sync_state()
         return self.x

@@ -186,6 +186,49 @@ def test_asymmetric_collision_lists_are_refused():
     assert bool(np.isfinite(h.x.cpu().numpy()).all())
 
 
+def test_an_impulse_beyond_the_reach_bound_is_reported_by_a_later_step_and_a_new_state_clears_it(monkeypatch):
+    """ADVICE r2 (low), the checked bound: a particle with candidates whose pre-impulse test (widened by 2 mm = 40 m/s of velocity
+    change in one substep) found no mesh in reach is finished without a query (k_contact_finish part 2).  One sheet thrown at the
+    other at 200 m/s gets impulses beyond that bound: the kernel raises the sticky fault word, the first step() after that step
+    has finished returns R2S_ERR_INVALID with the reason, every later one too — until set_state hands in a new state."""
+    import torch
+    from r2s_hip import synth
+    from r2s_hip._lib import R2SError
+
+    monkeypatch.setenv("R2S_MESH_DEFER", "1")       # the finishing kernel in the graph although the fingers are 5 cm away
+    n_sub = 4
+    ob, nA = two_sheets()
+    far = far_apart(ob, nA)
+    c = ob["points"].mean(0)
+    fingers = [synth.finger_mesh((c[0], c[1] - 0.05, c[2])), synth.finger_mesh((c[0], c[1] + 0.05, c[2]))]
+    interp, centers, dv, om = gripper_motion(fingers, n_sub, 5e-5, vel=(0.0, 0.0, 0.0), closing=0.0)
+    h = hip_env(far, n_env=1, num_substeps=n_sub, dynamic_meshes=fingers, self_collision=True)
+    x0 = torch.from_numpy(ob["points"])[None]
+    v0 = torch.zeros_like(x0)
+    toward = np.sign(ob["points"][nA:, 1].mean() - ob["points"][:nA, 1].mean())
+    v0[0, :nA, 1] = 200.0 * float(toward)
+    t = lambda a: _t(a)[None]  # noqa: E731
+
+    def arm(v):
+        h.set_state(x0, v)
+        h.update_collision_graph()
+        h.set_mesh_interactive(t(interp), t(centers), t(dv), t(om))
+
+    arm(v0)
+    h.step()                                          # raises the word on the device; this call still returns OK
+    fl = h.last_flavour()
+    assert fl["self_collision_kernel"] and fl["deferred_mesh_queries"], fl
+    torch.cuda.synchronize()
+    for _ in range(2):                                # sticky
+        with pytest.raises(R2SError, match="40 m/s"):
+            h.step()
+    arm(torch.zeros_like(x0))                         # a new state: usable again
+    for _ in range(3):
+        h.step()
+        torch.cuda.synchronize()
+    assert bool(torch.isfinite(h.x).all())
+
+
 def test_bench_scene_one_env_20_substeps_in_the_grasp_vs_oracle_driven_through_eef_oracle():
     """ONE environment of bench.py's own workload (sloth_arms, 15 066 particles, grasp trace) through the
     product path; in the first env step after the fingers closed — arms pressed together, finger contact, the flavour the

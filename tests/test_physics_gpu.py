@@ -531,7 +531,7 @@ def test_a_large_dynamic_mesh_that_deforms_is_reported_by_a_later_step():
     t = lambda a: torch.from_numpy(a)[None].cuda()  # noqa: E731
     h.set_mesh_interactive(t(interp), t(centers), t(dv), t(om))
     torch.cuda.synchronize()
-    with pytest.raises(R2SError):
+    with pytest.raises(R2SError, match="does not move rigidly"):
         for _ in range(3):
             h.step()
             torch.cuda.synchronize()
