@@ -120,6 +120,12 @@ int r2s_phys_set_eef_table(R2SPhys* h, int32_t n_knots, const double* eef_pts, c
 int r2s_phys_set_eef_motion(R2SPhys* h, const float* eef_xyz, const float* eef_vel, const float* eef_rot,
                             const float* eef_rot_vel, const float* gripper_openness, r2s_stream_t stream);
 int r2s_phys_eef_state(R2SPhys* h, double** current_openness, int32_t** grasped);
+/* Episode reset inside a batch (BaseEnv.reset, env.py:30-51 -> PhysTwinDynamics.reset, phystwin.py:39-102, builds a NEW
+ * SpringMassDynamicsModule per reset): the environments whose entry of the DEVICE int32 [n_env] mask is non-zero (NULL: all) get
+ * what a new module starts from — current_openness = None, grasped = False (phystwin.py:358-360), collision_forces zero — while
+ * the others keep running (episodes are independent, eval_policy_parallel.py:266-280).  The particle state of those
+ * environments is the caller's to set (r2s_phys_set_state); r2s_phys_update_collision_graph rebuilds the candidate lists. */
+int r2s_phys_reset_envs(R2SPhys* h, const int32_t* env_mask, r2s_stream_t stream);
 int r2s_phys_mesh_motion(R2SPhys* h, float** interp_points, float** interp_center, float** dynamic_velocity,
                          float** dynamic_omega);
 

@@ -3484,6 +3484,31 @@ int r2s_phys_eef_state(R2SPhys* h, double** current_openness, int32_t** grasped)
     return R2S_OK;
 }
 
+// Episode reset of the environments whose mask entry is non-zero (no mask: all): what a NEW SpringMassDynamicsModule starts from
+// (phystwin.py:39-102 builds one per reset) — current_openness = None, grasped = False (phystwin.py:358-360), collision_forces zero.
+__global__ void k_reset_envs(int nF, const int* __restrict__ mask, double* __restrict__ open, int* __restrict__ grasped, int* __restrict__ has,
+                             float* __restrict__ coll_forces, int* __restrict__ hit_cnt)
+{
+    const int e = (int)blockIdx.y;
+    if (mask && mask[e] == 0) return;
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t == 0) {
+        if (open) { open[e] = 0.0; grasped[e] = 0; has[e] = 0; }
+        if (hit_cnt) hit_cnt[e] = 0;
+    }
+    if (coll_forces && t < 3 * nF) coll_forces[(size_t)e * 3 * nF + t] = 0.f;
+}
+
+int r2s_phys_reset_envs(R2SPhys* h, const int32_t* env_mask, r2s_stream_t stream_)
+{
+    if (!h) return R2S_ERR_INVALID;
+    const unsigned gx = (unsigned)std::max(1, (3 * h->nF + 255) / 256);
+    hipLaunchKernelGGL(k_reset_envs, dim3(gx, (unsigned)h->E), dim3(256), 0, (hipStream_t)stream_, h->nF, env_mask, h->d_eef_open, h->d_eef_grasped,
+                       h->d_eef_has, h->nF > 0 ? h->d_coll_forces : nullptr, h->d_hit_cnt);
+    R2S_HIP_TRY(hipGetLastError());
+    return R2S_OK;
+}
+
 int r2s_phys_mesh_motion(R2SPhys* h, float** interp_points, float** interp_center, float** dynamic_velocity, float** dynamic_omega)
 {
     if (!h || h->n_dyn_mesh == 0) return R2S_ERR_INVALID;

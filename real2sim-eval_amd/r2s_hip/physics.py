@@ -53,7 +53,7 @@ def _bind():
         r2s_phys_mesh_maps=[vp, vp, vp], r2s_phys_collision_lists=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32)],
         r2s_phys_collision_max_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_set_spring_Y=[vp, vp, vp],
         r2s_phys_set_eef_table=[vp, C.c_int32, vp, vp, C.c_float, vp], r2s_phys_set_eef_motion=[vp, vp, vp, vp, vp, vp, vp],
-        r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
+        r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_reset_envs=[vp, vp, vp], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
         r2s_phys_set_collision_lists=[vp, vp, vp, vp], r2s_phys_contact_stats=[vp, C.POINTER(C.c_int32), C.POINTER(vp)],
         r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32], r2s_phys_set_resident=[vp, i32], r2s_phys_side_stream=[i32, C.POINTER(vp)],
         r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
@@ -247,6 +247,16 @@ class PhysBatch:
         _memcpy_d2d(o.data_ptr(), po.value, o.numel() * 8, self.device)
         _memcpy_d2d(g.data_ptr(), pg.value, g.numel() * 4, self.device)
         return o.cpu(), g.cpu()
+
+    def reset_envs(self, mask: Optional[torch.Tensor] = None):
+        """Episode reset of the environments with a non-zero entry in ``mask`` ([n_env], default all): grasp state machine at its
+        initial values, collision forces zero (r2s_phys_reset_envs).  Set their particle state with ``set_state``."""
+        mp = None
+        if mask is not None:
+            mask = mask.to(self.device, torch.int32).contiguous().reshape(self.n_env)
+            mp = mask.data_ptr()
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_reset_envs(self._h, mp, self._s()), "r2s_phys_reset_envs")
 
     def mesh_motion(self, points: bool = True):
         """Copies of the stepper's current motion inputs: interp_points [n_env, n_sub, n_dyn_pts, 3] (optional),

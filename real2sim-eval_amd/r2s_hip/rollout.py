@@ -212,7 +212,7 @@ class BatchedRollout:
                                          out_color=self.out_color[e, vi], out_depth=self.out_depth[e, vi]))
         self.t = 0
         self._vel_trace = None
-        self._dephase, self._env_delay = 1, None
+        self._dephase, self._env_delay, self._restarted = 1, None, False
         self._cand_fresh = False
         self._prepared = None
         self._log = None
@@ -231,6 +231,11 @@ class BatchedRollout:
             self.phys.set_eef_table(self.eef_table, self.eef_init, 3e4)   # forget the parked pose: current_openness = None, grasped = False
             self.phys.sync_state()
             self._update_means()
+        # what an episode starts from (reset): particles at rest, the object's Gaussians on them, the end effector at its start pose
+        self._env_t0 = torch.zeros(E, dtype=torch.long, device=self.device)
+        self._init = dict(x=self.phys.x.clone(), v=self.phys.v.clone(), means=self.means[:, : self.n_obj].clone())
+        if with_gripper:
+            self._init.update(eef_xyz=self.eef_xyz.clone(), eef_rot=self.eef_rot.clone())
 
     # ---- end-effector trace: fixed Lissajous path at <= 0.1 m/s; the gripper closes at step 100 and opens at 300 ------
     # (SURVEY.md §8d).  Only the eef pose / rates / commanded opening are produced here — what BaseEnv hands to
@@ -262,12 +267,14 @@ class BatchedRollout:
         environment e by ``e % dephase`` steps along the same trace, so that the environments are not all in the same phase of
         their episode (episodes of eval_policy_parallel.py are independent: they do not share a phase)."""
         E = self.n_env
-        if self._vel_trace is None or step >= len(self._vel_trace) - self._dephase:
+        if self._vel_trace is None or step >= len(self._vel_trace) - self._dephase:   # (a restarted episode only looks further back)
             n = max(1024, 2 * (step + 1 + self._dephase))
             self._vel_trace = torch.from_numpy(np.stack([self._eef_velocity(k) for k in range(n)])).to(self.device)
             self._open_cmd = torch.tensor([0.3 if self.close_at <= k < self.open_at else 1.0 for k in range(n)], dtype=torch.float32, device=self.device)
-        if self._dephase > 1:
-            idx = step - self._env_delay                          # environment e replays the trace (e % dephase) steps late
+        if self._dephase > 1 or self._restarted:
+            idx = step - self._env_t0                             # an environment's episode starts at its last reset ...
+            if self._dephase > 1:
+                idx = idx - self._env_delay                       # ... and environment e replays the trace (e % dephase) steps late
             act, idc = idx >= 0, idx.clamp(min=0)
             vel = torch.where(act[:, None], self._vel_trace[idc], torch.zeros(E, 3, device=self.device))
             openness = torch.where(act, self._open_cmd[idc], torch.ones(E, device=self.device))
@@ -343,6 +350,45 @@ class BatchedRollout:
             self.link_pose = self._pose_dev[k]
             self.robot.transform(self.link_pose, self.means[:, self.n_obj:], self.rot_env[:, self.n_obj:], normalize=True, write_static=self._robot_first)
             self._robot_first = False
+
+    # ---- episode reset of some environments ------------------------------------------------------------------------
+    def reset(self, env_ids=None):
+        """BaseEnv.reset (env.py:30-51) for some environments of the batch (``env_ids``: indices, a bool mask [n_env], or None =
+        all) while the others keep running — episodes are independent and end at different steps (eval_policy_parallel.py:
+        266-280).  The reference rebuilds renderer state and a NEW dynamics module per reset (gs_renderer.reset_state,
+        phystwin.py:39-102); here the environment's slice of the batch goes back to what the rollout started from: particles at
+        rest in their start pose (zero collision forces, grasp state machine at current_openness = None / grasped = False), the
+        object's Gaussians and their bones as loaded, the end effector at its start pose; the synthetic action trace of that
+        environment starts over.  Everything stays on the device, nothing is synchronised; the candidate lists are rebuilt by
+        the next step."""
+        E, dev = self.n_env, self.device
+        if env_ids is None:
+            mask = torch.ones(E, dtype=torch.bool, device=dev)
+        else:
+            ids = torch.as_tensor(env_ids, device=dev)
+            if ids.dtype == torch.bool:
+                mask = ids.reshape(E).clone()
+            else:
+                mask = torch.zeros(E, dtype=torch.bool, device=dev)
+                mask[ids.long().reshape(-1)] = True
+        main = torch.cuda.current_stream(dev)
+        ev = getattr(self, "_cand_done", None)
+        if ev is not None:                      # a candidate rebuild on the side stream is still reading the state about to be replaced
+            main.wait_event(ev)
+            self._cand_done = None
+        self.wait_render()                      # pipelined mode: the render stream reads the Gaussians about to be replaced
+        m3 = mask[:, None, None]
+        self.phys.set_state(torch.where(m3, self._init["x"], self.phys.x), torch.where(m3, self._init["v"], self.phys.v))
+        self.phys.reset_envs(mask)
+        obj = self.means[:, : self.n_obj]
+        obj.copy_(torch.where(m3, self._init["means"], obj))     # in place: the prepared raster sets point at this storage
+        self.bones.copy_(torch.where(m3, self._init["x"], self.bones))
+        if self.with_gripper:
+            self.eef_xyz = torch.where(mask[:, None], self._init["eef_xyz"], self.eef_xyz)
+            self.eef_rot = torch.where(m3, self._init["eef_rot"], self.eef_rot)
+        self._env_t0 = torch.where(mask, torch.full_like(self._env_t0, self.t), self._env_t0)
+        self._restarted = True
+        self._cand_fresh = False
 
     # ---- one batched env step -----------------------------------------------------------------------------------
     def physics_step(self, action=None):
