@@ -65,6 +65,33 @@ def rotation_matrix_to_axis_angle(R: torch.Tensor) -> torch.Tensor:
     return v * scale[:, None]
 
 
+def rotation_matrix_to_quaternion(R: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """[N,3,3] -> [N,4] (w, x, y, z): the role of kornia.geometry.conversions.rotation_matrix_to_quaternion at phystwin.py:117 /
+    gs_renderer's eef_quat (kornia >= 0.7: scalar first).  The published branch scheme (largest of trace / diagonal entries picks
+    the component computed by the square root, sq = 2 sqrt(. + eps)); the sign is the one that scheme yields — w > 0 on the trace
+    branch, the pivot component > 0 otherwise — not canonicalised, like kornia's.  Parity unpinned (kornia absent): pinned against
+    scipy up to the sign in tests/test_host_logic.py."""
+    m = R.reshape(-1, 9)
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = [m[:, k] for k in range(9)]
+    tr = m00 + m11 + m22
+
+    s0 = torch.sqrt(tr + 1.0 + eps) * 2.0
+    d0 = s0.clamp(min=torch.finfo(R.dtype).tiny)
+    q0 = torch.stack([0.25 * s0, (m21 - m12) / d0, (m02 - m20) / d0, (m10 - m01) / d0], 1)
+    s1 = torch.sqrt(1.0 + m00 - m11 - m22 + eps) * 2.0
+    d1 = s1.clamp(min=torch.finfo(R.dtype).tiny)
+    q1 = torch.stack([(m21 - m12) / d1, 0.25 * s1, (m01 + m10) / d1, (m02 + m20) / d1], 1)
+    s2 = torch.sqrt(1.0 + m11 - m00 - m22 + eps) * 2.0
+    d2 = s2.clamp(min=torch.finfo(R.dtype).tiny)
+    q2 = torch.stack([(m02 - m20) / d2, (m01 + m10) / d2, 0.25 * s2, (m12 + m21) / d2], 1)
+    s3 = torch.sqrt(1.0 + m22 - m00 - m11 + eps) * 2.0
+    d3 = s3.clamp(min=torch.finfo(R.dtype).tiny)
+    q3 = torch.stack([(m10 - m01) / d3, (m02 + m20) / d3, (m12 + m21) / d3, 0.25 * s3], 1)
+    w2 = torch.where((m11 > m22)[:, None], q2, q3)
+    w1 = torch.where(((m00 > m11) & (m00 > m22))[:, None], q1, w2)
+    return torch.where((tr > 0.0)[:, None], q0, w1)
+
+
 class BatchedRollout:
     def __init__(self, config="sloth_32env", device="cuda:0", seed=0, n_env=None, num_substeps=667, views=2,
                  self_collision=True, with_gripper=True, with_static=True, tile_culling=True, schedule=None, close_at=15, open_at=10**9,
@@ -247,6 +274,7 @@ class BatchedRollout:
         self.eef_xyz = t(np.repeat(self.eef0[None], E, 0) + self.env_shift)
         self.eef_rot = torch.eye(3, device=self.device).repeat(E, 1, 1)
         self.eef_rot_vel = torch.zeros(E, 3, device=self.device)
+        self.eef_gripper = torch.ones(E, device=self.device)      # commanded opening of the last step (state['eef_gripper'], phystwin.py:165)
 
     def _eef_velocity(self, step):
         w = 2 * np.pi * 0.25
@@ -314,6 +342,8 @@ class BatchedRollout:
         xyz, vel = action["eef_xyz"].reshape(E, 3), action["eef_vel"].reshape(E, 3)
         rot, rv = action["eef_rot"].reshape(E, 3, 3), action["eef_rot_vel"].reshape(E, 3)
         self.phys.set_eef_motion(xyz, vel, rot, rv, action.get("gripper_openness"))
+        if action.get("gripper_openness") is not None:
+            self.eef_gripper = action["gripper_openness"].reshape(E)
         T = self.num_substeps * self.dt
         self.eef_xyz = action["eef_xyz_next"] if "eef_xyz_next" in action else xyz + vel * T
         if "eef_rot_next" in action:
@@ -386,6 +416,7 @@ class BatchedRollout:
         if self.with_gripper:
             self.eef_xyz = torch.where(mask[:, None], self._init["eef_xyz"], self.eef_xyz)
             self.eef_rot = torch.where(m3, self._init["eef_rot"], self.eef_rot)
+            self.eef_gripper = torch.where(mask, torch.ones_like(self.eef_gripper), self.eef_gripper)
         self._env_t0 = torch.where(mask, torch.full_like(self._env_t0, self.t), self._env_t0)
         self._restarted = True
         self._cand_fresh = False
@@ -495,6 +526,22 @@ class BatchedRollout:
             self.last_num_rendered = self.raster.forward(self._prepared, None, self.W, self.H)
             self._poll_raster(wait=True)
         return self.out_color, self.out_depth
+
+    def robot_state(self):
+        """obs['robot'] of BaseEnv.get_obs (env.py:62-66) for every environment, device tensors: eef_xyz [E,3], eef_quat [E,4]
+        (w, x, y, z of the current end-effector rotation, phystwin.py:117), eef_gripper [E,1] (the opening commanded by the last
+        action; 1 = open)."""
+        return dict(eef_xyz=self.eef_xyz, eef_quat=rotation_matrix_to_quaternion(self.eef_rot), eef_gripper=self.eef_gripper[:, None])
+
+    def get_obs(self):
+        """BaseEnv.get_obs (env.py:53-74) for the batch: the fixed-camera and wrist-camera images of the last step — complete and
+        validated (``observations``), views of the output arrays, [E,3,H,W] / [E,1,H,W] per camera — and the robot state."""
+        col, dep = self.observations()
+        wrist = [1] if self.wrist is not None else []
+        fixed = [v for v in range(self.views) if v not in wrist]
+        return dict(image_list=[col[:, v] for v in fixed], depth_list=[dep[:, v] for v in fixed],
+                    image_wrist_list=[col[:, v] for v in wrist], depth_wrist_list=[dep[:, v] for v in wrist],
+                    image_extra=None, depth_extra=None, robot=self.robot_state() if self.with_gripper else None)
 
     def camera_numpy(self, e, v):
         """Settings of view ``v`` of environment ``e`` as the rasteriser currently sees them (numpy; parity tests, cpu_baseline)."""

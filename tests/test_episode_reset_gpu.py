@@ -82,3 +82,31 @@ def test_reset_of_all_environments_while_a_candidate_rebuild_is_in_flight_and_in
         assert float((x1 - x2).abs().max()) <= 2e-6, k
         assert _frac_differing(c1, c2) <= 1e-3, k
     assert bool(torch.isfinite(ro.phys.x).all()) and np.isfinite(float(second[-1][1].sum()))
+
+
+def test_get_obs_mirrors_base_env_get_obs_for_the_batch():
+    """BaseEnv.get_obs (env.py:53-74): fixed-camera and wrist-camera image lists + obs['robot'] = the state an action left behind
+    (PhysTwinDynamics.step's next_state, phystwin.py:158-167: eef_xyz_next, quaternion of eef_rot_next, the commanded opening)."""
+    import torch
+    from scipy.spatial.transform import Rotation
+    from r2s_hip.rollout import BatchedRollout
+
+    ro = BatchedRollout("tiny", num_substeps=10, seed=2, n_env=2)
+    rv = np.array([[0.0, 0.02, 0.3], [0.25, -0.1, 0.0]])
+    rot0 = ro.eef_rot.cpu().numpy().astype(np.float64)
+    rot_next = np.stack([Rotation.from_rotvec(rv[e]).as_matrix().T @ rot0[e] for e in range(2)])
+    xyz_next = ro.eef_xyz + torch.tensor([[0.001, 0.0, -0.002], [0.0, 0.0015, 0.001]], device=ro.device)
+    act = torch.cat([xyz_next, torch.from_numpy(rot_next).float().to(ro.device).reshape(2, 9), torch.tensor([[0.7], [0.4]], device=ro.device)], 1)
+    ro.step(act)
+    obs = ro.get_obs()
+    torch.cuda.synchronize()
+    assert len(obs["image_list"]) == 1 and len(obs["image_wrist_list"]) == 1 and obs["image_list"][0].shape == (2, 3, ro.H, ro.W)
+    assert obs["depth_wrist_list"][0].shape == (2, 1, ro.H, ro.W)
+    assert torch.equal(obs["image_list"][0], ro.out_color[:, 0]) and torch.equal(obs["image_wrist_list"][0], ro.out_color[:, 1])
+    assert float(obs["image_list"][0].std()) > 0
+    r = obs["robot"]
+    assert torch.equal(r["eef_xyz"], xyz_next) and torch.equal(r["eef_gripper"], act[:, 12:13])
+    q = r["eef_quat"].cpu().numpy().astype(np.float64)
+    ref = Rotation.from_matrix(rot_next).as_quat()[:, [3, 0, 1, 2]]
+    assert np.abs(q - np.sign((q * ref).sum(1, keepdims=True)) * ref).max() < 2e-6
+    assert (q[:, 0] > 0).all()                     # small rotations: the trace branch, scalar part positive

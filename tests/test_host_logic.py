@@ -30,6 +30,33 @@ def test_rotation_helpers_of_the_action_path_against_scipy():
     assert np.abs(got - step).max() < 2e-6
 
 
+def test_rotation_matrix_to_quaternion_of_the_robot_state_against_scipy():
+    """obs['robot']['eef_quat'] (env.py:62-66): scalar-first quaternion of the end-effector rotation.  All four branches of the
+    conversion (trace > 0; each diagonal entry the largest), against scipy up to the sign, and back to the matrix."""
+    import torch
+    from scipy.spatial.transform import Rotation
+    from r2s_hip.rollout import rotation_matrix_to_quaternion
+
+    rng = np.random.default_rng(2)
+    rv = np.concatenate([rng.normal(0, 0.5, (32, 3)),                                     # trace > 0
+                         np.pi * 0.98 * np.eye(3), np.pi * 0.9 * np.eye(3)[[0, 1, 2, 0]] + 0.05,  # half turns: one branch per axis
+                         rng.normal(0, 2.5, (64, 3)), np.zeros((1, 3))])
+    Rm = Rotation.from_rotvec(rv).as_matrix()
+    q = rotation_matrix_to_quaternion(torch.from_numpy(Rm.astype(np.float32))).numpy().astype(np.float64)
+    assert np.abs(np.linalg.norm(q, axis=1) - 1.0).max() < 1e-6
+    ref = Rotation.from_matrix(Rm).as_quat()[:, [3, 0, 1, 2]]                                # scipy: x, y, z, w
+    sign = np.sign((q * ref).sum(1, keepdims=True))
+    assert np.abs(q - sign * ref).max() < 2e-6
+    assert np.abs(Rotation.from_quat(q[:, [1, 2, 3, 0]]).as_matrix() - Rm).max() < 2e-6
+    tr = np.trace(Rm, axis1=1, axis2=2)
+    used = {"trace": int((tr > 0).sum())}
+    d = np.stack([Rm[:, 0, 0], Rm[:, 1, 1], Rm[:, 2, 2]], 1)
+    for k in range(3):
+        used[f"pivot {k}"] = int(((tr <= 0) & (d.argmax(1) == k)).sum())
+    assert all(v > 0 for v in used.values()), used
+    assert np.array_equal(q[-1], [1.0, 0.0, 0.0, 0.0]) or np.abs(q[-1] - [1, 0, 0, 0]).max() < 1e-7   # identity -> (1, 0, 0, 0)
+
+
 def test_counter_summaries_are_keyed_by_the_kernel_sources_and_stale_ones_are_labelled(tmp_path, monkeypatch):
     from r2s_hip._lib import kernel_source_sha16
 
