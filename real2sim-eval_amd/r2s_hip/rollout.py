@@ -92,6 +92,17 @@ def rotation_matrix_to_quaternion(R: torch.Tensor, eps: float = 1e-8) -> torch.T
     return torch.where((tr > 0.0)[:, None], q0, w1)
 
 
+def quaternion_to_rotation_matrix(q: torch.Tensor) -> torch.Tensor:
+    """[N,4] (w, x, y, z) -> [N,3,3], the quaternion normalised first (kornia.geometry.conversions.quaternion_to_rotation_matrix at
+    phystwin.py:111 and experiments/eval_policy.py: the policy's eef_quat -> the action's rotation block)."""
+    q = torch.nn.functional.normalize(q.reshape(-1, 4), dim=1, eps=1e-12)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    tx, ty, tz = 2.0 * x, 2.0 * y, 2.0 * z
+    return torch.stack([1.0 - ty * y - tz * z, tx * y - tz * w, tx * z + ty * w,
+                        tx * y + tz * w, 1.0 - tx * x - tz * z, ty * z - tx * w,
+                        tx * z - ty * w, ty * z + tx * w, 1.0 - tx * x - ty * y], 1).reshape(-1, 3, 3)
+
+
 class BatchedRollout:
     def __init__(self, config="sloth_32env", device="cuda:0", seed=0, n_env=None, num_substeps=667, views=2,
                  self_collision=True, with_gripper=True, with_static=True, tile_culling=True, schedule=None, close_at=15, open_at=10**9,

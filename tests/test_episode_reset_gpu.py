@@ -110,3 +110,39 @@ def test_get_obs_mirrors_base_env_get_obs_for_the_batch():
     ref = Rotation.from_matrix(rot_next).as_quat()[:, [3, 0, 1, 2]]
     assert np.abs(q - np.sign((q * ref).sum(1, keepdims=True)) * ref).max() < 2e-6
     assert (q[:, 0] > 0).all()                     # small rotations: the trace branch, scalar part positive
+
+
+def test_episode_scheduler_on_the_real_rollout():
+    """r2s_hip.evaluate.run_episodes (the loop of experiments/eval_policy_parallel.py:40-255 over the slots of a batch) on the HIP
+    rollout: five episodes on two environments = three waves of resets; a 13-dim policy action per step, the settling steps hold
+    the pose (the end effector does not move during them), every episode of a slot starts from the same state."""
+    import torch
+    from r2s_hip.evaluate import hold_pose_action, run_episodes, summarize
+    from r2s_hip.rollout import BatchedRollout
+
+    ro = BatchedRollout("tiny", num_substeps=10, seed=6, n_env=2)
+    start_xyz = ro._init["eef_xyz"].clone()
+    seen = []
+
+    def policy(obs, episode_step, active):
+        a = hold_pose_action(obs)
+        a[:, 2] -= 0.001                       # 1 mm down per step
+        a[:, 12] = 0.8
+        return a
+
+    def on_step(r, slot_episode, episode_step):
+        seen.append((slot_episode.tolist(), episode_step.tolist(), r.eef_xyz.clone(), r.phys.x.clone()))
+
+    rec = run_episodes(ro, [3, 4, 5, 6, 7], policy=policy, max_steps=3, settle_steps=2, on_step=on_step)
+    torch.cuda.synchronize()
+    assert rec[:, 0].tolist() == [3, 4, 5, 6, 7] and rec[:, 2].tolist() == [3.0] * 5 and (rec[:, 3] > 0).all()
+    assert len(seen) == 3 * (2 + 3)
+    assert [s[0] for s in seen[::5]] == [[3, 4], [5, 6], [7, -1]]
+    for w in range(3):
+        first = seen[5 * w]
+        assert torch.allclose(first[2][0], start_xyz[0], atol=1e-7), "the settling steps hold the start pose"
+        last = seen[5 * w + 4]
+        assert abs(float(last[2][0, 2] - start_xyz[0, 2]) + 0.003) < 1e-6       # three policy steps of 1 mm
+        if w:
+            assert torch.equal(first[3][0], seen[0][3][0]), "every episode of a slot starts from the same state"
+    assert bool(torch.isfinite(ro.phys.x).all()) and summarize(rec)["episodes"] == 5

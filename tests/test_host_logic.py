@@ -35,7 +35,7 @@ def test_rotation_matrix_to_quaternion_of_the_robot_state_against_scipy():
     conversion (trace > 0; each diagonal entry the largest), against scipy up to the sign, and back to the matrix."""
     import torch
     from scipy.spatial.transform import Rotation
-    from r2s_hip.rollout import rotation_matrix_to_quaternion
+    from r2s_hip.rollout import quaternion_to_rotation_matrix, rotation_matrix_to_quaternion
 
     rng = np.random.default_rng(2)
     rv = np.concatenate([rng.normal(0, 0.5, (32, 3)),                                     # trace > 0
@@ -48,6 +48,8 @@ def test_rotation_matrix_to_quaternion_of_the_robot_state_against_scipy():
     sign = np.sign((q * ref).sum(1, keepdims=True))
     assert np.abs(q - sign * ref).max() < 2e-6
     assert np.abs(Rotation.from_quat(q[:, [1, 2, 3, 0]]).as_matrix() - Rm).max() < 2e-6
+    back = quaternion_to_rotation_matrix(torch.from_numpy((q * 3.0).astype(np.float32))).numpy()      # normalises its input
+    assert np.abs(back - Rm).max() < 2e-6
     tr = np.trace(Rm, axis1=1, axis2=2)
     used = {"trace": int((tr > 0).sum())}
     d = np.stack([Rm[:, 0, 0], Rm[:, 1, 1], Rm[:, 2, 2]], 1)
