@@ -105,6 +105,11 @@ struct PhysDev {
     int* mesh_cnt;             // [n_sub + 1] entries of mesh_list per substep; [n_sub] = particles NEAR a mesh over the whole env step
                                // (margin + NEAR_PAD: what the host picks the next step's flavour from); zeroed once per env step
     int mesh_cap, mesh_defer;  // defer = 1: needy particles go to the list; 0: they are queried in place
+    int4* mesh_rec;            // large-mesh scenes (MESH 2) list per ENVIRONMENT instead: [E][N][2] self-contained 32-byte records
+                               // {candidate count, particle | tag << 31, x0.x, x0.y} {x0.z, v}, counted in rec_cnt [E][n_sub] — the
+                               // finishing workgroup knows its environment from blockIdx, so count + record + the mesh's rigid
+                               // transform are ONE round trip before the query (the chain-wide list costs two: entry, then state)
+    int* rec_cnt;
     int* cand_mark;            // [E,N] = substep + 1 when a particle with candidates was handed to the mesh list in that substep
     const int2* cand_list;     // (env, particle) of every particle with candidates
     const int* cand_count;
@@ -897,6 +902,19 @@ __device__ __forceinline__ bool resident_in_range(const ResidentIO& io, f3 next_
 // Called by EVERY lane of a workgroup at the same point (the mesh queries of MESH 2 / 3 are workgroup-cooperative, with a
 // barrier inside); `fin` says whether this lane has a particle to finish, `store` whether it is the one that writes it back.
 // Shared by the fused substep and the finishing kernels.
+// Large-mesh scenes: hand a particle to the substep's finishing launch through its environment's list (a particle is listed at most
+// once per substep: N slots cannot overflow).  ncand > 0 = tagged: the particle also has self-collision candidates, `v` is its published
+// pre-impulse velocity and k_contact_finish applies the impulses first.
+__device__ __forceinline__ bool mesh_rec_push(const PhysDev& p, int e, int step, int i, int ncand, f3 x0, f3 v)
+{
+    const int slot = atomicAdd(p.rec_cnt + (size_t)e * p.n_sub + step, 1);
+    if (slot >= p.N) return false;
+    int4* r = p.mesh_rec + 2 * ((size_t)e * p.N + slot);
+    r[0] = make_int4(ncand, ncand > 0 ? (i | (int)0x80000000) : i, __float_as_int(x0.x), __float_as_int(x0.y));
+    r[1] = make_int4(__float_as_int(x0.z), __float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z));
+    return true;
+}
+
 // MESH: 0 no meshes, 1 small meshes only (per-lane queries), 2 a large mesh is present (never queried in the fused kernel)
 // MAIN + p.mesh_defer (the fused kernel and k_self_finish): a particle that needs a mesh query is not queried here.  A query
 // is thousands of instructions (closest point over the near meshes' faces + the exact winding number over all faces, twice
@@ -938,7 +956,9 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
             // next step's flavour from (r2s_phys_step) — their free flavour is the resident launch, worth keeping while the gripper merely hovers
             const unsigned long long qm = __builtin_amdgcn_ballot_w64(need);
             if (qm && (int)(threadIdx.x & 63) == __builtin_ctzll(qm)) p.fault[1] = 1;
-            if (need && (p.mesh_defer || MESH == 2)) { // large scenes always defer: the fused kernel carries no query code
+            if (MESH == 2) { // large scenes always defer (the fused kernel carries no query code), through the per-environment records
+                if (need && mesh_rec_push(p, e, step, i, 0, x0, v)) { fin = false; need = false; }
+            } else if (need && p.mesh_defer) {
                 const int slot = atomicAdd(p.mesh_cnt + step, 1);
                 if (slot < p.mesh_cap) {
                     p.vdef[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
@@ -1182,10 +1202,14 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
                 bool near;
                 if (mesh_need(p, e, step, x0 + v * p.dt, 0.002f, near)) {
                     p.fault[1] = 1;
-                    const int slot = atomicAdd(p.mesh_cnt + step, 1);
-                    if (slot < p.mesh_cap) {
-                        p.mesh_list[slot] = make_int2(e | (ncand << 12), i | (int)0x80000000);
-                        p.cand_mark[eb + i] = step + 1;
+                    if (MESH == 2) {
+                        if (mesh_rec_push(p, e, step, i, ncand, x0, v)) p.cand_mark[eb + i] = step + 1;
+                    } else {
+                        const int slot = atomicAdd(p.mesh_cnt + step, 1);
+                        if (slot < p.mesh_cap) {
+                            p.mesh_list[slot] = make_int2(e | (ncand << 12), i | (int)0x80000000);
+                            p.cand_mark[eb + i] = step + 1;
+                        }
                     }
                 }
                 const unsigned long long nm = __builtin_amdgcn_ballot_w64(near);
@@ -1515,10 +1539,14 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                         bool near;
                         if (mesh_need(p, e, step, x0 + v * p.dt, 0.002f, near)) {
                             p.fault[1] = 1;
-                            const int slot = atomicAdd(p.mesh_cnt + step, 1);
-                            if (slot < p.mesh_cap) {
-                                p.mesh_list[slot] = make_int2(e | (ncand << 12), i | (int)0x80000000);
-                                p.cand_mark[eb + i] = step + 1;
+                            if (MESH == 2) {
+                                if (mesh_rec_push(p, e, step, i, ncand, x0, v)) p.cand_mark[eb + i] = step + 1;
+                            } else {
+                                const int slot = atomicAdd(p.mesh_cnt + step, 1);
+                                if (slot < p.mesh_cap) {
+                                    p.mesh_list[slot] = make_int2(e | (ncand << 12), i | (int)0x80000000);
+                                    p.cand_mark[eb + i] = step + 1;
+                                }
                             }
                         }
                         const unsigned long long nm = __builtin_amdgcn_ballot_w64(near);
@@ -1647,30 +1675,54 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
     // one WORKGROUP per listed particle — four wavefronts (MESHQ 2) or two (MESHQ 3, 128 threads) that run the same code on the
     // same particle (identical results) and share the triangles of the queries; only the first wavefront stores
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
-    const int t0 = (int)blockIdx.x;
     __shared__ QShare qshare;
     int qpar = 0;
 #ifdef R2S_PHASE_PROBE
     const long long probe_entry = (long long)wall_clock64();
 #endif
-    int2 ei = p.mesh_list[min(t0, p.mesh_cap - 1)];
+    // Large-mesh scenes (MESHQ 2): the grid is (environments, slots) — environment fastest, so the workgroups dispatched first are
+    // slot 0 of every environment, the ones that have work — and the list is the ENVIRONMENT's, of self-contained records: record count,
+    // record (x0, v, candidate count) and the mesh's rigid transform are ONE round trip (measured on the 25k-face pusher scene: 23.8 ->
+    // 22.3 us per contact substep).  Small scenes keep the chain-wide list of (env, particle) entries on a 1-D grid: their triangles
+    // hang on the triangle ids, a second round trip either way, and the per-environment form cost them 0.3 - 0.8 us.
+    const int t_stride = (int)(MESHQ == 2 ? gridDim.y : gridDim.x);
+    const int t0 = (int)(MESHQ == 2 ? blockIdx.y : blockIdx.x);
+    const int e_wg = p.e0 + (int)(MESHQ == 2 ? blockIdx.x : 0u);
+    const int4* rec = MESHQ == 2 ? p.mesh_rec + 2 * (size_t)e_wg * p.N : nullptr;
+    int2 ei = make_int2(0, 0);
+    int4 ra = make_int4(0, 0, 0, 0), rc = ra;
+    if (MESHQ == 2) { ra = rec[2 * min(t0, p.N - 1)]; rc = rec[2 * min(t0, p.N - 1) + 1]; }
+    else ei = p.mesh_list[min(t0, p.mesh_cap - 1)];
     TriIds tid = {0, 0, 0, 0, 0, 0, false};
     if (MESHQ == 3) tid = load_tri_ids(p, lane, wave);
-    const int n_mesh = min(p.mesh_cnt[step], p.mesh_cap);
-    for (int t = t0; t < n_mesh; t += gridDim.x) { // a workgroup-uniform trip count (barriers inside)
-        if (t != t0) ei = p.mesh_list[t];
-        const bool tagged = ei.y < 0;
-        const int e = ei.x & 0xfff, i = ei.y & 0x7fffffff, cnt = ei.x >> 12;
+    Xf Xw; // MESHQ 2: the substep's rigid transform of the first large dynamic mesh of this workgroup's environment
+#pragma unroll
+    for (int j = 0; j < 9; ++j) Xw.r[j] = (j % 4 == 0) ? 1.f : 0.f;
+    Xw.t[0] = Xw.t[1] = Xw.t[2] = 0.f;
+    if (MESHQ == 2 && p.n_xf > 0) Xw = xf_load_slot(p, __builtin_amdgcn_readfirstlane(e_wg), step, 0);
+    const int n_mesh = MESHQ == 2 ? min(p.rec_cnt[(size_t)e_wg * p.n_sub + step], p.N) : min(p.mesh_cnt[step], p.mesh_cap);
+    for (int t = t0; t < n_mesh; t += t_stride) { // a workgroup-uniform trip count (barriers inside)
+        bool tagged;
+        int e, i, cnt;
+        if (MESHQ == 2) {
+            if (t != t0) { ra = rec[2 * t]; rc = rec[2 * t + 1]; }
+            tagged = ra.y < 0; e = e_wg; i = ra.y & 0x7fffffff; cnt = ra.x;
+        } else {
+            if (t != t0) ei = p.mesh_list[t];
+            tagged = ei.y < 0; e = ei.x & 0xfff; i = ei.y & 0x7fffffff; cnt = ei.x >> 12;
+        }
         const size_t eb = (size_t)e * p.N;
         TriRegs tr;
         if (MESHQ == 3) tr = load_tris(p, e, step, tid); // in flight while the impulses are summed
-        Xf X0; // the substep's rigid transform of the first large dynamic mesh: in flight with the particle's state
-#pragma unroll
-        for (int j = 0; j < 9; ++j) X0.r[j] = (j % 4 == 0) ? 1.f : 0.f;
-        X0.t[0] = X0.t[1] = X0.t[2] = 0.f;
-        if (MESHQ == 2 && p.n_xf > 0) X0 = xf_load_slot(p, __builtin_amdgcn_readfirstlane(e), step, 0);
-        const f3 x0 = st_x(xv_in, eb + i);
-        f3 v = xyz(tagged ? p.vbc[eb + i] : p.vdef[eb + i]);
+        const Xf X0 = Xw;
+        f3 x0, v;
+        if (MESHQ == 2) {
+            x0 = mk(__int_as_float(ra.z), __int_as_float(ra.w), __int_as_float(rc.x));
+            v = mk(__int_as_float(rc.y), __int_as_float(rc.z), __int_as_float(rc.w));
+        } else {
+            x0 = st_x(xv_in, eb + i);
+            v = xyz(tagged ? p.vbc[eb + i] : p.vdef[eb + i]);
+        }
         if (WITH_SELF && tagged) v = self_impulse<64>(p, xv_in, eb, i, true, x0, v, lane, cnt);
         R2S_QP_DECL(step == p.n_sub - 2 ? t * (MESHQ == 2 ? 4 : 2) + wave : -1); // stamps of the last-but-one substep (no force accumulation)
 #ifdef R2S_PHASE_PROBE
@@ -1690,11 +1742,12 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
         // part 1 fills the grid from its first workgroup, part 2 from its LAST: a wavefront that spent 7 us on a mesh particle
         // should not also be the one that starts a candidate particle afterwards (in-kernel stamps: the kernel ended at 10.8 us,
         // 3.3 us after the last mesh particle, with most of the grid idle)
-        const int rb = (int)(gridDim.x - 1 - blockIdx.x);
+        const int nblk = (int)(gridDim.x * gridDim.y);
+        const int rb = nblk - 1 - (int)(blockIdx.y * gridDim.x + blockIdx.x);
         const int g0 = rb * gpb + grp;
         int2 ci = p.cand_list[min(g0, p.E * p.N - 1)];
         const int n = *p.cand_count;
-        for (int base = rb * gpb; base < n; base += gridDim.x * gpb) { // wave-uniform trip count
+        for (int base = rb * gpb; base < n; base += nblk * gpb) { // wave-uniform trip count
             const int t = base + grp;
             if (t != g0 || t >= n) ci = p.cand_list[t < n ? t : 0]; // (the speculative entry of a slot past the count is stale or was never written: never index with it)
             const int e = ci.x & 0xfff, i = ci.y, cnt = ci.x >> 12;
@@ -2274,6 +2327,7 @@ struct R2SPhys {
     float4* d_vbc = nullptr;
     int2* d_mesh_list = nullptr; int* d_mesh_cnt = nullptr; int mesh_cap = 0; // deferred mesh queries: [E * N] (a chain's slice starts at its first env), [chains][n_sub + 1]
     float4* d_vdef = nullptr;
+    int4* d_mesh_rec = nullptr; int* d_rec_cnt = nullptr; // large-mesh scenes: per-environment records [E][N][2] and their counters [E][n_sub]
     int* d_cand_mark = nullptr;
     int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false, fault_stale = false;
     void* d_xch = nullptr;    // resident stepper: exchange array (96 B per particle)
@@ -2364,7 +2418,7 @@ struct R2SPhys {
         p.self_collision = prm.self_collision; p.use_pusher = prm.use_pusher;
         p.coll_num = d_coll_num; p.coll_idx = d_coll_idx; p.coll_cap = coll_cap;
         p.vbc = d_vbc; p.cand_list = d_cand_list; p.cand_count = d_cand_count;
-        p.mesh_list = d_mesh_list; p.mesh_cnt = d_mesh_cnt; p.mesh_cap = mesh_cap; p.mesh_defer = mesh_defer; p.vdef = d_vdef; p.cand_mark = d_cand_mark;
+        p.mesh_list = d_mesh_list; p.mesh_cnt = d_mesh_cnt; p.mesh_cap = mesh_cap; p.mesh_defer = mesh_defer; p.vdef = d_vdef; p.cand_mark = d_cand_mark; p.mesh_rec = d_mesh_rec; p.rec_cnt = d_rec_cnt;
         p.n_mesh = n_mesh; p.n_dyn_mesh = n_dyn_mesh; p.nF = nF; p.nV = nV; p.n_dyn_pts = n_dyn_pts;
         p.faces = d_faces; p.mesh_map = d_mesh_map; p.face_map = d_face_map; p.mesh_face_off = d_mesh_face_off;
         p.face_orig = d_face_orig; p.n_cl = n_cl; p.n_xf = n_xf;
@@ -2490,7 +2544,9 @@ void launch_finish(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
     const StateM out = h->state(in_buf ^ 1);
     if (has_contact_finish(h, p)) {
         const bool small = mesh == 1 && h->nF <= 128; // every mesh small: the substep's triangles fit two per lane
-        const dim3 g(small ? 1024 : 512);             // 2048 wavefronts (an idle launch costs the same ~2.5 us with 16 workgroups: it is the launch boundary), grid-stride: workgroups of two (small) or four wavefronts
+        // 2048 wavefronts (an idle launch costs the same ~2.5 us with 16 workgroups: it is the launch boundary), grid-stride: workgroups of
+        // two (small) or four wavefronts; large-mesh scenes: (environments of this chain, slots), a workgroup strides over ITS environment's records
+        const dim3 g = mesh == 2 ? dim3((unsigned)p.ne, (unsigned)std::max(16, 512 / std::max(1, p.ne))) : dim3(small ? 1024 : 512);
 #define R2S_FIN(Q, S) hipLaunchKernelGGL((k_contact_finish<Q, S>), g, dim3(small ? 128 : 256), 0, s, p, in, out, step, write_forces)
         if (small) { if (with_self) R2S_FIN(3, true); else R2S_FIN(3, false); }
         else { if (with_self) R2S_FIN(2, true); else R2S_FIN(2, false); }
@@ -2539,6 +2595,10 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
         p.mesh_cap = ne * h->N;
         p.mesh_cnt = h->d_mesh_cnt + (size_t)chain * (h->prm.num_substeps + 1);
         hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((h->prm.num_substeps + 256) / 256)), dim3(256), 0, s, (float*)p.mesh_cnt, (size_t)h->prm.num_substeps + 1);
+        if (h->d_rec_cnt) { // large-mesh scenes: the record counters of this chain's environments
+            const size_t cw = (size_t)ne * h->prm.num_substeps;
+            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cw + 255) / 256)), dim3(256), 0, s, (float*)(h->d_rec_cnt + (size_t)e0 * h->prm.num_substeps), cw);
+        }
         if (with_self && p.mesh_defer) { // marks of the previous env step must not match this step's substep numbers
             const size_t cnt = (size_t)ne * h->N;
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (float*)(h->d_cand_mark + (size_t)e0 * h->N), cnt);
@@ -3232,6 +3292,12 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_list, 0, sizeof(int2) * (size_t)h->mesh_cap, s));
         TRY(dev_alloc(&h->d_mesh_cnt, (size_t)8 * (h->prm.num_substeps + 1)));
         TRY(dev_alloc(&h->d_vdef, (size_t)E * N));
+        if (h->any_large) {
+            TRY(dev_alloc(&h->d_mesh_rec, (size_t)2 * E * N));
+            R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_rec, 0, sizeof(int4) * (size_t)2 * E * N, s));
+            TRY(dev_alloc(&h->d_rec_cnt, (size_t)E * h->prm.num_substeps));
+            R2S_HIP_TRY(hipMemsetAsync(h->d_rec_cnt, 0, sizeof(int) * (size_t)E * h->prm.num_substeps, s));
+        }
         if (h->prm.self_collision) { TRY(dev_alloc(&h->d_cand_mark, (size_t)E * N)); R2S_HIP_TRY(hipMemsetAsync(h->d_cand_mark, 0, sizeof(int) * (size_t)E * N, s)); }
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_cnt, 0, sizeof(int) * 8 * (size_t)(h->prm.num_substeps + 1), s));
     }
@@ -3304,7 +3370,7 @@ void r2s_phys_destroy(R2SPhys* h)
     (void)hipDeviceSynchronize();
     drop_graph(h);
     void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_slice_int, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
-                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_mesh_list, h->d_mesh_cnt, h->d_vdef, h->d_cand_mark, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
+                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_mesh_list, h->d_mesh_cnt, h->d_vdef, h->d_mesh_rec, h->d_rec_cnt, h->d_cand_mark, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
                     h->d_faces, h->d_face_orig, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
                     h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_sup_info, h->d_sup_box, h->d_small_mesh, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
@@ -3731,6 +3797,13 @@ int r2s_phys_deferred_counts(R2SPhys* h, int32_t* out, r2s_stream_t stream_)
     R2S_HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
     for (int c = 0; c < 8; ++c)
         for (int k = 0; k < n; ++k) out[k] += tmp[(size_t)c * n + k];
+    if (h->d_rec_cnt) { // large-mesh scenes count their records per environment
+        std::vector<int> rc((size_t)h->E * (n - 1));
+        R2S_HIP_TRY(hipMemcpyAsync(rc.data(), h->d_rec_cnt, sizeof(int) * rc.size(), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+        R2S_HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+        for (int e = 0; e < h->E; ++e)
+            for (int k = 0; k < n - 1; ++k) out[k] += rc[(size_t)e * (n - 1) + k];
+    }
     return R2S_OK;
 }
 
