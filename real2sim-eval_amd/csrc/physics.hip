@@ -1685,13 +1685,16 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
     // record (x0, v, candidate count) and the mesh's rigid transform are ONE round trip (measured on the 25k-face pusher scene: 23.8 ->
     // 22.3 us per contact substep).  Small scenes keep the chain-wide list of (env, particle) entries on a 1-D grid: their triangles
     // hang on the triangle ids, a second round trip either way, and the per-environment form cost them 0.3 - 0.8 us.
-    const int t_stride = (int)(MESHQ == 2 ? gridDim.y : gridDim.x);
-    const int t0 = (int)(MESHQ == 2 ? blockIdx.y : blockIdx.x);
-    const int e_wg = p.e0 + (int)(MESHQ == 2 ? blockIdx.x : 0u);
-    const int4* rec = MESHQ == 2 ? p.mesh_rec + 2 * (size_t)e_wg * p.N : nullptr;
+    // (MESHQ 2 also serves scenes of SMALL meshes with more than 128 faces in total: their fused kernel is the MESH 1 one and lists
+    // chain-wide — `per_env`, uniform, tells the two apart at run time: the records exist only when a large mesh does)
+    const bool per_env = MESHQ == 2 && p.mesh_rec != nullptr;
+    const int t_stride = (int)(per_env ? gridDim.y : gridDim.x);
+    const int t0 = (int)(per_env ? blockIdx.y : blockIdx.x);
+    const int e_wg = p.e0 + (int)(per_env ? blockIdx.x : 0u);
+    const int4* rec = per_env ? p.mesh_rec + 2 * (size_t)e_wg * p.N : nullptr;
     int2 ei = make_int2(0, 0);
     int4 ra = make_int4(0, 0, 0, 0), rc = ra;
-    if (MESHQ == 2) { ra = rec[2 * min(t0, p.N - 1)]; rc = rec[2 * min(t0, p.N - 1) + 1]; }
+    if (per_env) { ra = rec[2 * min(t0, p.N - 1)]; rc = rec[2 * min(t0, p.N - 1) + 1]; }
     else ei = p.mesh_list[min(t0, p.mesh_cap - 1)];
     TriIds tid = {0, 0, 0, 0, 0, 0, false};
     if (MESHQ == 3) tid = load_tri_ids(p, lane, wave);
@@ -1699,12 +1702,12 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
 #pragma unroll
     for (int j = 0; j < 9; ++j) Xw.r[j] = (j % 4 == 0) ? 1.f : 0.f;
     Xw.t[0] = Xw.t[1] = Xw.t[2] = 0.f;
-    if (MESHQ == 2 && p.n_xf > 0) Xw = xf_load_slot(p, __builtin_amdgcn_readfirstlane(e_wg), step, 0);
-    const int n_mesh = MESHQ == 2 ? min(p.rec_cnt[(size_t)e_wg * p.n_sub + step], p.N) : min(p.mesh_cnt[step], p.mesh_cap);
+    if (per_env && p.n_xf > 0) Xw = xf_load_slot(p, __builtin_amdgcn_readfirstlane(e_wg), step, 0);
+    const int n_mesh = per_env ? min(p.rec_cnt[(size_t)e_wg * p.n_sub + step], p.N) : min(p.mesh_cnt[step], p.mesh_cap);
     for (int t = t0; t < n_mesh; t += t_stride) { // a workgroup-uniform trip count (barriers inside)
         bool tagged;
         int e, i, cnt;
-        if (MESHQ == 2) {
+        if (per_env) {
             if (t != t0) { ra = rec[2 * t]; rc = rec[2 * t + 1]; }
             tagged = ra.y < 0; e = e_wg; i = ra.y & 0x7fffffff; cnt = ra.x;
         } else {
@@ -1714,9 +1717,10 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
         const size_t eb = (size_t)e * p.N;
         TriRegs tr;
         if (MESHQ == 3) tr = load_tris(p, e, step, tid); // in flight while the impulses are summed
-        const Xf X0 = Xw;
+        Xf X0 = Xw;
+        if (MESHQ == 2 && !per_env && p.n_xf > 0) X0 = xf_load_slot(p, __builtin_amdgcn_readfirstlane(e), step, 0);
         f3 x0, v;
-        if (MESHQ == 2) {
+        if (per_env) {
             x0 = mk(__int_as_float(ra.z), __int_as_float(ra.w), __int_as_float(rc.x));
             v = mk(__int_as_float(rc.y), __int_as_float(rc.z), __int_as_float(rc.w));
         } else {
