@@ -3,7 +3,7 @@ PhysTwin, stepped by the fused HIP substep kernel.  torch is used for device mem
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence
+from typing import Optional
 
 import numpy as np
 import torch
