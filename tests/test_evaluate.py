@@ -149,3 +149,21 @@ def test_two_ranks_gather_one_table_of_all_episodes():
     # on each rank the episodes alternate between its slot 0 (0.3: fail) and slot 1 (0.6: success)
     assert [row[1] for row in t0] == [0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 1.0]
     assert s0 == s1 and s0["episodes"] == 7
+
+
+@pytest.mark.timeout(300)
+def test_eval_batched_cli_two_ranks_stub():
+    """tools/eval_batched.py (the eval_policy_parallel.py of this repository) from a plain process with --gpus 2: self-launch through
+    torch.distributed.run, episodes e -> rank e % 2, the scheduler on a stand-in rollout, ONE all-gather, one JSON line from rank 0."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "eval_batched.py"), "--stub", "--episodes", "13", "--gpus", "2", "--envs", "3",
+                        "--max-steps", "5", "--stop-on-success"], capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["episodes"] == 13 and d["episode_ids_seen"] == 13 and d["episodes_per_rank"] == [7, 6]
+    assert d["success_rate"] == 1.0 and 3.0 <= d["mean_steps"] <= 4.0 and d["env_steps_per_s"] > 0
