@@ -2,11 +2,17 @@
 calls ``set_mesh_interactive`` (reference sim/physics/phystwin.py:362-513) — gripper openness / grasp state machine,
 finger-vertex interpolation, per-substep rigid motion of the dynamic collision meshes.
 
-TEST INFRASTRUCTURE ONLY: imported by tests/ (and nothing else) as the checker of the HIP kernels k_eef_prepare /
-k_eef_points.  PARITY UNPINNED: phystwin.py cannot be imported here (it imports warp at module top) and kornia (the
-reference's axis_angle_to_rotation_matrix) is not installed; the torch / numpy / scipy operations of the cited lines are
-re-issued here in the same order on the CPU (same dtypes: python float64 for the state machine, scipy interp1d for the
-vertices, float32 torch ops for the motion), and kornia's conversion is restated from its published source.
+TEST INFRASTRUCTURE ONLY: imported by tests/ and oracle/parity_gate.py (and nothing else) as the checker of the HIP kernels
+k_eef_prepare / k_eef_points.  PINNED (round 4): tests/golden/eef_step.npz holds inputs and outputs of the REFERENCE's own
+``SpringMassDynamicsModule.step`` — phystwin.py imported with tests/golden/warp_shim.py standing in for warp, placeholder modules
+for open3d / sapien / transforms3d / urdfpy, the module object created without ``__init__`` and a recorder in place of the warp
+simulator (tests/golden/make_eef_golden.py) — over scripted open -> closing -> grasp -> held -> creep -> release sequences of the
+gripper branch (40 and 667 substeps) and the pusher branch; this restatement reproduces the fixture BIT FOR BIT
+(tests/test_eef_reference_fixture.py), the device kernels within 1e-6 m / state machine exact (tests/test_eef_gpu.py).
+Still unpinned: kornia's ``axis_angle_to_rotation_matrix`` (third party, not installed; restated from its published source here,
+in the fixture's generator and in the kernel).  The torch / numpy / scipy operations of the cited lines are re-issued in the same
+order on the CPU (same dtypes: python float64 for the state machine, scipy interp1d for the vertices, float32 torch ops for the
+motion).
 """
 from __future__ import annotations
 

@@ -155,3 +155,75 @@ def test_pusher_large_rigid_mesh_only_touches_the_vertices_the_stepper_reads():
         rot = (Rotation.from_rotvec(rv[0].astype(np.float64) * n_sub * DT).as_matrix().T @ rot[0].astype(np.float64)).astype(np.float32)[None]
     moved = h.x[0].cpu().numpy()[:, 0] - pts[:, 0]
     assert moved.max() > 1e-3, "the rod must push the block in this scenario"
+
+
+# ---- against the fixture the REFERENCE's own SpringMassDynamicsModule.step produced (tests/golden/make_eef_golden.py) -------------
+def _fixture():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "eef_step.npz"))
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_device_kinematics_and_grasp_state_machine_equal_the_reference_step(tag):
+    """k_eef_prepare / k_eef_points vs phystwin.py:367-460 as executed by the reference itself: scripted open -> closing -> grasp
+    (both filtered finger forces > 3e4) -> held -> 0.05-per-step creep -> release (< 100) -> re-opening; A: 40 substeps,
+    B: the real 667.  Two environments replay the script one step apart (per-environment state)."""
+    import torch
+    from r2s_hip import synth
+
+    G = _fixture()
+    n_sub, thr = int(G[f"{tag}_n_sub"]), float(G["thr"])
+    tab, init, mesh_map = G["table"], G["init_eef_xyz"], G["mesh_map"]
+    K = len(G[f"{tag}_xyz"])
+    ob = make_object("sloth", 300, seed=1)
+    w0 = synth.eef_world_points(tab[-1], init, G[f"{tag}_xyz"][0][0], G[f"{tag}_rot"][0][0])
+    M = len(w0) // 2
+    box = synth.box_mesh((0.9, 0.9, 0.05), (0.05, 0.05, 0.05))
+    E = 2
+    h = hip_env(ob, num_substeps=n_sub, n_env=E, dynamic_meshes=[(w0[:M], G["faces_left"]), (w0[M:], G["faces_right"])], static_meshes=[box],
+                self_collision=False)
+    assert np.array_equal(h.mesh_map, mesh_map)
+    h.set_eef_table(tab, init, thr)
+    keep = G["B_keep"] if tag == "B" else np.arange(n_sub)
+    worst = dict(pts=0.0, center=0.0, dvel=0.0, omega=0.0)
+    for k in range(K + 1):
+        idx = [min(k, K - 1), max(k - 1, 0)]                     # env 1 lags one step behind env 0
+        g = lambda name: np.stack([G[f"{tag}_{name}"][i] for i in idx])  # noqa: E731
+        _write_forces(h, g("force"))
+        cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()  # noqa: E731
+        h.set_eef_motion(cu(g("xyz")[:, 0]), cu(g("vel")[:, 0]), cu(g("rot")[:, 0]), cu(g("rv")[:, 0]), cu(g("open")))
+        pts, ctr, dv, om = [t.cpu().numpy() for t in h.mesh_motion()]
+        cur, grasped = h.eef_state()
+        for e, i in enumerate(idx):
+            if (e == 0 and k == K) or (e == 1 and k == 0):
+                continue                                          # a repeated step of the script: not what the fixture holds
+            r = lambda name: G[f"{tag}_{name}"][i]  # noqa: E731
+            assert cur[e].item() == float(r("cur")) and bool(grasped[e]) == bool(r("grasped")), (k, e, cur[e].item(), r("cur"))
+            worst["pts"] = max(worst["pts"], float(np.abs(pts[e][keep] - r("pts")).max()))
+            worst["center"] = max(worst["center"], float(np.abs(ctr[e][keep] - r("center")).max()))
+            worst["dvel"] = max(worst["dvel"], float(np.abs(dv[e] - r("dvel")).max()))
+            worst["omega"] = max(worst["omega"], float(np.abs(om[e][None] - r("omega")).max()))
+    from util_parity import record
+    record(f"eef_reference_fixture_{tag}", **worst, gates="pts 1e-6, center 2e-7, dvel 1e-5, omega 1e-7; state machine exact")
+    assert worst["pts"] < 1e-6 and worst["center"] < 2e-7 and worst["dvel"] < 1e-5 and worst["omega"] < 1e-7, worst
+
+
+def test_device_pusher_branch_equals_the_reference_step():
+    """phystwin.py:462-513 as executed by the reference: rigid rod, dynamic_velocity [1, 3] = eef_vel / 2, omega = -rate / 2."""
+    import torch
+    from r2s_hip import synth
+
+    G = _fixture()
+    n_sub = int(G["P_n_sub"])
+    tab, init = G["P_table"], G["P_init_eef_xyz"]
+    ob = make_object("T", 300, seed=2)
+    w0 = synth.eef_world_points(tab[-1], init, G["P_xyz"][0][0], G["P_rot"][0][0])
+    h = hip_env(ob, num_substeps=n_sub, n_env=1, dynamic_meshes=[(w0, G["P_faces"])], use_pusher=True, self_collision=False)
+    h.set_eef_table(tab, init, float(G["thr"]))
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()  # noqa: E731
+    for k in range(len(G["P_xyz"])):
+        h.set_eef_motion(cu(G["P_xyz"][k]), cu(G["P_vel"][k]), cu(G["P_rot"][k]), cu(G["P_rv"][k]))
+        pts, ctr, dv, om = [t.cpu().numpy() for t in h.mesh_motion()]
+        assert np.abs(pts[0] - G["P_pts"][k]).max() < 1e-6, (k, np.abs(pts[0] - G["P_pts"][k]).max())
+        assert np.abs(ctr[0] - G["P_center"][k]).max() < 2e-7
+        assert np.abs(dv[0, :1] - G["P_dvel"][k]).max() < 1e-7 and np.abs(om[0][None] - G["P_omega"][k]).max() < 1e-7
