@@ -126,6 +126,14 @@ int r2s_phys_eef_state(R2SPhys* h, double** current_openness, int32_t** grasped)
  * the others keep running (episodes are independent, eval_policy_parallel.py:266-280).  The particle state of those
  * environments is the caller's to set (r2s_phys_set_state); r2s_phys_update_collision_graph rebuilds the candidate lists. */
 int r2s_phys_reset_envs(R2SPhys* h, const int32_t* env_mask, r2s_stream_t stream);
+/* The particle state of an episode reset: like r2s_phys_set_state for the environments with a non-zero mask entry (DEVICE int32
+ * [n_env], required), the others are not touched — and neither is the sticky fault word of r2s_phys_step: it is per handle and may
+ * have been raised by an environment that keeps running (a full r2s_phys_set_state is what clears it). */
+int r2s_phys_set_state_envs(R2SPhys* h, const float* x, const float* v, const int32_t* env_mask, r2s_stream_t stream);
+/* create_resting_case (:729-740) for the masked environments only: a reset episode that starts from ANOTHER pose (the reference
+ * builds a new stepper per reset, whose resting-pair set comes from the new initial positions — and depends on them through the
+ * hash-grid cells) while the other environments keep theirs. */
+int r2s_phys_create_resting_case_envs(R2SPhys* h, const int32_t* env_mask, r2s_stream_t stream);
 int r2s_phys_mesh_motion(R2SPhys* h, float** interp_points, float** interp_center, float** dynamic_velocity,
                          float** dynamic_omega);
 

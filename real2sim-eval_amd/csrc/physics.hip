@@ -1795,11 +1795,12 @@ __global__ void k_sum_i32(const int* __restrict__ a, int n, int stride, int* __r
 }
 
 // ---- state pack / unpack: caller order [env][user index][3]  <->  internal [env][Morton index]{x,v} -------
-__global__ void k_pack(int N, int E, const int* __restrict__ inv, const float* __restrict__ x, const float* __restrict__ v, const StateM xv)
+__global__ void k_pack(int N, int E, const int* __restrict__ inv, const float* __restrict__ x, const float* __restrict__ v, const StateM xv,
+                       const int* __restrict__ env_mask)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
-    if (u >= N) return;
+    if (u >= N || (env_mask && env_mask[e] == 0)) return;
     const size_t src = ((size_t)e * N + u) * 3, dst = (size_t)e * N + inv[u];
     float* f = (float*)xv.p; // x and v may be set separately: plane 1 holds one component of each
     if (x) { xv.p[st_at(xv.n, dst, 0)] = (v2f){x[src], x[src + 1]}; f[2 * st_at(xv.n, dst, 1)] = x[src + 2]; }
@@ -2120,11 +2121,11 @@ __device__ __forceinline__ QBox query_box(float4 q, float r, float cell_inv)
 // `index < i` test is on USER indices like the reference)
 __global__ void k_build_resting(int N, int E, int words, const int* __restrict__ perm, const int* __restrict__ inv,
                                 const StateC xv, float radius, float cell_inv, const uint32_t* __restrict__ keys,
-                                const uint32_t* __restrict__ ids, uint32_t* __restrict__ bits)
+                                const uint32_t* __restrict__ ids, uint32_t* __restrict__ bits, const int* __restrict__ env_mask)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = blockIdx.y;
-    if (i >= N) return;
+    if (i >= N || (env_mask && env_mask[e] == 0)) return;
     const int ui = perm[i];
     const float4 q = st_x4(xv, (size_t)e * N + i);
     const QBox b = query_box(q, radius, cell_inv);
@@ -3397,7 +3398,7 @@ void r2s_phys_destroy(R2SPhys* h)
 int r2s_phys_set_state(R2SPhys* h, const float* x, const float* v, r2s_stream_t stream_)
 {
     if (!h) return R2S_ERR_INVALID;
-    hipLaunchKernelGGL(k_pack, dim3((h->N + 255) / 256, h->E), dim3(256), 0, (hipStream_t)stream_, h->N, h->E, h->d_inv, x, v, h->state(h->cur));
+    hipLaunchKernelGGL(k_pack, dim3((h->N + 255) / 256, h->E), dim3(256), 0, (hipStream_t)stream_, h->N, h->E, h->d_inv, x, v, h->state(h->cur), (const int*)nullptr);
     R2S_HIP_TRY(hipGetLastError());
     // A fault word (r2s_phys_step) says "the state is invalid": a state set by the caller makes the handle usable again.
     if (h->d_mesh_total) {
@@ -3405,6 +3406,15 @@ int r2s_phys_set_state(R2SPhys* h, const float* x, const float* v, r2s_stream_t 
         if (h->mesh_pending) h->fault_stale = true; // a copy still in flight may carry the old word: dropped when it lands
         else h->h_mesh_total[1] = 0;
     }
+    return R2S_OK;
+}
+
+int r2s_phys_set_state_envs(R2SPhys* h, const float* x, const float* v, const int32_t* env_mask, r2s_stream_t stream_)
+{
+    if (!h || !env_mask) return R2S_ERR_INVALID;
+    // an episode reset of SOME environments: the fault word is per handle and may belong to an environment that keeps running — untouched
+    hipLaunchKernelGGL(k_pack, dim3((h->N + 255) / 256, h->E), dim3(256), 0, (hipStream_t)stream_, h->N, h->E, h->d_inv, x, v, h->state(h->cur), env_mask);
+    R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
 }
 
@@ -3416,19 +3426,40 @@ int r2s_phys_get_state(R2SPhys* h, float* x, float* v, r2s_stream_t stream_)
     return R2S_OK;
 }
 
-int r2s_phys_create_resting_case(R2SPhys* h, r2s_stream_t stream_)
+__global__ void k_zero_env_rows(size_t words_per_env, const int* __restrict__ env_mask, uint32_t* __restrict__ bits)
 {
-    if (!h || !h->prm.self_collision) return R2S_ERR_INVALID;
-    hipStream_t s = (hipStream_t)stream_;
+    const int e = blockIdx.y;
+    if (env_mask[e] == 0) return;
+    uint32_t* row = bits + (size_t)e * words_per_env;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < words_per_env; k += (size_t)gridDim.x * blockDim.x) row[k] = 0u;
+}
+
+static int create_resting_case(R2SPhys* h, const int32_t* env_mask, hipStream_t s)
+{
     const uint32_t *keys, *ids;
     int rc = grid_sort(h, s, &keys, &ids);
     if (rc) return rc;
-    R2S_HIP_TRY(hipMemsetAsync(h->d_bits, 0, sizeof(uint32_t) * (size_t)h->E * h->N * h->words, s));
+    const size_t per_env = (size_t)h->N * h->words;
+    if (env_mask) hipLaunchKernelGGL(k_zero_env_rows, dim3(256, (unsigned)h->E), dim3(256), 0, s, per_env, env_mask, h->d_bits);
+    else R2S_HIP_TRY(hipMemsetAsync(h->d_bits, 0, sizeof(uint32_t) * (size_t)h->E * per_env, s));
     const float r = h->prm.collision_dist * 5.0f;
     dim3 grid((h->N + TPB - 1) / TPB, h->E);
-    hipLaunchKernelGGL(k_build_resting, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->d_perm, h->d_inv, h->state(h->cur), r, 1.0f / r, keys, ids, h->d_bits);
+    hipLaunchKernelGGL(k_build_resting, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->d_perm, h->d_inv, h->state(h->cur), r, 1.0f / r, keys, ids, h->d_bits,
+                       (const int*)env_mask);
     R2S_HIP_TRY(hipGetLastError());
     return R2S_OK;
+}
+
+int r2s_phys_create_resting_case(R2SPhys* h, r2s_stream_t stream_)
+{
+    if (!h || !h->prm.self_collision) return R2S_ERR_INVALID;
+    return create_resting_case(h, nullptr, (hipStream_t)stream_);
+}
+
+int r2s_phys_create_resting_case_envs(R2SPhys* h, const int32_t* env_mask, r2s_stream_t stream_)
+{
+    if (!h || !h->prm.self_collision || !env_mask) return R2S_ERR_INVALID;
+    return create_resting_case(h, env_mask, (hipStream_t)stream_);
 }
 
 int r2s_phys_update_collision_graph(R2SPhys* h, r2s_stream_t stream_)

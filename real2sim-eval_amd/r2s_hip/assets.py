@@ -292,12 +292,15 @@ def _grid_pose(grid, idx):
     return float(xy[xi][0]), float(xy[xi][1]), 0.0, float(theta[ti]) * np.pi / 180.0
 
 
-def _randomised_pose(pose, entry, randomize, use_grid, grid_index, rng, random_variables):
+def _randomised_pose(pose, entry, randomize, use_grid, grid_index, rng, random_variables, is_mesh=False):
+    """The reference's two condition chains differ: a static mesh without a grid of its own is STILL drawn from its
+    translation_range / azimuth_range under use_grid_randomization (`elif randomize:`, gs_renderer.py:393), the object only when
+    grid randomisation is off (`elif randomize and not use_grid_randomization`, :639)."""
     pose = np.array(pose, dtype=np.float64).reshape(4, 4).copy()
     rand = None
     if randomize and use_grid and entry.get("grid_randomization"):
         rand = _grid_pose(entry["grid_randomization"], grid_index)
-    elif randomize and not use_grid:
+    elif randomize and (is_mesh or not use_grid):
         tr, az = np.array(entry["translation_range"]), np.array(entry["azimuth_range"])
         rand = (rng.uniform(tr[0], tr[1]), rng.uniform(tr[2], tr[3]), rng.uniform(tr[4], tr[5]), rng.uniform(az[0], az[1]) * np.pi / 180.0)
     if rand is not None:
@@ -351,7 +354,7 @@ def load_scaniverse(gs_cfg, randomize=False, index=None, rng=None):
             g = m["grid_randomization"]
             n_this = len(g["xy"]) if g.get("one_to_one", False) else len(g["xy"]) * len(g["theta"])
             gi, true_index_mesh = true_index_mesh % n_this, true_index_mesh // n_this
-        pose = _randomised_pose(m["pose"], m, randomize, use_grid, gi, rng, random_variables)
+        pose = _randomised_pose(m["pose"], m, randomize, use_grid, gi, rng, random_variables, is_mesh=True)
         pts, shs, scales, quats, opac = _splat_arrays(load_gaussians_ply(m["splat_path"]), m)
         pts = pts @ pose[:3, :3].T + pose[:3, 3]
         q = quats / np.maximum(np.linalg.norm(quats, axis=-1, keepdims=True), 1e-12)

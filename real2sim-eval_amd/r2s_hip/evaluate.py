@@ -4,7 +4,9 @@ processes (episode e -> rank e % n_processes, :266-271), and inside a rank the e
 limit).  No data-path collective: ranks meet once, at the end, to all-gather one fixed-size record per episode — {episode_id,
 success, steps, wall_ms} — so that every rank holds the global success rate.
 
-The rollout is duck-typed (``n_env``, ``reset(mask)``, ``get_obs()``, ``step(action)``, ``success_flags()``), so the scheduler is
+The rollout is duck-typed (``n_env``, ``reset(mask)`` — ``reset(mask, episode_ids=[...])`` when it has a true ``randomize`` attribute:
+the episode id picks the object's start pose like the reference's ``env.reset(seed=episode_id)`` —, ``get_obs()``, ``step(action)``,
+``success_flags()``), so the scheduler is
 covered on the CPU with a stand-in (tests/test_evaluate.py) and on the GPU with the real one (tests/test_episode_reset_gpu.py)."""
 from __future__ import annotations
 
@@ -71,7 +73,11 @@ def run_episodes(ro, episode_ids: Sequence[int], policy: Optional[Callable] = No
             else:
                 slot_row[s] = -1
         if bool(mask.any()):
-            ro.reset(mask.to(dev))
+            if getattr(ro, "randomize", False):
+                # env.reset(seed=episode_id) (eval_policy.py:67, eval_policy_parallel.py:47): the episode id is the index of the object's randomised start pose
+                ro.reset(mask, episode_ids=[ids[slot_row[s]] if slot_row[s] >= 0 else 0 for s in range(E)])
+            else:
+                ro.reset(mask.to(dev))
 
     deal(range(E))
     while any(r >= 0 for r in slot_row):

@@ -53,7 +53,7 @@ def _bind():
         r2s_phys_mesh_maps=[vp, vp, vp], r2s_phys_collision_lists=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32)],
         r2s_phys_collision_max_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_set_spring_Y=[vp, vp, vp],
         r2s_phys_set_eef_table=[vp, C.c_int32, vp, vp, C.c_float, vp], r2s_phys_set_eef_motion=[vp, vp, vp, vp, vp, vp, vp],
-        r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_reset_envs=[vp, vp, vp], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
+        r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_reset_envs=[vp, vp, vp], r2s_phys_set_state_envs=[vp, vp, vp, vp, vp], r2s_phys_create_resting_case_envs=[vp, vp, vp], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
         r2s_phys_set_collision_lists=[vp, vp, vp, vp], r2s_phys_contact_stats=[vp, C.POINTER(C.c_int32), C.POINTER(vp)],
         r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32], r2s_phys_set_resident=[vp, i32], r2s_phys_side_stream=[i32, C.POINTER(vp)],
         r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
@@ -188,6 +188,20 @@ class PhysBatch:
             vp = v.data_ptr()
         with torch.cuda.device(self.device):
             check(_bind().r2s_phys_set_state(self._h, x.data_ptr(), vp, self._s()), "r2s_phys_set_state")
+        self.sync_state()
+
+    def set_state_envs(self, x: torch.Tensor, v: torch.Tensor, mask: torch.Tensor, resting_case: bool = False):
+        """The particle state of an episode reset: rows of ``x`` / ``v`` ([n_env, N, 3]) of the environments with a non-zero ``mask``
+        entry replace the device state, the others keep running untouched — including a pending fault of theirs, which the next
+        ``step`` still reports (``set_state`` clears it; r2s_phys_set_state_envs).  ``resting_case``: also rebuild those
+        environments' resting-pair set from the new positions (a reset into ANOTHER pose; the reference builds a new stepper)."""
+        x = x.to(self.device, torch.float32).contiguous().reshape(self.n_env, self.N, 3)
+        v = v.to(self.device, torch.float32).contiguous().reshape(self.n_env, self.N, 3)
+        m = mask.to(self.device, torch.int32).contiguous().reshape(self.n_env)
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_set_state_envs(self._h, x.data_ptr(), v.data_ptr(), m.data_ptr(), self._s()), "r2s_phys_set_state_envs")
+            if resting_case and self.self_collision:
+                check(_bind().r2s_phys_create_resting_case_envs(self._h, m.data_ptr(), self._s()), "r2s_phys_create_resting_case_envs")
         self.sync_state()
 
     # -- per-env-step protocol (phystwin.py:362-521) ------------------------------------------------------

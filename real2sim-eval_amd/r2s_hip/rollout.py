@@ -106,7 +106,7 @@ def quaternion_to_rotation_matrix(q: torch.Tensor) -> torch.Tensor:
 class BatchedRollout:
     def __init__(self, config="sloth_32env", device="cuda:0", seed=0, n_env=None, num_substeps=667, views=2,
                  self_collision=True, with_gripper=True, with_static=True, tile_culling=True, schedule=None, close_at=15, open_at=10**9,
-                 settle_steps=None):
+                 settle_steps=None, randomize=False):
         """``schedule``: the synthetic action trace.  "grasp" (default for the sloth scenes): the open gripper comes down over
         the toy's raised arms (free motion), closes on them at env step ``close_at`` — finger contact, the two arms pressed
         together (live self-collision candidates), grasp detection — and lifts.  "lissajous" (default otherwise, SURVEY.md
@@ -114,7 +114,9 @@ class BatchedRollout:
         scene pushes along +x and reaches the block at ``close_at``.  ``settle_steps`` (default 40 for "grasp"): env steps run
         inside the constructor with the gripper parked 15 cm higher, so that the toy is AT REST when the rollout starts
         (SURVEY.md §8d places the objects resting on the table; a jittered lattice with random stiffness is not in equilibrium
-        under gravity and its arms sway by ~1 cm for the first second)."""
+        under gravity and its arms sway by ~1 cm for the first second).  ``randomize``: ``reset(env_ids, episode_ids=...)`` places
+        each reset environment's object at the grid pose of its episode id (``episode_pose``; the reference: env.reset(seed=episode_id)
+        -> load_scaniverse(randomize, index), gs_renderer.py:333-637) — costs one rotation array per environment."""
         shape, n_particles, n_gauss, envs, W, H = CONFIGS[config]
         self.config = config
         self.n_env = int(n_env if n_env is not None else envs)
@@ -204,6 +206,10 @@ class BatchedRollout:
         self.bones = self.phys.x.clone()                          # particle positions the Gaussians currently correspond to
         self.g = {k: t(v) for k, v in sc.items() if k != "means3D"}
         self.rot_env = None
+        self.randomize = bool(randomize)
+        self.random_variables = {}                                # episode id -> [x, y, z, angle] as the reference records them (gs_renderer.py:637)
+        if self.randomize and not self.with_robot:
+            self.rot_env = torch.nn.functional.normalize(self.g["rotations"], dim=-1)[None].repeat(E, 1, 1).contiguous()
         if self.with_robot:
             # per-environment rotations (the robot's splats turn with their links); object / table rows are the shared values
             from .robot import RobotGaussians
@@ -238,7 +244,7 @@ class BatchedRollout:
         self.out_depth = torch.empty(E, views, 1, H, W, dtype=torch.float32, device=self.device)
         self._update_means()
         self._sets = [RasterBatch.make_set(self.means[e], self.g["opacities"], shs=self.g["shs"], scales=self.g["scales"],
-                                           rotations=self.rot_env[e] if self.with_robot else self.g["rotations"]) for e in range(E)]
+                                           rotations=self.rot_env[e] if self.rot_env is not None else self.g["rotations"]) for e in range(E)]
         self._frames = []
         for e in range(E):
             for vi, cam in enumerate(self.cam_t):
@@ -272,8 +278,13 @@ class BatchedRollout:
         # what an episode starts from (reset): particles at rest, the object's Gaussians on them, the end effector at its start pose
         self._env_t0 = torch.zeros(E, dtype=torch.long, device=self.device)
         self._init = dict(x=self.phys.x.clone(), v=self.phys.v.clone(), means=self.means[:, : self.n_obj].clone())
+        if self.rot_env is not None:
+            self._init["rot"] = self.rot_env[:, : self.n_obj].clone()
         if with_gripper:
             self._init.update(eef_xyz=self.eef_xyz.clone(), eef_rot=self.eef_rot.clone())
+        self._obj_center = torch.tensor([float(c[0]), float(c[1]), 0.0], device=self.device)
+        # nothing has been rendered yet: the first get_obs() / observations() renders the start state (BaseEnv.reset returns get_obs())
+        self._frame_dirty = True
 
     # ---- end-effector trace: fixed Lissajous path at <= 0.1 m/s; the gripper closes at step 100 and opens at 300 ------
     # (SURVEY.md §8d).  Only the eef pose / rates / commanded opening are produced here — what BaseEnv hands to
@@ -393,7 +404,25 @@ class BatchedRollout:
             self._robot_first = False
 
     # ---- episode reset of some environments ------------------------------------------------------------------------
-    def reset(self, env_ids=None):
+    # grid randomisation of the object pose per scene: cfg/gs/{rope,sloth,T}.yaml `object.grid_randomization` (xy in m, theta in degrees)
+    GRIDS = {"rope": dict(xy=[(-0.05, -0.05), (-0.05, 0.0), (-0.05, 0.05), (0.0, -0.05), (0.0, 0.0), (0.0, 0.05), (0.05, -0.05), (0.05, 0.0), (0.05, 0.05)],
+                          theta=[-10, 0, 10], one_to_one=False),
+             "sloth": dict(xy=[(0, 0), (-0.05, 0), (0.05, 0), (0, -0.05), (0, 0.03)], theta=[0, -5, 5, -5, 5], one_to_one=True),
+             "T": dict(xy=[(-0.05, -0.05), (-0.05, 0.05), (0.05, -0.05), (0.05, 0.05)], theta=[45, 135, 225, 315], one_to_one=False)}
+
+    def episode_pose(self, episode_id: int):
+        """(x, y, z = 0, angle in radians) of episode ``episode_id``: the reference's grid arithmetic (gs_renderer.py:340-347, :614-637:
+        index = episode_id mod n_object_rand; one_to_one: xy[i], theta[i]; else xy[i // n_theta], theta[i % n_theta])."""
+        g = self.GRIDS[self.ob_shape]
+        n = len(g["xy"]) if g["one_to_one"] else len(g["xy"]) * len(g["theta"])
+        i = int(episode_id) % n
+        if g["one_to_one"]:
+            xy, th = g["xy"][i], g["theta"][i]
+        else:
+            xy, th = g["xy"][i // len(g["theta"])], g["theta"][i % len(g["theta"])]
+        return float(xy[0]), float(xy[1]), 0.0, float(th) * np.pi / 180.0
+
+    def reset(self, env_ids=None, episode_ids=None):
         """BaseEnv.reset (env.py:30-51) for some environments of the batch (``env_ids``: indices, a bool mask [n_env], or None =
         all) while the others keep running — episodes are independent and end at different steps (eval_policy_parallel.py:
         266-280).  The reference rebuilds renderer state and a NEW dynamics module per reset (gs_renderer.reset_state,
@@ -401,10 +430,22 @@ class BatchedRollout:
         rest in their start pose (zero collision forces, grasp state machine at current_openness = None / grasped = False), the
         object's Gaussians and their bones as loaded, the end effector at its start pose; the synthetic action trace of that
         environment starts over.  Everything stays on the device, nothing is synchronised; the candidate lists are rebuilt by
-        the next step."""
+        the next step, and the next ``get_obs()`` renders the reset state before it hands anything out (the reference's reset
+        returns get_obs()).
+
+        ``episode_ids`` (a sequence / tensor [n_env]; entries of environments outside ``env_ids`` are ignored; needs
+        ``randomize=True``): the reference's ``env.reset(seed=episode_id)`` — the object of a reset environment is placed at the grid
+        pose of its episode id (``episode_pose``): particles, Gaussian centres and rotations turned about the object's vertical axis
+        and shifted, the resting-pair set of those environments rebuilt from the new positions, the gripper's start pose shifted
+        along (and turned with the object for the gripper scenes, whose synthetic trace closes the fingers across the object).
+        ``random_variables[episode_id]`` records [x, y, z, angle] like the reference.
+
+        A fault raised by an environment that is NOT being reset survives a partial reset (the next ``step`` reports it); resetting
+        every environment hands in a whole new state and clears it."""
         E, dev = self.n_env, self.device
         if env_ids is None:
             mask = torch.ones(E, dtype=torch.bool, device=dev)
+            everything = True
         else:
             ids = torch.as_tensor(env_ids, device=dev)
             if ids.dtype == torch.bool:
@@ -412,6 +453,7 @@ class BatchedRollout:
             else:
                 mask = torch.zeros(E, dtype=torch.bool, device=dev)
                 mask[ids.long().reshape(-1)] = True
+            everything = False
         main = torch.cuda.current_stream(dev)
         ev = getattr(self, "_cand_done", None)
         if ev is not None:                      # a candidate rebuild on the side stream is still reading the state about to be replaced
@@ -419,18 +461,69 @@ class BatchedRollout:
             self._cand_done = None
         self.wait_render()                      # pipelined mode: the render stream reads the Gaussians about to be replaced
         m3 = mask[:, None, None]
-        self.phys.set_state(torch.where(m3, self._init["x"], self.phys.x), torch.where(m3, self._init["v"], self.phys.v))
+        x_new, v_new, means_new = self._init["x"], self._init["v"], self._init["means"]
+        rot_new = self._init.get("rot")
+        eef_xyz_new, eef_rot_new = self._init.get("eef_xyz"), self._init.get("eef_rot")
+        posed = episode_ids is not None
+        if posed:
+            if not self.randomize:
+                raise ValueError("reset(episode_ids=...) needs BatchedRollout(randomize=True)")
+            eids = [int(e) for e in (episode_ids.tolist() if torch.is_tensor(episode_ids) else episode_ids)]
+            assert len(eids) == E, "episode_ids has one entry per environment"
+            if env_ids is None:
+                mask_host = [True] * E
+            else:       # which rows to fill: from the caller's own (host) ids when they are on the host — no device read then
+                src = torch.as_tensor(env_ids).cpu()
+                mask_host = src.reshape(E).tolist() if src.dtype == torch.bool else [e in set(src.long().reshape(-1).tolist()) for e in range(E)]
+            pose = np.zeros((E, 4), np.float32)
+            for e in range(E):
+                if mask_host[e]:
+                    pose[e] = self.episode_pose(eids[e])
+                    self.random_variables[eids[e]] = [float(a) for a in pose[e]]
+            pose_t = torch.from_numpy(pose).to(dev)
+            ca, sa = torch.cos(pose_t[:, 3]), torch.sin(pose_t[:, 3])
+            Rz = torch.zeros(E, 3, 3, device=dev)
+            Rz[:, 0, 0], Rz[:, 0, 1], Rz[:, 1, 0], Rz[:, 1, 1], Rz[:, 2, 2] = ca, -sa, sa, ca, 1.0
+            shift = torch.cat([pose_t[:, :2], torch.zeros(E, 1, device=dev)], 1)
+            c = self._obj_center
+            turn = lambda p: (p - c).matmul(Rz.transpose(1, 2)) + c + shift[:, None]  # noqa: E731  env 0 (unshifted) is the template of every pose
+            x_new = turn(self._init["x"][0][None].expand(E, -1, -1))
+            v_new = self._init["v"][0][None].expand(E, -1, -1).matmul(Rz.transpose(1, 2))
+            means_new = turn(self._init["means"][0][None].expand(E, -1, -1))
+            half = 0.5 * pose_t[:, 3]
+            qz = torch.stack([torch.cos(half), torch.zeros_like(half), torch.zeros_like(half), torch.sin(half)], 1)      # (w, x, y, z)
+            q = self._init["rot"][0][None].expand(E, -1, -1)
+            w1, z1 = qz[:, None, 0], qz[:, None, 3]
+            rot_new = torch.nn.functional.normalize(torch.stack([w1 * q[..., 0] - z1 * q[..., 3], w1 * q[..., 1] - z1 * q[..., 2],
+                                                                 w1 * q[..., 2] + z1 * q[..., 1], w1 * q[..., 3] + z1 * q[..., 0]], -1), dim=-1)
+            if self.with_gripper:
+                e0 = self._init["eef_xyz"][0][None].expand(E, -1)
+                if self.use_pusher:
+                    eef_xyz_new, eef_rot_new = e0 + shift, self._init["eef_rot"]
+                else:
+                    eef_xyz_new = (e0 - c)[:, None].matmul(Rz.transpose(1, 2))[:, 0] + c + shift
+                    eef_rot_new = Rz.bmm(self._init["eef_rot"][0][None].expand(E, -1, -1))
+        if everything:
+            self.phys.set_state(x_new, v_new)   # a whole new state: clears a sticky fault
+            if posed and self.phys.self_collision:
+                self.phys.create_resting_case()
+        else:
+            self.phys.set_state_envs(x_new, v_new, mask, resting_case=posed)
         self.phys.reset_envs(mask)
         obj = self.means[:, : self.n_obj]
-        obj.copy_(torch.where(m3, self._init["means"], obj))     # in place: the prepared raster sets point at this storage
-        self.bones.copy_(torch.where(m3, self._init["x"], self.bones))
+        obj.copy_(torch.where(m3, means_new, obj))     # in place: the prepared raster sets point at this storage
+        if rot_new is not None:
+            ro_ = self.rot_env[:, : self.n_obj]
+            ro_.copy_(torch.where(m3, rot_new, ro_))
+        self.bones.copy_(torch.where(m3, x_new, self.bones))
         if self.with_gripper:
-            self.eef_xyz = torch.where(mask[:, None], self._init["eef_xyz"], self.eef_xyz)
-            self.eef_rot = torch.where(m3, self._init["eef_rot"], self.eef_rot)
+            self.eef_xyz = torch.where(mask[:, None], eef_xyz_new, self.eef_xyz)
+            self.eef_rot = torch.where(m3, eef_rot_new, self.eef_rot)
             self.eef_gripper = torch.where(mask, torch.ones_like(self.eef_gripper), self.eef_gripper)
         self._env_t0 = torch.where(mask, torch.full_like(self._env_t0, self.t), self._env_t0)
         self._restarted = True
         self._cand_fresh = False
+        self._frame_dirty = True
 
     # ---- one batched env step -----------------------------------------------------------------------------------
     def physics_step(self, action=None):
@@ -525,6 +618,7 @@ class BatchedRollout:
             self._prepared = self.raster.prepare(self._sets, self._frames)
         self.last_num_rendered = self.raster.forward(self._prepared, None, self.W, self.H)
         self._poll_raster()          # non-blocking: an EARLIER batch that overflowed its capacity is counted in lossy_batches
+        self._frame_dirty = False
         return self.out_color, self.out_depth
 
     def observations(self):
@@ -533,6 +627,8 @@ class BatchedRollout:
         re-sizes by reading the count once — so what is returned is always the complete frame.  (`lossy_batches` counts how often
         that happened; an open-loop caller that only reads ``out_color`` after a device synchronisation should look at it.)"""
         self.wait_render()
+        if self._frame_dirty:                   # a reset since the last render (or nothing rendered yet): the frame of the state as it is now
+            self.render()
         if self._poll_raster(wait=True):
             self.last_num_rendered = self.raster.forward(self._prepared, None, self.W, self.H)
             self._poll_raster(wait=True)
@@ -598,6 +694,7 @@ class BatchedRollout:
                 self._prepared = self.raster.prepare(self._sets, self._frames)
             self.last_num_rendered = self.raster.forward(self._prepared, None, self.W, self.H)
             self._poll_raster()
+            self._frame_dirty = False
             self._render_done = torch.cuda.Event()
             self._render_done.record(rs)
         main.wait_event(skinned)                 # the next step's state write-back must not overtake the skinning that reads x
@@ -618,7 +715,7 @@ class BatchedRollout:
 
     # ---- the Gaussian cloud of one environment as the rasteriser currently sees it (parity tests) ----------------------
     def g_env(self, e):
-        if not self.with_robot:
+        if self.rot_env is None:
             return self.g
         return dict(self.g, rotations=self.rot_env[e])
 

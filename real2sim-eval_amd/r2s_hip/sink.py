@@ -155,9 +155,13 @@ class ObservationSink:
         """``vis_camera_C.mp4`` per episode and camera from the frames written so far — eval_policy.py:261-267 -> make_video
         (experiments/utils/ffmpeg.py:5-21: ffmpeg, libx264, yuv420p), run by the worker processes after the frame queue has
         drained.  Returns the number of videos written (0 when ffmpeg is not installed, or with the BMP fallback format)."""
+        if self._err:
+            raise self._err
+        self._videos_done = threading.Event()          # before the work item: the dispatcher may finish (BMP fallback: at once) and set() it
         self._work.put(("videos", int(frame_rate)))
-        self._videos_done = threading.Event()
-        self._videos_done.wait()
+        while not self._videos_done.wait(0.5):
+            if self._err or not self._thread.is_alive():     # a dispatcher that died never sets the event
+                break
         if self._err:
             raise self._err
         return self.videos_written

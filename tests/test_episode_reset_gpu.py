@@ -146,3 +146,120 @@ def test_episode_scheduler_on_the_real_rollout():
         if w:
             assert torch.equal(first[3][0], seen[0][3][0]), "every episode of a slot starts from the same state"
     assert bool(torch.isfinite(ro.phys.x).all()) and summarize(rec)["episodes"] == 5
+
+
+def test_get_obs_renders_the_start_state_and_the_state_a_reset_left():
+    """the reference's env.reset() returns get_obs() rendered FROM the reset state (env.py:30-51).  The first
+    get_obs() of a rollout must show the start state (not the uninitialised output arrays), and the first get_obs() after a partial
+    reset must show the reset environment as a fresh rollout shows it — next to the other environments' current frames."""
+    import torch
+    from r2s_hip.rollout import BatchedRollout
+
+    kw = dict(num_substeps=20, seed=11, n_env=3)
+    a, b = BatchedRollout("tiny", **kw), BatchedRollout("tiny", **kw)
+    a.out_color.fill_(float("nan"))                       # whatever torch.empty held: must never reach a caller
+    first_a = [t.clone() for t in a.get_obs()["image_list"] + a.get_obs()["image_wrist_list"]]
+    first_b = [t.clone() for t in b.get_obs()["image_list"] + b.get_obs()["image_wrist_list"]]
+    torch.cuda.synchronize()
+    for ia, ib in zip(first_a, first_b):
+        assert bool(torch.isfinite(ia).all()) and float(ia.std()) > 0
+        assert torch.equal(ia, ib), "same seed: the two start frames are the same frame"
+    for _ in range(3):
+        a.step()
+    last = a.get_obs()
+    last_side, last_wrist = last["image_list"][0].clone(), last["image_wrist_list"][0].clone()
+    assert _frac_differing(last_wrist[1], first_a[1][1]) > 1e-3, "three steps must have changed environment 1's wrist view"
+    a.reset([1])
+    obs = a.get_obs()                                      # no step in between
+    torch.cuda.synchronize()
+    side, wrist = obs["image_list"][0], obs["image_wrist_list"][0]
+    assert _frac_differing(side[1], first_b[0][1]) <= 1e-3 and _frac_differing(wrist[1], first_b[1][1]) <= 1e-3, "reset slot: the start frame"
+    for e in (0, 2):
+        assert _frac_differing(side[e], last_side[e]) <= 1e-3 and _frac_differing(wrist[e], last_wrist[e]) <= 1e-3, "running slots: their current frame"
+    assert torch.equal(a.robot_state()["eef_xyz"][1], b._init["eef_xyz"][1])
+
+
+def test_a_fault_of_a_running_environment_survives_the_reset_of_another(monkeypatch):
+    """the sticky fault word is per handle.  An episode reset of environment 1 (r2s_phys_set_state_envs) must
+    not clear a fault raised by environment 0, which keeps stepping on invalid state otherwise; a whole new state does clear it."""
+    import torch
+    from r2s_hip import synth
+    from r2s_hip._lib import R2SError
+    from util_physics import far_apart, gripper_motion, hip_env, two_sheets
+
+    monkeypatch.setenv("R2S_MESH_DEFER", "1")
+    n_sub = 4
+    ob, nA = two_sheets()
+    far = far_apart(ob, nA)
+    c = ob["points"].mean(0)
+    fingers = [synth.finger_mesh((c[0], c[1] - 0.05, c[2])), synth.finger_mesh((c[0], c[1] + 0.05, c[2]))]
+    interp, centers, dv, om = gripper_motion(fingers, n_sub, 5e-5, vel=(0.0, 0.0, 0.0), closing=0.0)
+    h = hip_env(far, n_env=2, num_substeps=n_sub, dynamic_meshes=fingers, self_collision=True)
+    x0 = torch.from_numpy(ob["points"])[None].repeat(2, 1, 1)
+    v0 = torch.zeros_like(x0)
+    toward = np.sign(ob["points"][nA:, 1].mean() - ob["points"][:nA, 1].mean())
+    v0[0, :nA, 1] = 200.0 * float(toward)                  # environment 0 only: impulses beyond the 40 m/s bound
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None].repeat(2, *([1] * a.ndim)).cuda()  # noqa: E731
+    h.set_state(x0, v0)
+    h.update_collision_graph()
+    h.set_mesh_interactive(t(interp), t(centers), t(dv), t(om))
+    h.step()
+    torch.cuda.synchronize()
+    h.set_state_envs(x0, torch.zeros_like(x0), torch.tensor([0, 1]))       # episode reset of environment 1
+    torch.cuda.synchronize()
+    with pytest.raises(R2SError, match="40 m/s"):
+        h.step()
+    assert torch.equal(h.x[1].cpu(), x0[1]) and float(h.v[1].abs().max()) == 0.0
+    h.set_state(x0, torch.zeros_like(x0))                   # every environment: usable again
+    h.update_collision_graph()
+    h.step()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(h.x).all())
+
+
+def test_episode_ids_place_the_object_at_the_grid_pose_of_the_episode():
+    """env.reset(seed=episode_id) -> load_scaniverse(randomize, index) (env.py:30-34, gs_renderer.py:340-347,
+    :614-637): the episode id indexes the object's grid pose.  Episodes of one batch must start from DIFFERENT poses, an episode's
+    pose must not depend on the slot it runs in, and random_variables must record [x, y, z, angle]."""
+    import torch
+    from r2s_hip.evaluate import run_episodes
+    from r2s_hip.rollout import BatchedRollout
+
+    ro = BatchedRollout("tiny", num_substeps=10, seed=6, n_env=2, randomize=True)
+    base = ro._init["x"][0].clone()
+    c = ro._obj_center
+    seen = {}
+
+    def on_step(r, slot_episode, episode_step):
+        for s, ep in enumerate(slot_episode.tolist()):
+            if ep >= 0 and ep not in seen:
+                seen[ep] = (s, r.bones[s].clone(), r.means[s, : r.n_obj].clone(), r.eef_xyz[s].clone())
+
+    ids = [0, 4, 13, 27, 31]
+    poses = {e: ro.episode_pose(e) for e in ids}
+    assert poses[0] == (-0.05, -0.05, 0.0, -10 * np.pi / 180) and poses[4][:2] == (-0.05, 0.0) and abs(poses[4][3]) < 1e-12      # rope grid: 9 xy x 3 theta
+    assert poses[27] == poses[0] and poses[13] != poses[0]
+    # reset by hand for exact checks (run_episodes below exercises the scheduler path)
+    ro.reset([0, 1], episode_ids=[13, 4])
+    torch.cuda.synchronize()
+    for s, ep in ((0, 13), (1, 4)):
+        x, y, _, a = poses[ep]
+        Rz = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=torch.float32, device=ro.device)
+        want = (base - c) @ Rz.T + c + torch.tensor([x, y, 0.0], device=ro.device)
+        assert float((ro.phys.x[s] - want).abs().max()) < 2e-6
+        assert float((ro.bones[s] - want).abs().max()) < 2e-6
+        assert ro.random_variables[ep] == [float(np.float32(v)) for v in poses[ep]]
+    assert float((ro.phys.x[0] - ro.phys.x[1]).abs().max()) > 0.02, "two episodes, two start poses"
+    col = ro.get_obs()["image_list"][0]
+    assert _frac_differing(col[0], col[1]) > 1e-3
+    rec = run_episodes(ro, ids, policy=None, max_steps=2, settle_steps=0, on_step=on_step)
+    torch.cuda.synchronize()
+    assert rec[:, 0].tolist() == ids and set(ro.random_variables) >= set(ids)
+    assert bool(torch.isfinite(ro.phys.x).all())
+    # the same episode in another slot of another rollout starts from the same pose
+    ro2 = BatchedRollout("tiny", num_substeps=10, seed=6, n_env=2, randomize=True)
+    ro2.reset([1], episode_ids=[0, 13])
+    torch.cuda.synchronize()
+    ro.reset([0], episode_ids=[13, 0])
+    torch.cuda.synchronize()
+    assert float((ro2.phys.x[1] - ro.phys.x[0]).abs().max()) < 2e-6

@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--settle-steps", type=int, default=0, help="holding steps after a reset (the reference: 30; the synthetic scenes start at rest)")
     ap.add_argument("--substeps", type=int, default=667)
     ap.add_argument("--stop-on-success", action="store_true")
+    ap.add_argument("--no-randomize", action="store_true", help="every episode from the same start pose (default: the episode id indexes the object's "
+                                                                "grid pose like env.reset(seed=episode_id), eval_policy_parallel.py:47)")
     ap.add_argument("--stub", action="store_true", help="CPU stand-in rollout over gloo")
     args = ap.parse_args()
 
@@ -81,7 +83,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
         from r2s_hip.rollout import BatchedRollout
 
-        ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps)
+        ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, randomize=not args.no_randomize)
     mine = ev.episodes_of_rank(args.episodes, rank, world)
     if world > 1:
         dist.barrier()
@@ -97,7 +99,10 @@ def main():
         print(json.dumps({"workload": "stub" if args.stub else args.config, "n_gpus": world, "envs_per_gpu": ro.n_env, **s,
                           "episodes_per_rank": [len(ev.episodes_of_rank(args.episodes, r, world)) for r in range(world)],
                           "elapsed_s": elapsed, "env_steps_per_s": env_steps / elapsed if elapsed > 0 else 0.0,
-                          "episode_ids_seen": int(table.shape[0]), "collective": "one all_gather of [ceil(episodes / ranks), 4] float64 per rank"}))
+                          "episode_ids_seen": int(table.shape[0]),
+                          "randomized": bool(getattr(ro, "randomize", False)),   # object start pose = grid pose of the episode id (rank 0's episodes listed)
+                          "random_variables": {str(k): v for k, v in sorted(getattr(ro, "random_variables", {}).items())[:16]},
+                          "collective": "one all_gather of [ceil(episodes / ranks), 4] float64 per rank"}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
