@@ -16,6 +16,7 @@ imported as a whole in the authoring container.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -30,29 +31,58 @@ _lib = None
 def build(force: bool = False) -> str:
     """Compile the C oracles with gcc (``make -C oracle``)."""
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".inc"))]
-    stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
-    )
+    libs = [_LIB_PATH, os.path.join(_HERE, "libr2s_cpu_baseline.so")]
+    stale = any((not os.path.exists(p)) or any(os.path.getmtime(s) > os.path.getmtime(p) for s in srcs) for p in libs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
     return _LIB_PATH
 
 
+def _load(path) -> C.CDLL:
+    L = C.CDLL(path)
+    L.r2s_oracle_raster_forward_f32.restype = C.c_int64
+    L.r2s_oracle_raster_forward_f64.restype = C.c_int64
+    L.r2s_oracle_higher_msb.restype = C.c_uint32
+    L.r2s_oracle_higher_msb.argtypes = [C.c_uint32]
+    L.r2s_oracle_max_threads.restype = C.c_int
+    L.r2s_oracle_phys_update_collision_f32.restype = C.c_int
+    L.r2s_oracle_phys_update_collision_f64.restype = C.c_int
+    L.r2s_oracle_mesh_query_f32.restype = C.c_int
+    L.r2s_oracle_mesh_query_f64.restype = C.c_int
+    L.r2s_oracle_phys_step_batch_par_f32.restype = C.c_int
+    return L
+
+
 def lib() -> C.CDLL:
+    """The CHECKER build (strict IEEE flags) — or, inside ``with baseline_build():``, the optimised build of the same sources
+    that bench.py's cpu_baseline leg times (never used to check anything)."""
     global _lib
+    if _override is not None:
+        return _override
     if _lib is None:
         build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.r2s_oracle_raster_forward_f32.restype = C.c_int64
-        _lib.r2s_oracle_raster_forward_f64.restype = C.c_int64
-        _lib.r2s_oracle_higher_msb.restype = C.c_uint32
-        _lib.r2s_oracle_higher_msb.argtypes = [C.c_uint32]
-        _lib.r2s_oracle_max_threads.restype = C.c_int
-        _lib.r2s_oracle_phys_update_collision_f32.restype = C.c_int
-        _lib.r2s_oracle_phys_update_collision_f64.restype = C.c_int
-        _lib.r2s_oracle_mesh_query_f32.restype = C.c_int
-        _lib.r2s_oracle_mesh_query_f64.restype = C.c_int
+        _lib = _load(_LIB_PATH)
     return _lib
+
+
+_BASE_PATH = os.path.join(_HERE, "libr2s_cpu_baseline.so")
+_blib = None
+_override = None
+
+
+@contextlib.contextmanager
+def baseline_build():
+    """Route every call of this module to libr2s_cpu_baseline.so (same sources, -O3 / AVX2 / FMA contraction; oracle/Makefile)
+    for the duration of the block: bench.py's ``cpu_baseline`` leg.  A timing build, not a checker."""
+    global _blib, _override
+    if _blib is None:
+        build()
+        _blib = _load(_BASE_PATH)
+    _override = _blib
+    try:
+        yield _blib
+    finally:
+        _override = None
 
 
 def set_threads(n: int) -> None:
@@ -368,6 +398,19 @@ def phys_step_batch(envs, n_substeps=None):
     vs = (C.c_void_p * n)(*[e.v.ctypes.data for e in envs])
     ns = envs[0].num_substeps if n_substeps is None else int(n_substeps)
     lib().r2s_oracle_phys_step_batch_f32(arr, xs, vs, C.c_int(n), C.c_int(0), C.c_int(ns))
+
+
+def phys_step_batch_par(envs, n_substeps=None, threads_per_env=1):
+    """``phys_step_batch`` with every environment's per-particle loops split over ``threads_per_env`` threads (environments x
+    particle chunks; r2s_oracle_phys_step_batch_par_f32).  Positions / velocities equal the sequential stepper's bit for bit under
+    the checker build (per-face force sums are atomic adds: equal up to their order).  Returns the threads that ran."""
+    assert all(not e.f64 for e in envs)
+    n = len(envs)
+    arr = (_PhysF32 * n)(*[e._S for e in envs])
+    xs = (C.c_void_p * n)(*[e.x.ctypes.data for e in envs])
+    vs = (C.c_void_p * n)(*[e.v.ctypes.data for e in envs])
+    ns = envs[0].num_substeps if n_substeps is None else int(n_substeps)
+    return int(lib().r2s_oracle_phys_step_batch_par_f32(arr, xs, vs, C.c_int(n), C.c_int(0), C.c_int(ns), C.c_int(int(threads_per_env))))
 
 
 def mesh_query(pts, faces, p, max_dist=0.02, threshold=0.6, f64=False):
