@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default: the config's)")
     ap.add_argument("--substeps", type=int, default=667)
     ap.add_argument("--schedule", default=None, help="grasp | lissajous (default: the scene's; see r2s_hip/rollout.py)")
+    ap.add_argument("--res", default=None, help="WxH frame size instead of the config's (the reference's default frame: 848x480, cfg/env/xarm_gripper.yaml:21-49)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the throughput-mode comparison that follows the timed window")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -210,23 +211,29 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
-    from r2s_hip.rollout import BatchedRollout
+    from r2s_hip.rollout import CONFIGS, BatchedRollout
 
+    res = tuple(int(v) for v in args.res.lower().split("x")) if args.res else None
     # ---- parity gate (every timed configuration first passes the position and image gates) ----------------
-    # One environment of THIS workload through the product path into the phase the window times in contact, 20 substeps + one
-    # frame against the oracle (oracle/parity_gate.py: the oracle is the checker, never the thing timed).  Rank 0 only; the
-    # other ranks wait at the first barrier.
+    # THIS workload through the product path into the phase the window times in contact, 20 substeps + the side and wrist frames
+    # against the oracle (oracle/parity_gate.py: the oracle is the checker, never the thing timed).  A multi-environment window is
+    # gated on a 9-environment batch — the large-batch layout with two concurrent kernel chains, the flavour family the window
+    # times (the first and the last environment, one per chain, each against its own oracle) —, a one-environment window on one
+    # environment (the resident layout).  `parity_gate.flavour / chains / layout` say what ran.  Rank 0 only; the other ranks wait
+    # at the first barrier.
     gate = None
     if not args.no_parity_gate and rank == 0:
         from oracle import parity_gate
         try:
-            gate = parity_gate.run(args.config, device=dev, seed=rank, num_substeps=args.substeps, n_compare=20, close_at=2)
+            n_bench = args.envs if args.envs is not None else CONFIGS[args.config][3]
+            gate = parity_gate.run(args.config, device=dev, seed=rank, num_substeps=args.substeps, n_compare=20, close_at=2,
+                                   n_env=9 if n_bench >= 9 else n_bench, res=res)
         except Exception as e:  # a gate that cannot run is a failed gate
             gate = {"passed": False, "error": f"{type(e).__name__}: {e}"}
 
     close_at = args.warmup + args.steps // 2   # the timed window is half free motion, half contact (grasp schedule / pusher)
     tc0 = time.perf_counter()
-    ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=close_at)
+    ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=close_at, res=res)
 
     torch.cuda.synchronize(dev)
     construct_s = time.perf_counter() - tc0            # scene synthesis, topology upload, graph capture of every flavour, settling
@@ -295,13 +302,40 @@ def main():
                                "env step t on a second stream next to the substeps of step t+1; results are bit-identical (tested).  Valid when the "
                                "next action does not depend on this step's observation (inside an action chunk); `value` above is the closed loop"}
 
+    # closed-loop accounting (outside the timed region): the timed loop above only ENQUEUES steps — a policy in the
+    # loop reads an observation before it picks the next action.  Here every step ends in get_obs(): wait for the render, poll the
+    # sync-free raster batch for overflow, re-render a lossy one.  Same state, same number of steps, first enqueue-only, then with
+    # get_obs(): the ratio is what the read costs; `re_rendered` counts lossy batches that get_obs() had to render again.
+    closed_report = None
+    if not args.stub:
+        kc = max(4, min(args.steps, 10))
+        rates = []
+        lossy0 = 0
+        for with_obs in (False, True):
+            for _ in range(2):
+                ro.step()
+            ro.get_obs()
+            torch.cuda.synchronize(dev)
+            lossy0 = ro.lossy_batches
+            t0c = time.perf_counter()
+            for _ in range(kc):
+                ro.step()
+                if with_obs:
+                    ro.get_obs()
+            torch.cuda.synchronize(dev)
+            rates.append(ro.n_env * kc / (time.perf_counter() - t0c))
+        closed_report = {"env_steps_per_s": rates[1], "enqueue_only_env_steps_per_s": rates[0], "ratio": rates[1] / rates[0], "steps": kc,
+                         "re_rendered_batches": int(ro.lossy_batches - lossy0),
+                         "note": "this rank, after the timed window, in the state it ended in (contact): the same steps enqueue-only and with "
+                                 "get_obs() after every step (host waits for the frame, validates the sync-free raster batch, re-renders a lossy one)"}
+
     # de-phased window (outside the timed region): same workload, same number of steps, the same half of the env-steps in
     # contact — but the environments enter contact one after the other instead of together, so every step of the window runs
     # the contact flavour for SOME environments (the graph flavour is picked per handle, not per environment)
     dephase_report = None
     K = args.steps if args.dephase < 0 else args.dephase
     if K > 1 and not args.stub and ro.with_gripper and ro.schedule == "grasp":
-        ro2 = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=args.warmup)
+        ro2 = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=args.warmup, res=res)
         ro2.set_dephase(K)
         for _ in range(args.warmup):
             ro2.step()
@@ -403,8 +437,16 @@ def main():
         resident_steps = sum("k_steps_resident" in f for f in log["flavour"])   # env steps of the window that ran as one resident launch
         first_contact = ro.close_at - args.warmup  # index in the timed window of the step in which the fingers close / rod arrives
         (pmc_sub, src), (pmc_comp, _) = pmc_summary("k_substep", args.config), pmc_summary("k_composite", args.config)
+        shared_bytes = 16 * ro.S + 48 * ro.N * ro.n_env        # the topology once (it is shared by the environments and L2-resident) + every environment's state
+        traffic = pmc_sub["hbm_bytes_per_launch"] if pmc_sub and ro.n_env == 32 and n_sub == 667 else None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_sub["hbm_bytes_per_launch"] if pmc_sub and ro.n_env == 32 and n_sub == 667 else None,
+                "frac_shared_topology": shared_bytes / t_kernel / 1e9 / HBM_PEAK_GBS,
+                "shared_topology_bytes_per_launch": shared_bytes,
+                "traffic_over_shared": (traffic / shared_bytes) if traffic else None,
+                "bound_in_practice": "VALU issue + dependent latency (valu_busy_frac of the SIMD issue cycles; hbm_actual_frac of the HBM peak): neither "
+                                     "pipe is saturated — `frac` is the SURVEY.md §8d CONTRACT figure (every environment charged its own copy of the "
+                                     "topology), `frac_shared_topology` charges the topology once and is the physical lower bound on HBM bytes",
+                "traffic": traffic,
                 "traffic_source": src if pmc_sub else None,
                 "hbm_actual_frac": (pmc_sub["hbm_bytes_per_launch"] / t_kernel / 1e9 / HBM_PEAK_GBS) if pmc_sub and ro.n_env == 32 and n_sub == 667 else None,
                 "valu_busy_frac": pmc_sub.get("valu_busy_frac") if pmc_sub else None,
@@ -423,6 +465,9 @@ def main():
                         "reach HBM are hbm_actual_frac of peak; valu_busy_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel span), the share of SIMD issue cycles spent on VALU instructions: the kernel is "
                         f"VALU-issue / latency bound, not HBM bound.  One 'launch' = one batched substep of all {ro.n_env} envs, issued as {chains} concurrent "
                         "kernels over disjoint env ranges, each chain its own captured graph on its own stream (per-kernel durations overlap); avg_launch_us = HIP-event time of the 667-substep step / 667"}
+        if roof["frac"] > 1.0:
+            roof["frac_exceeds_one"] = ("the contract charges 16 S bytes of topology PER ENVIRONMENT; the environments share one copy that stays in L2, so "
+                                        "the contract figure is not bounded by 1 — read frac_shared_topology / hbm_actual_frac for the physical picture")
         out = {
             "metric": "sim env-steps/sec (phys+render) per node at 32 envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -458,6 +503,13 @@ def main():
             out["observation_sink"] = sink_report
         if pipe_report is not None:
             out["throughput_mode"] = pipe_report
+        if closed_report is not None:
+            closed_report["ratio_to_value"] = closed_report["env_steps_per_s"] / (ro.n_env * args.steps / elapsed) if world == 1 else None
+            out["closed_loop_get_obs"] = closed_report
+        if ro.lossy_batches:
+            out["lossy_batches_in_run"] = int(ro.lossy_batches)
+            out["note_lossy"] = ("sync-free raster batches overflowed their capacity during this run: frames read without get_obs() / observations() "
+                                 "were incomplete; `value` counts those steps (see raster.lossy_batches)")
         if dephase_report is not None:
             dephase_report["vs_synchronised_window"] = dephase_report["env_steps_per_s"] / (ro.n_env * args.steps / elapsed) if world == 1 else None
             out["dephased_window"] = dephase_report

@@ -167,11 +167,15 @@ def raster_forward(
     z_threshold=0.2,
     f64=False,
     debug=False,
+    fragile=False,
 ):
     """Oracle for ``_C.rasterize_gaussians`` (rasterize_points.cu:36-117).
 
     Returns ``(num_rendered, color[3,H,W], radii[P], depth[1,H,W])`` and, with
-    ``debug=True``, a dict of intermediates as the fifth element.
+    ``debug=True``, a dict of intermediates as the fifth element.  ``fragile=True`` appends (or adds to the dict) a uint8
+    [H, W] mask of pixels on which a per-pixel DECISION sat within a relative 5e-5 of flipping — bit 0: power > 0 / alpha < 1/255 /
+    test_T < 1e-4 (a "threshold flip" changes the pixel's colour by ~1/255), bit 1: the median-depth crossing — checker
+    bookkeeping for the image gate (tests/util_raster.compare_images), no effect on the outputs.
     """
     L = lib()
     means3D = _f32(means3D).reshape(-1, 3)
@@ -215,6 +219,7 @@ def raster_forward(
             tiles_touched=np.zeros(P, dtype=np.uint32),
             ranges=np.zeros((gx * gy, 2), dtype=np.uint32),
         )
+    frag = np.zeros((H, W), dtype=np.uint8) if fragile else None
     cap = 0
     point_list = None
     if debug:
@@ -228,14 +233,18 @@ def raster_forward(
         C.c_float(tanfovy), C.c_int(int(bool(prefiltered))), C.c_float(z_threshold), _ptr(out_color),
         _ptr(out_depth), _ptr(radii), _ptr(dbg.get("final_T")), _ptr(dbg.get("n_contrib")),
         _ptr(dbg.get("depths")), _ptr(dbg.get("means2D")), _ptr(dbg.get("conic_opacity")), _ptr(dbg.get("rgb")),
-        _ptr(dbg.get("tiles_touched")), _ptr(dbg.get("ranges")), _ptr(point_list), C.c_int64(cap),
+        _ptr(dbg.get("tiles_touched")), _ptr(dbg.get("ranges")), _ptr(point_list), C.c_int64(cap), _ptr(frag),
     )
     n = int(n)
     if n < 0:
         raise RuntimeError("Point is filtered although prefiltered is set (device __trap in the reference)")
     if debug:
         dbg["point_list"] = point_list[:n].copy()
+        if frag is not None:
+            dbg["fragile"] = frag
         return n, out_color, radii, out_depth, dbg
+    if frag is not None:
+        return n, out_color, radii, out_depth, frag
     return n, out_color, radii, out_depth
 
 

@@ -106,18 +106,24 @@ def quaternion_to_rotation_matrix(q: torch.Tensor) -> torch.Tensor:
 class BatchedRollout:
     def __init__(self, config="sloth_32env", device="cuda:0", seed=0, n_env=None, num_substeps=667, views=2,
                  self_collision=True, with_gripper=True, with_static=True, tile_culling=True, schedule=None, close_at=15, open_at=10**9,
-                 settle_steps=None, randomize=False):
-        """``schedule``: the synthetic action trace.  "grasp" (default for the sloth scenes): the open gripper comes down over
-        the toy's raised arms (free motion), closes on them at env step ``close_at`` — finger contact, the two arms pressed
-        together (live self-collision candidates), grasp detection — and lifts.  "lissajous" (default otherwise, SURVEY.md
-        §8d): the gripper hovers 10 cm above the object on a Lissajous path, closes at step 100, opens at 300.  The pusher
-        scene pushes along +x and reaches the block at ``close_at``.  ``settle_steps`` (default 40 for "grasp"): env steps run
+                 settle_steps=None, randomize=False, res=None):
+        """``schedule``: the synthetic action trace.  "grasp" (default for the sloth scenes and rope_1env): the open gripper comes down over
+        the object (free motion) — the toy's raised arms, the middle of the rope —, closes on it at env step
+        ``close_at`` — finger contact, for the toy the two arms pressed together (live self-collision candidates), grasp detection —
+        and lifts: the reference's episodes are spent with the gripper ON the object (eval_policy.py:124-213), so a timed window has a
+        contact half.  "lissajous" (the default of the small test scenes and of T_32env — a gripper over the push-T block is
+        not a scene of the reference, which pushes it with the rod: T_pusher_32env): the gripper hovers 10 cm above the object on a Lissajous path, closes at
+        step 100, opens at 300 — no contact inside a short window.  The pusher scene pushes along +x and reaches the block at
+        ``close_at``.  ``res``: (W, H) instead of the config's frame size (the reference's default frame is 848x480,
+        cfg/env/xarm_gripper.yaml:21-49).  ``settle_steps`` (default 40 for "grasp"): env steps run
         inside the constructor with the gripper parked 15 cm higher, so that the toy is AT REST when the rollout starts
         (SURVEY.md §8d places the objects resting on the table; a jittered lattice with random stiffness is not in equilibrium
         under gravity and its arms sway by ~1 cm for the first second).  ``randomize``: ``reset(env_ids, episode_ids=...)`` places
         each reset environment's object at the grid pose of its episode id (``episode_pose``; the reference: env.reset(seed=episode_id)
         -> load_scaniverse(randomize, index), gs_renderer.py:333-637) — costs one rotation array per environment."""
         shape, n_particles, n_gauss, envs, W, H = CONFIGS[config]
+        if res is not None:
+            W, H = int(res[0]), int(res[1])
         self.config = config
         self.n_env = int(n_env if n_env is not None else envs)
         if "multicam" in config:
@@ -159,13 +165,15 @@ class BatchedRollout:
             dyn = [(synth.eef_world_points(self.eef_table[-1], self.eef_init, self.eef0), rod_f)]
         elif with_gripper:
             self.eef_table, self.eef_init, fl, fr = synth.gripper_eef_table()
-            self.schedule = schedule or ("grasp" if shape == "sloth_arms" else "lissajous")
+            self.schedule = schedule or ("grasp" if shape == "sloth_arms" or config == "rope_1env" else "lissajous")
             self.close_at, self.open_at = (int(close_at), int(open_at)) if self.schedule == "grasp" else (100, 300)
             if self.schedule == "grasp":
                 # fingers (5 cm tall, centred 6 cm below the eef) end up centred on the arms' upper 8 cm: eef = top + 2 cm at
-                # `close_at`, reached by a straight descent at 0.1 m/s (3.3 mm per env step)
+                # `close_at`, reached by a straight descent at 0.1 m/s (3.3 mm per env step); for a flat object (rope, T block) the
+                # finger tips stop 2 mm above the table instead of going through it
                 self.v_down = 0.1
-                self.eef0 = np.array([c[0], c[1], top + 0.02 + self.v_down * self.close_at * num_substeps * 5e-5], np.float32)
+                z_close = max(top + 0.02, 0.002 + 0.025 + 0.06)
+                self.eef0 = np.array([c[0], c[1], z_close + self.v_down * self.close_at * num_substeps * 5e-5], np.float32)
             else:
                 self.eef0 = np.array([c[0], c[1], top + 0.1], np.float32)
             w0 = synth.eef_world_points(self.eef_table[-1], self.eef_init, self.eef0)
@@ -701,17 +709,23 @@ class BatchedRollout:
         return self.out_color, self.out_depth
 
     def step(self, action=None):
-        """One batched env step.  ``action``: None (the synthetic trace), a dict of per-environment motion tensors, or an
-        [n_env, 13] 'xyz_rot' action tensor — see ``apply_action``.  Returns (out_color [E,V,3,H,W], out_depth [E,V,1,H,W]); they
-        are complete once the launch stream has drained (``observations()`` waits and validates)."""
+        """One batched env step, ENQUEUED: ``action``: None (the synthetic trace), a dict of per-environment motion tensors, or an
+        [n_env, 13] 'xyz_rot' action tensor — see ``apply_action``.  Nothing is waited for and nothing is returned: the images of
+        the step are read through ``get_obs()`` / ``observations()``, which wait for the render, check the sync-free raster batch
+        and re-render a lossy one — the raw ``out_color`` / ``out_depth`` arrays may hold an incomplete frame until then
+        (``lossy_batches``).  ``enqueue_step`` is the same method under the name that says so."""
         self.physics_step(action)
-        out = self._render_pipelined() if getattr(self, "_pipelined", False) else self.render()
+        if getattr(self, "_pipelined", False):
+            self._render_pipelined()
+        else:
+            self.render()
         self.t += 1
         lg = self._log
         if lg is not None and lg["i"] < lg["n"]:
             lg["i"] += 1
             lg["s"][lg["i"]].record()
-        return out
+
+    enqueue_step = step
 
     # ---- the Gaussian cloud of one environment as the rasteriser currently sees it (parity tests) ----------------------
     def g_env(self, e):

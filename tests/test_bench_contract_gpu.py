@@ -29,8 +29,15 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "env-steps/s" and isinstance(c["sample"], str) and c["value"] > 0
     assert abs(d["value"] - d["config"]["envs_per_gpu"] * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert set(d["phases"]) >= {"free", "contact", "note"} and d["phases"]["free"]["steps"] == 2
-    for k in ("traffic_source", "hbm_actual_frac", "valu_busy_frac", "algorithmic_bytes_per_launch", "avg_launch_us"):
+    for k in ("traffic_source", "hbm_actual_frac", "valu_busy_frac", "algorithmic_bytes_per_launch", "avg_launch_us", "frac_shared_topology",
+              "traffic_over_shared", "bound_in_practice"):
         assert k in r, k
+    assert r["frac_shared_topology"] <= r["frac"] + 1e-12
+    assert c["threads"]["physics"] == c["cores"] and "libr2s_cpu_baseline" in c["sample"]
+    g = d["parity_gate"]
+    assert g["passed"] and "flavour" in g and "threshold_flip_pixels" in g and g["hard_rgb_mismatch_pixels"] == 0, g
+    cl = d["closed_loop_get_obs"]
+    assert cl["env_steps_per_s"] > 0 and 0 < cl["ratio"] <= 1.05 and "re_rendered_batches" in cl, cl
 
 
 def test_headline_schedule_contains_free_motion_finger_contact_and_live_self_collision():

@@ -243,7 +243,22 @@ def test_bench_scene_one_env_20_substeps_in_the_grasp_vs_oracle_driven_through_e
     assert r["tagged_entries"] >= 0 and r["deferred_per_substep_max"] > 0, r
     assert r["eef_pts_max_abs"] < 2e-6 and r["eef_center_max_abs"] < 5e-7, r
     assert r["x_max_abs"] < 1e-5, r
-    assert r["bad_pixels"] <= 1e-4 * r["pixels"], r
+    assert r["hard_rgb_mismatch_pixels"] == 0 and r["hard_depth_mismatch_pixels"] == 0, r
+    assert r["threshold_flip_pixels"] <= 1e-4 * r["pixels"] and r["median_depth_crossing_pixels"] <= 1e-4 * r["pixels"], r
+    assert r["passed"], r
+
+
+def test_bench_gate_on_the_batched_flavour_two_chains_first_and_last_environment():
+    """the gate bench.py runs before a multi-environment window — a 9-environment batch of the bench's own scene
+    (large-batch layout, two concurrent kernel chains), environments 0 and 8 (one per chain) each against an oracle of its own, in
+    the contact flavour (candidates + finger contact), + the side and wrist frames of environment 8."""
+    from oracle import parity_gate
+
+    r = parity_gate.run("sloth_32env", num_substeps=667, n_compare=20, close_at=2, n_env=9)
+    record("bench scene, 9-env batch (2 chains), envs 0 and 8, 20 substeps in contact", **{k: v for k, v in r.items() if isinstance(v, (int, float)) and not isinstance(v, bool)}, tol=1e-5)
+    assert r["chains"] == 2 and r["envs_checked"] == [0, 8] and "k_substep" in r["flavour"] and "k_contact_finish" in r["flavour"], r
+    assert r["mesh_contact"] and r["particles_with_candidates"] > 0 and r["x_max_abs"] < 1e-5, r
+    assert r["hard_rgb_mismatch_pixels"] == 0 and r["hard_depth_mismatch_pixels"] == 0, r
     assert r["passed"], r
 
 

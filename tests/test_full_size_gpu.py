@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from util_physics import hip_env, make_object, oracle_env
-from util_raster import compare_images, hip_render, oracle_render, scene_and_camera
+from util_raster import assert_image_gate, compare_images, hip_render, oracle_render, scene_and_camera
 from util_parity import close
 
 pytestmark = pytest.mark.gpu
@@ -17,20 +17,20 @@ def test_C1_rope_scene_full_resolution_vs_oracle():
     """configs[1]: ~40k Gaussians, 640x480, both cameras."""
     for cam in ("side", "wrist"):
         sc, c = scene_and_camera(40000, 640, 480, 31, cam=cam)
-        n_ref, col_ref, radii_ref, dep_ref = oracle_render(sc, c)
+        n_ref, col_ref, radii_ref, dep_ref, frag = oracle_render(sc, c, fragile=True)
         col, radii, dep = hip_render(sc, c)
         assert np.array_equal(radii, radii_ref)
-        r = compare_images(col, dep, col_ref, dep_ref)
-        assert r["frac_rgb"] <= 1e-4 and r["frac_depth"] <= 1e-4, (cam, r)
+        r = compare_images(col, dep, col_ref, dep_ref, fragile=frag, what=f"C1 40k Gaussians 640x480 {cam} camera vs oracle")
+        assert_image_gate(r, 640 * 480, cam)
 
 
 def test_C2_sloth_scene_80k_gaussians_vs_oracle_and_permutation_invariance():
     sc, c = scene_and_camera(80000, 640, 480, 32)
-    _, col_ref, radii_ref, dep_ref = oracle_render(sc, c)
+    _, col_ref, radii_ref, dep_ref, frag = oracle_render(sc, c, fragile=True)
     col, radii, dep = hip_render(sc, c)
     assert np.array_equal(radii, radii_ref)
-    r = compare_images(col, dep, col_ref, dep_ref)
-    assert r["frac_rgb"] <= 1e-4 and r["frac_depth"] <= 1e-4, r
+    r = compare_images(col, dep, col_ref, dep_ref, fragile=frag, what="C2 80k Gaussians 640x480 vs oracle")
+    assert_image_gate(r, 640 * 480)
     # the image does not depend on the order Gaussians are given in, except where two splats share the exact float
     # depth (the stable sort then keeps index order, rasterizer_impl.cu:306-311; with 80k splats a few hundred pairs
     # collide in float32, so compare to rounding, not bitwise)
@@ -72,9 +72,9 @@ def test_C4_multi_view_1280x720_batched_equals_single_calls():
             col, _, dep = hip_render(scenes[e], c)
             assert np.array_equal(out_c[e, v].cpu().numpy(), col) and np.array_equal(out_d[e, v].cpu().numpy(), dep), (e, v)
     # one view against the oracle at 1280x720
-    _, col_ref, _, dep_ref = oracle_render(scenes[1], cams[0])
-    r = compare_images(out_c[1, 0].cpu().numpy(), out_d[1, 0].cpu().numpy(), col_ref, dep_ref)
-    assert r["frac_rgb"] <= 1e-4 and r["frac_depth"] <= 1e-4, r
+    _, col_ref, _, dep_ref, frag = oracle_render(scenes[1], cams[0], fragile=True)
+    r = compare_images(out_c[1, 0].cpu().numpy(), out_d[1, 0].cpu().numpy(), col_ref, dep_ref, fragile=frag, what="C4 one view 1280x720 vs oracle")
+    assert_image_gate(r, W * H)
 
 
 def test_C2_sloth_15k_particles_one_env_vs_oracle_short_horizon():

@@ -9,7 +9,7 @@ import pytest
 
 from util_parity import close, record
 from util_physics import hip_env, make_object, oracle_env
-from util_raster import compare_images, oracle_render
+from util_raster import assert_image_gate, compare_images, oracle_render
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -155,9 +155,10 @@ def test_C4_full_per_gpu_size_8_envs_4_views_1280x720_140k_gaussians():
     for e, v in ((0, 0), (7, 3)):
         sc = dict(ro.scene_numpy(e))
         c = ro.camera_numpy(e, v)          # view 1 is the wrist camera of THIS environment's gripper pose
-        _, col_ref, _, dep_ref = oracle_render(sc, c)
-        r = compare_images(ro.out_color[e, v].cpu().numpy(), ro.out_depth[e, v].cpu().numpy(), col_ref, dep_ref, what=f"env {e} view {v} vs oracle, 1280x720, 140k")
-        assert r["frac_rgb"] <= 1e-4 and r["frac_depth"] <= 1e-4, (e, v, r)
+        _, col_ref, _, dep_ref, frag = oracle_render(sc, c, fragile=True)
+        r = compare_images(ro.out_color[e, v].cpu().numpy(), ro.out_depth[e, v].cpu().numpy(), col_ref, dep_ref, fragile=frag,
+                           what=f"env {e} view {v} vs oracle, 1280x720, 140k")
+        assert_image_gate(r, 1280 * 720, (e, v))
     assert g["opacities"].shape[0] == 140000
     assert ro.last_num_rendered > 0
 

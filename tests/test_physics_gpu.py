@@ -131,6 +131,39 @@ def test_self_collision_with_concurrent_chains_and_odd_substeps(monkeypatch):
     assert close(x, x[0:1], 1e-6)
 
 
+@pytest.mark.parametrize("n_env,chains", [(1, None), (9, "2")])
+def test_ten_substeps_with_live_self_collision_contacts_hold_1e_5(monkeypatch, n_env, chains):
+    """"particle positions within 1e-5 abs ... after 10 substeps with contacts" — the horizon the two long runs above
+    (800 substeps, held to 5e-5: contacts amplify rounding differences) do not state.  Same scenario; at the first env step whose
+    rebuild finds candidates the oracle takes the device state, both rebuild and both run TEN substeps in which impulses act."""
+    import torch
+
+    if chains:
+        monkeypatch.setenv("R2S_CHAINS", chains)
+    ob = two_blobs(seed=1, gap=0.06, speed=3.0)
+    kw = dict(num_substeps=200, collide_self_fric=0.3)
+    o = oracle_env(ob, **kw)
+    h = hip_env(ob, n_env=n_env, **kw)
+    done = False
+    for _ in range(5):
+        h.update_collision_graph()
+        x, v = h.sync_state()
+        o.x[:] = x[0].cpu().numpy(); o.v[:] = v[0].cpu().numpy()
+        o.update_collision_graph()
+        if int(o.coll_num.sum()) > 0:
+            free = oracle_env(ob, self_collision=False, **kw)          # the same ten substeps without impulses
+            free.x[:] = o.x; free.v[:] = o.v
+            o.step(10, 0); free.step(10, 0); h.step(10, 0)
+            assert float(np.abs(o.v - free.v).max()) > 1e-2, "impulses must act inside the ten substeps"
+            xs = h.x.cpu().numpy()
+            for e in range(n_env):
+                assert close(xs[e], o.x, 1e-5, what=f"10 substeps with self-collision contacts, env {e} of {n_env}"), e
+            done = True
+            break
+        h.step()
+    assert done, "scenario must produce contacts"
+
+
 def test_static_box_mesh_collision():
     from r2s_hip import synth
 

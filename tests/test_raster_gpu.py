@@ -258,3 +258,26 @@ def test_sync_free_batches_are_bit_identical_and_report_overflow():
     rb.forward(prep_big, None, W, H)       # sync-free again
     torch.cuda.synchronize()
     assert torch.equal(oc, ref["big"][1]) and torch.equal(od, ref["big"][2]) and rb.poll(wait=True)[2] == 1
+
+
+def test_inline_assembly_blend_equals_its_cxx_specification_bit_for_bit():
+    """k_composite's blend is inline assembly (predicates in EXEC, raster.hip); its C++ form stays in
+    the source as the specification (-DR2S_COMP_CXX).  Both builds ship (csrc/Makefile: libr2s_hip.so, libr2s_hip_cxx.so); the same
+    frames rendered through each — single-frame and batched entry points, full and ragged tiles, the reference's 848x480 frame —
+    must be bit-identical, so that a compiler bump that changes a register constraint cannot silently change an image."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg = os.path.join(os.path.dirname(here), "real2sim-eval_amd")
+    libs = {"asm": os.path.join(pkg, "libr2s_hip.so"), "cxx": os.path.join(pkg, "libr2s_hip_cxx.so")}
+    assert os.path.exists(libs["cxx"]), "libr2s_hip_cxx.so missing: __graft_entry__.build() builds it next to libr2s_hip.so"
+    got = {}
+    for k, path in libs.items():
+        out = subprocess.run([sys.executable, os.path.join(here, "frame_hash_helper.py")], env=dict(os.environ, R2S_HIP_LIB=path), capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        got[k] = {l.split()[1]: l.split()[2] for l in out.stdout.splitlines() if l.startswith("HASH ")}
+    assert set(got["asm"]) == {"side", "wrist", "ref_frame", "ragged", "rollout"} == set(got["cxx"])
+    assert got["asm"] == got["cxx"], (got["asm"], got["cxx"])
