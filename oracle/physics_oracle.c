@@ -69,7 +69,7 @@ int r2s_oracle_phys_step_batch_par_f32(const phys_t_f32 *envs, float **x, float 
         float *vbc = (float *)malloc(sizeof(float) * 3 * (size_t)N);
         float *vbg = (float *)malloc(sizeof(float) * 3 * (size_t)N);
         float *xe = x[e], *ve = v[e];
-        mesh_t_f32 m = {P->nV, P->nF, P->mesh_pts, P->faces, 0, {0, 0, 0}, {0, 0, 0}};
+        mesh_t_f32 m = {P->nV, P->nF, P->mesh_pts, P->faces, 0, {0, 0, 0}, {0, 0, 0}, 0, 0, 0};
         int team = 0;
 #pragma omp parallel num_threads(threads_per_env)
         {
@@ -99,6 +99,7 @@ int r2s_oracle_phys_step_batch_par_f32(const phys_t_f32 *envs, float **x, float 
             }
         }
         granted += team;
+        mesh_release_f32(&m);
         free(off); free(inc); free(ey); free(f); free(vbc); free(vbg);
     }
     return granted;

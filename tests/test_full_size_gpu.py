@@ -130,3 +130,36 @@ def test_spring_forces_conserve_momentum_in_free_space():
         v = (v + g * dt) * np.exp(-dt * drag)
     vc = h.v[0].double().mean(0).cpu().numpy()
     assert abs(vc[2] - v) < 2e-5 and abs(vc[0]) < 2e-5 and abs(vc[1]) < 2e-5
+
+
+def test_reference_default_frame_848x480_side_and_wrist_cameras_vs_oracle():
+    """VERDICT r3 item 7 / missing #5: the reference renders 848x480 (53x30 tiles: a ragged last tile column) from the fixed side
+    camera and the wrist camera on the gripper (cfg/env/xarm_gripper.yaml:21-49, env.py:55-56).  Two environments of the headline
+    scene at that frame size through the batched rollout (skinning -> per-environment wrist camera -> raster), after two env steps;
+    every frame of environment 1 against the raster oracle under the classified image gate."""
+    import torch
+    from r2s_hip.rollout import BatchedRollout
+
+    W, H = 848, 480
+    ro = BatchedRollout("sloth_32env", n_env=2, num_substeps=30, seed=9, res=(W, H), close_at=1, settle_steps=0)
+    assert (ro.W, ro.H) == (W, H)
+    for _ in range(2):
+        ro.step()
+    col, dep = ro.observations()
+    torch.cuda.synchronize()
+    assert ro.lossy_batches == 0
+    sc = ro.scene_numpy(1)
+    for v, name in ((0, "side"), (1, "wrist")):
+        c = ro.camera_numpy(1, v)
+        assert c["image_width"] == W and c["image_height"] == H
+        n_ref, col_ref, _, dep_ref, frag = oracle_render(sc, c, fragile=True)
+        assert n_ref > 0 and col_ref.std() > 0
+        r = compare_images(col[1, v].cpu().numpy(), dep[1, v].cpu().numpy(), col_ref, dep_ref, fragile=frag, what=f"848x480 {name} camera, env 1, vs oracle")
+        assert_image_gate(r, W * H, name)
+    # the side camera at this size IS the calibrated camera of the reference (no rescaling): its matrices are the pinned fixture's
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "camera_side_848x480.json")))
+    c0 = ro.camera_numpy(0, 0)
+    assert np.allclose(np.asarray(fx["viewmatrix"], np.float32).reshape(4, 4), c0["viewmatrix"].reshape(4, 4), atol=1e-6)
+    assert np.allclose(np.asarray(fx["projmatrix"], np.float32).reshape(4, 4), c0["projmatrix"].reshape(4, 4), atol=2e-6)
