@@ -148,6 +148,12 @@ struct PhysDev {
     int* fault;                // [0] sticky: 1 = a self-collision impulse exceeded the bound the "no mesh in reach" decision relies on; 2 = a
                                // hand-off of the resident stepper timed out; [1] a particle needed a mesh query since the host last looked
     void* xch;                 // resident stepper: exchange array [E][2 buffers][3 planes][N] x 16 B {value, tag, value, tag}
+    // resident stepper, mesh-query SERVERS (small scenes; see k_steps_resident): workgroups of the same launch beyond the blocks' own,
+    // two wavefronts per served particle
+    int srv_slots;             // server wavefront pairs of this launch (0: none — queries in place)
+    void* srv_claim;           // [srv_slots] x 16 B {env * N + particle, 1, first substep of the launch it is served from, 1}
+    void* srv_rr;              // [E][N][6] x 16 B tagged granules: planes 0-2 the REQUEST (x0.x x0.y | x0.z v.x | v.y v.z), 3-5 the RESULT (xy | z vz | vxy)
+    int* srv_ctl;              // [0] next free slot, [1] blocks that have left the launch
 };
 
 // Everything from here to the spring gather is compiled WITHOUT fused multiply-add contraction: the collision
@@ -391,7 +397,21 @@ struct QShare {
     float pt[2][QWPB][6];            // what a slow one is still reading (closest point, q - p; mesh frame)
     int meta[2][QWPB][5];            // stored face, feature region, mesh kind, transform slot, cluster
     volatile int sup[QWPB][8];       // per wavefront: lanes that own the super-clusters of the current round
+    int bar;                         // pair mode (the resident stepper's query servers): arrivals at the two-wavefront barrier, zeroed by the workgroup
 };
+// mesh_query_regs is run by TWO wavefronts: a 128-thread workgroup of k_contact_finish<3> (barrier = __syncthreads), or one of the four
+// wavefront PAIRS of a server workgroup of k_steps_resident, each on its own particle at its own pace (barrier = a counter in the pair's
+// QShare).  `parity` carries the mode: bit 0 the buffer parity, bit 8 pair mode, bits 16.. the pair barrier's generation.
+constexpr int QPAIR = 1 << 8;
+__device__ __forceinline__ void pair_barrier(QShare& sm, int& parity)
+{
+    const int gen = (parity >> 16) + 1;
+    parity = (parity & 0xffff) | (gen << 16);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // this wavefront's LDS writes before its arrival
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&sm.bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(&sm.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * gen) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, f3 q, int e, bool want, int hint, QShare& sm, int& parity, const Xf& X0 R2S_QP_PARAM)
 {
@@ -684,9 +704,9 @@ __device__ __forceinline__ TriRegs load_tris(const PhysDev& p, int e, int step, 
 __device__ __forceinline__ MeshHit mesh_query_regs(const TriRegs& t, f3 q, bool want, QShare& sm, int& parity)
 {
     MeshHit out = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
-    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6) & 1;
     const float MAXD2 = MESH_MAX_DIST * MESH_MAX_DIST;
-    const int par = parity;
+    const int par = parity & 1;
     parity ^= 1;
     if (want) {
         float u, v;
@@ -711,7 +731,8 @@ __device__ __forceinline__ MeshHit mesh_query_regs(const TriRegs& t, f3 q, bool 
             sm.meta[par][wave][0] = wmm; sm.meta[par][wave][1] = wfm; sm.meta[par][wave][2] = mm0; sm.meta[par][wave][3] = fm0;
         }
     }
-    __syncthreads();
+    if (parity & QPAIR) pair_barrier(sm, parity);
+    else __syncthreads();
     if (!want) return out;
     const unsigned long long k0 = sm.key[par][0], k1 = sm.key[par][1];
     const int fw = k1 < k0 ? 1 : 0;
@@ -855,12 +876,15 @@ __device__ __forceinline__ float mesh_margin(const PhysDev& p, int m)
 {
     return (p.mesh_kind[m] & 2) ? MESH_MAX_DIST : ((m < p.n_dyn_mesh && !p.use_pusher) ? 0.005f : 0.001f);
 }
-__device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 next_x, float pad, bool& near)
+// `staged` (the resident stepper): the substep's boxes [n_mesh][6], already in LDS — the two dependent loads below are then off the
+// critical path of a substep in which something is in reach
+__device__ __forceinline__ bool mesh_need(const PhysDev& p, int e, int step, f3 next_x, float pad, bool& near, const float* staged = nullptr)
 {
     bool need = false;
     near = false;
     for (int m = 0; m < p.n_mesh; ++m) {
-        const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
+        const float* bb = staged ? staged + 6 * m
+                        : m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
                                            : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
         const float mg = mesh_margin(p, m) + pad;
         const float d2 = box_dist2(next_x, bb);
@@ -884,6 +908,8 @@ constexpr int RES_MAX_MESH = 4;
 // raised from within this reach.
 constexpr float RES_RANGE_PAD = 0.002f;
 struct ResidentIO {
+    bool srv_on, srv_need; // in: needy particles go to a query server instead of being queried in place; out: this lane's particle does
+    const float* step_boxes; // in (LDS) or null: this substep's mesh boxes [n_mesh][6], staged by the launch at the top of the substep
     f3 x, v;               // out: the particle's new state
     const float* boxes;    // in (LDS, wave-uniform values — 35 registers per lane if they lived there): [0..5] union of everything, [6] (largest
                            // margin + RES_RANGE_PAD)^2 widened by 1e-4 relative; then per mesh slot m at 8 + 8 m: [0..5] its union over the substeps,
@@ -944,7 +970,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
       if (in_range) {
         bool need = false, near = false;
         if (NEED == 1) need = fin;
-        else if (NEED == 0 && fin) need = mesh_need(p, e, step, next_x, 0.f, near);
+        else if (NEED == 0 && fin) need = mesh_need(p, e, step, next_x, 0.f, near, KEEP ? keep->step_boxes : nullptr);
         if (MAIN) { // count the particles near a mesh (the host picks the next step's graph flavour from the total) and, in
                     // deferring mode, hand the ones that need a query to k_contact_finish
             // only "anything near?" is consumed (the host picks the next step's flavour from it): one plain store per wavefront
@@ -967,6 +993,10 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
                     need = false;
                 }
                 // list full (never with the sizing below): fall through to the in-place query
+            } else if (KEEP && need && keep->srv_on) { // resident launch with query servers: not finished here (see k_steps_resident)
+                keep->srv_need = true;
+                fin = false;
+                need = false;
             }
         }
         // large scenes (MESH 2): never queried in the fused kernel; in k_contact_finish by the whole workgroup for the particle of
@@ -1328,6 +1358,112 @@ __device__ __forceinline__ void spring_groups_n(const PhysDev& p, int n, const A
     else if (n == 1) spring_groups<RCAP, 1>(p, g, win, xi, vi, fxy, fz);
 }
 
+// ---- mesh-query servers of the resident launch (round 4) ---------------------------------------------------------------------------
+// A resident launch must not answer mesh queries inside the blocks that own the particles: a query is thousands of instructions, and
+// every block of the environment waits, hand-off by hand-off, for the slowest (measured in round 3 on the rope in a grasp: 54.8 us per
+// substep with per-lane queries in the finishing wavefronts against 2.5 us in free motion; the per-substep kernels + finishing launch the
+// step then fell back to: 11.8 us).  A one-environment launch leaves about half of the chip idle (130 blocks of the 8 k-particle rope on
+// 256 CUs), so the launch carries extra workgroups — SERVERS, four wavefront pairs each — and a particle that needs a query is handed to
+// a pair of its own through the same tagged write-through granules the blocks exchange their halos with:
+//   claim    the first time a particle needs a query its block (wavefront 0 of the finishers) takes the next free pair (one atomic) and
+//            writes {env * N + particle, first substep}; the pair serves that particle until the launch ends;
+//   request  per substep, three 16-byte granules {x0, post-force v} tagged 2 (k + 1) + 1 — or one granule tagged 2 (k + 1) when the
+//            particle is out of every mesh's reach in substep k (nothing to wait for: the pair skips ahead to the next tag it sees);
+//   result   the pair runs finish_wave<3> (k_contact_finish's small-scene code: the substep's triangles one per lane in two wavefronts,
+//            loaded BEFORE the request arrives; mesh response, re-query, per-face forces on the last substep, ground) and returns the
+//            particle's new state in three granules tagged k + 1; the block's three finishing wavefronts poll them, publish, go on;
+//   end      a block that leaves the launch ends its pairs (tag SRV_END) and counts itself out; pairs nobody claimed leave when every
+//            block has.
+// No more pairs than particles that ever need one are busy; a claim beyond the last pair is answered in place (result tag SRV_INPLACE).
+// Every poll is bounded like the halo polls (sticky fault word, never a hang); the launch is resident as a whole (blocks + servers <=
+// CUs), which the host guarantees when it sizes the grid.
+constexpr unsigned SRV_END = 0x7ffffffeu, SRV_INPLACE = 0x40000000u;
+constexpr int SRV_MAX_SLOTS = 512, SRV_MIN_WG = 8; // four pairs per server workgroup: at most 128 server workgroups; fewer than 8 are not worth the claims
+__device__ __forceinline__ v4u srv_load(const __amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, RES_AUX_LOAD); }
+__device__ __forceinline__ void srv_store(const __amdgpu_buffer_rsrc_t r, unsigned off, unsigned a, unsigned b, unsigned tag)
+{
+    const v4u w = {a, tag, b, tag};
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, off, 0, RES_AUX_SC1);
+}
+__device__ __forceinline__ bool srv_claimed(v4u c) { return c.y == 1u && c.w == 1u; }
+
+__device__ void resident_server(const PhysDev& p, int first, int n_steps, int write_forces_last)
+{
+    __shared__ QShare qsrv[4];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = wave >> 1;
+    if (tid < 4) qsrv[tid].bar = 0;
+    __syncthreads();
+    const int g = ((int)blockIdx.x - 8 * p.cb) * 4 + pair;
+    if (g >= p.srv_slots) return; // (whole pairs)
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.srv_claim, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(p.srv_rr, 0, 0x7fffffff, 0x00020000);
+    // every lane loads the same words: decisions are wave-uniform, and the two wavefronts of a pair reach the same ones (a claim is
+    // written — write-through, drained — before its block counts itself out, so "everybody left and no claim" is final)
+    unsigned ei = 0, k = 0;
+    for (unsigned spins = 0;; ++spins) {
+        v4u c = srv_load(rc, (unsigned)g * 16u);
+        if (srv_claimed(c)) { ei = c.x; k = c.z; break; }
+        if (__hip_atomic_load(p.srv_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.nb * p.ne) {
+            c = srv_load(rc, (unsigned)g * 16u);
+            if (srv_claimed(c)) { ei = c.x; k = c.z; break; }
+            return;
+        }
+        if (spins >= RES_SPIN_LIMIT) return; // (a stuck launch is reported by the blocks' own limits)
+        // an idle pair polls rarely (a claim is waited for once per particle and launch; ~500 idle wavefronts polling at the rate of the
+        // hand-offs slowed every halo exchange of the launch: 2.87 vs 2.50 us per free substep of the rope)
+        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+    }
+    ei = (unsigned)__builtin_amdgcn_readfirstlane((int)ei); k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+    const int e = (int)(ei / (unsigned)p.N), i = (int)(ei % (unsigned)p.N);
+    const size_t eb = (size_t)e * p.N;
+    const unsigned base = ei * 96u;
+    const TriIds tids = load_tri_ids(p, lane, wave & 1);
+    int qpar = QPAIR;
+    Xf X0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) X0.r[j] = (j % 4 == 0) ? 1.f : 0.f;
+    X0.t[0] = X0.t[1] = X0.t[2] = 0.f;
+    ResidentIO io;
+    io.srv_on = false; io.srv_need = false; io.boxes = nullptr; io.step_boxes = nullptr;
+    io.x = mk(0.f, 0.f, 0.f); io.v = io.x;
+    const StateM none = {nullptr, 0};
+    while ((int)k < n_steps) {
+        TriRegs tr = load_tris(p, e, first + (int)k, tids); // in flight while the request is awaited
+        v4u r0 = {0u, 0u, 0u, 0u};
+        unsigned t0 = 0;
+        for (unsigned spins = 0;; ++spins) {
+            r0 = srv_load(rr, base);
+            t0 = r0.y;
+            if (r0.w == t0 && t0 >= 2u * (k + 1u)) break;
+            if (spins >= RES_SPIN_LIMIT) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (t0 == SRV_END) return;
+        const unsigned ks = (t0 >> 1) - 1u; // a later substep's tag: the ones in between were skipped (a request always waits for its result)
+        if (!(t0 & 1u)) { k = ks + 1u; continue; }
+        if (ks != k) { k = ks; tr = load_tris(p, e, first + (int)k, tids); }
+        v4u r1 = {0u, 0u, 0u, 0u}, r2 = r1;
+        for (unsigned spins = 0;; ++spins) {
+            r1 = srv_load(rr, base + 16u); r2 = srv_load(rr, base + 32u);
+            if (r1.y == t0 && r1.w == t0 && r2.y == t0 && r2.w == t0) break;
+            if (spins >= RES_SPIN_LIMIT) return;
+        }
+        const f3 x0 = mk(__uint_as_float(r0.x), __uint_as_float(r0.z), __uint_as_float(r1.x));
+        const f3 v = mk(__uint_as_float(r1.z), __uint_as_float(r2.x), __uint_as_float(r2.z));
+        const bool last = (int)k == n_steps - 1;
+        R2S_QP_DECL(-1);
+        finish_wave<3, false, 1, true>(p, e, i, eb, first + (int)k, last ? write_forces_last : 0, x0, v, lane == 0, none, &tr, &qsrv[pair], &qpar, &X0,
+                                       (wave & 1) == 0, &io R2S_QP_ARG);
+        if ((wave & 1) == 0 && lane == 0) {
+            const unsigned tag = k + 1u;
+            srv_store(rr, base + 48u, __float_as_uint(io.x.x), __float_as_uint(io.x.y), tag);
+            srv_store(rr, base + 64u, __float_as_uint(io.x.z), __float_as_uint(io.v.z), tag);
+            srv_store(rr, base + 80u, __float_as_uint(io.v.x), __float_as_uint(io.v.y), tag);
+        }
+        k = k + 1u;
+    }
+}
+
 // The same kernel is the small-batch layout's PER-SUBSTEP kernel (n_steps = 1: no hand-off at all, the window comes from the state
 // arrays, wavefront 0 alone finishes and owns every side effect): the contact flavours — deferred mesh queries, self-collision
 // candidates (SELF; only ever with n_steps = 1) — keep their finishing kernels and a launch per substep, but a block's springs are
@@ -1342,6 +1478,10 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     __shared__ __attribute__((aligned(16))) v2f win_s[3 * (RCAP + 1)]; // planes xy | (z, vz) | vxy like the fused substep's window
     __shared__ float4 part_s[NW][B]; // partial forces of the eight wavefronts: one 16-byte write per lane, eight 16-byte reads per finishing lane
     __shared__ volatile int fail_s;
+    if ((int)blockIdx.x >= 8 * p.cb) { // workgroups beyond the blocks' own: mesh-query servers (small scenes only)
+        if (MESH == 1 && !SELF) resident_server(p, first, n_steps, write_forces_last);
+        return;
+    }
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int item = xcd * p.cb + q;      // XCD c owns a contiguous run of blocks: most hand-offs stay inside one L2
     if (q >= p.cb || item >= p.nb * p.ne) return;
@@ -1394,6 +1534,15 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     const float inv_m1 = 1.0f / m1;
     ResidentIO io;
     io.x = mk(0.f, 0.f, 0.f); io.v = io.x;
+    const bool srv_on = MESH == 1 && !SELF && p.srv_slots > 0 && n_steps > 1;
+    io.srv_on = srv_on; io.srv_need = false;
+    constexpr int RES_STAGE_MESH = 8;        // meshes whose per-substep boxes are staged in LDS at the top of every substep (more: loaded where they are used)
+    __shared__ float sbox_s[6 * RES_STAGE_MESH];
+    const bool stage_boxes = MESH != 0 && n_steps > 1 && p.n_mesh <= RES_STAGE_MESH;
+    io.step_boxes = stage_boxes ? sbox_s : nullptr;
+    bool srv_mine = false; // wavefront 0: this lane's particle has a server pair
+    const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(p.srv_rr, 0, 0x7fffffff, 0x00020000);
+    const unsigned sbase = ((unsigned)e * (unsigned)p.N + (unsigned)ic) * 96u;
     __shared__ float box_s[8 * (1 + RES_MAX_MESH)];
     io.boxes = (MESH && n_steps > 1) ? box_s : nullptr;
     if (MESH && n_steps > 1) { // unions of the mesh boxes over the launch's substeps (once per launch: a few loads per lane, a reduction through LDS)
@@ -1459,6 +1608,12 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
         const int step = first + k;
         const bool last = k == n_steps - 1;
         __syncthreads(); // A: the block's own records of version k are in the window (k = 0: its halo too)
+        if (stage_boxes && tid >= RES_THREADS - 64 && lane < 6 * p.n_mesh) { // the last wavefront: this substep's mesh boxes -> LDS (read after barrier C)
+            const int m = lane / 6, c = lane - 6 * m;
+            const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
+                                               : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
+            sbox_s[lane] = bb[c];
+        }
         const v2f oa = win_s[lane], ob = win_s[RCAP + 1 + lane], oc = win_s[2 * (RCAP + 1) + lane];
         const f3 x0 = mk(oa.x, oa.y, ob.x), v0 = mk(oc.x, oc.y, ob.y);
 
@@ -1555,7 +1710,56 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                 }
             }
             R2S_QP_DECL(-1);
+            io.srv_need = false;
             finish_wave<MESH, MESH != 0, 0, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, v, fin, out, nullptr, nullptr, nullptr, nullptr, wave == 0, &io R2S_QP_ARG);
+            if (MESH == 1 && !SELF && srv_on) { // particles that need a mesh query: handed to a server pair (resident_server), not finished above
+                const bool sneed = io.srv_need; // the same in the three finishing wavefronts (same inputs, same instructions)
+                const unsigned uk = (unsigned)k;
+                if (wave == 0) {
+                    if (sneed && !srv_mine) {
+                        const int slot = atomicAdd(p.srv_ctl, 1);
+                        if (slot < p.srv_slots) {
+                            srv_mine = true;
+                            const __amdgpu_buffer_rsrc_t rcl = __builtin_amdgcn_make_buffer_rsrc(p.srv_claim, 0, 0x7fffffff, 0x00020000);
+                            srv_store(rcl, (unsigned)slot * 16u, (unsigned)e * (unsigned)p.N + (unsigned)i, uk, 1u);
+                        } else
+                            srv_store(rsv, sbase + 48u, 0u, 0u, SRV_INPLACE | (uk + 1u)); // no pair left: every finishing wavefront answers in place
+                    }
+                    if (srv_mine) {
+                        if (sneed) {
+                            const unsigned tag = 2u * (uk + 1u) + 1u;
+                            srv_store(rsv, sbase + 16u, __float_as_uint(x0.z), __float_as_uint(v.x), tag);
+                            srv_store(rsv, sbase + 32u, __float_as_uint(v.y), __float_as_uint(v.z), tag);
+                            srv_store(rsv, sbase, __float_as_uint(x0.x), __float_as_uint(x0.y), tag);
+                        } else
+                            srv_store(rsv, sbase, 0u, 0u, 2u * (uk + 1u)); // nothing in reach in this substep: the pair skips it
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(sneed) != 0ull) {
+                    bool inplace = false;
+                    for (unsigned spins = 0;; ++spins) {
+                        bool ok = true;
+                        if (sneed && !inplace) {
+                            const v4u d0 = srv_load(rsv, sbase + 48u), d1 = srv_load(rsv, sbase + 64u), d2 = srv_load(rsv, sbase + 80u);
+                            if (d0.y == (SRV_INPLACE | (uk + 1u)) && d0.w == d0.y) inplace = true;
+                            else if (d0.y == uk + 1u && d0.w == uk + 1u && d1.y == uk + 1u && d1.w == uk + 1u && d2.y == uk + 1u && d2.w == uk + 1u) {
+                                io.x = mk(__uint_as_float(d0.x), __uint_as_float(d0.z), __uint_as_float(d1.x));
+                                io.v = mk(__uint_as_float(d2.x), __uint_as_float(d2.z), __uint_as_float(d1.z));
+                            } else
+                                ok = false;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                        if (spins >= RES_SPIN_LIMIT) {
+                            if (lane == 0) { if (p.fault) *p.fault = 2; fail_s = 1; }
+                            break;
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(inplace) != 0ull) // (wave-uniform branch: finish_wave's queries are per lane here)
+                        finish_wave<MESH, false, 1, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, v, sneed && inplace, out, nullptr, nullptr, nullptr, nullptr,
+                                                          wave == 0, &io R2S_QP_ARG);
+                    if (last && wave == 0 && sneed && !inplace && xv_out.p != nullptr) st_store(xv_out, eb + i, io.x, io.v);
+                }
+            }
 #ifdef R2S_PHASE_PROBE
             if (io.x.x == 1.2345e33f) return;
 #endif
@@ -1572,6 +1776,12 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             }
             R2S_RSTAMP(3);
         }
+    }
+    if (MESH == 1 && !SELF && srv_on) { // end this block's server pairs, then count the block out (pairs nobody claimed leave when every block has)
+        if (wave == 0 && srv_mine) srv_store(rsv, sbase, 0u, 0u, SRV_END);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.srv_ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifdef R2S_PHASE_PROBE
     if (tid == 0 && item < 8192 / 2) {
@@ -2336,6 +2546,10 @@ struct R2SPhys {
     int* d_cand_mark = nullptr;
     int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false, fault_stale = false;
     void* d_xch = nullptr;    // resident stepper: exchange array (96 B per particle)
+    void* d_srv_claim = nullptr; void* d_srv_rr = nullptr; // resident stepper's mesh-query servers: claims [SRV_MAX_SLOTS] x 16 B + 2 control words, request / result granules 96 B per particle
+    bool srv_ok = false;      // small scene (every mesh small, <= 128 faces in total): a resident launch may carry query servers
+    int srv_wg_cap = SRV_MAX_SLOTS / 4; // R2S_RES_SRV_WG: at most this many server workgroups per launch
+    int n_cu = 256;
     bool split_ok = false;    // 64-particle layout whose slices fit k_steps_resident's registers (no remote neighbours, <= 64 interior / halo slots)
     bool resident_ok = false; // the handle can run the env step as ONE resident launch (k_steps_resident) in its free flavour
     int resident_pref = 1;    // R2S_RESIDENT=0 / r2s_phys_set_tuning: never pick the 64-particle layout / the resident launch
@@ -2434,6 +2648,7 @@ struct R2SPhys {
         p.aabb_dyn = d_aabb_dyn; p.aabb_static = d_aabb_static; p.coll_forces = d_coll_forces; p.hit_cnt = d_hit_cnt;
         p.fault = d_mesh_total ? d_mesh_total + 1 : nullptr;
         p.xch = d_xch;
+        p.srv_slots = 0; p.srv_claim = d_srv_claim; p.srv_rr = d_srv_rr; p.srv_ctl = d_srv_claim ? (int*)d_srv_claim + 4 * SRV_MAX_SLOTS : nullptr;
         return p;
     }
 };
@@ -2619,7 +2834,18 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
         }
         const size_t words = (size_t)24 * ne * h->N; // this chain's environments: 2 buffers x 3 planes x 16 B per particle
         hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_xch + (size_t)24 * e0 * h->N, words);
-        const dim3 grid(8u * (unsigned)p.cb);
+        // mesh-query servers: workgroups beyond the blocks' own, as many as the chip has CUs left (the whole launch is resident at once)
+        int n_srv = 0;
+        if (h->srv_ok && n > 1) {
+            n_srv = std::min(h->n_cu - h->nb * ne, h->srv_wg_cap);
+            if (n_srv < SRV_MIN_WG) n_srv = 0;
+        }
+        if (n_srv > 0) {
+            p.srv_slots = 4 * n_srv;
+            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((4 * SRV_MAX_SLOTS + 4 + 255) / 256)), dim3(256), 0, s, (float*)h->d_srv_claim, (size_t)4 * SRV_MAX_SLOTS + 4);
+            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_srv_rr + (size_t)24 * e0 * h->N, words);
+        }
+        const dim3 grid(8u * (unsigned)p.cb + (unsigned)n_srv);
         const StateC in = h->state(start_buf);
         const StateM out = h->state(start_buf ^ 1);
         const bool with_mesh = h->nF > 0;
@@ -3325,9 +3551,22 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         R2S_HIP_TRY(hipGetDevice(&dev));
         R2S_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         h->resident_ok = h->split_ok && !h->any_large && (int64_t)h->nb * E <= std::min(RES_MAX_ITEMS, n_cu);
+        h->n_cu = n_cu;
         if (h->resident_ok) {
             TRY(dev_alloc((char**)&h->d_xch, (size_t)96 * E * N));
             R2S_HIP_TRY(hipMemsetAsync(h->d_xch, 0, (size_t)96 * E * N, s));
+            // query servers ride in the launch when every mesh is small enough for k_contact_finish<3>'s code (triangles in registers, one per
+            // lane in two wavefronts) and the blocks leave CUs free; R2S_RES_SERVERS=0: queries in place / per-substep flavour as in round 3
+            bool pref = true;
+            if (const char* ev = getenv("R2S_RES_SERVERS")) pref = atoi(ev) != 0;
+            if (const char* ev = getenv("R2S_RES_SRV_WG")) h->srv_wg_cap = std::max(1, std::min(atoi(ev), SRV_MAX_SLOTS / 4));
+            h->srv_ok = pref && h->nF > 0 && h->nF <= 128 && n_cu - (int)((int64_t)h->nb * E) >= SRV_MIN_WG;
+            if (h->srv_ok) {
+                TRY(dev_alloc((char**)&h->d_srv_claim, (size_t)16 * SRV_MAX_SLOTS + 16));
+                TRY(dev_alloc((char**)&h->d_srv_rr, (size_t)96 * E * N));
+                R2S_HIP_TRY(hipMemsetAsync(h->d_srv_claim, 0, (size_t)16 * SRV_MAX_SLOTS + 16, s));
+                R2S_HIP_TRY(hipMemsetAsync(h->d_srv_rr, 0, (size_t)96 * E * N, s));
+            }
         }
     }
     if (h->prm.self_collision) {
@@ -3379,7 +3618,8 @@ void r2s_phys_destroy(R2SPhys* h)
                     h->d_faces, h->d_face_orig, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
                     h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_sup_info, h->d_sup_box, h->d_small_mesh, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
-                    h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta, h->d_hit_cnt, h->d_xch};
+                    h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta, h->d_hit_cnt, h->d_xch,
+                    h->d_srv_claim, h->d_srv_rr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_cand_count) (void)hipHostFree(h->h_cand_count);
     if (h->h_mesh_total) (void)hipHostFree(h->h_mesh_total);
@@ -3665,13 +3905,21 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         // their free flavour is the resident launch (2.3 vs 7.2 us per substep for the rope), and a gripper hovering within 3 cm is free
         // motion — the step in which the first particle enters a margin pays for its in-place queries once
         if (!h->mesh_pending) h->mesh_defer = (h->resident_ok && h->resident_pref ? h->h_mesh_total[2] : h->h_mesh_total[0]) > 0 ? 1 : 0;
+        // ... and with query servers in the launch (round 4) a small batch stays resident THROUGH contact: a particle that needs a query is
+        // answered by a server pair of the same launch (resident_server); only the self-collision flavour still takes the per-substep path
+        if (h->resident_ok && h->resident_pref && h->srv_ok && variant == 0) h->mesh_defer = 0;
         if (h->force_defer >= 0) h->mesh_defer = h->force_defer; // test / tuning: force a flavour
         if (h->any_large) h->mesh_defer = 1;
     }
     h->last_flavour[0] = variant | (h->split_ok ? 2 : 0); h->last_flavour[1] = h->nF > 0 ? (h->any_large ? 2 : 1) : 0; h->last_flavour[2] = h->mesh_defer;
     h->last_flavour[3] = use_graph ? h->chains() : 1;
     const bool resident = resident_flavour(h, variant == 1, h->mesh_defer);
-    if (resident) h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)
+    if (resident) {
+        h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)
+        int n_srv = h->srv_ok && n > 1 ? std::min(h->n_cu - h->nb * h->E, h->srv_wg_cap) : 0; // as enqueue_steps sizes the grid
+        if (n_srv < SRV_MIN_WG) n_srv = 0;
+        h->last_flavour[3] = 1 | (n_srv << 8);
+    }
     int gate_dev = -1;
     if (resident) { int rcg = resident_enter(s, &gate_dev); if (rcg) return rcg; }
     struct GateLeave { hipStream_t s; int dev; ~GateLeave() { if (dev >= 0) (void)resident_leave(s, dev); } } gate_leave{s, gate_dev};

@@ -105,13 +105,18 @@ def test_resident_launch_is_deterministic_and_partial_steps_compose():
     assert np.array_equal(xa, xc) and np.array_equal(a.v.cpu().numpy(), c.v.cpu().numpy())
 
 
-def test_resident_launch_with_fingers_hovering_then_touching():
+@pytest.mark.parametrize("servers", [True, False], ids=["query servers in the launch", "R2S_RES_SERVERS=0 (round-3 behaviour)"])
+def test_resident_launch_with_fingers_hovering_then_touching(monkeypatch, servers):
     """Moving finger meshes: while they hover the union-box early-out skips every per-mesh test and the batch stays on the resident
     launch (small batches defer once a query was NEEDED, not when something is merely near); when the fingers come down the
-    wavefronts in reach run the exact tests and the in-place queries inside the resident launch (the first env step in reach: the
-    host switches to the deferred flavour one step later).  All against the oracle, forces included."""
+    wavefronts in reach run the exact tests and hand the particles that need a query to the launch's server pairs (round 4) — the
+    batch stays resident — or, without servers, answer them in place inside the launch (the first env step in reach: the host then
+    switches to the deferred flavour one step later).  All against the oracle, forces included."""
     import torch
     from r2s_hip import synth
+
+    if not servers:
+        monkeypatch.setenv("R2S_RES_SERVERS", "0")
 
     n_sub = 120
     ob = make_object("sloth", 500, seed=6)
@@ -148,8 +153,70 @@ def test_resident_launch_with_fingers_hovering_then_touching():
     assert fl["resident"], "a small batch stays on the resident launch while no particle needs a mesh query"
     e_hit, near_hit, fl = run(0.03, (0.0, 0.0, -6.0), True)   # the scenario of test_gripper_fingers_dynamic_mesh
     assert near_hit != 0, "particles inside a margin must be reported"
-    assert not fl["resident"] and fl["deferred_mesh_queries"], "after a step that needed queries the next one runs the deferred flavour"
-    record("resident stepper with finger meshes (hovering / in-place queries)", x_max_abs_hover=e_far, x_max_abs_contact=e_hit, tol=1e-5)
+    if servers:
+        assert fl["resident"], "with query servers in the launch a small batch stays resident through contact"
+    else:
+        assert not fl["resident"] and fl["deferred_mesh_queries"], "after a step that needed queries the next one runs the deferred flavour"
+    record(f"resident stepper with finger meshes (hovering / {'server' if servers else 'in-place'} queries)", x_max_abs_hover=e_far, x_max_abs_contact=e_hit, tol=1e-5)
+
+
+@pytest.mark.parametrize("n_env", [1, 2])
+def test_resident_launch_stays_resident_through_a_held_grasp(n_env):
+    """one environment IN CONTACT used to leave the resident launch (per-substep kernels + finishing launch: 11.8 us
+    per substep for the rope against 2.5 free).  With query servers in the launch the fingers close on the rope, squeeze it, hold it and
+    lift it over five env steps and EVERY step is one resident launch: positions against the oracle (1e-5, BASELINE.json), against the
+    per-substep kernels + finishing launch of a second handle (2e-6: the same queries, another summation order of the springs), the
+    per-finger force totals of the last substep, and the server protocol's corner cases on the way — particles that enter a margin in
+    different substeps (claims mid-launch), particles that leave it again (skipped substeps), a step in which nothing touches."""
+    import torch
+    from r2s_hip import synth
+
+    n_sub = 300
+    ob = make_object("rope", 900, seed=4)
+    c = ob["points"].mean(0)
+    top = ob["points"][:, 2].max()
+    kw = dict(self_collision=False, num_substeps=n_sub)
+    z = 0.002 + 0.025 + 0.004                                            # finger centres: tips 6 mm above the table after the descent below
+    fingers = [synth.finger_mesh((c[0], c[1] - 0.030, z + 0.012), pad_normal=(0.0, 1.0, 0.0)), synth.finger_mesh((c[0], c[1] + 0.030, z + 0.012), pad_normal=(0.0, -1.0, 0.0))]
+    o = oracle_env(ob, dynamic_meshes=fingers, **kw)
+    h = hip_env(ob, n_env=n_env, dynamic_meshes=fingers, **kw)
+    g = hip_env(ob, n_env=n_env, dynamic_meshes=fingers, **kw)
+    g.set_resident(False)
+    T = n_sub * 5e-5
+    #        eef velocity           closing speed (each finger towards the other), m/s
+    script = [((0.0, 0.0, -0.012 / T), 0.0),          # down: nothing touches yet (rope radius 12 mm, pads 30 mm from the axis)
+              ((0.0, 0.0, 0.0), 0.010 / T),           # close: pads from 13 mm to 3 mm off the rope's surface -> particles enter the 5 mm margin mid-step
+              ((0.0, 0.0, 0.0), 0.002 / T),           # squeeze by 2 mm
+              ((0.0, 0.0, 0.0), 0.0),                 # hold
+              ((0.0, 0.0, 0.01 / T), 0.0)]            # lift 1 cm with the rope in the fingers
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None].repeat(n_env, *([1] * a.ndim)).cuda()  # noqa: E731
+    worst_o, worst_g, touched = 0.0, 0.0, []
+    for k, (vel, closing) in enumerate(script):
+        interp, centers, dv, om = gripper_motion(fingers, n_sub, 5e-5, vel=vel, closing=closing)
+        o.set_mesh_interactive(interp, centers, dv, om)
+        for hh in (h, g):
+            hh.set_mesh_interactive(tt(interp), tt(centers), tt(dv), tt(om))
+        o.step(); h.step(); g.step()
+        fl, fg = h.last_flavour(), g.last_flavour()
+        assert fl["resident"], (k, fl)
+        assert not fg["resident"], (k, fg)
+        x, xg = h.x.cpu().numpy(), g.x.cpu().numpy()
+        eo, eg = float(np.abs(x - o.x[None]).max()), float(np.abs(x - xg).max())
+        worst_o, worst_g = max(worst_o, eo), max(worst_g, eg)
+        assert eo < 1e-5 and eg < 2e-6, (k, eo, eg)
+        f = h.collision_forces().cpu().numpy()
+        hit = float(np.abs(o.collision_forces).max()) > 0
+        touched.append(hit)
+        for e in range(n_env):
+            for m in (0, 1):
+                tot_o, tot_h = o.collision_forces[h.mesh_map == m].sum(0), f[e][h.mesh_map == m].sum(0)
+                assert np.allclose(tot_h, tot_o, rtol=1e-3, atol=max(np.abs(tot_o).max() * 1e-3, 1e-6)), (k, e, m, tot_o, tot_h)
+        nl = len(fingers[0][0])
+        fingers = [(interp[-1][:nl], fingers[0][1]), (interp[-1][nl:], fingers[1][1])]
+    assert touched[0] is False and all(touched[2:]), touched
+    assert float(o.x[:, 2].max()) > top + 0.002, "the rope must have been lifted"
+    h.step()            # a timed-out hand-off (halo or server) would have raised the sticky fault: this call reports it
+    record(f"resident launch through a held grasp, {n_env} env(s), 5 env steps", x_max_abs_vs_oracle=worst_o, x_max_abs_vs_per_substep_kernels=worst_g, tol=1e-5)
 
 
 def test_resident_launch_next_to_a_busy_second_stream():
