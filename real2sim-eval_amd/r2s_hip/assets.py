@@ -335,7 +335,10 @@ def load_scaniverse(gs_cfg, randomize=False, index=None, rng=None):
       total_mask_full  link id of every table / robot splat (float32, the reference's dtype)                          (:503-505)
       pose_obj, random_variables
     The episode ``index`` is decoded like the reference: with grid randomisation the object takes index % n_object_rand and the
-    meshes share index // n_object_rand, peeled mesh by mesh (:343-352, :368-371)."""
+    meshes share index // n_object_rand, peeled mesh by mesh (:343-352, :368-371).  ``rng``: uniform randomisation draws from it in the
+    reference's order (meshes first, then the object; x, y, z, angle each) — ``np.random.RandomState(seed)`` reproduces the reference's
+    ``np.random.seed(seed)`` (env.py:32).  Pinned: tests/golden/scene_assembly.npz holds what the reference's own function returned for
+    a scene directory (tests/golden/make_scene_golden.py), tests/test_assets.py compares."""
     rng = np.random.default_rng() if rng is None else rng
     use_grid = bool(gs_cfg.get("use_grid_randomization", False))
     obj_cfg, scene_cfg = gs_cfg["object"], gs_cfg["scene"]
@@ -377,3 +380,15 @@ def load_scaniverse(gs_cfg, randomize=False, index=None, rng=None):
     table_rendervar = dict(means3D=tpts, shs=tshs, scales=tscales, rotations=tquats, opacities=topac)
     return dict(rendervar=rendervar, table_rendervar=table_rendervar, params_meshes=params_meshes, meshes=meshes, total_mask_full=total_mask_full,
                 pose_obj=pose_obj, random_variables=random_variables)
+
+
+def assemble_rendervar(rendervar, params_meshes, table_params):
+    """``GSRenderer.update_rendervar``'s scene assembly (gs_renderer.py:758-769, :797-813, :886-921): the object's splats (already skinned to
+    the particles' new positions; their rotations normalised, :758), then every static mesh's splats in the order of ``params_meshes``,
+    then the table + robot scan as ``transform_gs_xarm_gripper / _pusher`` returned it; every rotation of the result normalised
+    (:906).  Numpy arrays in, the ``rendervar_full`` dictionary out (without the unused ``means2D``)."""
+    parts = [dict(rendervar)] + [params_meshes[k] for k in params_meshes] + [table_params]
+    out = {k: np.concatenate([np.asarray(q[k], np.float32) for q in parts]) for k in ("means3D", "shs", "rotations", "opacities", "scales")}
+    r = out["rotations"].astype(np.float32)
+    out["rotations"] = r / np.maximum(np.linalg.norm(r, axis=-1, keepdims=True), 1e-12).astype(np.float32)
+    return out

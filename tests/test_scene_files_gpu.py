@@ -26,9 +26,8 @@ def test_scene_loaded_from_ply_files_renders_like_the_oracle(tmp_path):
     dev = torch.device("cuda:0")
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)  # noqa: E731
     # update_rendervar: object, then the static meshes' splats, then the table / robot scan; every rotation normalised (:906)
-    parts = [sc["rendervar"], sc["params_meshes"]["box"], sc["table_rendervar"]]
-    cat = {k: np.concatenate([q[k] for q in parts]) for k in ("means3D", "shs", "scales", "rotations", "opacities")}
-    cat["rotations"] = cat["rotations"] / np.linalg.norm(cat["rotations"], axis=1, keepdims=True)
+    # (assets.assemble_rendervar: pinned by the reference's own update_rendervar, tests/test_assets.py / tests/golden/scene_assembly.npz)
+    cat = assets.assemble_rendervar(sc["rendervar"], sc["params_meshes"], sc["table_rendervar"])
     n_front = len(cat["means3D"]) - len(sc["table_rendervar"]["means3D"])
     means = t(cat["means3D"]).clone()
     rots = t(cat["rotations"]).clone()
