@@ -30,12 +30,13 @@ for p in (ROOT, os.path.join(ROOT, "real2sim-eval_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = os.path.join("profiles", "r3_pmc_summary.json")
+PMC_FILE = next((f for f in (os.path.join("profiles", "r4_pmc_summary.json"), os.path.join("profiles", "r3_pmc_summary.json")) if os.path.exists(os.path.join(ROOT, f))),
+                os.path.join("profiles", "r4_pmc_summary.json"))   # the newest committed counter summary (labelled STALE when collected on other kernel sources)
 
 
 def pmc_summary(kernel, config):
     """Counter-derived figures of `kernel` from the committed rocprofv3 --pmc passes over THIS workload (profiles/, produced
-    by tools/profiling/pmc_r3.sh; FETCH_SIZE x2 + WRITE_SIZE per the microarchitecture guide).  They are NOT measured in this
+    by tools/profiling/pmc_r4.sh; FETCH_SIZE x2 + WRITE_SIZE per the microarchitecture guide).  They are NOT measured in this
     run — the JSON says so next to every number taken from here — and the summary names the kernel sources it was collected
     on (`source_sha16`, r2s_hip._lib.kernel_source_sha16): a summary of OTHER sources is labelled stale.
     Returns (entry or None, provenance string)."""

@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 KERNELS = {"k_substep<256, 1024, false, 1>": "k_substep", "k_substep<256, 1024, true, 1>": "k_substep_contact", "k_contact_finish<3, true>": "k_contact_finish",
-           "k_contact_finish<3, false>": "k_contact_finish_mesh_only", "k_composite": "k_composite", "k_emit_keys": "k_emit_keys", "k_preprocess": "k_preprocess",
+           "k_contact_finish<3, false>": "k_contact_finish_mesh_only", "k_composite": "k_composite", "k_steps_resident": "k_steps_resident", "k_emit_keys": "k_emit_keys", "k_preprocess": "k_preprocess",
            "k_skin": "k_skin", "k_bone_fit": "k_bone_fit", "k_candidates_fine": "k_candidates_fine", "k_tile_ranges": "k_tile_ranges",
            "direct_copy_kernel": "calibration_copy_512MiB", "__amd_rocclr_copyBuffer": "calibration_copy_512MiB"}
 
@@ -53,13 +53,13 @@ def main():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "real2sim-eval_amd"))
     from r2s_hip._lib import kernel_source_sha16
     res = {"source_sha16": kernel_source_sha16(), "git_head": os.environ.get("PMC_GIT_HEAD", "unknown (no .git on the GPU box; pass PMC_GIT_HEAD)"),
-           "note": "rocprofv3 --pmc passes (tools/profiling/pmc_r3.sh) over tools/profiling/pmc_run.py on one MI355X: " + os.environ.get("PMC_CONFIG", "sloth_32env") + ", R2S_CHAINS=1 (a k_substep dispatch = "
+           "note": "rocprofv3 --pmc passes (tools/profiling/pmc_r3.sh / pmc_r4.sh) over tools/profiling/pmc_run.py on one MI355X: " + os.environ.get("PMC_CONFIG", "sloth_32env") + ", R2S_CHAINS=1 (a k_substep dispatch = "
                    "one batched substep of all 32 envs), 2 free + 3 contact env steps.  hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                    "(FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md; the 512 MiB calibration copy of the same run is listed).  "
                    "valu_busy_frac = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 shader engines): the share of SIMD issue cycles taken by VALU instructions (a floor: quarter-rate instructions count 4 cycles too), at most 1; lds_busy_frac = SQ_LDS_IDX_ACTIVE / 256 CUs "
                    "over the same span.",
            os.environ.get("PMC_CONFIG", "sloth_32env"): out}
-    json.dump(res, open(os.path.join(root, "r3_pmc_summary.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(root, os.environ.get("PMC_SUMMARY_NAME", "r3_pmc_summary.json")), "w"), indent=1)
     for k, e in out.items():
         print(k, {a: b for a, b in e.items() if a != "counters_mean_per_dispatch"})
 

@@ -1,9 +1,10 @@
 #!/bin/bash
-# Round-2 counter passes over tools/profiling/pmc_run.py: SQ activity (3 passes), FETCH_SIZE and WRITE_SIZE (one pass each, as
-# the microarchitecture guide prescribes), then tools/profiling/pmc_r2_summary.py -> gpurun_out/pmc_r2/r2_pmc_summary.json
-R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/pmc_r2; rm -rf $out; mkdir -p $out
+# Round-4 counter passes over tools/profiling/pmc_run.py: SQ activity (3 passes), FETCH_SIZE and WRITE_SIZE (one pass each, as
+# the microarchitecture guide prescribes), then tools/profiling/pmc_r3_summary.py -> gpurun_out/pmc_r4/r4_pmc_summary.json (PMC_SUMMARY_NAME)
+R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/pmc_r4; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 export R2S_CHAINS=1
+export PMC_SUMMARY_NAME=r4_pmc_summary.json
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CYCLES" \
@@ -12,6 +13,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   timeout 280 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -o p$i -- python $R/tools/profiling/pmc_run.py > $out/p$i.log 2>&1 || echo "pass $i failed: $(tail -2 $out/p$i.log)"
 done
-cd $R; python tools/profiling/pmc_r2_summary.py $out > $out/summary.log 2>&1; tail -40 $out/summary.log
+cd $R; python tools/profiling/pmc_r3_summary.py $out > $out/summary.log 2>&1; tail -40 $out/summary.log
 # keep only the summaries (the raw CSVs are hundreds of MB)
 find $out -name "*.csv" -size +2M -delete
