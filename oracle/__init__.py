@@ -11,8 +11,12 @@ imported as a whole in the authoring container.
    known-answer tests (``tests/test_raster_oracle_kat.py``); the camera builder is pinned
    (``tests/golden/camera_side_848x480.json``, made by the reference's own setup_camera);
  * physics stepper: arithmetic kernels pinned by fixtures made by executing the reference's
-   kernel bodies through a float32 shim (``tests/golden/physics_kernels.npz``); warp's HashGrid
-   traversal and mesh query: PARITY UNPINNED (restated, ``tests/test_physics_oracle_kat.py``).
+   kernel bodies through a float32 shim (``tests/golden/physics_kernels.npz``); its caller
+   (``SpringMassDynamicsModule.step``) by ``tests/golden/eef_step.npz``, made by the reference's own
+   method; warp's HashGrid traversal and mesh query: PARITY UNPINNED (restated,
+   ``tests/test_physics_oracle_kat.py``).
+ * ``libr2s_cpu_baseline.so`` (same sources, optimised flags) is a TIMING build for bench.py's
+   cpu_baseline leg (``baseline_build()``); nothing is checked against it.
 """
 from __future__ import annotations
 
