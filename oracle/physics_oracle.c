@@ -56,15 +56,14 @@ int r2s_oracle_phys_step_batch_par_f32(const phys_t_f32 *envs, float **x, float 
         const phys_t_f32 *P = &envs[e];
         const int N = P->N, S = P->S;
         int *off = (int *)calloc((size_t)N + 2, sizeof(int));
-        int *inc = (int *)malloc(sizeof(int) * 2 * (size_t)(S ? S : 1));
+        inc_rec_f32 *rec = (inc_rec_f32 *)malloc(sizeof(inc_rec_f32) * 2 * (size_t)(S > 0 ? S : 1));
         for (int s = 0; s < 2 * S; ++s) off[P->springs[s] + 2]++;
         for (int i = 0; i < N; ++i) off[i + 2] += off[i + 1];
-        for (int s = 0; s < S; ++s) {            /* ascending s: a particle's list is in the order the scatter reaches it */
-            inc[off[P->springs[2 * s] + 1]++] = 2 * s;
-            inc[off[P->springs[2 * s + 1] + 1]++] = 2 * s + 1;
+        for (int s = 0; s < S; ++s) {            /* ascending s: a particle's records are in the order the scatter reaches it */
+            const inc_rec_f32 r = {P->springs[2 * s], P->springs[2 * s + 1], P->rest[s], expf(P->log_Y[s])};
+            rec[off[r.i1 + 1]++] = r;
+            rec[off[r.i2 + 1]++] = r;          /* (a spring whose two ends are one particle contributes +F then -F: listed twice, like the scatter) */
         }
-        float *ey = (float *)malloc(sizeof(float) * (size_t)(S > 0 ? S : 1));   /* exp(log Y) once per call instead of once per spring end and substep */
-        for (int s = 0; s < S; ++s) ey[s] = expf(P->log_Y[s]);
         float *f = (float *)malloc(sizeof(float) * 3 * (size_t)N);
         float *vbc = (float *)malloc(sizeof(float) * 3 * (size_t)N);
         float *vbg = (float *)malloc(sizeof(float) * 3 * (size_t)N);
@@ -77,7 +76,7 @@ int r2s_oracle_phys_step_batch_par_f32(const phys_t_f32 *envs, float **x, float 
             const int lo = (int)((long long)N * t / nt), hi = (int)((long long)N * (t + 1) / nt);
             if (t == 0) team = nt;
             for (int s = first_substep; s < first_substep + n_run; ++s) {
-                eval_springs_gather_f32(P, off, inc, ey, xe, ve, f, lo, hi);
+                eval_springs_gather_f32(P, off, rec, xe, ve, f, lo, hi);
                 update_vel_range_f32(P, ve, f, P->self_collision ? vbc : vbg, lo, hi);
                 if (P->self_collision) {
 #pragma omp barrier
@@ -100,7 +99,7 @@ int r2s_oracle_phys_step_batch_par_f32(const phys_t_f32 *envs, float **x, float 
         }
         granted += team;
         mesh_release_f32(&m);
-        free(off); free(inc); free(ey); free(f); free(vbc); free(vbg);
+        free(off); free(rec); free(f); free(vbc); free(vbg);
     }
     return granted;
 }
