@@ -151,9 +151,10 @@ struct PhysDev {
     // resident stepper, mesh-query SERVERS (small scenes; see k_steps_resident): workgroups of the same launch beyond the blocks' own,
     // two wavefronts per served particle
     int srv_slots;             // server wavefront pairs of this launch (0: none — queries in place)
-    void* srv_claim;           // [srv_slots] x 16 B {env * N + particle, 1, first substep of the launch it is served from, 1}
-    void* srv_rr;              // [E][N][6] x 16 B tagged granules: planes 0-2 the REQUEST (x0.x x0.y | x0.z v.x | v.y v.z), 3-5 the RESULT (xy | z vz | vxy)
+    void* srv_claim;           // [srv_slots] x 128 B, first granule {env * N + particle, 1, first substep of the launch it is served from, 1}; then control words and fault-report state (SRV_CTL_OFF, SRV_DBG_OFF)
+    void* srv_rr;              // [E][N] x 256 B of tagged 16-byte granules: line 0 the REQUEST (x0.x x0.y | x0.z v.x | v.y v.z), line 1 the RESULT (xy | z vz | vxy)
     int* srv_ctl;              // [0] next free slot, [1] blocks that have left the launch
+    unsigned spin_limit;       // poll passes before a workgroup of the resident launch gives up (RES_SPIN_LIMIT; R2S_RES_SPIN_LIMIT at create: diagnostics)
 };
 
 // Everything from here to the spring gather is compiled WITHOUT fused multiply-add contraction: the collision
@@ -398,18 +399,34 @@ struct QShare {
     int meta[2][QWPB][5];            // stored face, feature region, mesh kind, transform slot, cluster
     volatile int sup[QWPB][8];       // per wavefront: lanes that own the super-clusters of the current round
     int bar;                         // pair mode (the resident stepper's query servers): arrivals at the two-wavefront barrier, zeroed by the workgroup
+    int arrived[2];                  // pair mode: the last barrier generation each of the two wavefronts has arrived at
 };
 // mesh_query_regs is run by TWO wavefronts: a 128-thread workgroup of k_contact_finish<3> (barrier = __syncthreads), or one of the four
 // wavefront PAIRS of a server workgroup of k_steps_resident, each on its own particle at its own pace (barrier = a counter in the pair's
 // QShare).  `parity` carries the mode: bit 0 the buffer parity, bit 8 pair mode, bits 16.. the pair barrier's generation.
-constexpr int QPAIR = 1 << 8;
+constexpr int QPAIR = 1 << 8, QFAIL = 1 << 9; // QFAIL: the partner never arrived (bounded wait; the caller reports a fault and leaves)
+// A hardware barrier (s_barrier) counts WAVEFRONTS, so it does not care with which lanes a wavefront reaches it.  This one counts an
+// arrival per wavefront in LDS and spins on the counter — and is written to be correct for ANY set of active lanes: inlined into
+// finish_wave, nothing stops the compiler from duplicating the (non-convergent) code into the two sides of a divergent branch, and a
+// version whose lane 0 makes the arrival then waits for itself.  Whichever lanes come first elect one of themselves, which makes the
+// wavefront's arrival for this generation unless it has been made already (`arrived`, one word per wavefront of the pair).  The wait is
+// bounded (QFAIL -> the server reports fault 4 and leaves).  (A non-inlined function would be convergent, but gives the kernel a stack:
+// scratch memory, and with it fewer resident workgroups than the launch needs — measured: hand-offs timing out all over the rope.)
 __device__ __forceinline__ void pair_barrier(QShare& sm, int& parity)
 {
     const int gen = (parity >> 16) + 1;
     parity = (parity & 0xffff) | (gen << 16);
+    const int w = (int)(threadIdx.x >> 6) & 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // this wavefront's LDS writes before its arrival
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&sm.bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(&sm.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * gen) __builtin_amdgcn_s_sleep(1);
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(act) && __hip_atomic_load(&sm.arrived[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) {
+        __hip_atomic_store(&sm.arrived[w], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sm.bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    for (unsigned spins = 0; __hip_atomic_load(&sm.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * gen; ++spins) {
+        if (spins >= (1u << 22)) { parity |= QFAIL; break; }         // ~0.3 s: the partner is gone (never in a sound launch)
+        __builtin_amdgcn_s_sleep(1);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
@@ -1374,12 +1391,41 @@ __device__ __forceinline__ void spring_groups_n(const PhysDev& p, int n, const A
 //            particle's new state in three granules tagged k + 1; the block's three finishing wavefronts poll them, publish, go on;
 //   end      a block that leaves the launch ends its pairs (tag SRV_END) and counts itself out; pairs nobody claimed leave when every
 //            block has.
-// No more pairs than particles that ever need one are busy; a claim beyond the last pair is answered in place (result tag SRV_INPLACE).
+// No more pairs than particles that ever need one are busy; a claim beyond the last pair is answered in place by the block's wavefront 0.
 // Every poll is bounded like the halo polls (sticky fault word, never a hang); the launch is resident as a whole (blocks + servers <=
 // CUs), which the host guarantees when it sizes the grid.
-constexpr unsigned SRV_END = 0x7ffffffeu, SRV_INPLACE = 0x40000000u;
-constexpr int SRV_MAX_SLOTS = 512, SRV_MIN_WG = 8; // four pairs per server workgroup: at most 128 server workgroups; fewer than 8 are not worth the claims
+// the first fault of a launch wins and records where it happened (p.fault + 3 .. + 14 = the handle's words [4..15]): code, work item,
+// substep, and six words of context — what the host's error message prints
+__device__ __forceinline__ void resident_fault(const PhysDev& p, int code, int item, int k, unsigned a, unsigned b, unsigned c, unsigned d, unsigned e2, unsigned f)
+{
+    if (!p.fault) return;
+    if (atomicCAS(p.fault, 0, code) == 0) {
+        int* w = p.fault + 3;
+        w[0] = code; w[1] = item; w[2] = k; w[3] = (int)a; w[4] = (int)b; w[5] = (int)c; w[6] = (int)d; w[7] = (int)e2; w[8] = (int)f;
+    }
+}
+constexpr unsigned SRV_END = 0x7ffffffeu;
+// Every granule array below is laid out so that no 128-byte line has writers in two workgroups (= possibly two XCDs, whose L2s are not
+// coherent): a claim per line, a line of requests (written by the particle's block) and a line of results (by its server pair) per
+// particle.  With 96-byte records back to back — a neighbour's results and this particle's request in one line — a request or a claim was
+// lost now and then (the rope in a grasp: one env step in ~1 000 timed out with the request's first granule visible and its second or
+// third still carrying the previous tag, for as long as anybody looked): a write-through store of 16 bytes into a line of which the
+// writer's L2 holds an older copy is not guaranteed to leave the other bytes of the line in memory alone.
+constexpr int SRV_LINE = 128, SRV_REC = 2 * SRV_LINE, SRV_RES = SRV_LINE;
+constexpr int SRV_MAX_SLOTS = 512, SRV_MIN_WG = 8;
+constexpr int SRV_CTL_OFF = SRV_LINE * SRV_MAX_SLOTS, SRV_DBG_OFF = SRV_CTL_OFF + SRV_LINE, SRV_CLAIM_BYTES = SRV_DBG_OFF + SRV_LINE * SRV_MAX_SLOTS; // four pairs per server workgroup: at most 128 server workgroups; fewer than 8 are not worth the claims
 __device__ __forceinline__ v4u srv_load(const __amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, RES_AUX_LOAD); }
+// The server's polls: EVERY lane loads the same granule and the wavefront branches on it.  A wave64 memory instruction is served in
+// several passes, and nothing promises that an L1-bypassing load of a granule that is being rewritten hands all lanes the same version
+// (some lanes leaving the request poll with the tag of a "skip", the rest a moment later with the next "need", would run the finishing
+// code and its two-wavefront barriers with partial lane masks).  The first lane's copy is the wavefront's.
+__device__ __forceinline__ v4u srv_load_uniform(const __amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    const v4u d = srv_load(r, off);
+    const v4u u = {(unsigned)__builtin_amdgcn_readfirstlane((int)d.x), (unsigned)__builtin_amdgcn_readfirstlane((int)d.y),
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)d.z), (unsigned)__builtin_amdgcn_readfirstlane((int)d.w)};
+    return u;
+}
 __device__ __forceinline__ void srv_store(const __amdgpu_buffer_rsrc_t r, unsigned off, unsigned a, unsigned b, unsigned tag)
 {
     const v4u w = {a, tag, b, tag};
@@ -1391,7 +1437,7 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
 {
     __shared__ QShare qsrv[4];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = wave >> 1;
-    if (tid < 4) qsrv[tid].bar = 0;
+    if (tid < 4) { qsrv[tid].bar = 0; qsrv[tid].arrived[0] = 0; qsrv[tid].arrived[1] = 0; }
     __syncthreads();
     const int g = ((int)blockIdx.x - 8 * p.cb) * 4 + pair;
     if (g >= p.srv_slots) return; // (whole pairs)
@@ -1401,14 +1447,14 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
     // written — write-through, drained — before its block counts itself out, so "everybody left and no claim" is final)
     unsigned ei = 0, k = 0;
     for (unsigned spins = 0;; ++spins) {
-        v4u c = srv_load(rc, (unsigned)g * 16u);
+        v4u c = srv_load_uniform(rc, (unsigned)g * (unsigned)SRV_LINE);
         if (srv_claimed(c)) { ei = c.x; k = c.z; break; }
-        if (__hip_atomic_load(p.srv_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.nb * p.ne) {
-            c = srv_load(rc, (unsigned)g * 16u);
+        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p.srv_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= p.nb * p.ne) {
+            c = srv_load_uniform(rc, (unsigned)g * (unsigned)SRV_LINE);
             if (srv_claimed(c)) { ei = c.x; k = c.z; break; }
             return;
         }
-        if (spins >= RES_SPIN_LIMIT) return; // (a stuck launch is reported by the blocks' own limits)
+        if (spins >= p.spin_limit) return; // (a stuck launch is reported by the blocks' own limits)
         // an idle pair polls rarely (a claim is waited for once per particle and launch; ~500 idle wavefronts polling at the rate of the
         // hand-offs slowed every halo exchange of the launch: 2.87 vs 2.50 us per free substep of the rope)
         __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
@@ -1416,7 +1462,7 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
     ei = (unsigned)__builtin_amdgcn_readfirstlane((int)ei); k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
     const int e = (int)(ei / (unsigned)p.N), i = (int)(ei % (unsigned)p.N);
     const size_t eb = (size_t)e * p.N;
-    const unsigned base = ei * 96u;
+    const unsigned base = ei * (unsigned)SRV_REC;
     const TriIds tids = load_tri_ids(p, lane, wave & 1);
     int qpar = QPAIR;
     Xf X0;
@@ -1427,38 +1473,48 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
     io.srv_on = false; io.srv_need = false; io.boxes = nullptr; io.step_boxes = nullptr;
     io.x = mk(0.f, 0.f, 0.f); io.v = io.x;
     const StateM none = {nullptr, 0};
+    // where this wavefront of the pair is (fault reports only): {phase, substep, last request tag, barrier generation} behind the control words
+    const unsigned dbg = (unsigned)SRV_DBG_OFF + (unsigned)g * (unsigned)SRV_LINE + (unsigned)(wave & 1) * 16u;
+#define R2S_SRV_STATE(ph, tg) do { if (lane == 0) { const v4u w_ = {(unsigned)(ph), k, (unsigned)(tg), (unsigned)qpar}; __builtin_amdgcn_raw_buffer_store_b128(w_, rc, dbg, 0, RES_AUX_SC1); } } while (0)
     while ((int)k < n_steps) {
         TriRegs tr = load_tris(p, e, first + (int)k, tids); // in flight while the request is awaited
+        R2S_SRV_STATE(1, 0);
         v4u r0 = {0u, 0u, 0u, 0u};
         unsigned t0 = 0;
         for (unsigned spins = 0;; ++spins) {
-            r0 = srv_load(rr, base);
+            r0 = srv_load_uniform(rr, base);
             t0 = r0.y;
             if (r0.w == t0 && t0 >= 2u * (k + 1u)) break;
-            if (spins >= RES_SPIN_LIMIT) return;
+            if (spins >= p.spin_limit) return;
             __builtin_amdgcn_s_sleep(1);
         }
-        if (t0 == SRV_END) return;
+        if (t0 == SRV_END) { R2S_SRV_STATE(9, t0); return; }
         const unsigned ks = (t0 >> 1) - 1u; // a later substep's tag: the ones in between were skipped (a request always waits for its result)
         if (!(t0 & 1u)) { k = ks + 1u; continue; }
         if (ks != k) { k = ks; tr = load_tris(p, e, first + (int)k, tids); }
+        R2S_SRV_STATE(2, t0);
         v4u r1 = {0u, 0u, 0u, 0u}, r2 = r1;
         for (unsigned spins = 0;; ++spins) {
-            r1 = srv_load(rr, base + 16u); r2 = srv_load(rr, base + 32u);
+            r1 = srv_load_uniform(rr, base + 16u); r2 = srv_load_uniform(rr, base + 32u);
             if (r1.y == t0 && r1.w == t0 && r2.y == t0 && r2.w == t0) break;
-            if (spins >= RES_SPIN_LIMIT) return;
+            if (spins >= p.spin_limit) return;
         }
         const f3 x0 = mk(__uint_as_float(r0.x), __uint_as_float(r0.z), __uint_as_float(r1.x));
         const f3 v = mk(__uint_as_float(r1.z), __uint_as_float(r2.x), __uint_as_float(r2.z));
         const bool last = (int)k == n_steps - 1;
+        R2S_SRV_STATE(3, t0);
         R2S_QP_DECL(-1);
         finish_wave<3, false, 1, true>(p, e, i, eb, first + (int)k, last ? write_forces_last : 0, x0, v, lane == 0, none, &tr, &qsrv[pair], &qpar, &X0,
                                        (wave & 1) == 0, &io R2S_QP_ARG);
+        if (qpar & QFAIL) { // the pair's other wavefront did not reach a barrier of this request
+            if (lane == 0) resident_fault(p, 4, g, (int)k, (unsigned)wave, ei, (unsigned)qpar, (unsigned)qsrv[pair].bar, t0, 0u);
+            return;
+        }
         if ((wave & 1) == 0 && lane == 0) {
             const unsigned tag = k + 1u;
-            srv_store(rr, base + 48u, __float_as_uint(io.x.x), __float_as_uint(io.x.y), tag);
-            srv_store(rr, base + 64u, __float_as_uint(io.x.z), __float_as_uint(io.v.z), tag);
-            srv_store(rr, base + 80u, __float_as_uint(io.v.x), __float_as_uint(io.v.y), tag);
+            srv_store(rr, base + (unsigned)SRV_RES, __float_as_uint(io.x.x), __float_as_uint(io.x.y), tag);
+            srv_store(rr, base + (unsigned)SRV_RES + 16u, __float_as_uint(io.x.z), __float_as_uint(io.v.z), tag);
+            srv_store(rr, base + (unsigned)SRV_RES + 32u, __float_as_uint(io.v.x), __float_as_uint(io.v.y), tag);
         }
         k = k + 1u;
     }
@@ -1491,7 +1547,8 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     const bool valid = i < p.N;
     const int ic = min(i, p.N - 1);
     const size_t eb = (size_t)e * p.N;
-    const unsigned xe = (unsigned)e * 6u * (unsigned)p.N, xb = 3u * (unsigned)p.N * 16u; // exchange array: [env][buffer][plane][particle] x 16 B
+    const unsigned xn = ((unsigned)p.N + 7u) & ~7u; // plane stride: whole 128-byte lines, so that no line has two writer blocks (see SRV_LINE)
+    const unsigned xe = (unsigned)e * 6u * xn, xb = 3u * xn * 16u; // exchange array: [env][buffer][plane][particle, padded to 8] x 16 B
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, 0x7fffffff, 0x00020000);
     __attribute__((address_space(3))) char* win_w = (__attribute__((address_space(3))) char*)win_s;
     const __attribute__((address_space(3))) char* win = win_w;
@@ -1509,7 +1566,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
         if (t < nt) {
             const int pl = t / nh, r = t - pl * nh;
             const int hid = p.halo_ids[h0 + r];
-            t_off[k] = (xe + (unsigned)pl * (unsigned)p.N + (unsigned)hid) * 16u;
+            t_off[k] = (xe + (unsigned)pl * xn + (unsigned)hid) * 16u;
             t_lds[k] = (unsigned)(pl * (RCAP + 1) + B + r) * 8u;
             pend0 |= 1u << k;
             win_s[pl * (RCAP + 1) + B + r] = xv_in.p[st_at(xv_in.n, eb + (size_t)hid, pl)];
@@ -1541,8 +1598,9 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     const bool stage_boxes = MESH != 0 && n_steps > 1 && p.n_mesh <= RES_STAGE_MESH;
     io.step_boxes = stage_boxes ? sbox_s : nullptr;
     bool srv_mine = false; // wavefront 0: this lane's particle has a server pair
+    int srv_slot = -1;
     const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(p.srv_rr, 0, 0x7fffffff, 0x00020000);
-    const unsigned sbase = ((unsigned)e * (unsigned)p.N + (unsigned)ic) * 96u;
+    const unsigned sbase = ((unsigned)e * (unsigned)p.N + (unsigned)ic) * (unsigned)SRV_REC;
     __shared__ float box_s[8 * (1 + RES_MAX_MESH)];
     io.boxes = (MESH && n_steps > 1) ? box_s : nullptr;
     if (MESH && n_steps > 1) { // unions of the mesh boxes over the launch's substeps (once per launch: a few loads per lane, a reduction through LDS)
@@ -1646,8 +1704,20 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             ++pr_acc[4];
 #endif
             if (__builtin_amdgcn_ballot_w64(pend != 0) == 0ull) break;
-            if (spins >= RES_SPIN_LIMIT) {
-                if (lane == 0) { if (p.fault) *p.fault = 2; fail_s = 1; }
+            if (spins >= p.spin_limit) {
+                {   // the first still-pending task of the first lane that has one: which neighbour record, what its tags read
+                    const unsigned long long pm = __builtin_amdgcn_ballot_w64(pend != 0);
+                    if (pm && lane == __builtin_ctzll(pm)) {
+                        int kk0 = 0;
+#pragma unroll
+                        for (int kk = KT - 1; kk >= 0; --kk) if (pend & (1u << kk)) kk0 = kk;
+                        unsigned off0 = 0, ty = 0, tw = 0;
+#pragma unroll
+                        for (int kk = 0; kk < KT; ++kk) if (kk == kk0) { off0 = t_off[kk]; ty = d[kk].y; tw = d[kk].w; }
+                        resident_fault(p, 2, item, k, (unsigned)wave, (unsigned)lane, off0 / 16u, ty, tw, pend);
+                        fail_s = 1;
+                    }
+                }
                 break;
             }
             asm volatile("" ::: "memory");
@@ -1712,18 +1782,23 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             R2S_QP_DECL(-1);
             io.srv_need = false;
             finish_wave<MESH, MESH != 0, 0, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, v, fin, out, nullptr, nullptr, nullptr, nullptr, wave == 0, &io R2S_QP_ARG);
-            if (MESH == 1 && !SELF && srv_on) { // particles that need a mesh query: handed to a server pair (resident_server), not finished above
-                const bool sneed = io.srv_need; // the same in the three finishing wavefronts (same inputs, same instructions)
+            // particles that need a mesh query were handed to a server pair (resident_server), not finished above.  Wavefront 0 alone waits
+            // for their results — the other two finishing wavefronts leave those lanes to it (three wavefronts polling the same granules
+            // tripled the poll traffic on the hand-offs of a block with twenty particles in a finger's reach) — and publishes all three planes
+            bool sneed = false;
+            if (MESH == 1 && !SELF && srv_on) {
+                sneed = io.srv_need; // the same in the three finishing wavefronts (same inputs, same instructions)
                 const unsigned uk = (unsigned)k;
                 if (wave == 0) {
+                    bool inplace = false;
                     if (sneed && !srv_mine) {
                         const int slot = atomicAdd(p.srv_ctl, 1);
                         if (slot < p.srv_slots) {
-                            srv_mine = true;
+                            srv_mine = true; srv_slot = slot;
                             const __amdgpu_buffer_rsrc_t rcl = __builtin_amdgcn_make_buffer_rsrc(p.srv_claim, 0, 0x7fffffff, 0x00020000);
-                            srv_store(rcl, (unsigned)slot * 16u, (unsigned)e * (unsigned)p.N + (unsigned)i, uk, 1u);
+                            srv_store(rcl, (unsigned)slot * (unsigned)SRV_LINE, (unsigned)e * (unsigned)p.N + (unsigned)i, uk, 1u);
                         } else
-                            srv_store(rsv, sbase + 48u, 0u, 0u, SRV_INPLACE | (uk + 1u)); // no pair left: every finishing wavefront answers in place
+                            inplace = true; // no pair left: answered in place, below
                     }
                     if (srv_mine) {
                         if (sneed) {
@@ -1734,30 +1809,37 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                         } else
                             srv_store(rsv, sbase, 0u, 0u, 2u * (uk + 1u)); // nothing in reach in this substep: the pair skips it
                     }
-                }
-                if (__builtin_amdgcn_ballot_w64(sneed) != 0ull) {
-                    bool inplace = false;
-                    for (unsigned spins = 0;; ++spins) {
-                        bool ok = true;
-                        if (sneed && !inplace) {
-                            const v4u d0 = srv_load(rsv, sbase + 48u), d1 = srv_load(rsv, sbase + 64u), d2 = srv_load(rsv, sbase + 80u);
-                            if (d0.y == (SRV_INPLACE | (uk + 1u)) && d0.w == d0.y) inplace = true;
-                            else if (d0.y == uk + 1u && d0.w == uk + 1u && d1.y == uk + 1u && d1.w == uk + 1u && d2.y == uk + 1u && d2.w == uk + 1u) {
-                                io.x = mk(__uint_as_float(d0.x), __uint_as_float(d0.z), __uint_as_float(d1.x));
-                                io.v = mk(__uint_as_float(d2.x), __uint_as_float(d2.z), __uint_as_float(d1.z));
-                            } else
-                                ok = false;
-                        }
-                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                        if (spins >= RES_SPIN_LIMIT) {
-                            if (lane == 0) { if (p.fault) *p.fault = 2; fail_s = 1; }
-                            break;
-                        }
-                    }
                     if (__builtin_amdgcn_ballot_w64(inplace) != 0ull) // (wave-uniform branch: finish_wave's queries are per lane here)
                         finish_wave<MESH, false, 1, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, v, sneed && inplace, out, nullptr, nullptr, nullptr, nullptr,
-                                                          wave == 0, &io R2S_QP_ARG);
-                    if (last && wave == 0 && sneed && !inplace && xv_out.p != nullptr) st_store(xv_out, eb + i, io.x, io.v);
+                                                          true, &io R2S_QP_ARG);
+                    if (__builtin_amdgcn_ballot_w64(sneed && !inplace) != 0ull) {
+                        for (unsigned spins = 0;; ++spins) {
+                            bool ok = true;
+                            if (sneed && !inplace) {
+                                const v4u d0 = srv_load(rsv, sbase + (unsigned)SRV_RES), d1 = srv_load(rsv, sbase + (unsigned)SRV_RES + 16u), d2 = srv_load(rsv, sbase + (unsigned)SRV_RES + 32u);
+                                if (d0.y == uk + 1u && d0.w == uk + 1u && d1.y == uk + 1u && d1.w == uk + 1u && d2.y == uk + 1u && d2.w == uk + 1u) {
+                                    io.x = mk(__uint_as_float(d0.x), __uint_as_float(d0.z), __uint_as_float(d1.x));
+                                    io.v = mk(__uint_as_float(d2.x), __uint_as_float(d2.z), __uint_as_float(d1.z));
+                                } else
+                                    ok = false;
+                            }
+                            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                            if (spins >= p.spin_limit) {
+                                const unsigned long long pm = __builtin_amdgcn_ballot_w64(!ok);
+                                if (pm && lane == __builtin_ctzll(pm)) {
+                                    const __amdgpu_buffer_rsrc_t rcl = __builtin_amdgcn_make_buffer_rsrc(p.srv_claim, 0, 0x7fffffff, 0x00020000);
+                                    const unsigned dbo = (unsigned)SRV_DBG_OFF + (unsigned)max(srv_slot, 0) * (unsigned)SRV_LINE;
+                                    const v4u d0 = srv_load(rsv, sbase + (unsigned)SRV_RES), sa = srv_load(rcl, dbo), sb = srv_load(rcl, dbo + 16u);
+                                    // context: particle | slot, result tag seen, then the pair's two wavefronts: phase << 28 | substep << 14 | barrier generation, request tag
+                                    resident_fault(p, 3, item, k, (unsigned)i | ((unsigned)srv_slot << 20), d0.y, (sa.x << 28) | (sa.y << 14) | (sa.w >> 16), sa.z,
+                                                   (sb.x << 28) | (sb.y << 14) | (sb.w >> 16), sb.z);
+                                    fail_s = 1;
+                                }
+                                break;
+                            }
+                        }
+                        if (last && sneed && !inplace && xv_out.p != nullptr) st_store(xv_out, eb + i, io.x, io.v);
+                    }
                 }
             }
 #ifdef R2S_PHASE_PROBE
@@ -1765,14 +1847,24 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
 #endif
             R2S_RSTAMP(2);
 
-            if (!last) { // publish version k + 1 (plane `wave`) and refresh the block's own records in the window
-                const float va = wave == 0 ? io.x.x : (wave == 1 ? io.x.z : io.v.x), vb = wave == 0 ? io.x.y : (wave == 1 ? io.v.z : io.v.y);
-                if (valid) {
-                    const unsigned tag = (unsigned)(k + 1);
-                    const v4u w = {__float_as_uint(va), tag, __float_as_uint(vb), tag};
-                    __builtin_amdgcn_raw_buffer_store_b128(w, rx, (xe + (unsigned)wave * (unsigned)p.N + (unsigned)i) * 16u + (unsigned)((k + 1) & 1) * xb, 0, RES_AUX_SC1);
+            if (!last) { // publish version k + 1 (plane `wave`; wavefront 0: all three planes of its served lanes) and refresh the block's own records in the window
+                const unsigned tag = (unsigned)(k + 1);
+                const unsigned pub = (xe + (unsigned)i) * 16u + (unsigned)((k + 1) & 1) * xb;
+                if (!(sneed && wave != 0)) {
+                    const float va = wave == 0 ? io.x.x : (wave == 1 ? io.x.z : io.v.x), vb = wave == 0 ? io.x.y : (wave == 1 ? io.v.z : io.v.y);
+                    if (valid) {
+                        const v4u w = {__float_as_uint(va), tag, __float_as_uint(vb), tag};
+                        __builtin_amdgcn_raw_buffer_store_b128(w, rx, pub + (unsigned)wave * xn * 16u, 0, RES_AUX_SC1);
+                    }
+                    win_s[wave * (RCAP + 1) + lane] = (v2f){va, vb};
                 }
-                win_s[wave * (RCAP + 1) + lane] = (v2f){va, vb};
+                if (sneed && wave == 0) { // (sneed implies valid)
+                    const v4u w1 = {__float_as_uint(io.x.z), tag, __float_as_uint(io.v.z), tag}, w2 = {__float_as_uint(io.v.x), tag, __float_as_uint(io.v.y), tag};
+                    __builtin_amdgcn_raw_buffer_store_b128(w1, rx, pub + xn * 16u, 0, RES_AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b128(w2, rx, pub + 2u * xn * 16u, 0, RES_AUX_SC1);
+                    win_s[(RCAP + 1) + lane] = (v2f){io.x.z, io.v.z};
+                    win_s[2 * (RCAP + 1) + lane] = (v2f){io.v.x, io.v.y};
+                }
             }
             R2S_RSTAMP(3);
         }
@@ -2546,10 +2638,11 @@ struct R2SPhys {
     int* d_cand_mark = nullptr;
     int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false, fault_stale = false;
     void* d_xch = nullptr;    // resident stepper: exchange array (96 B per particle)
-    void* d_srv_claim = nullptr; void* d_srv_rr = nullptr; // resident stepper's mesh-query servers: claims [SRV_MAX_SLOTS] x 16 B + 2 control words, request / result granules 96 B per particle
+    void* d_srv_claim = nullptr; void* d_srv_rr = nullptr; // resident stepper's mesh-query servers: a 128-byte line per claim, one of control words, one per pair of fault-report state; a line of request and a line of result granules per particle
     bool srv_ok = false;      // small scene (every mesh small, <= 128 faces in total): a resident launch may carry query servers
     int srv_wg_cap = SRV_MAX_SLOTS / 4; // R2S_RES_SRV_WG: at most this many server workgroups per launch
     int n_cu = 256;
+    unsigned spin_limit = RES_SPIN_LIMIT;
     bool split_ok = false;    // 64-particle layout whose slices fit k_steps_resident's registers (no remote neighbours, <= 64 interior / halo slots)
     bool resident_ok = false; // the handle can run the env step as ONE resident launch (k_steps_resident) in its free flavour
     int resident_pref = 1;    // R2S_RESIDENT=0 / r2s_phys_set_tuning: never pick the 64-particle layout / the resident launch
@@ -2648,7 +2741,8 @@ struct R2SPhys {
         p.aabb_dyn = d_aabb_dyn; p.aabb_static = d_aabb_static; p.coll_forces = d_coll_forces; p.hit_cnt = d_hit_cnt;
         p.fault = d_mesh_total ? d_mesh_total + 1 : nullptr;
         p.xch = d_xch;
-        p.srv_slots = 0; p.srv_claim = d_srv_claim; p.srv_rr = d_srv_rr; p.srv_ctl = d_srv_claim ? (int*)d_srv_claim + 4 * SRV_MAX_SLOTS : nullptr;
+        p.spin_limit = spin_limit;
+        p.srv_slots = 0; p.srv_claim = d_srv_claim; p.srv_rr = d_srv_rr; p.srv_ctl = d_srv_claim ? (int*)((char*)d_srv_claim + SRV_CTL_OFF) : nullptr;
         return p;
     }
 };
@@ -2832,8 +2926,9 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->d_coll_forces + 3 * (size_t)e0 * h->nF, cnt);
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, (float*)(h->d_hit_cnt + e0), (size_t)ne);
         }
-        const size_t words = (size_t)24 * ne * h->N; // this chain's environments: 2 buffers x 3 planes x 16 B per particle
-        hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_xch + (size_t)24 * e0 * h->N, words);
+        const size_t xn = ((size_t)h->N + 7) & ~(size_t)7; // (plane stride of the kernel: whole 128-byte lines)
+        const size_t words = (size_t)24 * ne * xn; // this chain's environments: 2 buffers x 3 planes x 16 B per particle
+        hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_xch + (size_t)24 * e0 * xn, words);
         // mesh-query servers: workgroups beyond the blocks' own, as many as the chip has CUs left (the whole launch is resident at once)
         int n_srv = 0;
         if (h->srv_ok && n > 1) {
@@ -2842,8 +2937,9 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
         }
         if (n_srv > 0) {
             p.srv_slots = 4 * n_srv;
-            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((4 * SRV_MAX_SLOTS + 4 + 255) / 256)), dim3(256), 0, s, (float*)h->d_srv_claim, (size_t)4 * SRV_MAX_SLOTS + 4);
-            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_srv_rr + (size_t)24 * e0 * h->N, words);
+            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((SRV_DBG_OFF / 4 + 255) / 256)), dim3(256), 0, s, (float*)h->d_srv_claim, (size_t)SRV_DBG_OFF / 4); // claims and control words
+            const size_t rw = (size_t)(SRV_REC / 4) * ne * h->N;
+            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((rw + 255) / 256)), dim3(256), 0, s, (float*)h->d_srv_rr + (size_t)(SRV_REC / 4) * e0 * h->N, rw);
         }
         const dim3 grid(8u * (unsigned)p.cb + (unsigned)n_srv);
         const StateC in = h->state(start_buf);
@@ -3532,8 +3628,8 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         if (h->prm.self_collision) { TRY(dev_alloc(&h->d_cand_mark, (size_t)E * N)); R2S_HIP_TRY(hipMemsetAsync(h->d_cand_mark, 0, sizeof(int) * (size_t)E * N, s)); }
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_cnt, 0, sizeof(int) * 8 * (size_t)(h->prm.num_substeps + 1), s));
     }
-    TRY(dev_alloc(&h->d_mesh_total, 4)); // [0] particles near a mesh in the last step, [1] sticky fault word (PhysDev::fault), [2] a mesh query was needed
-    R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int) * 4, s));
+    TRY(dev_alloc(&h->d_mesh_total, 16)); // [4..15]: where the first fault of the resident stepper happened (diagnostics); [0] particles near a mesh in the last step, [1] sticky fault word (PhysDev::fault), [2] a mesh query was needed
+    R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int) * 16, s));
     R2S_HIP_TRY(hipHostMalloc((void**)&h->h_mesh_total, 64, hipHostMallocDefault));
     h->h_mesh_total[0] = 0; h->h_mesh_total[1] = 0; h->h_mesh_total[2] = 0;
     R2S_HIP_TRY(hipEventCreateWithFlags(&h->mesh_event, hipEventDisableTiming));
@@ -3553,19 +3649,21 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         h->resident_ok = h->split_ok && !h->any_large && (int64_t)h->nb * E <= std::min(RES_MAX_ITEMS, n_cu);
         h->n_cu = n_cu;
         if (h->resident_ok) {
-            TRY(dev_alloc((char**)&h->d_xch, (size_t)96 * E * N));
-            R2S_HIP_TRY(hipMemsetAsync(h->d_xch, 0, (size_t)96 * E * N, s));
+            const size_t xn = ((size_t)N + 7) & ~(size_t)7;
+            TRY(dev_alloc((char**)&h->d_xch, (size_t)96 * E * xn));
+            R2S_HIP_TRY(hipMemsetAsync(h->d_xch, 0, (size_t)96 * E * xn, s));
             // query servers ride in the launch when every mesh is small enough for k_contact_finish<3>'s code (triangles in registers, one per
             // lane in two wavefronts) and the blocks leave CUs free; R2S_RES_SERVERS=0: queries in place / per-substep flavour as in round 3
             bool pref = true;
             if (const char* ev = getenv("R2S_RES_SERVERS")) pref = atoi(ev) != 0;
+            if (const char* ev = getenv("R2S_RES_SPIN_LIMIT")) h->spin_limit = (unsigned)std::max(1024, atoi(ev));
             if (const char* ev = getenv("R2S_RES_SRV_WG")) h->srv_wg_cap = std::max(1, std::min(atoi(ev), SRV_MAX_SLOTS / 4));
             h->srv_ok = pref && h->nF > 0 && h->nF <= 128 && n_cu - (int)((int64_t)h->nb * E) >= SRV_MIN_WG;
             if (h->srv_ok) {
-                TRY(dev_alloc((char**)&h->d_srv_claim, (size_t)16 * SRV_MAX_SLOTS + 16));
-                TRY(dev_alloc((char**)&h->d_srv_rr, (size_t)96 * E * N));
-                R2S_HIP_TRY(hipMemsetAsync(h->d_srv_claim, 0, (size_t)16 * SRV_MAX_SLOTS + 16, s));
-                R2S_HIP_TRY(hipMemsetAsync(h->d_srv_rr, 0, (size_t)96 * E * N, s));
+                TRY(dev_alloc((char**)&h->d_srv_claim, (size_t)SRV_CLAIM_BYTES)); // claims | 2 control words | per pair and wavefront: 16 B of state for fault reports
+                TRY(dev_alloc((char**)&h->d_srv_rr, (size_t)SRV_REC * E * N));
+                R2S_HIP_TRY(hipMemsetAsync(h->d_srv_claim, 0, (size_t)SRV_CLAIM_BYTES, s));
+                R2S_HIP_TRY(hipMemsetAsync(h->d_srv_rr, 0, (size_t)SRV_REC * E * N, s));
             }
         }
     }
@@ -3891,9 +3989,14 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         if (h->fault_stale) { h->h_mesh_total[1] = 0; h->fault_stale = false; } // the copy was in flight when set_state cleared the word
     }
     if (!h->mesh_pending && h->h_mesh_total[1] != 0) { // the sticky fault word of an earlier step
-        if (h->h_mesh_total[1] == 2)
-            r2s::set_last_error_msg("resident stepper: a workgroup waited for a neighbour block's substep beyond the poll limit (the launch was not "
-                                    "resident at once, or the device is shared with a kernel that never ends); the state is invalid");
+        if (h->h_mesh_total[1] >= 2 && h->h_mesh_total[1] <= 4) {
+            char buf[640];
+            const int* w = h->h_mesh_total + 4;
+            snprintf(buf, sizeof buf, "resident stepper: a workgroup waited for %s beyond the poll limit (the launch was not resident at once, or the device "
+                     "is shared with a kernel that never ends); the state is invalid [first fault: code %d, work item %d, substep %d of the launch, context %d %d %d %d %d %d]",
+                     h->h_mesh_total[1] == 2 ? "a neighbour block's substep" : "a mesh-query server's result", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+            r2s::set_last_error_msg(buf);
+        }
         else
             r2s::set_last_error_msg("a self-collision impulse changed a particle's velocity by more than 40 m/s within one substep: its mesh-contact "
                                     "test (widened by 2 mm) may have been skipped where the reference applies it (unsupported)");
@@ -3942,7 +4045,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     if ((h->nF > 0 || h->resident_ok) && !h->mesh_pending) { // particles near a mesh during this step (+ the fault word) -> pinned memory, read at a later step without waiting
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int), s));
         if (h->nF > 0) hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(64), 0, s, h->d_mesh_cnt + h->prm.num_substeps, 8, h->prm.num_substeps + 1, h->d_mesh_total);
-        R2S_HIP_TRY(hipMemcpyAsync(h->h_mesh_total, h->d_mesh_total, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+        R2S_HIP_TRY(hipMemcpyAsync(h->h_mesh_total, h->d_mesh_total, 16 * sizeof(int), hipMemcpyDeviceToHost, s));
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total + 2, 0, sizeof(int), s)); // "a query was needed": counted from here on
         R2S_HIP_TRY(hipEventRecord(h->mesh_event, s));
         h->mesh_pending = true;

@@ -328,7 +328,10 @@ class BatchedRollout:
         if self._vel_trace is None or step >= len(self._vel_trace) - self._dephase:   # (a restarted episode only looks further back)
             n = max(1024, 2 * (step + 1 + self._dephase))
             self._vel_trace = torch.from_numpy(np.stack([self._eef_velocity(k) for k in range(n)])).to(self.device)
-            self._open_cmd = torch.tensor([0.3 if self.close_at <= k < self.open_at else 1.0 for k in range(n)], dtype=torch.float32, device=self.device)
+            # commanded opening while closed: 0.3 (34 mm between the pads) squeezes the toy's 61 mm pair of arms; the 24 mm rope needs 0.08
+            # (18 mm): with 0.3 the pads stop at the rope's 5 mm contact margin, brush it and lift nothing
+            closed = 0.08 if self.ob_shape == "rope" else 0.3
+            self._open_cmd = torch.tensor([closed if self.close_at <= k < self.open_at else 1.0 for k in range(n)], dtype=torch.float32, device=self.device)
         if self._dephase > 1 or self._restarted:
             idx = step - self._env_t0                             # an environment's episode starts at its last reset ...
             if self._dephase > 1:

@@ -287,3 +287,41 @@ def test_large_batches_and_forced_layouts_keep_the_per_substep_path(monkeypatch)
     g = hip_env(ob, n_env=1, **kw)
     g.step()
     assert not g.last_flavour()["resident"] and g.layout_stats()["lds_bytes"] == 1024 * 24
+
+
+def test_resident_launch_with_query_servers_under_load_is_bit_identical_to_the_quiet_run():
+    """The server protocol under UNEVEN load (cdna_hip_programming.md Guideline 16: test every hand-off with loaded memory queues and
+    late workgroups): the bench's own `rope_1env` rollout — descend, close on the rope at step 3 (grasp detection holds the opening),
+    lift, open at step 12 (release: pairs keep serving "skip" substeps), 18 env steps of 667 substeps — once on a quiet chip and once
+    next to a second stream that keeps every CU streaming through HBM.  Claims, requests and results arrive in another order; the
+    particle states must not differ in a single bit, every step must have stayed ONE resident launch, and nothing may have timed out."""
+    import torch
+    from r2s_hip.rollout import BatchedRollout
+
+    def run(busy):
+        ro = BatchedRollout("rope_1env", close_at=3, open_at=12, seed=2)
+        side = torch.cuda.Stream()
+        big = torch.empty(1 << 27, dtype=torch.float32, device="cuda") if busy else None      # 512 MiB
+        flav, hits, ztop = [], [], []
+        for _ in range(18):
+            if busy:
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        big.mul_(1.0001)
+            ro.step()
+            flav.append(ro.phys.last_flavour())
+            hits.append(ro.contact_stats()["mesh_contacts"])
+            ztop.append(float(ro.phys.x[0, :, 2].max()))
+        torch.cuda.synchronize()
+        ro.phys.step(0, 0)                    # a sticky fault (a poll that hit its limit) would raise here
+        torch.cuda.synchronize()
+        return ro.phys.x.cpu().numpy().copy(), ro.phys.v.cpu().numpy().copy(), flav, hits, ro.phys.eef_state(), ztop
+
+    xq, vq, fq, hq, sq, zq = run(False)
+    xb, vb, fb, hb, sb, zb = run(True)
+    assert all(f["resident"] and f["query_server_workgroups"] > 0 for f in fq + fb), [f["kernel"] for f in fq if not f["resident"]]
+    assert max(hq[4:11]) > 0, ("the fingers must be on the rope between closing and opening", hq)
+    assert np.array_equal(xq, xb) and np.array_equal(vq, vb), float(np.abs(xq - xb).max())
+    assert hq == hb and torch.equal(sq[0], sb[0]) and torch.equal(sq[1], sb[1])
+    assert np.isfinite(xq).all() and zq == zb
+    assert max(zq[4:12]) > zq[0] + 0.004, ("the rope must have been lifted while the fingers held it", zq)
