@@ -154,6 +154,7 @@ struct PhysDev {
     void* srv_claim;           // [srv_slots] x 128 B, first granule {env * N + particle, 1, first substep of the launch it is served from, 1}; then control words and fault-report state (SRV_CTL_OFF, SRV_DBG_OFF)
     void* srv_rr;              // [E][N] x 256 B of tagged 16-byte granules: line 0 the REQUEST (x0.x x0.y | x0.z v.x | v.y v.z), line 1 the RESULT (xy | z vz | vxy)
     int* srv_ctl;              // [0] next free slot, [1] blocks that have left the launch
+    int srv_own;               // servers OWN their particle from the claim on: spring forces from the neighbours' exchange records, velocity update, mesh response, ground (0: one request per substep, round 4's first protocol)
     unsigned spin_limit;       // poll passes before a workgroup of the resident launch gives up (RES_SPIN_LIMIT; R2S_RES_SPIN_LIMIT at create: diagnostics)
 };
 
@@ -400,6 +401,7 @@ struct QShare {
     volatile int sup[QWPB][8];       // per wavefront: lanes that own the super-clusters of the current round
     int bar;                         // pair mode (the resident stepper's query servers): arrivals at the two-wavefront barrier, zeroed by the workgroup
     int arrived[2];                  // pair mode: the last barrier generation each of the two wavefronts has arrived at
+    float fs[2][4];                  // pair mode, owning servers: the two wavefronts' sums of the particle's spring forces
 };
 // mesh_query_regs is run by TWO wavefronts: a 128-thread workgroup of k_contact_finish<3> (barrier = __syncthreads), or one of the four
 // wavefront PAIRS of a server workgroup of k_steps_resident, each on its own particle at its own pace (barrier = a counter in the pair's
@@ -1384,16 +1386,27 @@ __device__ __forceinline__ void spring_groups_n(const PhysDev& p, int n, const A
 // a pair of its own through the same tagged write-through granules the blocks exchange their halos with:
 //   claim    the first time a particle needs a query its block (wavefront 0 of the finishers) takes the next free pair (one atomic) and
 //            writes {env * N + particle, first substep}; the pair serves that particle until the launch ends;
-//   request  per substep, three 16-byte granules {x0, post-force v} tagged 2 (k + 1) + 1 — or one granule tagged 2 (k + 1) when the
-//            particle is out of every mesh's reach in substep k (nothing to wait for: the pair skips ahead to the next tag it sees);
+//   request  three 16-byte granules {x0, post-force v} tagged 2 (k + 1) + 1, with the claim;
 //   result   the pair runs finish_wave<3> (k_contact_finish's small-scene code: the substep's triangles one per lane in two wavefronts,
-//            loaded BEFORE the request arrives; mesh response, re-query, per-face forces on the last substep, ground) and returns the
-//            particle's new state in three granules tagged k + 1; the block's three finishing wavefronts poll them, publish, go on;
+//            loaded BEFORE the inputs arrive; mesh response, re-query, per-face forces on the last substep, ground) and returns the
+//            particle's new state in three granules tagged k + 1 (two halves of a line, by version parity); wavefront 0 of the block
+//            polls them, publishes all three planes of the particle to the exchange array, goes on;
+//   owning   (default, p.srv_own) from the claim on the particle is the PAIR's: every later substep it gathers the particle's
+//            neighbours of version k itself — lane n of the pair holds slot n of the adjacency row and polls that neighbour's exchange
+//            granules (or, one hand-off earlier for a served neighbour, the result line of that neighbour's own pair) — sums the
+//            springs, updates the velocity, and continues as above.  The block no longer stands between two substeps of a particle in
+//            contact (result -> block -> forces -> request -> pair was three hand-offs per substep, 10.3 us for the rope in a grasp;
+//            pair -> pair is one: 7.4 us, of which 4.3 are the pair's own two queries).  The pair may run one version ahead of its
+//            block, never two: before it writes version k + 1 over version k - 1 it has seen the block's republished copy of k - 1;
+//   per-substep requests (R2S_RES_SRV_OWN=0, the first protocol): the block sums the forces and sends a request per substep — or one
+//            granule tagged 2 (k + 1) when the particle is out of every mesh's reach in substep k (the pair skips ahead);
 //   end      a block that leaves the launch ends its pairs (tag SRV_END) and counts itself out; pairs nobody claimed leave when every
-//            block has.
-// No more pairs than particles that ever need one are busy; a claim beyond the last pair is answered in place by the block's wavefront 0.
-// Every poll is bounded like the halo polls (sticky fault word, never a hang); the launch is resident as a whole (blocks + servers <=
-// CUs), which the host guarantees when it sizes the grid.
+//            block has; an owning pair leaves after the launch's last substep.
+// No more pairs than particles that ever need one are busy; a claim beyond the last pair is answered in place by the block's wavefront 0
+// (with owning pairs: in every later substep too).  Every poll is bounded like the halo polls (sticky fault word, never a hang); the
+// launch is resident as a whole (blocks + servers <= CUs), which the host guarantees when it sizes the grid.  The sums of an owning pair
+// are fixed trees over its lanes — the same in every run, not the order of the block's eight wavefronts (results differ from the
+// request protocol's in the last bits; both hold the oracle's 1e-5 and the per-substep kernels' 2e-6).
 // the first fault of a launch wins and records where it happened (p.fault + 3 .. + 14 = the handle's words [4..15]): code, work item,
 // substep, and six words of context — what the host's error message prints
 __device__ __forceinline__ void resident_fault(const PhysDev& p, int code, int item, int k, unsigned a, unsigned b, unsigned c, unsigned d, unsigned e2, unsigned f)
@@ -1476,48 +1489,146 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
     // where this wavefront of the pair is (fault reports only): {phase, substep, last request tag, barrier generation} behind the control words
     const unsigned dbg = (unsigned)SRV_DBG_OFF + (unsigned)g * (unsigned)SRV_LINE + (unsigned)(wave & 1) * 16u;
 #define R2S_SRV_STATE(ph, tg) do { if (lane == 0) { const v4u w_ = {(unsigned)(ph), k, (unsigned)(tg), (unsigned)qpar}; __builtin_amdgcn_raw_buffer_store_b128(w_, rc, dbg, 0, RES_AUX_SC1); } } while (0)
+    // An OWNING pair (p.srv_own) takes one request — the claim's substep, forces already summed by the block — and from then on advances the
+    // particle by itself: lane n of the pair (128 lanes >= the slice's slots) holds slot n of the particle's adjacency row, polls that
+    // neighbour's three exchange granules of version k (the same records the blocks hand their halos over with; a served neighbour's are
+    // republished by its block), evaluates the one spring, the pair sums, and the substep continues as for a request.  The block is no
+    // longer between two substeps of a particle in contact: it takes the result, republishes it, and that is all.
+    const bool own = p.srv_own != 0;
+    const int pl = (wave & 1) * 64 + lane;
+    const unsigned xn = ((unsigned)p.N + 7u) & ~7u, xe = (unsigned)e * 6u * xn, xb = 3u * xn * 16u; // (k_steps_resident's exchange array)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, 0x7fffffff, 0x00020000);
+    unsigned noff = 0, roff = 0;
+    float sk = 0.f, sa = 0.f, m1 = 1.f, inv_m1 = 1.f;
+    bool live = false;
+    if (own) {
+        const int b = i / SLICE, l = i - b * SLICE;
+        const int srow = p.slice_off[b] / GROUP, nslot = p.slice_deg[b];
+        if (pl < nslot) {
+            const size_t el = (size_t)(srow + (pl / GROUP) * SLICE + l) * GROUP + (size_t)(pl % GROUP);
+            const unsigned off = ((const unsigned short*)p.adj_idx)[el];
+            sk = ((const float*)p.adj_k)[el]; sa = ((const float*)p.adj_ir)[el];
+            const int w = (int)(off >> 3);
+            const int gid = w < SLICE ? b * SLICE + w : p.halo_ids[p.halo_off[b] + (w - SLICE)];
+            live = gid != i && (sk != 0.f || sa != 0.f); // (padding and inactive slots point at the owner: zero force)
+            noff = (xe + (unsigned)gid) * 16u;
+            roff = ((unsigned)e * (unsigned)p.N + (unsigned)gid) * (unsigned)SRV_REC + (unsigned)SRV_RES;
+        }
+        m1 = p.masses[i]; inv_m1 = 1.0f / m1;
+    }
+    f3 sx = mk(0.f, 0.f, 0.f), sv = sx; // the particle's state of version k, once the pair has produced one
+    bool have = false;
+    const unsigned k_first = k; // the claim's substep
+#ifdef R2S_PHASE_PROBE // wall clock (100 MHz) of the pair's first wavefront by phase, summed over the substeps it served: wait | force + sum | finish | store; [4] substeps, [5] poll passes
+    long long sp_acc[6] = {0, 0, 0, 0, 0, 0}, sp_t = (long long)wall_clock64();
+#define R2S_SSTAMP(kk) do { const long long now_ = (long long)wall_clock64(); sp_acc[kk] += now_ - sp_t; sp_t = now_; } while (0)
+#else
+#define R2S_SSTAMP(kk) do { } while (0)
+#endif
     while ((int)k < n_steps) {
-        TriRegs tr = load_tris(p, e, first + (int)k, tids); // in flight while the request is awaited
+        TriRegs tr = load_tris(p, e, first + (int)k, tids); // in flight while the request / the neighbours' records are awaited
         R2S_SRV_STATE(1, 0);
-        v4u r0 = {0u, 0u, 0u, 0u};
+        f3 x0, v;
         unsigned t0 = 0;
-        for (unsigned spins = 0;; ++spins) {
-            r0 = srv_load_uniform(rr, base);
-            t0 = r0.y;
-            if (r0.w == t0 && t0 >= 2u * (k + 1u)) break;
-            if (spins >= p.spin_limit) return;
-            __builtin_amdgcn_s_sleep(1);
+        if (!(own && have)) {
+            v4u r0 = {0u, 0u, 0u, 0u};
+            for (unsigned spins = 0;; ++spins) {
+                r0 = srv_load_uniform(rr, base);
+                t0 = r0.y;
+                if (r0.w == t0 && t0 >= 2u * (k + 1u)) break;
+                if (spins >= p.spin_limit) return;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (t0 == SRV_END) { R2S_SRV_STATE(9, t0); return; }
+            const unsigned ks = (t0 >> 1) - 1u; // a later substep's tag: the ones in between were skipped (a request always waits for its result)
+            if (!(t0 & 1u)) { k = ks + 1u; continue; }
+            if (ks != k) { k = ks; tr = load_tris(p, e, first + (int)k, tids); }
+            R2S_SRV_STATE(2, t0);
+            v4u r1 = {0u, 0u, 0u, 0u}, r2 = r1;
+            for (unsigned spins = 0;; ++spins) {
+                r1 = srv_load_uniform(rr, base + 16u); r2 = srv_load_uniform(rr, base + 32u);
+                if (r1.y == t0 && r1.w == t0 && r2.y == t0 && r2.w == t0) break;
+                if (spins >= p.spin_limit) return;
+            }
+            x0 = mk(__uint_as_float(r0.x), __uint_as_float(r0.z), __uint_as_float(r1.x));
+            v = mk(__uint_as_float(r1.z), __uint_as_float(r2.x), __uint_as_float(r2.z));
+        } else {
+            const unsigned bo = noff + (k & 1u) * xb;
+            v4u d0 = {0u, 0u, 0u, 0u}, d1 = d0, d2 = d0;
+            bool pend = live;
+            // the result of this substep (version k + 1) overwrites version k - 1 in its half of the result line: not before the block has
+            // taken that one — seen from here when the block's republished copy of it is in the exchange array (first lane of the pair)
+            bool pend_ack = pl == 0 && k >= k_first + 2u;
+            const unsigned ao = (xe + (unsigned)i) * 16u + ((k - 1u) & 1u) * xb;
+            for (unsigned spins = 0;; ++spins) {
+                if (pend) {
+                    // the neighbour's records of version k: in the exchange array (published by its block) or, one hand-off earlier for a
+                    // served neighbour, where its own pair left them (same three granules, same version tag)
+                    d0 = srv_load(rx, bo); d1 = srv_load(rx, bo + xn * 16u); d2 = srv_load(rx, bo + 2u * xn * 16u);
+                    const unsigned ro = roff + (k & 1u) * 64u;
+                    const v4u e0 = srv_load(rr, ro), e1 = srv_load(rr, ro + 16u), e2 = srv_load(rr, ro + 32u);
+                    pend = !(d0.y == k && d0.w == k && d1.y == k && d1.w == k && d2.y == k && d2.w == k);
+                    if (pend && e0.y == k && e0.w == k && e1.y == k && e1.w == k && e2.y == k && e2.w == k) { d0 = e0; d1 = e1; d2 = e2; pend = false; }
+                }
+                if (pend_ack) {
+                    const v4u a0 = srv_load(rx, ao);
+                    pend_ack = !(a0.y == k - 1u && a0.w == k - 1u);
+                }
+                const unsigned long long pm = __builtin_amdgcn_ballot_w64(pend || pend_ack);
+#ifdef R2S_PHASE_PROBE
+                ++sp_acc[5];
+#endif
+                if (pm == 0ull) break;
+                if (spins >= p.spin_limit) { // a neighbour's record of version k never came
+                    if (lane == __builtin_ctzll(pm)) resident_fault(p, 5, g, (int)k, (unsigned)wave, ei, bo / 16u, d0.y, d1.y, d2.y);
+                    return;
+                }
+            }
+            R2S_SSTAMP(0);
+            v2f fxy = {0.f, 0.f};
+            float fz = 0.f;
+            if (live) spring_term((v2f){__uint_as_float(d0.x), __uint_as_float(d0.z)}, __uint_as_float(d1.x), (v2f){__uint_as_float(d2.x), __uint_as_float(d2.z)},
+                                  __uint_as_float(d1.z), sx, sv, sk, sa, p.dashpot, fxy, fz);
+            const float fx = wave_sum(fxy.x), fy = wave_sum(fxy.y), fw = wave_sum(fz); // fixed trees: the same sums in every run
+            QShare& qs = qsrv[pair];
+            if (lane == 0) { qs.fs[wave & 1][0] = fx; qs.fs[wave & 1][1] = fy; qs.fs[wave & 1][2] = fw; }
+            pair_barrier(qs, qpar); // (the two barriers of the queries below separate these reads from the next substep's writes)
+            const f3 f = mk(qs.fs[0][0] + qs.fs[1][0], qs.fs[0][1] + qs.fs[1][1], qs.fs[0][2] + qs.fs[1][2]);
+            x0 = sx;
+            v = vel_update_rcp(p, sv, f, m1, inv_m1);
+            R2S_SSTAMP(1);
         }
-        if (t0 == SRV_END) { R2S_SRV_STATE(9, t0); return; }
-        const unsigned ks = (t0 >> 1) - 1u; // a later substep's tag: the ones in between were skipped (a request always waits for its result)
-        if (!(t0 & 1u)) { k = ks + 1u; continue; }
-        if (ks != k) { k = ks; tr = load_tris(p, e, first + (int)k, tids); }
-        R2S_SRV_STATE(2, t0);
-        v4u r1 = {0u, 0u, 0u, 0u}, r2 = r1;
-        for (unsigned spins = 0;; ++spins) {
-            r1 = srv_load_uniform(rr, base + 16u); r2 = srv_load_uniform(rr, base + 32u);
-            if (r1.y == t0 && r1.w == t0 && r2.y == t0 && r2.w == t0) break;
-            if (spins >= p.spin_limit) return;
-        }
-        const f3 x0 = mk(__uint_as_float(r0.x), __uint_as_float(r0.z), __uint_as_float(r1.x));
-        const f3 v = mk(__uint_as_float(r1.z), __uint_as_float(r2.x), __uint_as_float(r2.z));
         const bool last = (int)k == n_steps - 1;
         R2S_SRV_STATE(3, t0);
         R2S_QP_DECL(-1);
         finish_wave<3, false, 1, true>(p, e, i, eb, first + (int)k, last ? write_forces_last : 0, x0, v, lane == 0, none, &tr, &qsrv[pair], &qpar, &X0,
                                        (wave & 1) == 0, &io R2S_QP_ARG);
-        if (qpar & QFAIL) { // the pair's other wavefront did not reach a barrier of this request
+        if (qpar & QFAIL) { // the pair's other wavefront did not reach a barrier of this substep
             if (lane == 0) resident_fault(p, 4, g, (int)k, (unsigned)wave, ei, (unsigned)qpar, (unsigned)qsrv[pair].bar, t0, 0u);
             return;
         }
+        if (have) R2S_SSTAMP(2);
+        // (lane 0 carries the particle; the other lanes' io is their own scratch)
+        sx = mk(bcast(io.x.x, 0), bcast(io.x.y, 0), bcast(io.x.z, 0));
+        sv = mk(bcast(io.v.x, 0), bcast(io.v.y, 0), bcast(io.v.z, 0));
         if ((wave & 1) == 0 && lane == 0) {
-            const unsigned tag = k + 1u;
-            srv_store(rr, base + (unsigned)SRV_RES, __float_as_uint(io.x.x), __float_as_uint(io.x.y), tag);
-            srv_store(rr, base + (unsigned)SRV_RES + 16u, __float_as_uint(io.x.z), __float_as_uint(io.v.z), tag);
-            srv_store(rr, base + (unsigned)SRV_RES + 32u, __float_as_uint(io.v.x), __float_as_uint(io.v.y), tag);
+            // version k + 1 into half (k + 1) & 1 of the result line: an owning pair may be a substep ahead of its block (it waits for its
+            // neighbours' records, not for a request), never two — version k + 2 needs a neighbour's version k + 1, which nobody has before
+            // the block has taken version k (from the block itself, or through its republished copy)
+            const unsigned tag = k + 1u, ro = base + (unsigned)SRV_RES + (tag & 1u) * 64u;
+            srv_store(rr, ro, __float_as_uint(io.x.x), __float_as_uint(io.x.y), tag);
+            srv_store(rr, ro + 16u, __float_as_uint(io.x.z), __float_as_uint(io.v.z), tag);
+            srv_store(rr, ro + 32u, __float_as_uint(io.v.x), __float_as_uint(io.v.y), tag);
         }
+#ifdef R2S_PHASE_PROBE
+        if (have) { R2S_SSTAMP(3); ++sp_acc[4]; } else sp_t = (long long)wall_clock64();
+#endif
+        have = true;
         k = k + 1u;
     }
+#ifdef R2S_PHASE_PROBE
+    if ((wave & 1) == 0 && lane == 0 && g < 1024) for (int kk = 0; kk < 6; ++kk) g_phase_probe[16384 + g * 8 + kk] = sp_acc[kk];
+#endif
 }
 
 // The same kernel is the small-batch layout's PER-SUBSTEP kernel (n_steps = 1: no hand-off at all, the window comes from the state
@@ -1598,6 +1709,8 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     const bool stage_boxes = MESH != 0 && n_steps > 1 && p.n_mesh <= RES_STAGE_MESH;
     io.step_boxes = stage_boxes ? sbox_s : nullptr;
     bool srv_mine = false; // wavefront 0: this lane's particle has a server pair
+    bool srv_ever = false; // finishing wavefronts, owning servers: this lane's particle has needed a query in this launch (it is its pair's from then on)
+    const bool srv_own = srv_on && p.srv_own != 0;
     int srv_slot = -1;
     const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(p.srv_rr, 0, 0x7fffffff, 0x00020000);
     const unsigned sbase = ((unsigned)e * (unsigned)p.N + (unsigned)ic) * (unsigned)SRV_REC;
@@ -1754,7 +1867,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             StateM out = xv_out;
             if (!last) out.p = nullptr;
             io.x = x0; io.v = v0;
-            bool fin = valid;
+            bool fin = valid && !(srv_own && srv_ever); // (a particle a server pair owns is not finished here — wavefront 0 takes its state from the pair)
             if (SELF) { // as in substep_body: particles with candidates publish v_before_collision and are finished by k_self_finish / k_contact_finish
                 const int ncand = valid ? p.coll_num[eb + i] : 0;
                 if (ncand > 0) {
@@ -1785,23 +1898,26 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             // particles that need a mesh query were handed to a server pair (resident_server), not finished above.  Wavefront 0 alone waits
             // for their results — the other two finishing wavefronts leave those lanes to it (three wavefronts polling the same granules
             // tripled the poll traffic on the hand-offs of a block with twenty particles in a finger's reach) — and publishes all three planes
-            bool sneed = false;
+            bool sneed = false, early_pub = false; // early_pub: wavefront 0 has published its finished lanes already (wave-uniform)
             if (MESH == 1 && !SELF && srv_on) {
-                sneed = io.srv_need; // the same in the three finishing wavefronts (same inputs, same instructions)
+                const bool need_now = io.srv_need; // the same in the three finishing wavefronts (same inputs, same instructions)
+                srv_ever = srv_ever || need_now;
+                sneed = srv_own ? srv_ever : need_now;
                 const unsigned uk = (unsigned)k;
                 if (wave == 0) {
-                    bool inplace = false;
-                    if (sneed && !srv_mine) {
+                    bool inplace = srv_own && srv_ever && !srv_mine && !need_now; // owning servers, no pair was left at its first need: in place from then on
+                    bool claimed_now = false;
+                    if (need_now && !srv_mine) {
                         const int slot = atomicAdd(p.srv_ctl, 1);
                         if (slot < p.srv_slots) {
-                            srv_mine = true; srv_slot = slot;
+                            srv_mine = true; srv_slot = slot; claimed_now = true;
                             const __amdgpu_buffer_rsrc_t rcl = __builtin_amdgcn_make_buffer_rsrc(p.srv_claim, 0, 0x7fffffff, 0x00020000);
                             srv_store(rcl, (unsigned)slot * (unsigned)SRV_LINE, (unsigned)e * (unsigned)p.N + (unsigned)i, uk, 1u);
                         } else
                             inplace = true; // no pair left: answered in place, below
                     }
-                    if (srv_mine) {
-                        if (sneed) {
+                    if (srv_mine && (!srv_own || claimed_now)) { // owning servers: ONE request, with the claim
+                        if (need_now) {
                             const unsigned tag = 2u * (uk + 1u) + 1u;
                             srv_store(rsv, sbase + 16u, __float_as_uint(x0.z), __float_as_uint(v.x), tag);
                             srv_store(rsv, sbase + 32u, __float_as_uint(v.y), __float_as_uint(v.z), tag);
@@ -1813,10 +1929,23 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                         finish_wave<MESH, false, 1, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, v, sneed && inplace, out, nullptr, nullptr, nullptr, nullptr,
                                                           true, &io R2S_QP_ARG);
                     if (__builtin_amdgcn_ballot_w64(sneed && !inplace) != 0ull) {
+                        // the lanes that are finished publish BEFORE the wait: their records are what the pairs (and the neighbour blocks) need
+                        // for the next substep — behind the wait, every substep of a particle in contact paid a second hand-off for them
+                        if (!last) {
+                            early_pub = true;
+                            if (!sneed) {
+                                if (valid) {
+                                    const v4u w = {__float_as_uint(io.x.x), (unsigned)(k + 1), __float_as_uint(io.x.y), (unsigned)(k + 1)};
+                                    __builtin_amdgcn_raw_buffer_store_b128(w, rx, (xe + (unsigned)i) * 16u + (unsigned)((k + 1) & 1) * xb, 0, RES_AUX_SC1);
+                                }
+                                win_s[lane] = (v2f){io.x.x, io.x.y};
+                            }
+                        }
                         for (unsigned spins = 0;; ++spins) {
                             bool ok = true;
                             if (sneed && !inplace) {
-                                const v4u d0 = srv_load(rsv, sbase + (unsigned)SRV_RES), d1 = srv_load(rsv, sbase + (unsigned)SRV_RES + 16u), d2 = srv_load(rsv, sbase + (unsigned)SRV_RES + 32u);
+                                const unsigned ro = sbase + (unsigned)SRV_RES + ((uk + 1u) & 1u) * 64u;
+                                const v4u d0 = srv_load(rsv, ro), d1 = srv_load(rsv, ro + 16u), d2 = srv_load(rsv, ro + 32u);
                                 if (d0.y == uk + 1u && d0.w == uk + 1u && d1.y == uk + 1u && d1.w == uk + 1u && d2.y == uk + 1u && d2.w == uk + 1u) {
                                     io.x = mk(__uint_as_float(d0.x), __uint_as_float(d0.z), __uint_as_float(d1.x));
                                     io.v = mk(__uint_as_float(d2.x), __uint_as_float(d2.z), __uint_as_float(d1.z));
@@ -1829,7 +1958,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                                 if (pm && lane == __builtin_ctzll(pm)) {
                                     const __amdgpu_buffer_rsrc_t rcl = __builtin_amdgcn_make_buffer_rsrc(p.srv_claim, 0, 0x7fffffff, 0x00020000);
                                     const unsigned dbo = (unsigned)SRV_DBG_OFF + (unsigned)max(srv_slot, 0) * (unsigned)SRV_LINE;
-                                    const v4u d0 = srv_load(rsv, sbase + (unsigned)SRV_RES), sa = srv_load(rcl, dbo), sb = srv_load(rcl, dbo + 16u);
+                                    const v4u d0 = srv_load(rsv, sbase + (unsigned)SRV_RES + ((uk + 1u) & 1u) * 64u), sa = srv_load(rcl, dbo), sb = srv_load(rcl, dbo + 16u);
                                     // context: particle | slot, result tag seen, then the pair's two wavefronts: phase << 28 | substep << 14 | barrier generation, request tag
                                     resident_fault(p, 3, item, k, (unsigned)i | ((unsigned)srv_slot << 20), d0.y, (sa.x << 28) | (sa.y << 14) | (sa.w >> 16), sa.z,
                                                    (sb.x << 28) | (sb.y << 14) | (sb.w >> 16), sb.z);
@@ -1850,7 +1979,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             if (!last) { // publish version k + 1 (plane `wave`; wavefront 0: all three planes of its served lanes) and refresh the block's own records in the window
                 const unsigned tag = (unsigned)(k + 1);
                 const unsigned pub = (xe + (unsigned)i) * 16u + (unsigned)((k + 1) & 1) * xb;
-                if (!(sneed && wave != 0)) {
+                if (!(sneed && wave != 0) && !(early_pub && !sneed)) {
                     const float va = wave == 0 ? io.x.x : (wave == 1 ? io.x.z : io.v.x), vb = wave == 0 ? io.x.y : (wave == 1 ? io.v.z : io.v.y);
                     if (valid) {
                         const v4u w = {__float_as_uint(va), tag, __float_as_uint(vb), tag};
@@ -2643,6 +2772,7 @@ struct R2SPhys {
     int srv_wg_cap = SRV_MAX_SLOTS / 4; // R2S_RES_SRV_WG: at most this many server workgroups per launch
     int n_cu = 256;
     unsigned spin_limit = RES_SPIN_LIMIT;
+    int srv_own = 1;          // R2S_RES_SRV_OWN=0: one request per substep instead of pairs that own their particle
     bool split_ok = false;    // 64-particle layout whose slices fit k_steps_resident's registers (no remote neighbours, <= 64 interior / halo slots)
     bool resident_ok = false; // the handle can run the env step as ONE resident launch (k_steps_resident) in its free flavour
     int resident_pref = 1;    // R2S_RESIDENT=0 / r2s_phys_set_tuning: never pick the 64-particle layout / the resident launch
@@ -2742,7 +2872,7 @@ struct R2SPhys {
         p.fault = d_mesh_total ? d_mesh_total + 1 : nullptr;
         p.xch = d_xch;
         p.spin_limit = spin_limit;
-        p.srv_slots = 0; p.srv_claim = d_srv_claim; p.srv_rr = d_srv_rr; p.srv_ctl = d_srv_claim ? (int*)((char*)d_srv_claim + SRV_CTL_OFF) : nullptr;
+        p.srv_own = srv_own; p.srv_slots = 0; p.srv_claim = d_srv_claim; p.srv_rr = d_srv_rr; p.srv_ctl = d_srv_claim ? (int*)((char*)d_srv_claim + SRV_CTL_OFF) : nullptr;
         return p;
     }
 };
@@ -3657,6 +3787,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             bool pref = true;
             if (const char* ev = getenv("R2S_RES_SERVERS")) pref = atoi(ev) != 0;
             if (const char* ev = getenv("R2S_RES_SPIN_LIMIT")) h->spin_limit = (unsigned)std::max(1024, atoi(ev));
+            if (const char* ev = getenv("R2S_RES_SRV_OWN")) h->srv_own = atoi(ev) != 0;
             if (const char* ev = getenv("R2S_RES_SRV_WG")) h->srv_wg_cap = std::max(1, std::min(atoi(ev), SRV_MAX_SLOTS / 4));
             h->srv_ok = pref && h->nF > 0 && h->nF <= 128 && n_cu - (int)((int64_t)h->nb * E) >= SRV_MIN_WG;
             if (h->srv_ok) {
@@ -4021,7 +4152,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)
         int n_srv = h->srv_ok && n > 1 ? std::min(h->n_cu - h->nb * h->E, h->srv_wg_cap) : 0; // as enqueue_steps sizes the grid
         if (n_srv < SRV_MIN_WG) n_srv = 0;
-        h->last_flavour[3] = 1 | (n_srv << 8);
+        h->last_flavour[3] = 1 | (n_srv << 8) | ((h->srv_own ? 1 : 0) << 20);
     }
     int gate_dev = -1;
     if (resident) { int rcg = resident_enter(s, &gate_dev); if (rcg) return rcg; }

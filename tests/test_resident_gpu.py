@@ -160,17 +160,22 @@ def test_resident_launch_with_fingers_hovering_then_touching(monkeypatch, server
     record(f"resident stepper with finger meshes (hovering / {'server' if servers else 'in-place'} queries)", x_max_abs_hover=e_far, x_max_abs_contact=e_hit, tol=1e-5)
 
 
-@pytest.mark.parametrize("n_env", [1, 2])
-def test_resident_launch_stays_resident_through_a_held_grasp(n_env):
+@pytest.mark.parametrize("n_env,own", [(1, True), (2, True), (1, False)],
+                         ids=["1 env, pairs own their particle", "2 envs, pairs own their particle", "1 env, R2S_RES_SRV_OWN=0 (a request per substep)"])
+def test_resident_launch_stays_resident_through_a_held_grasp(monkeypatch, n_env, own):
     """one environment IN CONTACT used to leave the resident launch (per-substep kernels + finishing launch: 11.8 us
     per substep for the rope against 2.5 free).  With query servers in the launch the fingers close on the rope, squeeze it, hold it and
     lift it over five env steps and EVERY step is one resident launch: positions against the oracle (1e-5, BASELINE.json), against the
     per-substep kernels + finishing launch of a second handle (2e-6: the same queries, another summation order of the springs), the
     per-finger force totals of the last substep, and the server protocol's corner cases on the way — particles that enter a margin in
-    different substeps (claims mid-launch), particles that leave it again (skipped substeps), a step in which nothing touches."""
+    different substeps (claims mid-launch), particles that leave it again, a step in which nothing touches.  Both protocols: a pair
+    that OWNS its particle from the claim on (its springs from the neighbours' exchange records, velocity, mesh response, ground — the
+    default) and the first one (the block sends a request per substep, the pair answers the query)."""
     import torch
     from r2s_hip import synth
 
+    if not own:
+        monkeypatch.setenv("R2S_RES_SRV_OWN", "0")
     n_sub = 300
     ob = make_object("rope", 900, seed=4)
     c = ob["points"].mean(0)
@@ -216,7 +221,7 @@ def test_resident_launch_stays_resident_through_a_held_grasp(n_env):
     assert touched[0] is False and all(touched[2:]), touched
     assert float(o.x[:, 2].max()) > top + 0.002, "the rope must have been lifted"
     h.step()            # a timed-out hand-off (halo or server) would have raised the sticky fault: this call reports it
-    record(f"resident launch through a held grasp, {n_env} env(s), 5 env steps", x_max_abs_vs_oracle=worst_o, x_max_abs_vs_per_substep_kernels=worst_g, tol=1e-5)
+    record(f"resident launch through a held grasp, {n_env} env(s), 5 env steps, {'owning pairs' if own else 'a request per substep'}", x_max_abs_vs_oracle=worst_o, x_max_abs_vs_per_substep_kernels=worst_g, tol=1e-5)
 
 
 def test_resident_launch_next_to_a_busy_second_stream():
