@@ -399,7 +399,6 @@ struct QShare {
     float pt[2][QWPB][6];            // what a slow one is still reading (closest point, q - p; mesh frame)
     int meta[2][QWPB][5];            // stored face, feature region, mesh kind, transform slot, cluster
     volatile int sup[QWPB][8];       // per wavefront: lanes that own the super-clusters of the current round
-    int bar;                         // pair mode (the resident stepper's query servers): arrivals at the two-wavefront barrier, zeroed by the workgroup
     int arrived[2];                  // pair mode: the last barrier generation each of the two wavefronts has arrived at
     float fs[2][4];                  // pair mode, owning servers: the two wavefronts' sums of the particle's spring forces
 };
@@ -407,31 +406,25 @@ struct QShare {
 // wavefront PAIRS of a server workgroup of k_steps_resident, each on its own particle at its own pace (barrier = a counter in the pair's
 // QShare).  `parity` carries the mode: bit 0 the buffer parity, bit 8 pair mode, bits 16.. the pair barrier's generation.
 constexpr int QPAIR = 1 << 8, QFAIL = 1 << 9; // QFAIL: the partner never arrived (bounded wait; the caller reports a fault and leaves)
-// A hardware barrier (s_barrier) counts WAVEFRONTS, so it does not care with which lanes a wavefront reaches it.  This one counts an
-// arrival per wavefront in LDS and spins on the counter — and is written to be correct for ANY set of active lanes: inlined into
-// finish_wave, nothing stops the compiler from duplicating the (non-convergent) code into the two sides of a divergent branch, and a
-// version whose lane 0 makes the arrival then waits for itself.  Whichever lanes come first elect one of themselves, which makes the
-// wavefront's arrival for this generation unless it has been made already (`arrived`, one word per wavefront of the pair).  The wait is
-// bounded (QFAIL -> the server reports fault 4 and leaves).  (A non-inlined function would be convergent, but gives the kernel a stack:
-// scratch memory, and with it fewer resident workgroups than the launch needs — measured: hand-offs timing out all over the rope.)
+// A hardware barrier (s_barrier) counts the wavefronts of the WORKGROUP; a pair is two of a server workgroup's eight.  Each wavefront
+// of the pair has a word in the pair's QShare with the last generation it has arrived at: arriving is one LDS store of that number
+// (every active lane stores the same value to the same address — nothing to elect, correct for any lane mask the compiler may have
+// split the call into), waiting is reading the partner's word until it says the same.  A wavefront's LDS operations execute in
+// order, so the partner that sees the number also sees what was written before it.  The wait is bounded (QFAIL -> the server reports
+// fault 4 and leaves).  (First form: an arrival counter, fetch-add by an elected lane + spin with s_sleep; this one is the same speed
+// — 4.2 vs 4.3 us for the pair's two queries — and half the code.  A non-inlined function gives the kernel a stack: scratch memory,
+// and with it fewer resident workgroups than the launch needs — measured: hand-offs timing out all over the rope.)
 __device__ __forceinline__ void pair_barrier(QShare& sm, int& parity)
 {
     const int gen = (parity >> 16) + 1;
     parity = (parity & 0xffff) | (gen << 16);
     const int w = (int)(threadIdx.x >> 6) & 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // this wavefront's LDS writes before its arrival
-    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-    if ((int)(threadIdx.x & 63) == __builtin_ctzll(act) && __hip_atomic_load(&sm.arrived[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) {
-        __hip_atomic_store(&sm.arrived[w], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&sm.bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    for (unsigned spins = 0; __hip_atomic_load(&sm.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * gen; ++spins) {
-        if (spins >= (1u << 22)) { parity |= QFAIL; break; }         // ~0.3 s: the partner is gone (never in a sound launch)
-        __builtin_amdgcn_s_sleep(1);
-    }
+    __hip_atomic_store(&sm.arrived[w], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (unsigned spins = 0; __hip_atomic_load(&sm.arrived[w ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen; ++spins)
+        if (spins >= (1u << 23)) { parity |= QFAIL; break; }         // a fraction of a second: the partner is gone (never in a sound launch)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-
 __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, f3 q, int e, bool want, int hint, QShare& sm, int& parity, const Xf& X0 R2S_QP_PARAM)
 {
     MeshHit out = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0, -1};
@@ -1450,7 +1443,7 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
 {
     __shared__ QShare qsrv[4];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = wave >> 1;
-    if (tid < 4) { qsrv[tid].bar = 0; qsrv[tid].arrived[0] = 0; qsrv[tid].arrived[1] = 0; }
+    if (tid < 4) { qsrv[tid].arrived[0] = 0; qsrv[tid].arrived[1] = 0; }
     __syncthreads();
     const int g = ((int)blockIdx.x - 8 * p.cb) * 4 + pair;
     if (g >= p.srv_slots) return; // (whole pairs)
@@ -1600,11 +1593,13 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
         }
         const bool last = (int)k == n_steps - 1;
         R2S_SRV_STATE(3, t0);
-        R2S_QP_DECL(-1);
+        R2S_QP_DECL((wave & 1) == 0 ? g : -1); // (probe builds: the stamps of the pair's last substep — before, first query back, second back, after)
+        R2S_QSTAMP();
         finish_wave<3, false, 1, true>(p, e, i, eb, first + (int)k, last ? write_forces_last : 0, x0, v, lane == 0, none, &tr, &qsrv[pair], &qpar, &X0,
                                        (wave & 1) == 0, &io R2S_QP_ARG);
+        R2S_QSTAMP();
         if (qpar & QFAIL) { // the pair's other wavefront did not reach a barrier of this substep
-            if (lane == 0) resident_fault(p, 4, g, (int)k, (unsigned)wave, ei, (unsigned)qpar, (unsigned)qsrv[pair].bar, t0, 0u);
+            if (lane == 0) resident_fault(p, 4, g, (int)k, (unsigned)wave, ei, (unsigned)qpar, (unsigned)qsrv[pair].arrived[0], (unsigned)qsrv[pair].arrived[1], t0);
             return;
         }
         if (have) R2S_SSTAMP(2);

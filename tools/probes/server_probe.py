@@ -31,3 +31,10 @@ if len(srv):
     print("server pairs busy: %d; substeps served per pair: mean %.0f" % (len(srv), srv[:, 4].mean()))
     print("  us per served substep: wait %.2f  force+sum %.2f  finish %.2f  store %.2f  (sum %.2f); poll passes %.2f" % (*per.mean(0), per.sum(1).mean(), (srv[:, 5] / srv[:, 4]).mean()))
     print("  max over pairs:", [round(float(x), 2) for x in per.max(0)], " min:", [round(float(x), 2) for x in per.min(0)])
+    L.r2s_phys_debug_query_probe.argtypes = [C.c_void_p, C.c_int]
+    qb = (C.c_longlong * (1024 * 32))()
+    L.r2s_phys_debug_query_probe(qb, 1024)
+    q = np.array(qb, dtype=np.int64).reshape(1024, 32)[:len(srv), :4].astype(np.float64)
+    d = np.diff(q, axis=1) * 0.01
+    d = d[(d > 0).all(1) & (d < 50).all(1)]
+    print("  last substep of a pair, us: first query %.2f  response + second query %.2f  rest of the substep %.2f  (%d pairs)" % (*d.mean(0), len(d)))
