@@ -1908,8 +1908,10 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                             srv_mine = true; srv_slot = slot; claimed_now = true;
                             const __amdgpu_buffer_rsrc_t rcl = __builtin_amdgcn_make_buffer_rsrc(p.srv_claim, 0, 0x7fffffff, 0x00020000);
                             srv_store(rcl, (unsigned)slot * (unsigned)SRV_LINE, (unsigned)e * (unsigned)p.N + (unsigned)i, uk, 1u);
-                        } else
-                            inplace = true; // no pair left: answered in place, below
+                        } else {
+                            inplace = true; // no pair left: answered in place, below —
+                            p.fault[2] = 1; // — thousands of instructions inside the hand-off chain: the host takes the next steps off the resident launch
+                        }
                     }
                     if (srv_mine && (!srv_own || claimed_now)) { // owning servers: ONE request, with the claim
                         if (need_now) {
@@ -2763,6 +2765,7 @@ struct R2SPhys {
     int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false, fault_stale = false;
     void* d_xch = nullptr;    // resident stepper: exchange array (96 B per particle)
     void* d_srv_claim = nullptr; void* d_srv_rr = nullptr; // resident stepper's mesh-query servers: a 128-byte line per claim, one of control words, one per pair of fault-report state; a line of request and a line of result granules per particle
+    bool srv_exhausted = false; // a launch ran out of server pairs: per-substep kernels + finishing launch until the contact is over
     bool srv_ok = false;      // small scene (every mesh small, <= 128 faces in total): a resident launch may carry query servers
     int srv_wg_cap = SRV_MAX_SLOTS / 4; // R2S_RES_SRV_WG: at most this many server workgroups per launch
     int n_cu = 256;
@@ -3753,10 +3756,10 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         if (h->prm.self_collision) { TRY(dev_alloc(&h->d_cand_mark, (size_t)E * N)); R2S_HIP_TRY(hipMemsetAsync(h->d_cand_mark, 0, sizeof(int) * (size_t)E * N, s)); }
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_cnt, 0, sizeof(int) * 8 * (size_t)(h->prm.num_substeps + 1), s));
     }
-    TRY(dev_alloc(&h->d_mesh_total, 16)); // [4..15]: where the first fault of the resident stepper happened (diagnostics); [0] particles near a mesh in the last step, [1] sticky fault word (PhysDev::fault), [2] a mesh query was needed
+    TRY(dev_alloc(&h->d_mesh_total, 16)); // [4..15]: where the first fault of the resident stepper happened (diagnostics); [0] particles near a mesh in the last step, [1] sticky fault word (PhysDev::fault), [2] a mesh query was needed, [3] a resident launch ran out of server pairs
     R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int) * 16, s));
     R2S_HIP_TRY(hipHostMalloc((void**)&h->h_mesh_total, 64, hipHostMallocDefault));
-    h->h_mesh_total[0] = 0; h->h_mesh_total[1] = 0; h->h_mesh_total[2] = 0;
+    h->h_mesh_total[0] = 0; h->h_mesh_total[1] = 0; h->h_mesh_total[2] = 0; h->h_mesh_total[3] = 0;
     R2S_HIP_TRY(hipEventCreateWithFlags(&h->mesh_event, hipEventDisableTiming));
     {
         // the resident launch needs: the 64-particle layout, every neighbour inside the block's window (a remote neighbour would be read
@@ -4115,12 +4118,12 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         if (h->fault_stale) { h->h_mesh_total[1] = 0; h->fault_stale = false; } // the copy was in flight when set_state cleared the word
     }
     if (!h->mesh_pending && h->h_mesh_total[1] != 0) { // the sticky fault word of an earlier step
-        if (h->h_mesh_total[1] >= 2 && h->h_mesh_total[1] <= 4) {
+        if (h->h_mesh_total[1] >= 2 && h->h_mesh_total[1] <= 5) {
             char buf[640];
             const int* w = h->h_mesh_total + 4;
             snprintf(buf, sizeof buf, "resident stepper: a workgroup waited for %s beyond the poll limit (the launch was not resident at once, or the device "
                      "is shared with a kernel that never ends); the state is invalid [first fault: code %d, work item %d, substep %d of the launch, context %d %d %d %d %d %d]",
-                     h->h_mesh_total[1] == 2 ? "a neighbour block's substep" : "a mesh-query server's result", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+                     h->h_mesh_total[1] == 2 ? "a neighbour block's substep" : h->h_mesh_total[1] == 5 ? "a neighbour's record (server pair)" : "a mesh-query server's result", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
             r2s::set_last_error_msg(buf);
         }
         else
@@ -4136,7 +4139,11 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         if (!h->mesh_pending) h->mesh_defer = (h->resident_ok && h->resident_pref ? h->h_mesh_total[2] : h->h_mesh_total[0]) > 0 ? 1 : 0;
         // ... and with query servers in the launch (round 4) a small batch stays resident THROUGH contact: a particle that needs a query is
         // answered by a server pair of the same launch (resident_server); only the self-collision flavour still takes the per-substep path
-        if (h->resident_ok && h->resident_pref && h->srv_ok && variant == 0) h->mesh_defer = 0;
+        if (!h->mesh_pending) { // (more particles in contact than the launch has pairs: answered in place — correct, and 20 x slower than the finishing launch)
+            if (h->h_mesh_total[3] > 0) h->srv_exhausted = true;
+            else if (h->h_mesh_total[2] == 0) h->srv_exhausted = false;
+        }
+        if (h->resident_ok && h->resident_pref && h->srv_ok && variant == 0 && !h->srv_exhausted) h->mesh_defer = 0;
         if (h->force_defer >= 0) h->mesh_defer = h->force_defer; // test / tuning: force a flavour
         if (h->any_large) h->mesh_defer = 1;
     }
@@ -4172,7 +4179,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int), s));
         if (h->nF > 0) hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(64), 0, s, h->d_mesh_cnt + h->prm.num_substeps, 8, h->prm.num_substeps + 1, h->d_mesh_total);
         R2S_HIP_TRY(hipMemcpyAsync(h->h_mesh_total, h->d_mesh_total, 16 * sizeof(int), hipMemcpyDeviceToHost, s));
-        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total + 2, 0, sizeof(int), s)); // "a query was needed": counted from here on
+        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total + 2, 0, 2 * sizeof(int), s)); // "a query was needed", "no server pair was left": counted from here on
         R2S_HIP_TRY(hipEventRecord(h->mesh_event, s));
         h->mesh_pending = true;
     }

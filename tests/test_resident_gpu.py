@@ -330,3 +330,40 @@ def test_resident_launch_with_query_servers_under_load_is_bit_identical_to_the_q
     assert hq == hb and torch.equal(sq[0], sb[0]) and torch.equal(sq[1], sb[1])
     assert np.isfinite(xq).all() and zq == zb
     assert max(zq[4:12]) > zq[0] + 0.004, ("the rope must have been lifted while the fingers held it", zq)
+
+
+@pytest.mark.gpu
+def test_more_particles_in_contact_than_server_pairs_takes_the_step_off_the_resident_launch(monkeypatch):
+    """A launch whose server pairs run out (here: capped at 8 workgroups = 32 pairs, 45 particles of the rope inside the pads' margins)
+    answers the surplus in place — correct, and slow enough to stall every block of the launch — and says so; the host then runs the
+    following env steps as per-substep kernels + finishing launch until the contact is over, and returns to the resident launch after
+    the release.  The run must agree with the unconstrained one (same physics, other summation orders) and raise nothing."""
+    import torch
+    from r2s_hip.rollout import BatchedRollout
+
+    def run(cap):
+        if cap:
+            monkeypatch.setenv("R2S_RES_SRV_WG", str(cap))
+        else:
+            monkeypatch.delenv("R2S_RES_SRV_WG", raising=False)
+        ro = BatchedRollout("rope_1env", close_at=3, open_at=9, seed=2)
+        flav, ztop = [], []
+        for _ in range(14):
+            ro.step()
+            torch.cuda.synchronize()            # the flavour of a step follows from the last FINISHED one: finish each
+            flav.append(ro.phys.last_flavour())
+            ztop.append(float(ro.phys.x[0, :, 2].max()))
+        ro.phys.step(0, 0)
+        torch.cuda.synchronize()
+        return ro.phys.x.cpu().numpy().copy(), flav, ztop
+
+    xc, fc, zc = run(8)
+    xf, ff, zf = run(0)
+    assert all(f["resident"] for f in ff)
+    off = [k for k, f in enumerate(fc) if not f["resident"]]
+    assert off, "with 32 pairs for 45 particles some env steps must have left the resident launch"
+    assert all(fc[k]["deferred_mesh_queries"] for k in off)
+    assert fc[-1]["resident"] and fc[0]["resident"], ("free motion before the grasp and after the release is resident again", [f["resident"] for f in fc])
+    assert np.isfinite(xc).all() and max(zc[4:9]) > zc[0] + 0.004, zc
+    assert np.abs(xc - xf).max() < 2e-3, float(np.abs(xc - xf).max())   # 14 env steps of a grasp: a chaotic system summed in three different orders
+    record("rope grasp with the server pairs capped below the contact count", x_max_abs_vs_uncapped=float(np.abs(xc - xf).max()), steps_off_the_resident_launch=len(off), tol=2e-3)
