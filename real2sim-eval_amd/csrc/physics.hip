@@ -1445,7 +1445,9 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = wave >> 1;
     if (tid < 4) { qsrv[tid].arrived[0] = 0; qsrv[tid].arrived[1] = 0; }
     __syncthreads();
-    const int g = ((int)blockIdx.x - 8 * p.cb) * 4 + pair;
+    // slots are claimed in increasing order: slot = pair * (server workgroups) + workgroup, so that the first claims each get a CU of their
+    // own (a pair that shares its two SIMDs with another busy pair of the same workgroup ran its queries slower)
+    const int g = pair * (p.srv_slots / 4) + ((int)blockIdx.x - 8 * p.cb);
     if (g >= p.srv_slots) return; // (whole pairs)
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.srv_claim, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(p.srv_rr, 0, 0x7fffffff, 0x00020000);
@@ -3060,7 +3062,9 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
         // mesh-query servers: workgroups beyond the blocks' own, as many as the chip has CUs left (the whole launch is resident at once)
         int n_srv = 0;
         if (h->srv_ok && n > 1) {
-            n_srv = std::min(h->n_cu - h->nb * ne, h->srv_wg_cap);
+            // workgroups go to the XCDs round-robin and every XCD must hold its share at once: the grid (8 * cb block workgroups — up to 7
+            // of them idle, but their CUs may be on other XCDs than the servers that would need them — plus the servers) <= CUs
+            n_srv = std::min(h->n_cu - 8 * p.cb, h->srv_wg_cap);
             if (n_srv < SRV_MIN_WG) n_srv = 0;
         }
         if (n_srv > 0) {
@@ -3787,7 +3791,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             if (const char* ev = getenv("R2S_RES_SPIN_LIMIT")) h->spin_limit = (unsigned)std::max(1024, atoi(ev));
             if (const char* ev = getenv("R2S_RES_SRV_OWN")) h->srv_own = atoi(ev) != 0;
             if (const char* ev = getenv("R2S_RES_SRV_WG")) h->srv_wg_cap = std::max(1, std::min(atoi(ev), SRV_MAX_SLOTS / 4));
-            h->srv_ok = pref && h->nF > 0 && h->nF <= 128 && n_cu - (int)((int64_t)h->nb * E) >= SRV_MIN_WG;
+            h->srv_ok = pref && h->nF > 0 && h->nF <= 128 && n_cu - 8 * (int)(((int64_t)h->nb * E + 7) / 8) >= SRV_MIN_WG;
             if (h->srv_ok) {
                 TRY(dev_alloc((char**)&h->d_srv_claim, (size_t)SRV_CLAIM_BYTES)); // claims | 2 control words | per pair and wavefront: 16 B of state for fault reports
                 TRY(dev_alloc((char**)&h->d_srv_rr, (size_t)SRV_REC * E * N));
@@ -4152,7 +4156,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     const bool resident = resident_flavour(h, variant == 1, h->mesh_defer);
     if (resident) {
         h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)
-        int n_srv = h->srv_ok && n > 1 ? std::min(h->n_cu - h->nb * h->E, h->srv_wg_cap) : 0; // as enqueue_steps sizes the grid
+        int n_srv = h->srv_ok && n > 1 ? std::min(h->n_cu - 8 * ((h->nb * h->E + 7) / 8), h->srv_wg_cap) : 0; // as enqueue_steps sizes the grid
         if (n_srv < SRV_MIN_WG) n_srv = 0;
         h->last_flavour[3] = 1 | (n_srv << 8) | ((h->srv_own ? 1 : 0) << 20);
     }
