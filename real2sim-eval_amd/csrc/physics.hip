@@ -154,6 +154,7 @@ struct PhysDev {
     void* srv_claim;           // [srv_slots] x 128 B, first granule {env * N + particle, 1, first substep of the launch it is served from, 1}; then control words and fault-report state (SRV_CTL_OFF, SRV_DBG_OFF)
     void* srv_rr;              // [E][N] x 256 B of tagged 16-byte granules: line 0 the REQUEST (x0.x x0.y | x0.z v.x | v.y v.z), line 1 the RESULT (xy | z vz | vxy)
     int* srv_ctl;              // [0] next free slot, [1] blocks that have left the launch
+    int srv_quad;              // server units are quads of wavefronts (two particles per server workgroup) instead of pairs (four)
     int srv_own;               // servers OWN their particle from the claim on: spring forces from the neighbours' exchange records, velocity update, mesh response, ground (0: one request per substep, round 4's first protocol)
     unsigned spin_limit;       // poll passes before a workgroup of the resident launch gives up (RES_SPIN_LIMIT; R2S_RES_SPIN_LIMIT at create: diagnostics)
 };
@@ -399,30 +400,38 @@ struct QShare {
     float pt[2][QWPB][6];            // what a slow one is still reading (closest point, q - p; mesh frame)
     int meta[2][QWPB][5];            // stored face, feature region, mesh kind, transform slot, cluster
     volatile int sup[QWPB][8];       // per wavefront: lanes that own the super-clusters of the current round
-    int arrived[2];                  // pair mode: the last barrier generation each of the two wavefronts has arrived at
+    int arrived[4];                  // server units (pairs / quads of wavefronts): the last barrier generation each wavefront has arrived at
     float fs[2][4];                  // pair mode, owning servers: the two wavefronts' sums of the particle's spring forces
 };
 // mesh_query_regs is run by TWO wavefronts: a 128-thread workgroup of k_contact_finish<3> (barrier = __syncthreads), or one of the four
 // wavefront PAIRS of a server workgroup of k_steps_resident, each on its own particle at its own pace (barrier = a counter in the pair's
 // QShare).  `parity` carries the mode: bit 0 the buffer parity, bit 8 pair mode, bits 16.. the pair barrier's generation.
-constexpr int QPAIR = 1 << 8, QFAIL = 1 << 9; // QFAIL: the partner never arrived (bounded wait; the caller reports a fault and leaves)
-// A hardware barrier (s_barrier) counts the wavefronts of the WORKGROUP; a pair is two of a server workgroup's eight.  Each wavefront
-// of the pair has a word in the pair's QShare with the last generation it has arrived at: arriving is one LDS store of that number
-// (every active lane stores the same value to the same address — nothing to elect, correct for any lane mask the compiler may have
-// split the call into), waiting is reading the partner's word until it says the same.  A wavefront's LDS operations execute in
-// order, so the partner that sees the number also sees what was written before it.  The wait is bounded (QFAIL -> the server reports
+constexpr int QPAIR = 1 << 8, QFAIL = 1 << 9, QQUAD = 1 << 10; // QFAIL: a partner never arrived (bounded wait; the caller reports a fault and leaves)
+// QQUAD (with QPAIR): FOUR wavefronts per query — a lone wavefront issues one instruction per four cycles whatever its parallelism, so
+// the per-triangle arithmetic of a query (closest point: ~250 instructions; solid angle: ~200) is split by KIND over the four SIMDs of
+// the CU: wavefronts 0, 1 the closest points of triangles 0..63 / 64..127, wavefronts 2, 3 their solid angles.
+// A hardware barrier (s_barrier) counts the wavefronts of the WORKGROUP; a unit is two or four of a server workgroup's eight.  Each
+// wavefront of the unit has a word in the unit's QShare with the last generation it has arrived at: arriving is one LDS store of that
+// number (every active lane stores the same value to the same address — nothing to elect, correct for any lane mask the compiler may
+// have split the call into), waiting is reading the partners' words until they say the same.  A wavefront's LDS operations execute in
+// order, so a partner that sees the number also sees what was written before it.  The wait is bounded (QFAIL -> the server reports
 // fault 4 and leaves).  (First form: an arrival counter, fetch-add by an elected lane + spin with s_sleep; this one is the same speed
-// — 4.2 vs 4.3 us for the pair's two queries — and half the code.  A non-inlined function gives the kernel a stack: scratch memory,
-// and with it fewer resident workgroups than the launch needs — measured: hand-offs timing out all over the rope.)
+// and half the code.  A non-inlined function gives the kernel a stack: scratch memory, and with it fewer resident workgroups than the
+// launch needs — measured: hand-offs timing out all over the rope.)
 __device__ __forceinline__ void pair_barrier(QShare& sm, int& parity)
 {
     const int gen = (parity >> 16) + 1;
     parity = (parity & 0xffff) | (gen << 16);
-    const int w = (int)(threadIdx.x >> 6) & 1;
+    const bool quad = (parity & QQUAD) != 0;
+    const int w = (int)(threadIdx.x >> 6) & (quad ? 3 : 1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // this wavefront's LDS writes before its arrival
     __hip_atomic_store(&sm.arrived[w], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    for (unsigned spins = 0; __hip_atomic_load(&sm.arrived[w ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen; ++spins)
-        if (spins >= (1u << 23)) { parity |= QFAIL; break; }         // a fraction of a second: the partner is gone (never in a sound launch)
+    for (unsigned spins = 0;; ++spins) {
+        int m = __hip_atomic_load(&sm.arrived[w ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (quad) m = min(m, min(__hip_atomic_load(&sm.arrived[w ^ 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), __hip_atomic_load(&sm.arrived[w ^ 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
+        if (m >= gen) break;
+        if (spins >= (1u << 23)) { parity |= QFAIL; break; }         // a fraction of a second: a partner is gone (never in a sound launch)
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, f3 q, int e, bool want, int hint, QShare& sm, int& parity, const Xf& X0 R2S_QP_PARAM)
@@ -713,34 +722,52 @@ __device__ __forceinline__ TriRegs load_tris(const PhysDev& p, int e, int step, 
 // Same answer as mesh_query_lane on such a scene: lexicographic minimum of (distance^2, face id) over the faces closer than
 // max_dist, sign from the exact winding number over all faces.  `q` and `want` are uniform over the workgroup (the particle of
 // lane 0); one barrier per call whether or not the query is wanted.
+template <bool QUAD = false>
 __device__ __forceinline__ MeshHit mesh_query_regs(const TriRegs& t, f3 q, bool want, QShare& sm, int& parity)
 {
     MeshHit out = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
-    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6) & 1;
+    constexpr bool quad = QUAD; // (compile time: as a run-time mode the two-wavefront form lost 0.2 us per query to the split)
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6) & (quad ? 3 : 1);
+    const bool do_cp = !quad || wave < 2, do_wn = !quad || wave >= 2; // (quad: the two kinds of per-triangle arithmetic on different SIMDs)
     const float MAXD2 = MESH_MAX_DIST * MESH_MAX_DIST;
     const int par = parity & 1;
     parity ^= 1;
     if (want) {
-        float u, v;
-        int region;
-        closest_bary(t.a, t.b, t.c, q, u, v, region);
-        const f3 cp = t.a * u + t.b * v + t.c * (1.f - u - v);
-        const f3 d = cp - q;
-        const float d2 = dot(d, d);
-        const unsigned long long key = (t.ok && d2 < MAXD2) ? (((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)t.face) : ~0ull;
-        const f3 a = t.a - q, b = t.b - q, c3 = t.c - q;
-        const float la = len(a), lb = len(b), lc = len(c3);
-        const float det = dot(a, cross(b, c3));
-        const float den = la * lb * lc + dot(a, b) * lc + dot(b, c3) * la + dot(c3, a) * lb;
-        const float ws = wave_sum(t.ok ? 2.f * atan2f(det, den) : 0.f);
-        const unsigned long long mn = wave_min_u64(key);
-        const int w = mn != ~0ull ? __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == mn)) : 0;
-        const f3 pt = mk(bcast(cp.x, w), bcast(cp.y, w), bcast(cp.z, w));
-        const int wmm = bcasti(t.mm, w), wfm = bcasti(t.fm, w), mm0 = bcasti(t.mm, 0), fm0 = bcasti(t.fm, 0);
-        if (lane == 0) {
-            sm.key[par][wave] = mn;
-            sm.pt[par][wave][0] = pt.x; sm.pt[par][wave][1] = pt.y; sm.pt[par][wave][2] = pt.z; sm.pt[par][wave][3] = ws;
-            sm.meta[par][wave][0] = wmm; sm.meta[par][wave][1] = wfm; sm.meta[par][wave][2] = mm0; sm.meta[par][wave][3] = fm0;
+        // (per-triangle arithmetic first, reductions behind it: the wait states of the cross-lane instructions then have the other
+        // reduction's instructions to hide behind — the order the two-wavefront form always had)
+        f3 cp = mk(0.f, 0.f, 0.f);
+        unsigned long long key = ~0ull;
+        float sa = 0.f;
+        if (do_cp) {
+            float u, v;
+            int region;
+            closest_bary(t.a, t.b, t.c, q, u, v, region);
+            cp = t.a * u + t.b * v + t.c * (1.f - u - v);
+            const f3 d = cp - q;
+            const float d2 = dot(d, d);
+            key = (t.ok && d2 < MAXD2) ? (((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)t.face) : ~0ull;
+        }
+        if (do_wn) {
+            const f3 a = t.a - q, b = t.b - q, c3 = t.c - q;
+            const float la = len(a), lb = len(b), lc = len(c3);
+            const float det = dot(a, cross(b, c3));
+            const float den = la * lb * lc + dot(a, b) * lc + dot(b, c3) * la + dot(c3, a) * lb;
+            sa = t.ok ? 2.f * atan2f(det, den) : 0.f;
+        }
+        if (do_wn) {
+            const float ws = wave_sum(sa);
+            if (lane == 0) sm.pt[par][wave][3] = ws;
+        }
+        if (do_cp) {
+            const unsigned long long mn = wave_min_u64(key);
+            const int w = mn != ~0ull ? __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == mn)) : 0;
+            const f3 pt = mk(bcast(cp.x, w), bcast(cp.y, w), bcast(cp.z, w));
+            const int wmm = bcasti(t.mm, w), wfm = bcasti(t.fm, w), mm0 = bcasti(t.mm, 0), fm0 = bcasti(t.fm, 0);
+            if (lane == 0) {
+                sm.key[par][wave] = mn;
+                sm.pt[par][wave][0] = pt.x; sm.pt[par][wave][1] = pt.y; sm.pt[par][wave][2] = pt.z;
+                sm.meta[par][wave][0] = wmm; sm.meta[par][wave][1] = wfm; sm.meta[par][wave][2] = mm0; sm.meta[par][wave][3] = fm0;
+            }
         }
     }
     if (parity & QPAIR) pair_barrier(sm, parity);
@@ -750,7 +777,7 @@ __device__ __forceinline__ MeshHit mesh_query_regs(const TriRegs& t, f3 q, bool 
     const int fw = k1 < k0 ? 1 : 0;
     const unsigned long long mn = fw ? k1 : k0;
     const bool found = mn != ~0ull;
-    const float wn = (sm.pt[par][0][3] + sm.pt[par][1][3]) / (float)(4.0 * 3.14159265358979323846);
+    const float wn = (quad ? sm.pt[par][2][3] + sm.pt[par][3][3] : sm.pt[par][0][3] + sm.pt[par][1][3]) / (float)(4.0 * 3.14159265358979323846);
     out.result = found && lane == 0; // the answer belongs to the particle of lane 0
     out.sign = wn > WIND_THRESHOLD ? -1.f : 1.f;
     out.face = found ? (int)(unsigned)(mn & 0xffffffffull) : 0; // a miss reports face 0, like warp's zero-initialised query
@@ -967,7 +994,7 @@ __device__ __forceinline__ bool mesh_rec_push(const PhysDev& p, int e, int step,
 // found nothing in reach: mesh_collision then only advances the position, :321 / :420)
 // KEEP (the resident stepper): every lane with `fin` also returns its new state in keep->x / keep->v and only stores it when
 // xv_out.p is set (the launch's last substep); the mesh boxes of the early-out come from *keep.
-template <int MESH, bool MAIN = false, int NEED = 0, bool KEEP = false>
+template <int MESH, bool MAIN = false, int NEED = 0, bool KEEP = false, bool QUAD = false>
 __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v, bool fin,
                                             const StateM xv_out, const TriRegs* tr, QShare* qs, int* qpar, const Xf* xf0, bool store, ResidentIO* keep R2S_QP_PARAM)
 {
@@ -1016,7 +1043,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         constexpr bool IN_PLACE = !(MAIN && MESH == 2) && NEED != 2;
         MeshHit q = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
         if (IN_PLACE)
-            q = MESH == 3 ? mesh_query_regs(*tr, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), bcasti((int)need, 0) != 0, *qs, *qpar)
+            q = MESH == 3 ? mesh_query_regs<QUAD>(*tr, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), bcasti((int)need, 0) != 0, *qs, *qpar)
               : MESH == 2 ? mesh_query_block(p, step, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), e,
                                              bcasti((int)need, 0) != 0, -1, *qs, *qpar, *xf0 R2S_QP_ARG) // workgroup-cooperative, call site 1
                           : mesh_query_lane(p, e, step, next_x, need);
@@ -1068,7 +1095,7 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
         }
         MeshHit q2 = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0};
         if (IN_PLACE)
-            q2 = MESH == 3 ? mesh_query_regs(*tr, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), bcasti((int)requery, 0) != 0, *qs, *qpar)
+            q2 = MESH == 3 ? mesh_query_regs<QUAD>(*tr, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), bcasti((int)requery, 0) != 0, *qs, *qpar)
                : MESH == 2 ? mesh_query_block(p, step, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), e,
                                               bcasti((int)requery, 0) != 0, bcasti(q.hint, 0), *qs, *qpar, *xf0 R2S_QP_ARG) // call site 2
                            : mesh_query_lane(p, e, step, next_x, requery);
@@ -1442,12 +1469,14 @@ __device__ __forceinline__ bool srv_claimed(v4u c) { return c.y == 1u && c.w == 
 __device__ void resident_server(const PhysDev& p, int first, int n_steps, int write_forces_last)
 {
     __shared__ QShare qsrv[4];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, pair = wave >> 1;
-    if (tid < 4) { qsrv[tid].arrived[0] = 0; qsrv[tid].arrived[1] = 0; }
+    // a UNIT serves one particle: a pair of wavefronts (four units per workgroup) or, when the launch has server workgroups to spare, a quad
+    // (two units: see QQUAD) — `r` is the wavefront's place in its unit
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, wpp = p.srv_quad ? 4 : 2, pair = wave / wpp, r = wave % wpp;
+    if (tid < 4) { qsrv[tid].arrived[0] = 0; qsrv[tid].arrived[1] = 0; qsrv[tid].arrived[2] = 0; qsrv[tid].arrived[3] = 0; }
     __syncthreads();
     // slots are claimed in increasing order: slot = pair * (server workgroups) + workgroup, so that the first claims each get a CU of their
     // own (a pair that shares its two SIMDs with another busy pair of the same workgroup ran its queries slower)
-    const int g = pair * (p.srv_slots / 4) + ((int)blockIdx.x - 8 * p.cb);
+    const int g = pair * (p.srv_slots / (8 / wpp)) + ((int)blockIdx.x - 8 * p.cb);
     if (g >= p.srv_slots) return; // (whole pairs)
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.srv_claim, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(p.srv_rr, 0, 0x7fffffff, 0x00020000);
@@ -1471,8 +1500,8 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
     const int e = (int)(ei / (unsigned)p.N), i = (int)(ei % (unsigned)p.N);
     const size_t eb = (size_t)e * p.N;
     const unsigned base = ei * (unsigned)SRV_REC;
-    const TriIds tids = load_tri_ids(p, lane, wave & 1);
-    int qpar = QPAIR;
+    const TriIds tids = load_tri_ids(p, lane, r & 1);
+    int qpar = QPAIR | (p.srv_quad ? QQUAD : 0);
     Xf X0;
 #pragma unroll
     for (int j = 0; j < 9; ++j) X0.r[j] = (j % 4 == 0) ? 1.f : 0.f;
@@ -1482,7 +1511,7 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
     io.x = mk(0.f, 0.f, 0.f); io.v = io.x;
     const StateM none = {nullptr, 0};
     // where this wavefront of the pair is (fault reports only): {phase, substep, last request tag, barrier generation} behind the control words
-    const unsigned dbg = (unsigned)SRV_DBG_OFF + (unsigned)g * (unsigned)SRV_LINE + (unsigned)(wave & 1) * 16u;
+    const unsigned dbg = (unsigned)SRV_DBG_OFF + (unsigned)g * (unsigned)SRV_LINE + (unsigned)r * 16u;
 #define R2S_SRV_STATE(ph, tg) do { if (lane == 0) { const v4u w_ = {(unsigned)(ph), k, (unsigned)(tg), (unsigned)qpar}; __builtin_amdgcn_raw_buffer_store_b128(w_, rc, dbg, 0, RES_AUX_SC1); } } while (0)
     // An OWNING pair (p.srv_own) takes one request — the claim's substep, forces already summed by the block — and from then on advances the
     // particle by itself: lane n of the pair (128 lanes >= the slice's slots) holds slot n of the particle's adjacency row, polls that
@@ -1490,7 +1519,7 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
     // republished by its block), evaluates the one spring, the pair sums, and the substep continues as for a request.  The block is no
     // longer between two substeps of a particle in contact: it takes the result, republishes it, and that is all.
     const bool own = p.srv_own != 0;
-    const int pl = (wave & 1) * 64 + lane;
+    const int pl = r * 64 + lane; // (a quad's last two wavefronts hold no slots: a slice has at most 128)
     const unsigned xn = ((unsigned)p.N + 7u) & ~7u, xe = (unsigned)e * 6u * xn, xb = 3u * xn * 16u; // (k_steps_resident's exchange array)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, 0x7fffffff, 0x00020000);
     unsigned noff = 0, roff = 0;
@@ -1586,7 +1615,7 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
                                   __uint_as_float(d1.z), sx, sv, sk, sa, p.dashpot, fxy, fz);
             const float fx = wave_sum(fxy.x), fy = wave_sum(fxy.y), fw = wave_sum(fz); // fixed trees: the same sums in every run
             QShare& qs = qsrv[pair];
-            if (lane == 0) { qs.fs[wave & 1][0] = fx; qs.fs[wave & 1][1] = fy; qs.fs[wave & 1][2] = fw; }
+            if (lane == 0 && r < 2) { qs.fs[r][0] = fx; qs.fs[r][1] = fy; qs.fs[r][2] = fw; }
             pair_barrier(qs, qpar); // (the two barriers of the queries below separate these reads from the next substep's writes)
             const f3 f = mk(qs.fs[0][0] + qs.fs[1][0], qs.fs[0][1] + qs.fs[1][1], qs.fs[0][2] + qs.fs[1][2]);
             x0 = sx;
@@ -1595,10 +1624,14 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
         }
         const bool last = (int)k == n_steps - 1;
         R2S_SRV_STATE(3, t0);
-        R2S_QP_DECL((wave & 1) == 0 ? g : -1); // (probe builds: the stamps of the pair's last substep — before, first query back, second back, after)
+        R2S_QP_DECL(r == 0 ? g : -1); // (probe builds: the stamps of the pair's last substep — before, first query back, second back, after)
         R2S_QSTAMP();
-        finish_wave<3, false, 1, true>(p, e, i, eb, first + (int)k, last ? write_forces_last : 0, x0, v, lane == 0, none, &tr, &qsrv[pair], &qpar, &X0,
-                                       (wave & 1) == 0, &io R2S_QP_ARG);
+        if (p.srv_quad)
+            finish_wave<3, false, 1, true, true>(p, e, i, eb, first + (int)k, last ? write_forces_last : 0, x0, v, lane == 0, none, &tr, &qsrv[pair], &qpar, &X0,
+                                                 r == 0, &io R2S_QP_ARG);
+        else
+            finish_wave<3, false, 1, true>(p, e, i, eb, first + (int)k, last ? write_forces_last : 0, x0, v, lane == 0, none, &tr, &qsrv[pair], &qpar, &X0,
+                                           r == 0, &io R2S_QP_ARG);
         R2S_QSTAMP();
         if (qpar & QFAIL) { // the pair's other wavefront did not reach a barrier of this substep
             if (lane == 0) resident_fault(p, 4, g, (int)k, (unsigned)wave, ei, (unsigned)qpar, (unsigned)qsrv[pair].arrived[0], (unsigned)qsrv[pair].arrived[1], t0);
@@ -1608,7 +1641,7 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
         // (lane 0 carries the particle; the other lanes' io is their own scratch)
         sx = mk(bcast(io.x.x, 0), bcast(io.x.y, 0), bcast(io.x.z, 0));
         sv = mk(bcast(io.v.x, 0), bcast(io.v.y, 0), bcast(io.v.z, 0));
-        if ((wave & 1) == 0 && lane == 0) {
+        if (r == 0 && lane == 0) {
             // version k + 1 into half (k + 1) & 1 of the result line: an owning pair may be a substep ahead of its block (it waits for its
             // neighbours' records, not for a request), never two — version k + 2 needs a neighbour's version k + 1, which nobody has before
             // the block has taken version k (from the block itself, or through its republished copy)
@@ -1624,7 +1657,7 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
         k = k + 1u;
     }
 #ifdef R2S_PHASE_PROBE
-    if ((wave & 1) == 0 && lane == 0 && g < 1024) for (int kk = 0; kk < 6; ++kk) g_phase_probe[16384 + g * 8 + kk] = sp_acc[kk];
+    if (r == 0 && lane == 0 && g < 1024) for (int kk = 0; kk < 6; ++kk) g_phase_probe[16384 + g * 8 + kk] = sp_acc[kk];
 #endif
 }
 
@@ -2772,6 +2805,8 @@ struct R2SPhys {
     int srv_wg_cap = SRV_MAX_SLOTS / 4; // R2S_RES_SRV_WG: at most this many server workgroups per launch
     int n_cu = 256;
     unsigned spin_limit = RES_SPIN_LIMIT;
+    int srv_quad = -1;        // R2S_RES_SRV_QUAD=0 / 1: pairs / quads whatever the launch has room for (-1: quads when it has >= 64 server workgroups)
+    int srv_quad_for(int n_srv) const { return srv_quad >= 0 ? srv_quad : (n_srv >= 64 ? 1 : 0); }
     int srv_own = 1;          // R2S_RES_SRV_OWN=0: one request per substep instead of pairs that own their particle
     bool split_ok = false;    // 64-particle layout whose slices fit k_steps_resident's registers (no remote neighbours, <= 64 interior / halo slots)
     bool resident_ok = false; // the handle can run the env step as ONE resident launch (k_steps_resident) in its free flavour
@@ -2872,7 +2907,7 @@ struct R2SPhys {
         p.fault = d_mesh_total ? d_mesh_total + 1 : nullptr;
         p.xch = d_xch;
         p.spin_limit = spin_limit;
-        p.srv_own = srv_own; p.srv_slots = 0; p.srv_claim = d_srv_claim; p.srv_rr = d_srv_rr; p.srv_ctl = d_srv_claim ? (int*)((char*)d_srv_claim + SRV_CTL_OFF) : nullptr;
+        p.srv_own = srv_own; p.srv_quad = 0; p.srv_slots = 0; p.srv_claim = d_srv_claim; p.srv_rr = d_srv_rr; p.srv_ctl = d_srv_claim ? (int*)((char*)d_srv_claim + SRV_CTL_OFF) : nullptr;
         return p;
     }
 };
@@ -3068,7 +3103,7 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
             if (n_srv < SRV_MIN_WG) n_srv = 0;
         }
         if (n_srv > 0) {
-            p.srv_slots = 4 * n_srv;
+            p.srv_quad = h->srv_quad_for(n_srv); p.srv_slots = (p.srv_quad ? 2 : 4) * n_srv;
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((SRV_DBG_OFF / 4 + 255) / 256)), dim3(256), 0, s, (float*)h->d_srv_claim, (size_t)SRV_DBG_OFF / 4); // claims and control words
             const size_t rw = (size_t)(SRV_REC / 4) * ne * h->N;
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((rw + 255) / 256)), dim3(256), 0, s, (float*)h->d_srv_rr + (size_t)(SRV_REC / 4) * e0 * h->N, rw);
@@ -3790,6 +3825,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             if (const char* ev = getenv("R2S_RES_SERVERS")) pref = atoi(ev) != 0;
             if (const char* ev = getenv("R2S_RES_SPIN_LIMIT")) h->spin_limit = (unsigned)std::max(1024, atoi(ev));
             if (const char* ev = getenv("R2S_RES_SRV_OWN")) h->srv_own = atoi(ev) != 0;
+            if (const char* ev = getenv("R2S_RES_SRV_QUAD")) h->srv_quad = atoi(ev) != 0;
             if (const char* ev = getenv("R2S_RES_SRV_WG")) h->srv_wg_cap = std::max(1, std::min(atoi(ev), SRV_MAX_SLOTS / 4));
             h->srv_ok = pref && h->nF > 0 && h->nF <= 128 && n_cu - 8 * (int)(((int64_t)h->nb * E + 7) / 8) >= SRV_MIN_WG;
             if (h->srv_ok) {
@@ -4158,7 +4194,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)
         int n_srv = h->srv_ok && n > 1 ? std::min(h->n_cu - 8 * ((h->nb * h->E + 7) / 8), h->srv_wg_cap) : 0; // as enqueue_steps sizes the grid
         if (n_srv < SRV_MIN_WG) n_srv = 0;
-        h->last_flavour[3] = 1 | (n_srv << 8) | ((h->srv_own ? 1 : 0) << 20);
+        h->last_flavour[3] = 1 | (n_srv << 8) | ((h->srv_own ? 1 : 0) << 20) | ((n_srv > 0 && h->srv_quad_for(n_srv) ? 1 : 0) << 21);
     }
     int gate_dev = -1;
     if (resident) { int rcg = resident_enter(s, &gate_dev); if (rcg) return rcg; }
