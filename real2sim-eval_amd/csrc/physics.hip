@@ -1401,9 +1401,9 @@ __device__ __forceinline__ void spring_groups_n(const PhysDev& p, int n, const A
 // A resident launch must not answer mesh queries inside the blocks that own the particles: a query is thousands of instructions, and
 // every block of the environment waits, hand-off by hand-off, for the slowest (measured in round 3 on the rope in a grasp: 54.8 us per
 // substep with per-lane queries in the finishing wavefronts against 2.5 us in free motion; the per-substep kernels + finishing launch the
-// step then fell back to: 11.8 us).  A one-environment launch leaves about half of the chip idle (130 blocks of the 8 k-particle rope on
-// 256 CUs), so the launch carries extra workgroups — SERVERS, four wavefront pairs each — and a particle that needs a query is handed to
-// a pair of its own through the same tagged write-through granules the blocks exchange their halos with:
+// step then fell back to: 11.8 us, 22.5 with the gripper closed on the rope).  A one-environment launch leaves about half of the chip idle (130 blocks of the 8 k-particle rope on
+// 256 CUs), so the launch carries extra workgroups — SERVERS, four wavefront pairs (or, with workgroups to spare, two quads: QQUAD) each —
+// and a particle that needs a query is handed to a unit of its own ("pair" below) through the same tagged write-through granules the blocks exchange their halos with:
 //   claim    the first time a particle needs a query its block (wavefront 0 of the finishers) takes the next free pair (one atomic) and
 //            writes {env * N + particle, first substep}; the pair serves that particle until the launch ends;
 //   request  three 16-byte granules {x0, post-force v} tagged 2 (k + 1) + 1, with the claim;
@@ -1415,16 +1415,18 @@ __device__ __forceinline__ void spring_groups_n(const PhysDev& p, int n, const A
 //            neighbours of version k itself — lane n of the pair holds slot n of the adjacency row and polls that neighbour's exchange
 //            granules (or, one hand-off earlier for a served neighbour, the result line of that neighbour's own pair) — sums the
 //            springs, updates the velocity, and continues as above.  The block no longer stands between two substeps of a particle in
-//            contact (result -> block -> forces -> request -> pair was three hand-offs per substep, 10.3 us for the rope in a grasp;
-//            pair -> pair is one: 7.4 us, of which 4.3 are the pair's own two queries).  The pair may run one version ahead of its
+//            contact (result -> block -> forces -> request -> pair was three hand-offs per substep, 9.2 - 10.5 us for the rope in a
+//            grasp; pair -> pair is one: 5.7 us, of which 3.6 are the unit's two queries and the response).  The pair may run one version ahead of its
 //            block, never two: before it writes version k + 1 over version k - 1 it has seen the block's republished copy of k - 1;
 //   per-substep requests (R2S_RES_SRV_OWN=0, the first protocol): the block sums the forces and sends a request per substep — or one
 //            granule tagged 2 (k + 1) when the particle is out of every mesh's reach in substep k (the pair skips ahead);
 //   end      a block that leaves the launch ends its pairs (tag SRV_END) and counts itself out; pairs nobody claimed leave when every
 //            block has; an owning pair leaves after the launch's last substep.
 // No more pairs than particles that ever need one are busy; a claim beyond the last pair is answered in place by the block's wavefront 0
-// (with owning pairs: in every later substep too).  Every poll is bounded like the halo polls (sticky fault word, never a hang); the
-// launch is resident as a whole (blocks + servers <= CUs), which the host guarantees when it sizes the grid.  The sums of an owning pair
+// (with owning pairs: in every later substep too; the launch reports it — p.fault[2] — and the host leaves the resident launch until the
+// contact is over).  Slots are handed out so that the first claims each get a server workgroup, i.e. a CU, of their own.  Every poll is bounded like the halo polls (sticky fault word, never a hang); the
+// launch is resident as a whole (per XCD: the grid's round-robin share of every XCD <= its CUs), which the host guarantees when it sizes
+// the grid.  The sums of an owning pair
 // are fixed trees over its lanes — the same in every run, not the order of the block's eight wavefronts (results differ from the
 // request protocol's in the last bits; both hold the oracle's 1e-5 and the per-substep kernels' 2e-6).
 // the first fault of a launch wins and records where it happened (p.fault + 3 .. + 14 = the handle's words [4..15]): code, work item,
