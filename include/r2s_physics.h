@@ -188,8 +188,9 @@ int r2s_phys_tagged_count(R2SPhys* h, int32_t* out, r2s_stream_t stream);
 /* Which captured flavour the last r2s_phys_step ran: out[0] bit 0 self-collision variant, bit 1 the handle's per-substep kernel is
  * k_steps_resident with one substep (small-batch layout), out[1] mesh template (0 none,
  * 1 every mesh small: the fused kernel answers the rare query itself unless out[2], 2 a large mesh is present: the fused
- * kernel only lists), out[2] finishing kernel in the graph (0/1; always 1 with a large mesh; 2 = the env step ran as ONE resident
- * launch, see r2s_phys_set_resident), out[3] kernel chains. */
+ * kernel only lists), out[2] finishing code in the graph (0/1; always with a large mesh; 2 = the env step ran as ONE resident
+ * launch, see r2s_phys_set_resident; 3 = like 1 with the finishers of substep k at the head of substep k + 1's launch, see
+ * r2s_phys_set_pf), out[3] kernel chains. */
 int r2s_phys_last_flavour(R2SPhys* h, int32_t* out);
 /* Tuning (not part of the reference surface): chains > 0 overrides the number of concurrent kernel chains of the captured
  * env step (0 = default), mesh_defer 0/1 forces the deferred large-mesh-query flavour (-1 = automatic).  The environment
@@ -203,6 +204,12 @@ int r2s_phys_set_tuning(R2SPhys* h, int chains, int mesh_defer);
  * with the per-substep kernels of the same layout (tests compare the two; R2S_RESIDENT=0 at create also keeps the large-batch
  * layout).  Results of the two agree to the last bits (different summation order), not bit for bit. */
 int r2s_phys_set_resident(R2SPhys* h, int on);
+/* Large batches (the 256-particle layout), contact flavours: what the fused substep kernel cannot finish in its own thread — deferred
+ * mesh queries, particles with self-collision candidates (spring_mass_warp.py:845-943 runs object_collision and mesh_collision as
+ * launches of their own every substep) — is finished by the first workgroups of the NEXT substep's launch (k_substep_pf), and only
+ * the blocks that hold such a particle wait for it: one launch per substep instead of two.  on = 0 keeps the two-launch form
+ * (fused kernel + k_contact_finish per substep; also R2S_PF=0 at create); states agree bit for bit (tests/test_pf_gpu.py). */
+int r2s_phys_set_pf(R2SPhys* h, int on);
 /* The device's pooled side stream k (1 .. 7) — the streams the library launches the kernel chains 1.. of an env step on; created on
  * first use, shared by every handle of the current device, never destroyed.  For callers that want work of their own next to the
  * launch stream BETWEEN env steps (the rollout runs update_collision_graph there while the launch stream renders): a stream of the

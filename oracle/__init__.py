@@ -11,7 +11,11 @@ imported as a whole in the authoring container.
    known-answer tests (``tests/test_raster_oracle_kat.py``); the camera builder is pinned
    (``tests/golden/camera_side_848x480.json``, made by the reference's own setup_camera);
  * physics stepper: arithmetic kernels pinned by fixtures made by executing the reference's
-   kernel bodies through a float32 shim (``tests/golden/physics_kernels.npz``); its caller
+   kernel bodies through a float32 shim (``tests/golden/physics_kernels.npz``) — the fixtures pin the
+   kernel BODIES (which value is combined with which, in what order, under which branch), NOT
+   warp's primitives: ``tests/golden/warp_shim.py`` is a builder-written reading of ``wp.dot`` /
+   ``wp.length`` / ``wp.normalize`` / the atomics in thread order, and fixture C's mesh query is
+   answered by this oracle's own routine (a soft pin, and circular for the query); its caller
    (``SpringMassDynamicsModule.step``) by ``tests/golden/eef_step.npz``, made by the reference's own
    method; warp's HashGrid traversal and mesh query: PARITY UNPINNED (restated,
    ``tests/test_physics_oracle_kat.py``).
@@ -32,14 +36,24 @@ _LIB_PATH = os.path.join(_HERE, "libr2s_oracle.so")
 _lib = None
 
 
-def build(force: bool = False) -> str:
-    """Compile the C oracles with gcc (``make -C oracle``)."""
+def _stale(path: str) -> bool:
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".inc"))]
-    libs = [_LIB_PATH, os.path.join(_HERE, "libr2s_cpu_baseline.so")]
-    stale = any((not os.path.exists(p)) or any(os.path.getmtime(s) > os.path.getmtime(p) for s in srcs) for p in libs)
-    if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+    return (not os.path.exists(path)) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs)
+
+
+def build(force: bool = False) -> str:
+    """Compile the CHECKER (``make -C oracle libr2s_oracle.so``).  The timing build (libr2s_cpu_baseline.so: -march=x86-64-v3,
+    needs an x86 host and gcc >= 11) is built and loaded lazily by ``baseline_build()`` only: a failure there must never keep
+    the parity tests from loading the checker."""
+    if force or _stale(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "-s", "libr2s_oracle.so"])
     return _LIB_PATH
+
+
+def build_baseline(force: bool = False) -> str:
+    if force or _stale(_BASE_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "-s", "libr2s_cpu_baseline.so"])
+    return _BASE_PATH
 
 
 def _load(path) -> C.CDLL:
@@ -80,7 +94,7 @@ def baseline_build():
     for the duration of the block: bench.py's ``cpu_baseline`` leg.  A timing build, not a checker."""
     global _blib, _override
     if _blib is None:
-        build()
+        build_baseline()
         _blib = _load(_BASE_PATH)
     _override = _blib
     try:

@@ -92,7 +92,13 @@ int r2s_oracle_phys_step_batch_par_f32(const phys_t_f32 *envs, float **x, float 
                     }   /* implicit barrier */
                     mesh_collision_range_f32(P, &m, s, xe, vbg, lo, hi, 1);
                 }
-                /* x[i] / v[i] of this thread's own particles only from here on, but the next substep's gather reads its neighbours' */
+                /* x[i] / v[i] of this thread's own particles only from here on, but the next substep's gather reads its neighbours' —
+                 * and so does THIS substep's gather of a slower thread: integrate_ground overwrites x and v in place, so every thread's
+                 * gather must be over first.  The self-collision block and the `omp single` of the mesh block end in barriers; a scene with
+                 * neither (free springs over the ground) needs one of its own. */
+                if (!P->self_collision && !(P->nF > 0)) {
+#pragma omp barrier
+                }
                 integrate_ground_range_f32(P, xe, vbg, ve, lo, hi);
 #pragma omp barrier
             }

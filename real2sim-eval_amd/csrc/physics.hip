@@ -97,11 +97,16 @@ struct PhysDev {
     const int* coll_num;       // [E,N]
     const int* coll_idx;       // [E,N,cap]
     int coll_cap;
-    float4* vbc;               // [E,N] v_before_collision published by particles that have candidates; also the velocity of
+    // What a substep hands to its finishing code is kept per substep PARITY ([2][...], par_off(p, step)): with the finishing code of
+    // substep k at the head of substep k + 1's launch (p.pf, below) the fused blocks of k + 1 publish while the finishers of k still read.
+    size_t par_stride;         // E * N: element offset of the odd substeps' half of vbc / xbc / vdef / cand_mark / mesh_list (mesh_rec: 2 x)
+    float4* vbc;               // [2][E,N] v_before_collision published by particles that have candidates; also the velocity of
                                // particles whose large-mesh query is deferred to k_contact_finish
-    float4* vdef;              // [E,N] velocity of the particles whose mesh query is deferred to k_contact_finish (vbc must keep the
+    float4* xbc;               // [2][E,N] position at the top of the substep of every particle the fused kernel leaves to the finishing code
+                               // (candidates AND deferred mesh queries): the finishers read positions from here, never from the state arrays
+    float4* vdef;              // [2][E,N] velocity of the particles whose mesh query is deferred to k_contact_finish (vbc must keep the
                                // pre-impulse value while other particles' self-collision loops still read it)
-    int2* mesh_list;           // (env, particle) of the particles deferred in this substep (one list per chain, reused)
+    int2* mesh_list;           // [2][...] (env, particle) of the particles deferred in this substep (one list per chain and parity)
     int* mesh_cnt;             // [n_sub + 1] entries of mesh_list per substep; [n_sub] = particles NEAR a mesh over the whole env step
                                // (margin + NEAR_PAD: what the host picks the next step's flavour from); zeroed once per env step
     int mesh_cap, mesh_defer;  // defer = 1: needy particles go to the list; 0: they are queried in place
@@ -111,8 +116,9 @@ struct PhysDev {
                                // transform are ONE round trip before the query (the chain-wide list costs two: entry, then state)
     int* rec_cnt;
     int* cand_mark;            // [E,N] = substep + 1 when a particle with candidates was handed to the mesh list in that substep
-    const int2* cand_list;     // (env, particle) of every particle with candidates
-    const int* cand_count;
+    const int2* cand_list;     // [E][N] per ENVIRONMENT: (env | candidate count << 12, particle) of its particles with candidates, cand_cnt_env[e] of them
+    const int* cand_count;     // all of them
+    const int* cand_cnt_env;   // [E]
     // meshes
     int n_mesh, n_dyn_mesh, nF, nV, n_dyn_pts;
     const int* faces;          // [nF,3] global vertex ids, in STORED order (large meshes: Morton-sorted clusters)
@@ -157,7 +163,13 @@ struct PhysDev {
     int srv_quad;              // server units are quads of wavefronts (two particles per server workgroup) instead of pairs (four)
     int srv_own;               // servers OWN their particle from the claim on: spring forces from the neighbours' exchange records, velocity update, mesh response, ground (0: one request per substep, round 4's first protocol)
     unsigned spin_limit;       // poll passes before a workgroup of the resident launch gives up (RES_SPIN_LIMIT; R2S_RES_SPIN_LIMIT at create: diagnostics)
+    // large batches, contact flavours (round 5): the finishing code of substep k runs at the HEAD of substep k + 1's launch (k_substep_pf)
+    int pf;                    // this launch sequence runs that way
+    int pf_nfin;               // finishing workgroups at the head of a launch (a multiple of 8: the fused blocks behind them keep their XCDs)
+    void* pf_res;              // [E][N] x 128 B: a particle's finished state of substep k as three 16-byte granules {value, tag, value, tag},
+                               // tag = k + 1, written through (sc1) by its finisher: ONE writer per 128-byte line (see SRV_LINE)
 };
+__device__ __forceinline__ size_t par_off(const PhysDev& p, int step) { return (size_t)(step & 1) * p.par_stride; }
 
 // Everything from here to the spring gather is compiled WITHOUT fused multiply-add contraction: the collision
 // and mesh-query arithmetic then rounds exactly like the formulas read (and like the CPU oracle), so discrete
@@ -401,6 +413,7 @@ struct QShare {
     int meta[2][QWPB][5];            // stored face, feature region, mesh kind, transform slot, cluster
     volatile int sup[QWPB][8];       // per wavefront: lanes that own the super-clusters of the current round
     int arrived[4];                  // server units (pairs / quads of wavefronts): the last barrier generation each wavefront has arrived at
+    unsigned spin;                   // server units: passes of the unit barrier's wait before it gives up (4 x PhysDev::spin_limit: an LDS read per pass)
     float fs[2][4];                  // pair mode, owning servers: the two wavefronts' sums of the particle's spring forces
 };
 // mesh_query_regs is run by TWO wavefronts: a 128-thread workgroup of k_contact_finish<3> (barrier = __syncthreads), or one of the four
@@ -430,7 +443,7 @@ __device__ __forceinline__ void pair_barrier(QShare& sm, int& parity)
         int m = __hip_atomic_load(&sm.arrived[w ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (quad) m = min(m, min(__hip_atomic_load(&sm.arrived[w ^ 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), __hip_atomic_load(&sm.arrived[w ^ 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
         if (m >= gen) break;
-        if (spins >= (1u << 23)) { parity |= QFAIL; break; }         // a fraction of a second: a partner is gone (never in a sound launch)
+        if (spins >= sm.spin) { parity |= QFAIL; break; }            // a fraction of a second by default (R2S_RES_SPIN_LIMIT shortens it with the other limits): a partner is gone (never in a sound launch)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -787,6 +800,80 @@ __device__ __forceinline__ MeshHit mesh_query_regs(const TriRegs& t, f3 q, bool 
     return out;
 }
 
+// ---- finishing at the HEAD of the next launch (large batches in contact; round 5) --------------------------------------------------
+// The contact flavours of a large batch ran two dependent launches per substep: the fused kernel, then k_contact_finish for what it
+// could not finish in its own thread (deferred mesh queries, particles with self-collision candidates) — 18.6 us of kernels in a
+// 23.3 us period per chain of the headline scene, and every block of the next substep waited for the few hundred particles of the
+// finishing launch.  With p.pf the finishing code of substep k is the first pf_nfin workgroups of substep k + 1's launch
+// (k_substep_pf): it starts at once (workgroups are dispatched in order: it is resident before any fused block), the fused blocks of
+// k + 1 start next to it, and only a block that HOLDS an unfinished particle in its window waits for it:
+//   * the fused kernel of substep k stores PF_SENT in all six words of the state record of every particle it leaves to the finishers;
+//   * a finisher stores the particle's finished state in the particle's own 128-byte line of p.pf_res as three 16-byte granules
+//     {value, tag, value, tag}, tag = k + 1, write-through (sc1) — the data is the flag (cdna_hip_programming.md, Guideline 16 R2;
+//     the resident stepper's hand-off), one writer per line (a write-through store into a line of which the writer's L2 holds an
+//     older copy does not leave the line's other bytes alone: see SRV_LINE);
+//   * a block of substep k + 1 that stages a PF_SENT record polls that line with L1-bypassing loads until the three tags read k + 1
+//     (bounded: fault code 6, never a hang) and stages the finished record instead;
+//   * what the finishers READ — the list, positions (xbc), post-force velocities (vbc / vdef), marks — is kept per substep parity,
+//     because the fused blocks of k + 1 publish theirs at the same time; the state arrays are not read by finishers at all;
+//   * the last substep of an env step is finished by the stand-alone k_contact_finish, which writes the state array as before: no
+//     PF_SENT record survives a r2s_phys_step.
+// One launch boundary per substep instead of two, and the finishing latency overlaps the blocks that do not depend on it.  The
+// price: the launch carries the registers of the larger role (4 instead of 6 workgroups per CU for the fused blocks of the headline).
+// Same arithmetic on the same inputs in the same order as the two-launch flavour: bit-identical states (tests/test_pf_gpu.py).
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+constexpr unsigned PF_SENT = 0x7fc5e7a1u;          // a quiet NaN with a payload
+constexpr int PF_LINE = 128;
+constexpr int PF_AUX_STORE = 16;                   // buffer-instruction cache policy: sc1 = agent scope, write-through
+constexpr int PF_AUX_LOAD = 16 | (int)0x80000000;  // sc1 + the compiler-side volatile bit (= sc0 sc1 in the instruction): L1-bypassing
+// the first fault of a launch wins and records where it happened (p.fault + 3 .. + 14 = the handle's words [4..15]): code, work item,
+// substep, and six words of context — what the host's error message prints
+__device__ __forceinline__ void resident_fault(const PhysDev& p, int code, int item, int k, unsigned a, unsigned b, unsigned c, unsigned d, unsigned e2, unsigned f)
+{
+    if (!p.fault) return;
+    if (atomicCAS(p.fault, 0, code) == 0) {
+        int* w = p.fault + 3;
+        w[0] = code; w[1] = item; w[2] = k; w[3] = (int)a; w[4] = (int)b; w[5] = (int)c; w[6] = (int)d; w[7] = (int)e2; w[8] = (int)f;
+    }
+}
+__device__ __forceinline__ bool pf_pending(v2f a) { return __float_as_uint(a.x) == PF_SENT && __float_as_uint(a.y) == PF_SENT; }
+__device__ __forceinline__ void pf_mark(StateM s, size_t i) // "not finished in this launch": every word, so that a reader of any plane sees it
+{
+    const v2f w = {__uint_as_float(PF_SENT), __uint_as_float(PF_SENT)};
+    s.p[st_at(s.n, i, 0)] = w; s.p[st_at(s.n, i, 1)] = w; s.p[st_at(s.n, i, 2)] = w;
+}
+__device__ __forceinline__ void pf_store(const PhysDev& p, size_t ei, f3 x, f3 v, unsigned tag)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(p.pf_res, 0, 0x7fffffff, 0x00020000);
+    const unsigned off = (unsigned)ei * (unsigned)PF_LINE;
+    const v4u w0 = {__float_as_uint(x.x), tag, __float_as_uint(x.y), tag}, w1 = {__float_as_uint(x.z), tag, __float_as_uint(v.z), tag},
+              w2 = {__float_as_uint(v.x), tag, __float_as_uint(v.y), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(w0, r, off, 0, PF_AUX_STORE);
+    __builtin_amdgcn_raw_buffer_store_b128(w1, r, off + 16u, 0, PF_AUX_STORE);
+    __builtin_amdgcn_raw_buffer_store_b128(w2, r, off + 32u, 0, PF_AUX_STORE);
+}
+// the finished record (state words xy | z vz | vxy) of particle ei = env * N + particle from the substep before `step`; waits for it
+__device__ __forceinline__ void pf_wait(const PhysDev& p, size_t ei, int step, int item, v2f& a, v2f& b, v2f& c)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(p.pf_res, 0, 0x7fffffff, 0x00020000);
+    const unsigned off = (unsigned)ei * (unsigned)PF_LINE, tag = (unsigned)step;
+    for (unsigned spins = 0;; ++spins) {
+        const v4u d0 = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, PF_AUX_LOAD), d1 = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16u, 0, PF_AUX_LOAD),
+                  d2 = __builtin_amdgcn_raw_buffer_load_b128(r, off + 32u, 0, PF_AUX_LOAD);
+        if (d0.y == tag && d0.w == tag && d1.y == tag && d1.w == tag && d2.y == tag && d2.w == tag) {
+            a = (v2f){__uint_as_float(d0.x), __uint_as_float(d0.z)}; b = (v2f){__uint_as_float(d1.x), __uint_as_float(d1.z)};
+            c = (v2f){__uint_as_float(d2.x), __uint_as_float(d2.z)};
+            return;
+        }
+        if (spins >= p.spin_limit) { // the finisher never delivered: the state is invalid from here on, and the next r2s_phys_step says so
+            resident_fault(p, 6, item, step, (unsigned)ei, d0.y, d0.w, d1.y, d2.y, spins);
+            a = (v2f){0.f, 0.f}; b = a; c = a;
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 // ---- spring forces: gather form of eval_springs (:61-104) ----------------------------------------
 // Force on particle i from neighbour j:  [k (L/rest - 1) + c ((vj - vi) . d)] d,  d = (xj - xi) / max(L, 1e-6).
 // This is exactly the reference's +F on springs[s][0] and -F on springs[s][1] (the sign flips cancel), summed
@@ -877,7 +964,7 @@ __device__ __forceinline__ void spring_group(const PhysDev& p, const AdjGroup& g
 template <int RCAP>
 __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const StateC xv,
                                                const __attribute__((address_space(3))) char* win, size_t env_base, int sl, int ln, f3 xi,
-                                               f3 vi, int srow, int ngroups, AdjGroup g0)
+                                               f3 vi, int srow, int ngroups, AdjGroup g0, int pf_step = -1)
 {
     v2f fxy = {0.f, 0.f};
     float fz = 0.f;
@@ -898,7 +985,8 @@ __device__ __forceinline__ f3 spring_force_lds(const PhysDev& p, const StateC xv
     for (int n = 0; n < rdeg; ++n) {
         const int4 en = ra[n * SLICE];
         const size_t gi = env_base + (size_t)en.x;
-        const v2f jxy = xv.p[st_at(xv.n, gi, 0)], jz = xv.p[st_at(xv.n, gi, 1)], jv = xv.p[st_at(xv.n, gi, 2)];
+        v2f jxy = xv.p[st_at(xv.n, gi, 0)], jz = xv.p[st_at(xv.n, gi, 1)], jv = xv.p[st_at(xv.n, gi, 2)];
+        if (pf_step >= 0 && pf_pending(jxy)) pf_wait(p, gi, pf_step, -1, jxy, jz, jv); // (k_substep_pf: a neighbour the previous substep left to the finishers)
         spring_term(jxy, jz.x, jv, jz.y, xi, vi, __int_as_float(en.y), __int_as_float(en.z), p.dashpot, fxy, fz);
     }
     return {fxy.x, fxy.y, fz};
@@ -974,7 +1062,7 @@ __device__ __forceinline__ bool mesh_rec_push(const PhysDev& p, int e, int step,
 {
     const int slot = atomicAdd(p.rec_cnt + (size_t)e * p.n_sub + step, 1);
     if (slot >= p.N) return false;
-    int4* r = p.mesh_rec + 2 * ((size_t)e * p.N + slot);
+    int4* r = p.mesh_rec + 2 * (par_off(p, step) + (size_t)e * p.N + slot);
     r[0] = make_int4(ncand, ncand > 0 ? (i | (int)0x80000000) : i, __float_as_int(x0.x), __float_as_int(x0.y));
     r[1] = make_int4(__float_as_int(x0.z), __float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z));
     return true;
@@ -994,8 +1082,10 @@ __device__ __forceinline__ bool mesh_rec_push(const PhysDev& p, int e, int step,
 // found nothing in reach: mesh_collision then only advances the position, :321 / :420)
 // KEEP (the resident stepper): every lane with `fin` also returns its new state in keep->x / keep->v and only stores it when
 // xv_out.p is set (the launch's last substep); the mesh boxes of the early-out come from *keep.
-template <int MESH, bool MAIN = false, int NEED = 0, bool KEEP = false, bool QUAD = false>
-__device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v, bool fin,
+// PFOUT (the finishers at the head of the next launch, p.pf): the finished state goes to the particle's line of p.pf_res, tagged step + 1,
+// instead of the state array.  Returns whether THIS call finished (and stored / kept) the lane's particle.
+template <int MESH, bool MAIN = false, int NEED = 0, bool KEEP = false, bool QUAD = false, bool PFOUT = false>
+__device__ __forceinline__ bool finish_wave(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v, bool fin,
                                             const StateM xv_out, const TriRegs* tr, QShare* qs, int* qpar, const Xf* xf0, bool store, ResidentIO* keep R2S_QP_PARAM)
 {
     f3 x = x0;
@@ -1026,8 +1116,10 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
             } else if (need && p.mesh_defer) {
                 const int slot = atomicAdd(p.mesh_cnt + step, 1);
                 if (slot < p.mesh_cap) {
-                    p.vdef[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
-                    p.mesh_list[slot] = make_int2(e, i);
+                    const size_t po = par_off(p, step);
+                    p.vdef[po + eb + i] = make_float4(v.x, v.y, v.z, 0.f);
+                    p.xbc[po + eb + i] = make_float4(x0.x, x0.y, x0.z, 0.f);
+                    p.mesh_list[po + slot] = make_int2(e, i);
                     fin = false; // finished by k_contact_finish
                     need = false;
                 }
@@ -1146,9 +1238,12 @@ __device__ __forceinline__ void finish_wave(const PhysDev& p, int e, int i, size
             toi = 0.f;
         }
         const f3 xn = x + v * toi + v1 * (p.dt - toi);
-        if (store && (!KEEP || xv_out.p != nullptr)) st_store(xv_out, eb + i, xn, v1);
+        if (PFOUT) { if (store) pf_store(p, eb + (size_t)i, xn, v1, (unsigned)step + 1u); }
+        else if (store && (!KEEP || xv_out.p != nullptr)) st_store(xv_out, eb + i, xn, v1);
         if (KEEP) { keep->x = xn; keep->v = v1; }
+        return true;
     }
+    return false;
 }
 
 // ---- the fused substep ------------------------------------------------------------------------------
@@ -1172,13 +1267,15 @@ extern "C" int r2s_phys_debug_phase_probe(long long* out, int n)
 #define R2S_STAMP(k) do { } while (0)
 #endif
 
-template <int B, int RCAP, bool SELF, int MESH>
+// PF: the launch is a k_substep_pf — `bid` = the workgroup's number among the fused blocks (behind the finishers), records of particles the
+// previous substep left unfinished are PF_SENT and come from the finishers' result lines, particles this substep leaves unfinished get PF_SENT
+template <int B, int RCAP, bool SELF, int MESH, bool PF = false>
 __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_in, const StateM xv_out, int step,
-                                             int write_forces)
+                                             int write_forces, int bid)
 {
     static_assert(B % SLICE == 0 && RCAP >= B && RCAP * 8 <= 65536, "window offsets are u16 bytes");
     __shared__ __attribute__((aligned(16))) v2f win_s[3 * (RCAP + 1)]; // planes xy | (z, vz) | vxy, 24 B per record (+ 1 pad each)
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int xcd = bid & 7, q = bid >> 3;
     const int item = xcd * p.cb + q;
     if (q >= p.cb || item >= p.nb * p.ne) return; // whole workgroup
     const int b = item / p.ne, e = p.e0 + (item - b * p.ne);
@@ -1229,6 +1326,11 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
             if (part[k] < p.N) { qa[k] = xv_in.p[st_at(xv_in.n, g, 0)]; qb[k] = xv_in.p[st_at(xv_in.n, g, 1)]; qc[k] = xv_in.p[st_at(xv_in.n, g, 2)]; }
             else { qa[k] = (v2f){0.f, 0.f}; qb[k] = qa[k]; qc[k] = qa[k]; }
         }
+        if (PF) { // records the previous substep left to the finishers at the head of THIS launch: wait for theirs (a few blocks per environment)
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (part[k] < p.N && pf_pending(qa[k])) pf_wait(p, eb + (size_t)part[k], step, item, qa[k], qb[k], qc[k]);
+        }
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
             const int r = tid + (k0 + k) * B;
@@ -1249,7 +1351,7 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
 
     // eval_springs + update_vel_from_force
     const __attribute__((address_space(3))) char* win = (const __attribute__((address_space(3))) char*)win_s;
-    f3 v = vel_update(p, v0, spring_force_lds<RCAP>(p, xv_in, win, eb, sl, lane, x0, v0, srow, ngroups, g0), m1);
+    f3 v = vel_update(p, v0, spring_force_lds<RCAP>(p, xv_in, win, eb, sl, lane, x0, v0, srow, ngroups, g0, PF ? step : -1), m1);
 #ifdef R2S_PHASE_PROBE
     if (v.x == 1.2345e33f) return; // keep the stamp after the gather
 #endif
@@ -1262,7 +1364,9 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
     if (SELF) {
         const int ncand = valid ? p.coll_num[eb + i] : 0;
         if (ncand > 0) {
-            p.vbc[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
+            const size_t po = par_off(p, step);
+            p.vbc[po + eb + i] = make_float4(v.x, v.y, v.z, 0.f);
+            p.xbc[po + eb + i] = make_float4(x0.x, x0.y, x0.z, 0.f);
             fin = false; // finished by k_self_finish / k_contact_finish
             if (MESH != 0 && (p.mesh_defer || MESH == 2)) {
                 // Will it also need a mesh query?  Its velocity is not final (the impulses come later), so the test is widened
@@ -1272,12 +1376,12 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
                 if (mesh_need(p, e, step, x0 + v * p.dt, 0.002f, near)) {
                     p.fault[1] = 1;
                     if (MESH == 2) {
-                        if (mesh_rec_push(p, e, step, i, ncand, x0, v)) p.cand_mark[eb + i] = step + 1;
+                        if (mesh_rec_push(p, e, step, i, ncand, x0, v)) p.cand_mark[po + eb + i] = step + 1;
                     } else {
                         const int slot = atomicAdd(p.mesh_cnt + step, 1);
                         if (slot < p.mesh_cap) {
-                            p.mesh_list[slot] = make_int2(e | (ncand << 12), i | (int)0x80000000);
-                            p.cand_mark[eb + i] = step + 1;
+                            p.mesh_list[po + slot] = make_int2(e | (ncand << 12), i | (int)0x80000000);
+                            p.cand_mark[po + eb + i] = step + 1;
                         }
                     }
                 }
@@ -1287,7 +1391,8 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
         }
     }
     R2S_QP_DECL(-1);
-    finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
+    const bool done = finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
+    if (PF && valid && !done) pf_mark(xv_out, eb + i); // left to the finishers at the head of the next launch
     R2S_STAMP(3);
 }
 
@@ -1301,7 +1406,7 @@ template <int B, int RCAP, bool SELF, int MESH>
 __global__ void __launch_bounds__(B, (B == 256 ? 6 : 1)) k_substep(const PhysDev p, const StateC xv_in, const StateM xv_out, int step,
                                                int write_forces)
 {
-    substep_body<B, RCAP, SELF, MESH>(p, xv_in, xv_out, step, write_forces);
+    substep_body<B, RCAP, SELF, MESH>(p, xv_in, xv_out, step, write_forces, (int)blockIdx.x);
 }
 // ---- the resident stepper: every substep of an env step in ONE launch (small batches) ---------------------------
 // A batch whose (block, env) work items are all on the chip at once — one environment of the reference's own evaluation loop
@@ -1344,7 +1449,6 @@ constexpr int RES_AUX_SC1 = 16;                 // buffer-instruction cache poli
 #endif
 constexpr int RES_AUX_LOAD = R2S_RES_AUXLD;     // poll loads: sc1 + the compiler-side volatile bit (= sc0 sc1 in the instruction)
 constexpr int RES_PRE = R2S_RES_PRE;            // interior groups evaluated BEFORE the first poll pass is issued
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // NG groups back to back, no branch in between: the LDS reads of a later group are scheduled under the arithmetic of an earlier one
 // (two wavefronts share a SIMD here, six in the fused substep: most of the latency the instruction stream exposes is paid)
@@ -1431,14 +1535,7 @@ __device__ __forceinline__ void spring_groups_n(const PhysDev& p, int n, const A
 // request protocol's in the last bits; both hold the oracle's 1e-5 and the per-substep kernels' 2e-6).
 // the first fault of a launch wins and records where it happened (p.fault + 3 .. + 14 = the handle's words [4..15]): code, work item,
 // substep, and six words of context — what the host's error message prints
-__device__ __forceinline__ void resident_fault(const PhysDev& p, int code, int item, int k, unsigned a, unsigned b, unsigned c, unsigned d, unsigned e2, unsigned f)
-{
-    if (!p.fault) return;
-    if (atomicCAS(p.fault, 0, code) == 0) {
-        int* w = p.fault + 3;
-        w[0] = code; w[1] = item; w[2] = k; w[3] = (int)a; w[4] = (int)b; w[5] = (int)c; w[6] = (int)d; w[7] = (int)e2; w[8] = (int)f;
-    }
-}
+// (resident_fault: defined with the head-of-launch finishing helpers above finish_wave)
 constexpr unsigned SRV_END = 0x7ffffffeu;
 // Every granule array below is laid out so that no 128-byte line has writers in two workgroups (= possibly two XCDs, whose L2s are not
 // coherent): a claim per line, a line of requests (written by the particle's block) and a line of results (by its server pair) per
@@ -1474,7 +1571,7 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
     // a UNIT serves one particle: a pair of wavefronts (four units per workgroup) or, when the launch has server workgroups to spare, a quad
     // (two units: see QQUAD) — `r` is the wavefront's place in its unit
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, wpp = p.srv_quad ? 4 : 2, pair = wave / wpp, r = wave % wpp;
-    if (tid < 4) { qsrv[tid].arrived[0] = 0; qsrv[tid].arrived[1] = 0; qsrv[tid].arrived[2] = 0; qsrv[tid].arrived[3] = 0; }
+    if (tid < 4) { qsrv[tid].arrived[0] = 0; qsrv[tid].arrived[1] = 0; qsrv[tid].arrived[2] = 0; qsrv[tid].arrived[3] = 0; qsrv[tid].spin = p.spin_limit < (1u << 30) ? 4u * p.spin_limit : 0xffffffffu; }
     __syncthreads();
     // slots are claimed in increasing order: slot = pair * (server workgroups) + workgroup, so that the first claims each get a CU of their
     // own (a pair that shares its two SIMDs with another busy pair of the same workgroup ran its queries slower)
@@ -1903,19 +2000,21 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             if (SELF) { // as in substep_body: particles with candidates publish v_before_collision and are finished by k_self_finish / k_contact_finish
                 const int ncand = valid ? p.coll_num[eb + i] : 0;
                 if (ncand > 0) {
-                    p.vbc[eb + i] = make_float4(v.x, v.y, v.z, 0.f);
+                    const size_t po = par_off(p, step);
+                    p.vbc[po + eb + i] = make_float4(v.x, v.y, v.z, 0.f);
+                    p.xbc[po + eb + i] = make_float4(x0.x, x0.y, x0.z, 0.f);
                     fin = false;
                     if (MESH != 0 && (p.mesh_defer || MESH == 2)) {
                         bool near;
                         if (mesh_need(p, e, step, x0 + v * p.dt, 0.002f, near)) {
                             p.fault[1] = 1;
                             if (MESH == 2) {
-                                if (mesh_rec_push(p, e, step, i, ncand, x0, v)) p.cand_mark[eb + i] = step + 1;
+                                if (mesh_rec_push(p, e, step, i, ncand, x0, v)) p.cand_mark[po + eb + i] = step + 1;
                             } else {
                                 const int slot = atomicAdd(p.mesh_cnt + step, 1);
                                 if (slot < p.mesh_cap) {
-                                    p.mesh_list[slot] = make_int2(e | (ncand << 12), i | (int)0x80000000);
-                                    p.cand_mark[eb + i] = step + 1;
+                                    p.mesh_list[po + slot] = make_int2(e | (ncand << 12), i | (int)0x80000000);
+                                    p.cand_mark[po + eb + i] = step + 1;
                                 }
                             }
                         }
@@ -2051,7 +2150,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
 // object_collision for ONE particle by a whole wavefront / a group of lanes: the lanes stride over its candidates (up to 500,
 // each a dependent gather of the partner's position and published velocity), `G` = lanes per particle (a power of two).
 template <int G>
-__device__ __forceinline__ f3 self_impulse(const PhysDev& p, const StateC xv_in, size_t eb, int i, bool act, f3 x0, f3 v, int sub,
+__device__ __forceinline__ f3 self_impulse(const PhysDev& p, size_t po, size_t eb, int i, bool act, f3 x0, f3 v, int sub,
                                            int cnt)
 {
     float valid = 0.f, m1 = 1.f;
@@ -2061,9 +2160,9 @@ __device__ __forceinline__ f3 self_impulse(const PhysDev& p, const StateC xv_in,
         const int mask1 = p.masks[i];
         for (int k = sub; k < cnt; k += G) { // cnt rides in the list entry: the candidate indices load in the same round trip as x0 / v
             const int j = p.coll_idx[(eb + i) * (size_t)p.coll_cap + k];
-            const f3 x2 = st_x(xv_in, eb + j);
-            const f3 v2 = xyz(p.vbc[eb + j]); // j lists i too (the candidate relation is symmetric; a capped row still has
-                                               // coll_num > 0), so j published its velocity in the fused kernel
+            const f3 x2 = xyz(p.xbc[po + eb + j]);
+            const f3 v2 = xyz(p.vbc[po + eb + j]); // j lists i too (the candidate relation is symmetric; a capped row still has
+                                                    // coll_num > 0), so j published its position and velocity in the fused kernel (po: this substep's parity)
             const float m2 = p.masses[j];
             const f3 dis = x2 - x0;
             const float dis_len = len(dis);
@@ -2100,17 +2199,19 @@ __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const Stat
                                                      int write_forces)
 {
     constexpr int G = 16;
-    const int n = *p.cand_count;
     const int sub = (int)(threadIdx.x & (G - 1)), grp = (int)(threadIdx.x / G), gpb = (int)(blockDim.x / G);
-    // wave-uniform trip count: every lane of a wavefront reaches the cooperative mesh queries of finish_wave together
-    for (int base = blockIdx.x * gpb; base < n; base += gridDim.x * gpb) {
-        const int t = base + grp;
-        const int2 ei = p.cand_list[t < n ? t : 0];
-        const bool act = t < n && (ei.x & 0xfff) >= p.e0 && (ei.x & 0xfff) < p.e0 + p.ne; // this chain's environments only
-        const int e = ei.x & 0xfff, i = ei.y, cnt = ei.x >> 12;
-        const size_t eb = (size_t)e * p.N;
-        const f3 x0 = st_x(xv_in, eb + i);
-        const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, xyz(p.vbc[eb + i]), sub, cnt);
+    // the candidate lists are per environment: group g of the launch walks slots g / ne, g / ne + stride, ... of environment e0 + g % ne
+    // (this chain's environments only; a wave-uniform trip count: the group shuffles inside run with their lanes together)
+    const int g = (int)blockIdx.x * gpb + grp, stride = (int)gridDim.x * gpb / p.ne;
+    const int e = p.e0 + g % p.ne;
+    const int n = g / p.ne < stride ? p.cand_cnt_env[e] : 0;
+    for (int t = g / p.ne; __builtin_amdgcn_ballot_w64(t < n) != 0ull; t += stride) {
+        const bool act = t < n;
+        const int2 ei = p.cand_list[(size_t)e * p.N + (act ? t : 0)];
+        const int i = ei.y, cnt = ei.x >> 12;
+        const size_t eb = (size_t)e * p.N, po = par_off(p, step);
+        const f3 x0 = xyz(p.xbc[po + eb + i]);
+        const f3 v = self_impulse<G>(p, po, eb, i, act, x0, xyz(p.vbc[po + eb + i]), sub, cnt);
         R2S_QP_DECL(-1);
         finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
     }
@@ -2125,12 +2226,15 @@ __global__ void __launch_bounds__(256) k_self_finish(const PhysDev p, const Stat
 //   part 2  (WITH_SELF) the remaining particles of the candidate list, 16 lanes each, finished in place.
 // Both parts only read what the fused kernel published, so they need no order between them: one launch boundary per
 // substep instead of two (k_self_finish + a mesh kernel), and the two kinds of work overlap.
-template <int MESHQ, bool WITH_SELF>
-__global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const StateC xv_in, const StateM xv_out, int step,
-                                                        int write_forces)
+// The body is shared by the stand-alone kernel (k_contact_finish: its own launch behind the fused kernel; results into the state array)
+// and by the head of k_substep_pf (PFOUT: the finishers of the PREVIOUS substep at the head of a launch; results into p.pf_res).
+// `L` / `n_wg`: this finishing workgroup's number and their count; `nthr`: its live threads (128 for MESHQ 3, else 256).
+// Nothing here reads the state arrays: positions come from the records / p.xbc, velocities from p.vbc / p.vdef, all of the substep's parity.
+template <int MESHQ, bool WITH_SELF, bool PFOUT>
+__device__ __forceinline__ void contact_finish_body(const PhysDev& p, const StateM xv_out, int step, int write_forces, int L, int n_wg, int nthr, QShare& qshare)
 {
-    // The few wavefronts of this kernel are a chain of dependent round trips that the whole env step waits for, and they share
-    // the chip with the other chain's fused kernel: let them win the instruction-issue arbitration on their SIMDs.
+    // The few wavefronts of this code are a chain of dependent round trips that the whole env step waits for, and they share
+    // the chip with the fused kernels: let them win the instruction-issue arbitration on their SIMDs.
 #ifndef R2S_NO_FINISH_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
@@ -2140,27 +2244,28 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
     // one WORKGROUP per listed particle — four wavefronts (MESHQ 2) or two (MESHQ 3, 128 threads) that run the same code on the
     // same particle (identical results) and share the triangles of the queries; only the first wavefront stores
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
-    __shared__ QShare qshare;
+    const size_t po = par_off(p, step);
     int qpar = 0;
 #ifdef R2S_PHASE_PROBE
     const long long probe_entry = (long long)wall_clock64();
 #endif
-    // Large-mesh scenes (MESHQ 2): the grid is (environments, slots) — environment fastest, so the workgroups dispatched first are
+    // Large-mesh scenes (MESHQ 2): the workgroups are (environment, slot) pairs — environment fastest, so the workgroups dispatched first are
     // slot 0 of every environment, the ones that have work — and the list is the ENVIRONMENT's, of self-contained records: record count,
     // record (x0, v, candidate count) and the mesh's rigid transform are ONE round trip (measured on the 25k-face pusher scene: 23.8 ->
-    // 22.3 us per contact substep).  Small scenes keep the chain-wide list of (env, particle) entries on a 1-D grid: their triangles
+    // 22.3 us per contact substep).  Small scenes keep the chain-wide list of (env, particle) entries: their triangles
     // hang on the triangle ids, a second round trip either way, and the per-environment form cost them 0.3 - 0.8 us.
     // (MESHQ 2 also serves scenes of SMALL meshes with more than 128 faces in total: their fused kernel is the MESH 1 one and lists
     // chain-wide — `per_env`, uniform, tells the two apart at run time: the records exist only when a large mesh does)
     const bool per_env = MESHQ == 2 && p.mesh_rec != nullptr;
-    const int t_stride = (int)(per_env ? gridDim.y : gridDim.x);
-    const int t0 = (int)(per_env ? blockIdx.y : blockIdx.x);
-    const int e_wg = p.e0 + (int)(per_env ? blockIdx.x : 0u);
-    const int4* rec = per_env ? p.mesh_rec + 2 * (size_t)e_wg * p.N : nullptr;
+    const int t_stride = per_env ? n_wg / p.ne : n_wg;           // (a head of k_substep_pf is padded to a multiple of 8 workgroups: the surplus idles)
+    const int t0 = per_env ? L / p.ne : L;
+    const bool in_grid = !per_env || t0 < t_stride;
+    const int e_wg = p.e0 + (per_env ? L % p.ne : 0);
+    const int4* rec = per_env ? p.mesh_rec + 2 * (po + (size_t)e_wg * p.N) : nullptr;
     int2 ei = make_int2(0, 0);
     int4 ra = make_int4(0, 0, 0, 0), rc = ra;
     if (per_env) { ra = rec[2 * min(t0, p.N - 1)]; rc = rec[2 * min(t0, p.N - 1) + 1]; }
-    else ei = p.mesh_list[min(t0, p.mesh_cap - 1)];
+    else ei = p.mesh_list[po + min(t0, p.mesh_cap - 1)];
     TriIds tid = {0, 0, 0, 0, 0, 0, false};
     if (MESHQ == 3) tid = load_tri_ids(p, lane, wave);
     Xf Xw; // MESHQ 2: the substep's rigid transform of the first large dynamic mesh of this workgroup's environment
@@ -2168,7 +2273,7 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
     for (int j = 0; j < 9; ++j) Xw.r[j] = (j % 4 == 0) ? 1.f : 0.f;
     Xw.t[0] = Xw.t[1] = Xw.t[2] = 0.f;
     if (per_env && p.n_xf > 0) Xw = xf_load_slot(p, __builtin_amdgcn_readfirstlane(e_wg), step, 0);
-    const int n_mesh = per_env ? min(p.rec_cnt[(size_t)e_wg * p.n_sub + step], p.N) : min(p.mesh_cnt[step], p.mesh_cap);
+    const int n_mesh = !in_grid ? 0 : per_env ? min(p.rec_cnt[(size_t)e_wg * p.n_sub + step], p.N) : min(p.mesh_cnt[step], p.mesh_cap);
     for (int t = t0; t < n_mesh; t += t_stride) { // a workgroup-uniform trip count (barriers inside)
         bool tagged;
         int e, i, cnt;
@@ -2176,7 +2281,7 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
             if (t != t0) { ra = rec[2 * t]; rc = rec[2 * t + 1]; }
             tagged = ra.y < 0; e = e_wg; i = ra.y & 0x7fffffff; cnt = ra.x;
         } else {
-            if (t != t0) ei = p.mesh_list[t];
+            if (t != t0) ei = p.mesh_list[po + t];
             tagged = ei.y < 0; e = ei.x & 0xfff; i = ei.y & 0x7fffffff; cnt = ei.x >> 12;
         }
         const size_t eb = (size_t)e * p.N;
@@ -2189,42 +2294,51 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
             x0 = mk(__int_as_float(ra.z), __int_as_float(ra.w), __int_as_float(rc.x));
             v = mk(__int_as_float(rc.y), __int_as_float(rc.z), __int_as_float(rc.w));
         } else {
-            x0 = st_x(xv_in, eb + i);
-            v = xyz(tagged ? p.vbc[eb + i] : p.vdef[eb + i]);
+            x0 = xyz(p.xbc[po + eb + i]);
+            v = xyz(tagged ? p.vbc[po + eb + i] : p.vdef[po + eb + i]);
         }
-        if (WITH_SELF && tagged) v = self_impulse<64>(p, xv_in, eb, i, true, x0, v, lane, cnt);
+        if (WITH_SELF && tagged) v = self_impulse<64>(p, po, eb, i, true, x0, v, lane, cnt);
         R2S_QP_DECL(step == p.n_sub - 2 ? t * (MESHQ == 2 ? 4 : 2) + wave : -1); // stamps of the last-but-one substep (no force accumulation)
 #ifdef R2S_PHASE_PROBE
         if (lane == 0 && qp.wave >= 0 && qp.wave < 1024) g_query_probe[qp.wave * 32 + 31] = probe_entry;
 #endif
         R2S_QSTAMP(); // entry loaded, x0 / v (and the impulses) done
-        finish_wave<MESHQ, false, 1>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr, &qshare, &qpar, &X0, wave == 0, nullptr R2S_QP_ARG);
+        finish_wave<MESHQ, false, 1, false, false, PFOUT>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr, &qshare, &qpar, &X0, wave == 0, nullptr R2S_QP_ARG);
         R2S_QSTAMP(); // stored
     }
     if (WITH_SELF) {
 #ifdef R2S_PHASE_PROBE
-        const int gw = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave; // stamps 28 / 29 / 30: part 2 entered / left, kernel entry of this wavefront
+        // stamps 28 / 29 / 30: part 2 entered / left, kernel entry of this wavefront; 27: the largest candidate count a group of this wavefront walked.
+        // Indexed from the END of the grid (part 2 fills it from there: the busy wavefronts are the ones recorded), rows 512.. of the probe table
+        const int gw = 512 + (n_wg - 1 - L) * (nthr >> 6) + wave;
+        int probe_cnt = 0;
         if (lane == 0 && gw < 1024 && step == p.n_sub - 2) { g_query_probe[gw * 32 + 28] = (long long)wall_clock64(); g_query_probe[gw * 32 + 30] = probe_entry; }
 #endif
         constexpr int G = 16;
-        const int sub = (int)(threadIdx.x & (G - 1)), grp = (int)(threadIdx.x / G), gpb = (int)(blockDim.x / G);
+        const int sub = (int)(threadIdx.x & (G - 1)), grp = (int)(threadIdx.x / G), gpb = nthr / G;
         // part 1 fills the grid from its first workgroup, part 2 from its LAST: a wavefront that spent 7 us on a mesh particle
         // should not also be the one that starts a candidate particle afterwards (in-kernel stamps: the kernel ended at 10.8 us,
         // 3.3 us after the last mesh particle, with most of the grid idle)
-        const int nblk = (int)(gridDim.x * gridDim.y);
-        const int rb = nblk - 1 - (int)(blockIdx.y * gridDim.x + blockIdx.x);
-        const int g0 = rb * gpb + grp;
-        int2 ci = p.cand_list[min(g0, p.E * p.N - 1)];
-        const int n = *p.cand_count;
-        for (int base = rb * gpb; base < n; base += nblk * gpb) { // wave-uniform trip count
-            const int t = base + grp;
-            if (t != g0 || t >= n) ci = p.cand_list[t < n ? t : 0]; // (the speculative entry of a slot past the count is stale or was never written: never index with it)
-            const int e = ci.x & 0xfff, i = ci.y, cnt = ci.x >> 12;
-            const size_t eb = (size_t)e * p.N;
-            const bool act = t < n && e >= p.e0 && e < p.e0 + p.ne && p.cand_mark[eb + i] != step + 1; // not already done in part 1
-            const f3 x0 = st_x(xv_in, eb + i);
-            const f3 vpre = xyz(p.vbc[eb + i]);
-            const f3 v = self_impulse<G>(p, xv_in, eb, i, act, x0, vpre, sub, cnt);
+        // the candidate lists are per ENVIRONMENT (round 5; one list for the batch had every chain walk all of it — with the 256
+        // finishing workgroups at the head of a k_substep_pf launch that was a second round, the tail of the launch): group g, counted
+        // from the back of the grid, walks slots g / ne, g / ne + stride, ... of environment e0 + g % ne
+        const int rb = n_wg - 1 - L;
+        const int g = rb * gpb + grp, gstride = n_wg * gpb / p.ne;
+        const int e = p.e0 + g % p.ne;
+        const size_t eb = (size_t)e * p.N;
+        const int t0g = g / p.ne;
+        int2 ci = p.cand_list[eb + (size_t)min(t0g, p.N - 1)];                 // speculative, with the count (one round trip)
+        const int n = t0g < gstride ? p.cand_cnt_env[e] : 0;
+        for (int t = t0g; __builtin_amdgcn_ballot_w64(t < n) != 0ull; t += gstride) { // wave-uniform trip count (the group shuffles run with their lanes together)
+            if (t != t0g || t >= n) ci = p.cand_list[eb + (size_t)(t < n ? t : 0)]; // (the speculative entry of a slot past the count is stale or was never written: never index with it)
+            const int i = ci.y, cnt = ci.x >> 12;
+            const bool act = t < n && p.cand_mark[po + eb + i] != step + 1; // not already done in part 1
+            const f3 x0 = xyz(p.xbc[po + eb + i]);
+            const f3 vpre = xyz(p.vbc[po + eb + i]);
+            const f3 v = self_impulse<G>(p, po, eb, i, act, x0, vpre, sub, cnt);
+#ifdef R2S_PHASE_PROBE
+            probe_cnt = max(probe_cnt, act ? cnt : 0);
+#endif
             // the fused kernel's test — widened by 2 mm = 40 m/s of velocity change in one substep — found no mesh in reach of this
             // particle: no query, mesh_collision only advances it.  The bound is CHECKED: an impulse beyond it raises a sticky
             // fault word that the next r2s_phys_step reports (the reference would have applied a mesh response here).
@@ -2233,12 +2347,46 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
                 if (dot(dvi, dvi) * p.dt * p.dt > 0.002f * 0.002f) *p.fault = 1;
             }
             R2S_QP_DECL(-1);
-            finish_wave<MESHQ == 3 ? 1 : 2, false, 2>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
+            finish_wave<MESHQ == 3 ? 1 : 2, false, 2, false, false, PFOUT>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
         }
 #ifdef R2S_PHASE_PROBE
-        if (lane == 0 && gw < 1024 && step == p.n_sub - 2) g_query_probe[gw * 32 + 29] = (long long)wall_clock64();
+        for (int o = 32; o > 0; o >>= 1) probe_cnt = max(probe_cnt, __shfl_xor(probe_cnt, o));
+        if (lane == 0 && gw < 1024 && step == p.n_sub - 2) { g_query_probe[gw * 32 + 29] = (long long)wall_clock64(); g_query_probe[gw * 32 + 27] = probe_cnt; }
 #endif
     }
+}
+
+template <int MESHQ, bool WITH_SELF>
+__global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const StateC xv_in, const StateM xv_out, int step,
+                                                        int write_forces)
+{
+    __shared__ QShare qshare;
+    contact_finish_body<MESHQ, WITH_SELF, false>(p, xv_out, step, write_forces, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y),
+                                                 (int)blockDim.x, qshare);
+}
+
+// ---- the fused substep with the finishers of the PREVIOUS substep at its head (p.pf; see "finishing at the HEAD of the next launch") ----
+// Workgroups [0, p.pf_nfin): contact_finish_body for substep `step - 1` (nothing when `fin_skip`: the first launch of a sequence); the
+// rest: substep_body<PF> for substep `step`.  MESHQ 3 finishers live in the workgroup's first two wavefronts; the other two leave at once
+// (a hardware barrier counts the wavefronts that have not ended).  One register budget for both roles: the larger one's.
+// Register budget of the small-scene form (MESHQ 3: the headline): the fused role needs 72 VGPRs (six wavefronts per SIMD), the finishers 105
+// (four).  Measured per batched substep of the headline in the grasp (tools/profiling/variant_bench.py, one box): the launch held to 4 / 5 / 6
+// wavefronts per SIMD 23.3 / 22.05 / 22.8 us (two launches: 24.3) — five: 95 VGPRs, three dwords of the finishers spilled.
+#ifndef R2S_PF_WAVES3
+#define R2S_PF_WAVES3 5
+#endif
+template <int B, int RCAP, bool SELF, int MESH, int MESHQ>
+__global__ void __launch_bounds__(B, (MESHQ == 3 ? R2S_PF_WAVES3 : 1)) k_substep_pf(const PhysDev p, const StateC xv_in, const StateM xv_out, int step, int write_forces, int fin_skip)
+{
+    if ((int)blockIdx.x < p.pf_nfin) {
+        constexpr int NTHR = MESHQ == 3 ? 128 : 256;
+        static_assert(B >= NTHR, "the finishers need their wavefronts");
+        if (fin_skip || (int)threadIdx.x >= NTHR) return;
+        __shared__ QShare qshare_pf;
+        contact_finish_body<MESHQ, SELF, true>(p, xv_out, step - 1, 0, (int)blockIdx.x, p.pf_nfin, NTHR, qshare_pf);
+        return;
+    }
+    substep_body<B, RCAP, SELF, MESH, true>(p, xv_in, xv_out, step, write_forces, (int)blockIdx.x - p.pf_nfin);
 }
 
 // {particles with candidates, mesh hits of the last substep, grasped environments} -> out[3] (bench.py's phase log: no host sync)
@@ -2756,7 +2904,10 @@ __global__ void k_cand_list(int N, int E, const int* __restrict__ coll_num, int2
     const int e = blockIdx.y;
     if (i >= N) return;
     const int c = coll_num[(size_t)e * N + i];
-    if (c > 0) list[atomicAdd(count, 1)] = make_int2(e | (c << 12), i); // env (< 2048) | candidate count << 12
+    if (c > 0) { // per-environment lists (count[4 + e] entries at list + e * N), count[0] = all of them
+        list[(size_t)e * N + atomicAdd(count + 4 + e, 1)] = make_int2(e | (c << 12), i); // env (< 2048) | candidate count << 12
+        atomicAdd(count, 1);
+    }
 }
 
 } // namespace
@@ -2794,12 +2945,23 @@ struct R2SPhys {
     float* d_masses = nullptr;
     int* d_masks = nullptr;
     int *d_coll_num = nullptr, *d_coll_idx = nullptr, *d_max_count = nullptr;
-    float4* d_vbc = nullptr;
+    float4* d_vbc = nullptr; float4* d_xbc = nullptr; // [2][E,N] each (substep parity)
+    void* d_pf_res = nullptr;   // k_substep_pf: a 128-byte result line per particle
+    bool pf_ok = false;         // large-batch layout with meshes: the contact flavours can run with the finishers at the head of the next launch
+    int pf_pref = 1;            // R2S_PF=0 / r2s_phys_set_pf(h, 0): keep the two-launch contact flavours (A/B measurements, the bit-identity test)
     int2* d_mesh_list = nullptr; int* d_mesh_cnt = nullptr; int mesh_cap = 0; // deferred mesh queries: [E * N] (a chain's slice starts at its first env), [chains][n_sub + 1]
     float4* d_vdef = nullptr;
     int4* d_mesh_rec = nullptr; int* d_rec_cnt = nullptr; // large-mesh scenes: per-environment records [E][N][2] and their counters [E][n_sub]
     int* d_cand_mark = nullptr;
-    int* d_mesh_total = nullptr; int* h_mesh_total = nullptr; hipEvent_t mesh_event = nullptr; bool mesh_pending = false, fault_stale = false;
+    // Counters of an env step ([0] particles near a mesh, [1] sticky fault word, [2] a query was needed, [3] server pairs ran out, [4..15] fault
+    // context) travel to pinned memory behind the step and pick the FLAVOUR of a later step.  Which later step is fixed (round 5): step t
+    // runs the flavour that follows from the counters of step t - LAG, waited for if they have not landed (they have: two env steps ago) —
+    // never "whatever copy happens to have arrived", which made the bits of a run in contact depend on host timing (the flavours sum in
+    // different orders).  A full set_state starts a new history: its first LAG steps run the default flavour (queries in place).
+    static constexpr int LAG = 2, RING = 4;
+    int* d_mesh_total = nullptr; int* h_ring = nullptr; // pinned [RING][16]
+    hipEvent_t ring_ev[RING] = {}; bool ring_pending[RING] = {}, ring_stale_fault[RING] = {};
+    uint64_t step_no = 0; // env steps enqueued since the last full set_state
     void* d_xch = nullptr;    // resident stepper: exchange array (96 B per particle)
     void* d_srv_claim = nullptr; void* d_srv_rr = nullptr; // resident stepper's mesh-query servers: a 128-byte line per claim, one of control words, one per pair of fault-report state; a line of request and a line of result granules per particle
     bool srv_exhausted = false; // a launch ran out of server pairs: per-substep kernels + finishing launch until the contact is over
@@ -2896,7 +3058,8 @@ struct R2SPhys {
         p.cse = cl(prm.collide_self_elas, 0.f, 1.f); p.csf = cl(prm.collide_self_fric, 0.f, 2.f);
         p.self_collision = prm.self_collision; p.use_pusher = prm.use_pusher;
         p.coll_num = d_coll_num; p.coll_idx = d_coll_idx; p.coll_cap = coll_cap;
-        p.vbc = d_vbc; p.cand_list = d_cand_list; p.cand_count = d_cand_count;
+        p.vbc = d_vbc; p.xbc = d_xbc; p.par_stride = (size_t)E * N; p.cand_list = d_cand_list; p.cand_count = d_cand_count; p.cand_cnt_env = d_cand_count ? d_cand_count + 4 : nullptr;
+        p.pf = 0; p.pf_nfin = 0; p.pf_res = d_pf_res;
         p.mesh_list = d_mesh_list; p.mesh_cnt = d_mesh_cnt; p.mesh_cap = mesh_cap; p.mesh_defer = mesh_defer; p.vdef = d_vdef; p.cand_mark = d_cand_mark; p.mesh_rec = d_mesh_rec; p.rec_cnt = d_rec_cnt;
         p.n_mesh = n_mesh; p.n_dyn_mesh = n_dyn_mesh; p.nF = nF; p.nV = nV; p.n_dyn_pts = n_dyn_pts;
         p.faces = d_faces; p.mesh_map = d_mesh_map; p.face_map = d_face_map; p.mesh_face_off = d_mesh_face_off;
@@ -3047,6 +3210,31 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
     return R2S_OK;
 }
 
+// The contact flavours of a large batch with the finishers at the head of the next launch (k_substep_pf; PhysDev::pf)
+bool pf_flavour(const R2SPhys* h, const PhysDev& p) { return h->pf_ok && h->pf_pref != 0 && h->pb == 256 && has_contact_finish(h, p); }
+// finishing workgroups at the head of a launch: enough for the lists of a batch in contact without a second round (a workgroup strides
+// over its list if there is more), few enough not to stand between the launch and its fused blocks — every workgroup of the launch
+// holds the fused role's LDS window, so an idle finisher costs a block's slot for the microsecond it takes to read an empty list
+int pf_head_size(const R2SPhys* h, int ne)
+{
+    const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
+    int n = mesh == 2 ? ne * std::max(16, 256 / std::max(1, ne)) : std::min(1024, 32 * ne);
+    if (const char* ev = getenv("R2S_PF_HEAD")) n = std::max(8, atoi(ev) * ne); // tuning: finishing workgroups per environment
+    return (n + 7) & ~7;
+}
+void launch_fused_pf(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, int fin_skip, hipStream_t s)
+{
+    const dim3 grid((unsigned)p.pf_nfin + 8u * (unsigned)p.cb);
+    const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
+    const bool small = mesh == 1 && h->nF <= 128;
+    const StateC in = h->state(in_buf);
+    const StateM out = h->state(in_buf ^ 1);
+#define R2S_PF(SELF, MESH, Q) hipLaunchKernelGGL((k_substep_pf<256, 1024, SELF, MESH, Q>), grid, dim3(256), 0, s, p, in, out, step, write_forces, fin_skip)
+    if (with_self) { if (mesh == 2) R2S_PF(true, 2, 2); else if (small) R2S_PF(true, 1, 3); else R2S_PF(true, 1, 2); }
+    else { if (mesh == 2) R2S_PF(false, 2, 2); else if (small) R2S_PF(false, 1, 3); else R2S_PF(false, 1, 2); }
+#undef R2S_PF
+}
+
 // Enqueue substeps [first, first+n) starting from buffer `start_buf`; the final state is left in buffer
 // start_buf ^ (n & 1).
 // A captured hipMemsetAsync node zeroes on the first replay only with this runtime (later replays fill the buffer with
@@ -3080,9 +3268,10 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
             const size_t cw = (size_t)ne * h->prm.num_substeps;
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cw + 255) / 256)), dim3(256), 0, s, (float*)(h->d_rec_cnt + (size_t)e0 * h->prm.num_substeps), cw);
         }
-        if (with_self && p.mesh_defer) { // marks of the previous env step must not match this step's substep numbers
+        if (with_self && p.mesh_defer) { // marks of the previous env step must not match this step's substep numbers (both parities)
             const size_t cnt = (size_t)ne * h->N;
-            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (float*)(h->d_cand_mark + (size_t)e0 * h->N), cnt);
+            for (int par = 0; par < 2; ++par)
+                hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (float*)(h->d_cand_mark + (size_t)par * h->E * h->N + (size_t)e0 * h->N), cnt);
         }
     }
     if (resident_flavour(h, with_self, p.mesh_defer)) {
@@ -3119,6 +3308,12 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
         return R2S_OK;
     }
     int buf = start_buf;
+    const bool pf = pf_flavour(h, p);
+    if (pf) { // the finishers of substep k ride at the head of substep k + 1's launch; the last substep's are the stand-alone launch
+        p.pf = 1; p.pf_nfin = pf_head_size(h, ne);
+        const size_t words = (size_t)(PF_LINE / 4) * ne * h->N; // this chain's result lines: tags of the previous env step must not match
+        hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_pf_res + (size_t)(PF_LINE / 4) * e0 * h->N, words);
+    }
     for (int k = 0; k < n; ++k) {
         const int last = (k == n - 1);
         if (last && h->nF > 0 && zero_forces) { // this chain's slice of the accumulator
@@ -3126,8 +3321,13 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->d_coll_forces + 3 * (size_t)e0 * h->nF, cnt);
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, (float*)(h->d_hit_cnt + e0), (size_t)ne);
         }
-        int rc = launch_substep(h, p, buf, first + k, last, with_self, s);
-        if (rc) return rc;
+        if (pf) {
+            launch_fused_pf(h, p, buf, first + k, last, with_self, k == 0, s);
+            if (last) { PhysDev q = p; q.pf = 0; launch_finish(h, q, buf, first + k, last, with_self, s); }
+        } else {
+            int rc = launch_substep(h, p, buf, first + k, last, with_self, s);
+            if (rc) return rc;
+        }
         buf ^= 1;
     }
     return R2S_OK;
@@ -3784,24 +3984,33 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
     R2S_HIP_TRY(hipMemsetAsync(h->d_max_count, 0, sizeof(int) * 4, s));
     if (h->nF > 0) { // deferred mesh queries
         h->mesh_cap = E * N; // a particle is listed at most once per substep: the list cannot overflow
-        TRY(dev_alloc(&h->d_mesh_list, (size_t)h->mesh_cap));
-        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_list, 0, sizeof(int2) * (size_t)h->mesh_cap, s));
+        // (everything a substep hands to its finishing code exists twice, by substep parity: PhysDev::par_stride)
+        TRY(dev_alloc(&h->d_mesh_list, (size_t)2 * h->mesh_cap));
+        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_list, 0, sizeof(int2) * (size_t)2 * h->mesh_cap, s));
         TRY(dev_alloc(&h->d_mesh_cnt, (size_t)8 * (h->prm.num_substeps + 1)));
-        TRY(dev_alloc(&h->d_vdef, (size_t)E * N));
+        TRY(dev_alloc(&h->d_vdef, (size_t)2 * E * N));
         if (h->any_large) {
-            TRY(dev_alloc(&h->d_mesh_rec, (size_t)2 * E * N));
-            R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_rec, 0, sizeof(int4) * (size_t)2 * E * N, s));
+            TRY(dev_alloc(&h->d_mesh_rec, (size_t)4 * E * N));
+            R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_rec, 0, sizeof(int4) * (size_t)4 * E * N, s));
             TRY(dev_alloc(&h->d_rec_cnt, (size_t)E * h->prm.num_substeps));
             R2S_HIP_TRY(hipMemsetAsync(h->d_rec_cnt, 0, sizeof(int) * (size_t)E * h->prm.num_substeps, s));
         }
-        if (h->prm.self_collision) { TRY(dev_alloc(&h->d_cand_mark, (size_t)E * N)); R2S_HIP_TRY(hipMemsetAsync(h->d_cand_mark, 0, sizeof(int) * (size_t)E * N, s)); }
+        if (h->prm.self_collision) { TRY(dev_alloc(&h->d_cand_mark, (size_t)2 * E * N)); R2S_HIP_TRY(hipMemsetAsync(h->d_cand_mark, 0, sizeof(int) * (size_t)2 * E * N, s)); }
+        // the finishers at the head of the next launch (k_substep_pf): large-batch layout only; a result line per particle
+        if (const char* ev = getenv("R2S_PF")) h->pf_pref = atoi(ev) != 0;
+        h->pf_ok = h->pb == 256 && (uint64_t)E * N * PF_LINE < 0x7fffffffull;
+        if (h->pf_ok) {
+            TRY(dev_alloc((char**)&h->d_pf_res, (size_t)PF_LINE * E * N));
+            R2S_HIP_TRY(hipMemsetAsync(h->d_pf_res, 0, (size_t)PF_LINE * E * N, s));
+        }
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_cnt, 0, sizeof(int) * 8 * (size_t)(h->prm.num_substeps + 1), s));
     }
+    if (h->nF > 0 || h->prm.self_collision) TRY(dev_alloc(&h->d_xbc, (size_t)2 * E * N));
     TRY(dev_alloc(&h->d_mesh_total, 16)); // [4..15]: where the first fault of the resident stepper happened (diagnostics); [0] particles near a mesh in the last step, [1] sticky fault word (PhysDev::fault), [2] a mesh query was needed, [3] a resident launch ran out of server pairs
     R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int) * 16, s));
-    R2S_HIP_TRY(hipHostMalloc((void**)&h->h_mesh_total, 64, hipHostMallocDefault));
-    h->h_mesh_total[0] = 0; h->h_mesh_total[1] = 0; h->h_mesh_total[2] = 0; h->h_mesh_total[3] = 0;
-    R2S_HIP_TRY(hipEventCreateWithFlags(&h->mesh_event, hipEventDisableTiming));
+    R2S_HIP_TRY(hipHostMalloc((void**)&h->h_ring, sizeof(int) * 16 * R2SPhys::RING, hipHostMallocDefault));
+    memset(h->h_ring, 0, sizeof(int) * 16 * R2SPhys::RING);
+    for (int k = 0; k < R2SPhys::RING; ++k) R2S_HIP_TRY(hipEventCreateWithFlags(&h->ring_ev[k], hipEventDisableTiming));
     {
         // the resident launch needs: the 64-particle layout, every neighbour inside the block's window (a remote neighbour would be read
         // from the state arrays, which a resident launch only touches at its two ends), no large mesh (its queries are workgroup-cooperative
@@ -3815,7 +4024,29 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         int dev = 0, n_cu = 0; // one workgroup per CU, all resident at once: the device decides how many that is
         R2S_HIP_TRY(hipGetDevice(&dev));
         R2S_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        h->resident_ok = h->split_ok && !h->any_large && (int64_t)h->nb * E <= std::min(RES_MAX_ITEMS, n_cu);
+        // Residency is ASKED for, not assumed (round 5): the launch needs one 512-thread workgroup of k_steps_resident per CU at once — blocks
+        // and servers alike, they are the same kernel.  The occupancy query answers for this build's registers and LDS on this device; a
+        // compiler that pushes the kernel over its budget, or a CU budget smaller than the chip (R2S_RES_CU_BUDGET: a CU-masked partition, a
+        // shared device; also what the test uses), turns into the per-substep flavour at create time instead of poll-limit faults later.
+        // (The query over-reports by at most one block per CU for SGPR-heavy 256-thread kernels on ROCm 7.2; this launch needs ONE
+        // 512-thread block per CU and the kernel is register-bound at two wavefronts per SIMD: the answer is exact where it matters, 0 vs >= 1.)
+        if (const char* ev = getenv("R2S_RES_CU_BUDGET")) n_cu = std::max(0, std::min(n_cu, atoi(ev)));
+        int occ_min = 1 << 30;
+        {
+            int occ = 0;
+            const void* kernels[2] = {(const void*)k_steps_resident<512, false, 0>, (const void*)k_steps_resident<512, false, 1>};
+            for (int k = 0; k < (h->nF > 0 ? 2 : 1); ++k) {
+                R2S_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernels[k], RES_THREADS, 0));
+                occ_min = std::min(occ_min, occ);
+            }
+        }
+        h->resident_ok = h->split_ok && !h->any_large && (int64_t)h->nb * E <= std::min(RES_MAX_ITEMS, n_cu) && occ_min >= 1;
+        if (h->split_ok && !h->any_large && !h->resident_ok && h->resident_pref) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "resident stepper not used: %lld work items, %d CUs available to it, %d workgroup(s) of the kernel fit a CU at once — "
+                     "the env step runs as one launch per substep", (long long)h->nb * E, n_cu, occ_min == (1 << 30) ? -1 : occ_min);
+            r2s::set_last_error_msg(buf); // informational: r2s_phys_create still returns R2S_OK
+        }
         h->n_cu = n_cu;
         if (h->resident_ok) {
             const size_t xn = ((size_t)N + 7) & ~(size_t)7;
@@ -3839,11 +4070,11 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         }
     }
     if (h->prm.self_collision) {
-        TRY(dev_alloc(&h->d_vbc, (size_t)E * N));
+        TRY(dev_alloc(&h->d_vbc, (size_t)2 * E * N));
         TRY(dev_alloc(&h->d_cand_list, (size_t)E * N));
         R2S_HIP_TRY(hipMemsetAsync(h->d_cand_list, 0, sizeof(int2) * (size_t)E * N, s));
-        TRY(dev_alloc(&h->d_cand_count, 4));
-        R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int) * 4, s));
+        TRY(dev_alloc(&h->d_cand_count, (size_t)4 + E)); // [0] all particles with candidates, [4 + e] those of environment e
+        R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int) * ((size_t)4 + E), s));
         R2S_HIP_TRY(hipHostMalloc((void**)&h->h_cand_count, 64, hipHostMallocDefault));
         *h->h_cand_count = 0;
         R2S_HIP_TRY(hipEventCreateWithFlags(&h->cand_event, hipEventDisableTiming));
@@ -3883,7 +4114,7 @@ void r2s_phys_destroy(R2SPhys* h)
     (void)hipDeviceSynchronize();
     drop_graph(h);
     void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_slice_int, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
-                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_mesh_list, h->d_mesh_cnt, h->d_vdef, h->d_mesh_rec, h->d_rec_cnt, h->d_cand_mark, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
+                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_xbc, h->d_pf_res, h->d_mesh_list, h->d_mesh_cnt, h->d_vdef, h->d_mesh_rec, h->d_rec_cnt, h->d_cand_mark, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
                     h->d_faces, h->d_face_orig, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
                     h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_sup_info, h->d_sup_box, h->d_small_mesh, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
@@ -3891,8 +4122,8 @@ void r2s_phys_destroy(R2SPhys* h)
                     h->d_srv_claim, h->d_srv_rr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_cand_count) (void)hipHostFree(h->h_cand_count);
-    if (h->h_mesh_total) (void)hipHostFree(h->h_mesh_total);
-    if (h->mesh_event) (void)hipEventDestroy(h->mesh_event);
+    if (h->h_ring) (void)hipHostFree(h->h_ring);
+    for (int k = 0; k < R2SPhys::RING; ++k) if (h->ring_ev[k]) (void)hipEventDestroy(h->ring_ev[k]);
     if (h->rigid_event) (void)hipEventDestroy(h->rigid_event);
     if (h->h_rigid_err) (void)hipHostFree(h->h_rigid_err);
     if (h->cand_event) (void)hipEventDestroy(h->cand_event);
@@ -3912,8 +4143,10 @@ int r2s_phys_set_state(R2SPhys* h, const float* x, const float* v, r2s_stream_t 
     // A fault word (r2s_phys_step) says "the state is invalid": a state set by the caller makes the handle usable again.
     if (h->d_mesh_total) {
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total + 1, 0, sizeof(int), (hipStream_t)stream_));
-        if (h->mesh_pending) h->fault_stale = true; // a copy still in flight may carry the old word: dropped when it lands
-        else h->h_mesh_total[1] = 0;
+        R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total + 4, 0, 12 * sizeof(int), (hipStream_t)stream_)); // ... and where the fault happened
+        for (int k = 0; k < R2SPhys::RING; ++k) { h->ring_stale_fault[k] = true; } // copies in flight or unread may carry the old word: dropped
+        h->step_no = 0;            // a new history: the next LAG steps run the default flavour
+        h->srv_exhausted = false;
     }
     return R2S_OK;
 }
@@ -3991,7 +4224,7 @@ int r2s_phys_update_collision_graph(R2SPhys* h, r2s_stream_t stream_)
         hipLaunchKernelGGL(k_candidates, grid, dim3(TPB), 0, s, h->N, h->E, h->words, h->coll_cap, h->d_inv, h->state(h->cur), h->d_masks, h->prm.collision_dist, r,
                            1.0f / r, keys, ids, h->d_bits, h->d_coll_idx, h->d_coll_num, h->d_max_count);
     }
-    R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int), s));
+    R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int) * ((size_t)4 + h->E), s));
     hipLaunchKernelGGL(k_cand_list, grid, dim3(TPB), 0, s, h->N, h->E, h->d_coll_num, h->d_cand_list, h->d_cand_count);
     R2S_HIP_TRY(hipMemcpyAsync(h->h_cand_count, h->d_cand_count, sizeof(int), hipMemcpyDeviceToHost, s));
     R2S_HIP_TRY(hipEventRecord(h->cand_event, s));
@@ -4155,17 +4388,29 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         }
     }
     const int variant = (h->prm.self_collision && h->n_cand > 0) ? 1 : 0;
-    if (h->mesh_pending && hipEventQuery(h->mesh_event) == hipSuccess) {
-        h->mesh_pending = false;
-        if (h->fault_stale) { h->h_mesh_total[1] = 0; h->fault_stale = false; } // the copy was in flight when set_state cleared the word
+    // the counters this step's flavour follows from: those of step (step_no - LAG), waited for (long landed in any real loop)
+    int cnt[16] = {0};
+    bool have_cnt = false;
+    if (h->step_no >= (uint64_t)R2SPhys::LAG) {
+        const int k = (int)((h->step_no - R2SPhys::LAG) % R2SPhys::RING);
+        if (h->ring_pending[k]) { R2S_HIP_TRY(hipEventSynchronize(h->ring_ev[k])); h->ring_pending[k] = false; }
+        memcpy(cnt, h->h_ring + 16 * k, sizeof cnt);
+        if (h->ring_stale_fault[k]) cnt[1] = 0;
+        have_cnt = true;
     }
-    if (!h->mesh_pending && h->h_mesh_total[1] != 0) { // the sticky fault word of an earlier step
-        if (h->h_mesh_total[1] >= 2 && h->h_mesh_total[1] <= 5) {
+    // the sticky fault word is looked for in the NEWER copies too when they have landed: it only ends the run, it picks no flavour
+    for (uint64_t back = 1; back < (uint64_t)R2SPhys::LAG && back <= h->step_no && cnt[1] == 0; ++back) {
+        const int k = (int)((h->step_no - back) % R2SPhys::RING);
+        if (h->ring_pending[k] && hipEventQuery(h->ring_ev[k]) == hipSuccess) h->ring_pending[k] = false;
+        if (!h->ring_pending[k] && !h->ring_stale_fault[k] && h->h_ring[16 * k + 1] != 0) { cnt[1] = h->h_ring[16 * k + 1]; memcpy(cnt + 4, h->h_ring + 16 * k + 4, 12 * sizeof(int)); }
+    }
+    if (cnt[1] != 0) { // the sticky fault word of an earlier step
+        if (cnt[1] >= 2 && cnt[1] <= 6) {
             char buf[640];
-            const int* w = h->h_mesh_total + 4;
+            const int* w = cnt + 4;
             snprintf(buf, sizeof buf, "resident stepper: a workgroup waited for %s beyond the poll limit (the launch was not resident at once, or the device "
                      "is shared with a kernel that never ends); the state is invalid [first fault: code %d, work item %d, substep %d of the launch, context %d %d %d %d %d %d]",
-                     h->h_mesh_total[1] == 2 ? "a neighbour block's substep" : h->h_mesh_total[1] == 5 ? "a neighbour's record (server pair)" : "a mesh-query server's result", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+                     cnt[1] == 2 ? "a neighbour block's substep" : cnt[1] == 5 ? "a neighbour's record (server pair)" : cnt[1] == 6 ? "a particle finished by the head of its launch" : "a mesh-query server's result", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
             r2s::set_last_error_msg(buf);
         }
         else
@@ -4178,12 +4423,12 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         // costs them ~0.7 us per substep, an in-place query in the fused kernel up to 190); small batches only once a query was NEEDED:
         // their free flavour is the resident launch (2.3 vs 7.2 us per substep for the rope), and a gripper hovering within 3 cm is free
         // motion — the step in which the first particle enters a margin pays for its in-place queries once
-        if (!h->mesh_pending) h->mesh_defer = (h->resident_ok && h->resident_pref ? h->h_mesh_total[2] : h->h_mesh_total[0]) > 0 ? 1 : 0;
+        h->mesh_defer = (h->resident_ok && h->resident_pref ? cnt[2] : cnt[0]) > 0 ? 1 : 0;
         // ... and with query servers in the launch (round 4) a small batch stays resident THROUGH contact: a particle that needs a query is
         // answered by a server pair of the same launch (resident_server); only the self-collision flavour still takes the per-substep path
-        if (!h->mesh_pending) { // (more particles in contact than the launch has pairs: answered in place — correct, and 20 x slower than the finishing launch)
-            if (h->h_mesh_total[3] > 0) h->srv_exhausted = true;
-            else if (h->h_mesh_total[2] == 0) h->srv_exhausted = false;
+        if (have_cnt) { // (more particles in contact than the launch has pairs: answered in place — correct, and 20 x slower than the finishing launch)
+            if (cnt[3] > 0) h->srv_exhausted = true;
+            else if (cnt[2] == 0) h->srv_exhausted = false;
         }
         if (h->resident_ok && h->resident_pref && h->srv_ok && variant == 0 && !h->srv_exhausted) h->mesh_defer = 0;
         if (h->force_defer >= 0) h->mesh_defer = h->force_defer; // test / tuning: force a flavour
@@ -4191,6 +4436,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     }
     h->last_flavour[0] = variant | (h->split_ok ? 2 : 0); h->last_flavour[1] = h->nF > 0 ? (h->any_large ? 2 : 1) : 0; h->last_flavour[2] = h->mesh_defer;
     h->last_flavour[3] = use_graph ? h->chains() : 1;
+    if (h->nF > 0 && h->pf_ok && h->pf_pref != 0 && h->pb == 256 && (h->mesh_defer || h->any_large)) h->last_flavour[2] = 3; // 3 = deferred, finishers at the head of the next launch
     const bool resident = resident_flavour(h, variant == 1, h->mesh_defer);
     if (resident) {
         h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)
@@ -4217,13 +4463,15 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         if (rc) return rc;
     }
     h->cur ^= resident ? 1 : (n & 1);
-    if ((h->nF > 0 || h->resident_ok) && !h->mesh_pending) { // particles near a mesh during this step (+ the fault word) -> pinned memory, read at a later step without waiting
+    { // this step's counters (+ the fault word) -> the step's slot of the pinned ring, read LAG steps from now
+        const int k = (int)(h->step_no % R2SPhys::RING);
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total, 0, sizeof(int), s));
         if (h->nF > 0) hipLaunchKernelGGL(k_sum_i32, dim3(1), dim3(64), 0, s, h->d_mesh_cnt + h->prm.num_substeps, 8, h->prm.num_substeps + 1, h->d_mesh_total);
-        R2S_HIP_TRY(hipMemcpyAsync(h->h_mesh_total, h->d_mesh_total, 16 * sizeof(int), hipMemcpyDeviceToHost, s));
+        R2S_HIP_TRY(hipMemcpyAsync(h->h_ring + 16 * k, h->d_mesh_total, 16 * sizeof(int), hipMemcpyDeviceToHost, s));
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_total + 2, 0, 2 * sizeof(int), s)); // "a query was needed", "no server pair was left": counted from here on
-        R2S_HIP_TRY(hipEventRecord(h->mesh_event, s));
-        h->mesh_pending = true;
+        R2S_HIP_TRY(hipEventRecord(h->ring_ev[k], s));
+        h->ring_pending[k] = true; h->ring_stale_fault[k] = false;
+        ++h->step_no;
     }
     if (h->timing) { R2S_HIP_TRY(hipEventRecord(h->ev1, s)); h->ev_pending = true; h->last_kernels = n; }
     R2S_HIP_TRY(hipGetLastError());
@@ -4311,6 +4559,14 @@ int r2s_phys_side_stream(int32_t k, r2s_stream_t* out)
     return R2S_OK;
 }
 
+int r2s_phys_set_pf(R2SPhys* h, int on)
+{
+    if (!h) return R2S_ERR_INVALID;
+    h->pf_pref = on != 0;
+    drop_graph(h);
+    return R2S_OK;
+}
+
 int r2s_phys_set_resident(R2SPhys* h, int on)
 {
     if (!h) return R2S_ERR_INVALID;
@@ -4375,11 +4631,12 @@ int r2s_phys_tagged_count(R2SPhys* h, int32_t* out, r2s_stream_t stream_)
     if (!h || !out) return R2S_ERR_INVALID;
     *out = 0;
     if (!h->d_cand_mark) return R2S_OK;
-    std::vector<int> tmp((size_t)h->E * h->N);
+    const size_t en = (size_t)h->E * h->N;
+    std::vector<int> tmp(2 * en); // marks are kept per substep parity
     R2S_HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_cand_mark, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost, (hipStream_t)stream_));
     R2S_HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
     int n = 0;
-    for (int v : tmp) n += v != 0;
+    for (size_t k = 0; k < en; ++k) n += (tmp[k] != 0 || tmp[en + k] != 0);
     *out = n;
     return R2S_OK;
 }
@@ -4421,7 +4678,7 @@ int r2s_phys_set_collision_lists(R2SPhys* h, const int32_t* number, const int32_
     if (rc) return rc;
     rc = upload(h->d_coll_idx, idx.data(), idx.size(), s);
     if (rc) return rc;
-    R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int), s));
+    R2S_HIP_TRY(hipMemsetAsync(h->d_cand_count, 0, sizeof(int) * ((size_t)4 + h->E), s));
     hipLaunchKernelGGL(k_cand_list, dim3((N + TPB - 1) / TPB, E), dim3(TPB), 0, s, N, E, h->d_coll_num, h->d_cand_list, h->d_cand_count);
     R2S_HIP_TRY(hipMemcpyAsync(h->h_cand_count, h->d_cand_count, sizeof(int), hipMemcpyDeviceToHost, s));
     R2S_HIP_TRY(hipEventRecord(h->cand_event, s));

@@ -77,7 +77,7 @@ def run_episodes(ro, episode_ids: Sequence[int], policy: Optional[Callable] = No
                 # env.reset(seed=episode_id) (eval_policy.py:67, eval_policy_parallel.py:47): the episode id is the index of the object's randomised start pose
                 ro.reset(mask, episode_ids=[ids[slot_row[s]] if slot_row[s] >= 0 else 0 for s in range(E)])
             else:
-                ro.reset(mask.to(dev))
+                ro.reset(mask)      # a HOST mask: a deal that covers every slot is a full reset (clears a sticky fault word)
 
     deal(range(E))
     while any(r >= 0 for r in slot_row):

@@ -55,7 +55,7 @@ def _bind():
         r2s_phys_set_eef_table=[vp, C.c_int32, vp, vp, C.c_float, vp], r2s_phys_set_eef_motion=[vp, vp, vp, vp, vp, vp, vp],
         r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_reset_envs=[vp, vp, vp], r2s_phys_set_state_envs=[vp, vp, vp, vp, vp], r2s_phys_create_resting_case_envs=[vp, vp, vp], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
         r2s_phys_set_collision_lists=[vp, vp, vp, vp], r2s_phys_contact_stats=[vp, C.POINTER(C.c_int32), C.POINTER(vp)],
-        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32], r2s_phys_set_resident=[vp, i32], r2s_phys_side_stream=[i32, C.POINTER(vp)],
+        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32], r2s_phys_set_resident=[vp, i32], r2s_phys_set_pf=[vp, i32], r2s_phys_side_stream=[i32, C.POINTER(vp)],
         r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
     ).items():
         fn = getattr(L, name)
@@ -375,11 +375,13 @@ class PhysBatch:
                         servers_own_their_particle=own and srv > 0, wavefronts_per_served_particle=(4 if quad else 2) if srv else 0,
                         kernel=f"k_steps_resident<{rcap},false,{int(a[1])}>" + (f" + {srv} query-server workgroups in the launch"
                                                                                   + (f" ({'a quad' if quad else 'a pair'} of wavefronts owns its particle from the claim on)" if own else " (a request per substep)") if srv else ""))
-        sc, split = bool(a[0] & 1), bool(a[0] & 2)
-        return dict(self_collision_kernel=sc, mesh_template=int(a[1]), deferred_mesh_queries=bool(a[2]), chains=int(a[3]) & 0xff, resident=False,
+        sc, split, pf = bool(a[0] & 1), bool(a[0] & 2), a[2] == 3
+        fused = "k_substep_pf" if pf else "k_substep"
+        return dict(self_collision_kernel=sc, mesh_template=int(a[1]), deferred_mesh_queries=bool(a[2]), finishers_at_head_of_next_launch=pf,
+                    chains=int(a[3]) & 0xff, resident=False,
                     kernel=(f"k_steps_resident<{rcap},{'true' if sc else 'false'},{int(a[1])}> x 1 substep" if split else
-                            f"k_substep<{ {1024: 256, 768: 128}.get(rcap, 64)},{rcap},{'true' if sc else 'false'},{int(a[1])}>")
-                           + (" + k_contact_finish" if a[2] else (" + k_self_finish" if sc else "")))
+                            f"{fused}<{ {1024: 256, 768: 128}.get(rcap, 64)},{rcap},{'true' if sc else 'false'},{int(a[1])}>")
+                           + (" (finishers of substep k at the head of substep k+1's launch)" if pf else " + k_contact_finish" if a[2] else (" + k_self_finish" if sc else "")))
 
     def set_tuning(self, chains: int = 0, mesh_defer: int = -1):
         check(_bind().r2s_phys_set_tuning(self._h, int(chains), int(mesh_defer)), "r2s_phys_set_tuning")
@@ -396,6 +398,11 @@ class PhysBatch:
         """Small batches only (r2s_physics.h): run the env step's free flavour as one resident launch (default) or, off, with
         the per-substep kernels of the same 64-particle layout."""
         check(_bind().r2s_phys_set_resident(self._h, int(bool(on))), "r2s_phys_set_resident")
+
+    def set_pf(self, on: bool):
+        """Large batches only (r2s_physics.h): the contact flavours with the finishers of substep k at the head of substep k + 1's launch
+        (default) or, off, as two launches per substep.  Bit-identical states."""
+        check(_bind().r2s_phys_set_pf(self._h, int(bool(on))), "r2s_phys_set_pf")
 
     def collision_max_count(self) -> int:
         m = C.c_int32()

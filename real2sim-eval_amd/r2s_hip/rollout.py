@@ -458,13 +458,18 @@ class BatchedRollout:
             mask = torch.ones(E, dtype=torch.bool, device=dev)
             everything = True
         else:
-            ids = torch.as_tensor(env_ids, device=dev)
+            # a selection that lives on the HOST and names every environment is a full reset (a whole new state: clears a sticky fault
+            # word — the episode scheduler always resets through a mask, evaluate.run_episodes); a device-side selection is not read back
+            src = env_ids if torch.is_tensor(env_ids) else torch.as_tensor(env_ids)
+            everything = False
+            if src.device.type == "cpu":
+                everything = bool(src.reshape(E).all()) if src.dtype == torch.bool else len(set(src.long().reshape(-1).tolist())) == E
+            ids = src.to(dev)
             if ids.dtype == torch.bool:
                 mask = ids.reshape(E).clone()
             else:
                 mask = torch.zeros(E, dtype=torch.bool, device=dev)
                 mask[ids.long().reshape(-1)] = True
-            everything = False
         main = torch.cuda.current_stream(dev)
         ev = getattr(self, "_cand_done", None)
         if ev is not None:                      # a candidate rebuild on the side stream is still reading the state about to be replaced
@@ -713,20 +718,22 @@ class BatchedRollout:
 
     def step(self, action=None):
         """One batched env step, ENQUEUED: ``action``: None (the synthetic trace), a dict of per-environment motion tensors, or an
-        [n_env, 13] 'xyz_rot' action tensor — see ``apply_action``.  Nothing is waited for and nothing is returned: the images of
-        the step are read through ``get_obs()`` / ``observations()``, which wait for the render, check the sync-free raster batch
-        and re-render a lossy one — the raw ``out_color`` / ``out_depth`` arrays may hold an incomplete frame until then
-        (``lossy_batches``).  ``enqueue_step`` is the same method under the name that says so."""
+        [n_env, 13] 'xyz_rot' action tensor — see ``apply_action``.  Nothing is waited for.  Returns ``(out_color, out_depth)`` — the
+        output arrays the step's frames are being rendered into, as every round before round 4 did — UNVALIDATED: the kernels that
+        fill them are only enqueued, and a sync-free raster batch that overflowed its capacity leaves its deepest instances out
+        (``lossy_batches``).  What a closed loop reads is ``get_obs()`` / ``observations()``: they wait for the render, check the
+        batch and re-render a lossy one.  ``enqueue_step`` is the same method under the name that says so."""
         self.physics_step(action)
         if getattr(self, "_pipelined", False):
-            self._render_pipelined()
+            out = self._render_pipelined()
         else:
-            self.render()
+            out = self.render()
         self.t += 1
         lg = self._log
         if lg is not None and lg["i"] < lg["n"]:
             lg["i"] += 1
             lg["s"][lg["i"]].record()
+        return out
 
     enqueue_step = step
 

@@ -2,7 +2,8 @@
 ``save`` and ``apply_mask`` on the same parameter dictionary (torch float32: means3D [n,3], sh_colors [n,48], log_scales [n,3],
 unnorm_rotations [n,4] wxyz, logit_opacities [n,1]) — what ``GSRenderer.load_scaniverse`` calls.  PLY I/O goes through
 ``r2s_hip.assets`` (no ``plyfile``).  The scan-editing helpers (rotate / translate / scale / crop / merge), the viewer and the
-.splat export are out of scope (SURVEY.md §2.1 #9: only the PLY layout matters to the hot paths) and not provided."""
+.splat export are out of scope (only the PLY layout matters to the hot paths): they raise NotImplementedError
+with a pointer to the reference."""
 from __future__ import annotations
 
 import numpy as np
@@ -43,3 +44,34 @@ class GSProcessor:
 
     def apply_mask(self, params, mask):                                            # :239-247
         return {k: params[k][mask] for k in _KEYS}
+
+    # The scan-EDITING half of the reference class (:102-137, :173-237, :249-330) is out of scope (offline asset
+    # preparation, not on the evaluation path).  The names exist so that a caller finds out at the call, with a pointer, instead of
+    # through an AttributeError.
+    def _out_of_scope(self, name):
+        raise NotImplementedError(f"GSProcessor.{name}: scan editing is not part of this drop-in (file half only: load / load_phystwin / save / "
+                                  f"apply_mask); use the reference's sim/utils/gs/gs_processor.py for offline asset preparation")
+
+    def rotate(self, params, rot_mat):
+        self._out_of_scope("rotate")
+
+    def translate(self, params, translation):
+        self._out_of_scope("translate")
+
+    def scale(self, params, scale):
+        self._out_of_scope("scale")
+
+    def crop(self, params, bbox, invert=False):
+        self._out_of_scope("crop")
+
+    def merge(self, params_list):
+        self._out_of_scope("merge")
+
+    def save_to_splat(self, params, save_dir, center=True, rotate=True):
+        self._out_of_scope("save_to_splat")
+
+    def visualize_gs(self, gs_name_list, transform=False, merged=False, axis_on=False):
+        self._out_of_scope("visualize_gs")
+
+    def add_axis(self, params):
+        self._out_of_scope("add_axis")

@@ -53,6 +53,7 @@ def test_headline_schedule_contains_free_motion_finger_contact_and_live_self_col
     assert free["steps"] == 4 and contact["steps"] == 4
     assert free["mesh_contacts"] == 0 and free["self_collision_candidates"] == 0
     assert contact["mesh_contacts"] > 0 and contact["self_collision_candidates"] > 0, contact
-    assert any(",true," in f and "k_contact_finish" in f for f in contact["kernel_flavours"]), contact["kernel_flavours"]   # SELF=true + finishing kernel
+    # SELF=true + finishing code (round 5: at the head of the next substep's launch, k_substep_pf; before: k_contact_finish as a launch of its own)
+    assert any(",true," in f and ("k_contact_finish" in f or "k_substep_pf" in f) for f in contact["kernel_flavours"]), contact["kernel_flavours"]
     assert all(",true," not in f for f in free["kernel_flavours"]), free["kernel_flavours"]
     assert "sloth_32env" in d["config"]["workload"] and "grasp" in d["config"]["workload"]

@@ -239,7 +239,7 @@ def test_bench_scene_one_env_20_substeps_in_the_grasp_vs_oracle_driven_through_e
     r = parity_gate.run("sloth_32env", num_substeps=667, n_compare=20, close_at=2)
     record("bench scene (sloth_arms, grasp), 20 substeps in contact", **{k: v for k, v in r.items() if isinstance(v, (int, float)) and not isinstance(v, bool)}, tol=1e-5)
     assert r["mesh_contact"] and r["particles_with_candidates"] > 0, r
-    assert "true,1>" in r["flavour"] and "k_contact_finish" in r["flavour"], r["flavour"]
+    assert "true,1>" in r["flavour"] and "k_contact_finish" in r["flavour"], r["flavour"]   # (one environment: the small-batch layout, two launches per substep)
     assert r["tagged_entries"] >= 0 and r["deferred_per_substep_max"] > 0, r
     assert r["eef_pts_max_abs"] < 2e-6 and r["eef_center_max_abs"] < 5e-7, r
     assert r["x_max_abs"] < 1e-5, r
@@ -256,7 +256,8 @@ def test_bench_gate_on_the_batched_flavour_two_chains_first_and_last_environment
 
     r = parity_gate.run("sloth_32env", num_substeps=667, n_compare=20, close_at=2, n_env=9)
     record("bench scene, 9-env batch (2 chains), envs 0 and 8, 20 substeps in contact", **{k: v for k, v in r.items() if isinstance(v, (int, float)) and not isinstance(v, bool)}, tol=1e-5)
-    assert r["chains"] == 2 and r["envs_checked"] == [0, 8] and "k_substep" in r["flavour"] and "k_contact_finish" in r["flavour"], r
+    # (round 5: the large-batch contact flavour runs the finishers at the head of the next substep's launch: k_substep_pf)
+    assert r["chains"] == 2 and r["envs_checked"] == [0, 8] and "k_substep_pf<256,1024,true,1>" in r["flavour"], r
     assert r["mesh_contact"] and r["particles_with_candidates"] > 0 and r["x_max_abs"] < 1e-5, r
     assert r["hard_rgb_mismatch_pixels"] == 0 and r["hard_depth_mismatch_pixels"] == 0, r
     assert r["passed"], r

@@ -66,3 +66,19 @@ def test_optimised_baseline_build_stays_inside_the_position_gate():
     assert oracle.lib()._name.endswith("libr2s_oracle.so"), "the checker build is back after the block"
     for ea, eb in zip(a, b):
         assert float(np.abs(ea.x - eb.x).max()) < 1e-5
+
+
+def test_driver_without_meshes_or_self_collision_has_its_own_barrier():
+    """Advisor r4: with no mesh and no self-collision nothing separated a thread's gather (reads its neighbours' x, v) from another
+    thread's integrate_ground (overwrites them in place).  Many threads over a small object make a missing barrier show."""
+    n_sub = 40
+    ob = make_object("rope", 300, seed=2, lift=0.001)
+    a = [oracle_env(ob, num_substeps=n_sub, self_collision=False) for _ in range(2)]
+    b = [oracle_env(ob, num_substeps=n_sub, self_collision=False) for _ in range(2)]
+    oracle.phys_step_batch(a, n_sub)
+    for _ in range(3):
+        c = [oracle_env(ob, num_substeps=n_sub, self_collision=False) for _ in range(2)]
+        oracle.phys_step_batch_par(c, n_sub, threads_per_env=8)
+        for ea, ec in zip(a, c):
+            assert np.array_equal(ea.x, ec.x) and np.array_equal(ea.v, ec.v)
+    del b

@@ -28,12 +28,22 @@ buf = (C.c_longlong * (n * 32))()
 L.r2s_phys_debug_query_probe.argtypes = [C.c_void_p, C.c_int]
 print("rc", L.r2s_phys_debug_query_probe(buf, n), "flavour", ro.phys.last_flavour()["kernel"], "deferred (last-but-one substep)", int(ro.phys.deferred_counts()[-3]))
 a = np.array(buf, dtype=np.int64).reshape(n, 32).astype(np.float64) * 0.01  # us (100 MHz)
-p2 = a[a[:, 28] > 0]
+p2 = a[512:][a[512:, 28] > 0]   # rows 512..: part 2's wavefronts counted from the END of the grid (the busy ones)
 if len(p2):
-    print("part 2 (candidate particles, 16 lanes each): wavefronts", len(p2), "entered at (us since kernel entry) median/p90/max",
-          np.round(np.percentile(p2[:, 28] - p2[:, 30], [50, 90, 100]), 2), "left at", np.round(np.percentile(p2[:, 29] - p2[:, 30], [50, 90, 100]), 2))
-used = a[:, 0] > 0
-a = a[used]
+    busy = p2[p2[:, 27] > 0]
+    print("part 2 (candidate particles, 16 lanes each): wavefronts recorded", len(p2), "busy", len(busy))
+    if len(busy):
+        cnt = busy[:, 27] * 100.0   # (raw integer: undo the 0.01 scaling)
+        dur = busy[:, 29] - busy[:, 28]
+        print("  busy wavefronts: entered part 2 at (us since their kernel entry) median/p90/max", np.round(np.percentile(busy[:, 28] - busy[:, 30], [50, 90, 100]), 2),
+              "left at", np.round(np.percentile(busy[:, 29] - busy[:, 30], [50, 90, 100]), 2))
+        print("  largest candidate count per wavefront: median/p90/max", np.percentile(cnt, [50, 90, 100]), " time in part 2 (us) median/p90/max", np.round(np.percentile(dur, [50, 90, 100]), 2))
+        for lo, hi in ((1, 16), (17, 32), (33, 64), (65, 128), (129, 500)):
+            m = (cnt >= lo) & (cnt <= hi)
+            if m.any():
+                print(f"    count {lo}-{hi}: {int(m.sum())} wavefronts, part-2 time median {np.median(dur[m]):.2f} us")
+used = (a[:512, 0] > 0)
+a = a[:512][used]
 print("wavefronts with stamps:", len(a))
 if len(a):
     entry = a[:, 31]
