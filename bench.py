@@ -10,10 +10,15 @@ kinematics + grasp logic, 667 fused physics substeps, skinning, and 2 rasterised
 32 envs per GPU).  Inputs are resident in HBM before the timed region.  Envs shard across GPUs with no data-path
 collective (weak scaling); the only collective is the final all-gather of per-rank result records.
 
-The timed window is a SCHEDULE, not a best case: the first half of the K steps is free motion (the open gripper comes down
-over the toy's raised arms, nothing touches), at step W + K//2 the fingers close — finger contact, the arms pressed
-together (live self-collision candidates, k_self_finish in the graph), grasp detection — and the toy is lifted.  `value`
-is the mean over the whole window; `phases` splits it.
+The timed window is what a POLICY IN THE LOOP sees (round 5; eval_policy.py:124-213): every step ends in get_obs() — the host
+waits for the frames, validates the sync-free raster batch, re-renders a lossy one — before the next action is applied, and the
+environments are DE-PHASED: environment e runs the action trace (e K) // E steps late, so the grippers close one after the other
+across the window instead of all at its middle (episodes of eval_policy_parallel.py do not share a phase) and every step runs the
+contact flavour for some environments.  Over the window half of the env-steps are free motion (the open gripper comes down over
+the toy's raised arms) and half are in the grasp (finger contact, the arms pressed together: live self-collision candidates, grasp
+detection, lift).  `value` is the mean over that window.  Reported next to it, never as `value`: the same K steps with all
+environments in phase (`synchronised_window`: free first half, contact second half, `phases` splits it), enqueue-only, and
+with the rasterisation of step t next to the substeps of step t+1.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the fused physics substep) and `cpu_baseline`
 (the oracle — a CPU restatement of the reference algorithm, kind "port" — on a bounded sample).
@@ -197,10 +202,12 @@ def main():
     ap.add_argument("--stub", action="store_true", help="CPU stand-in workload over gloo (launcher test)")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the parity gate that precedes the timed window (default: on; a failing gate "
                                                                   "withholds `value`)")
-    ap.add_argument("--dephase", type=int, default=-1, help="after the timed window, time a second one in which environment e runs the same action trace "
-                                                            "(e %% K) steps late — the environments then close their grippers one after the other across the "
-                                                            "window instead of all at its middle (episodes of eval_policy_parallel.py do not share a phase); "
-                                                            "reported next to `value`, never as `value`.  -1: K = --steps (default), 0: skip")
+    ap.add_argument("--dephase", type=int, default=-1, help="the timed window's environments run the action trace (e K) // E steps late — they close their "
+                                                            "grippers one after the other across the window instead of all at its middle (episodes of "
+                                                            "eval_policy_parallel.py do not share a phase).  -1: K = --steps (default), 0: all environments "
+                                                            "in phase (the round-4 window; then no second, synchronised window is timed)")
+    ap.add_argument("--open-loop", action="store_true", help="the timed window only ENQUEUES steps (no get_obs() per step): the round-4 definition of `value`; "
+                                                             "for profiling runs (a kernel trace of back-to-back steps), never for a reported number")
     ap.add_argument("--sink", default=None, help="directory: also run the observation sink (row f4) every step — packed 8-bit frames + state "
                                                  "to pinned ring buffers, JPEG / pickle written by a host thread; not part of the headline")
     args = ap.parse_args()
@@ -243,12 +250,22 @@ def main():
         except Exception as e:  # a gate that cannot run is a failed gate
             gate = {"passed": False, "error": f"{type(e).__name__}: {e}"}
 
-    close_at = args.warmup + args.steps // 2   # the timed window is half free motion, half contact (grasp schedule / pusher)
+    close_sync = args.warmup + args.steps // 2   # all environments in phase: the window is half free motion, half contact (grasp schedule / pusher)
+    K_dephase = args.steps if args.dephase < 0 else args.dephase
     tc0 = time.perf_counter()
-    ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=close_at, res=res)
+    # the timed rollout: environment e closes its gripper / reaches the block at timed step (e K) // E — over the window the same share of
+    # env-steps is in contact as in the synchronised window
+    ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule,
+                        close_at=args.warmup if K_dephase > 1 else close_sync, res=res)
+    dephased = K_dephase > 1 and ro.with_gripper and ro.schedule in ("grasp", "push") and ro.n_env > 1   # (one environment: its contact event at the window's middle)
+    if dephased:
+        ro.set_dephase(K_dephase)
+    elif K_dephase > 1:   # a trace without a contact event (the small test scenes' lissajous path): nothing to de-phase
+        ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=close_sync, res=res)
 
     torch.cuda.synchronize(dev)
     construct_s = time.perf_counter() - tc0            # scene synthesis, topology upload, graph capture of every flavour, settling
+    closed_loop = not args.open_loop
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -263,17 +280,23 @@ def main():
                                state_bytes=2 * ro.n_env * ro.N * 12 + 4096)
     for _ in range(args.warmup):
         ro.step()
+        if closed_loop:
+            ro.get_obs()
     barrier()
     # per-step stamps on the launch stream (torch's current stream is the one every kernel of the step is enqueued on):
     # step boundaries + the physics graph alone.  Contact counters are logged on the device, read after the window.
     ro.start_log(args.steps)
+    lossy_before = ro.lossy_batches
     t0 = time.perf_counter()
     for k in range(args.steps):
         ro.step()
+        if closed_loop:
+            ro.get_obs()          # the policy's read: wait for the frames of THIS step, validate the batch, re-render a lossy one
         if sink is not None:
             sink.submit(k, ro.out_color, state=dict(x=ro.phys.x, v=ro.phys.v), ready=getattr(ro, "_render_done", None))
     barrier()
     elapsed = time.perf_counter() - t0
+    re_rendered = int(ro.lossy_batches - lossy_before)
     log = ro.read_log()
     ro._poll_raster(wait=True)   # the sync-free raster pipeline: the count of the LAST batch, and how many batches of the window overflowed
     sink_report = None
@@ -289,35 +312,57 @@ def main():
     records = rdist.gather_records([ro.n_env, args.steps, elapsed * 1e3, float(ro.last_num_rendered), float(n_success), construct_s], dev)
     total_envs = int(records[:, 0].sum().item())
 
-    # throughput mode (outside the timed region, reported next to `value`, never as `value`): the rollout continues from the state
-    # the window ended in, first serially, then with the rasterisation of step t on a second stream next to the substeps of
-    # step t+1 (BatchedRollout.set_pipelined) — what an open-loop stretch (an action chunk) can run at
+    # ---- the synchronised window (outside the timed region, reported next to `value`, never as `value`): the same K closed-loop steps with
+    # all environments in phase — free motion first half, every gripper closing at its middle, contact second half (`phases` splits it; round 4
+    # timed this one, enqueue-only, as `value`) — on a rollout of its own; the accounting runs below continue from the state it ends in
+    sync_report, plog, ra = None, log, ro
+    if dephased and not args.stub:
+        ra = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=close_sync, res=res)
+        for _ in range(args.warmup):
+            ra.step()
+            if closed_loop:
+                ra.get_obs()
+        torch.cuda.synchronize(dev)
+        ra.start_log(args.steps)
+        t0s = time.perf_counter()
+        for _ in range(args.steps):
+            ra.step()
+            if closed_loop:
+                ra.get_obs()
+        torch.cuda.synchronize(dev)
+        els = time.perf_counter() - t0s
+        plog = ra.read_log()
+        sync_report = {"env_steps_per_s": ra.n_env * args.steps / els, "ms_per_step": els / args.steps * 1e3, "closed_loop": closed_loop,
+                       "note": "this rank; the same workload with all environments in phase (every gripper closes at the window's middle): the window's "
+                               "first half runs the free flavour, its second half the contact flavour — see `phases`"}
+
+    # throughput mode (outside the timed region): the rollout continues from the state the window ended in, first serially, then with the
+    # rasterisation of step t on a second stream next to the substeps of step t+1 (BatchedRollout.set_pipelined) — what an open-loop stretch
+    # (an action chunk) can run at
     pipe_report = None
     if not args.stub and not args.no_pipelined:
         kp = max(4, min(args.steps, 10))
         rates = []
         for mode in (False, True):
-            ro.set_pipelined(mode)
+            ra.set_pipelined(mode)
             for _ in range(2):
-                ro.step()
-            ro.wait_render()
+                ra.step()
+            ra.wait_render()
             torch.cuda.synchronize(dev)
             t0p = time.perf_counter()
             for _ in range(kp):
-                ro.step()
-            ro.wait_render()
+                ra.step()
+            ra.wait_render()
             torch.cuda.synchronize(dev)
-            rates.append(ro.n_env * kp / (time.perf_counter() - t0p))
-        ro.set_pipelined(False)
+            rates.append(ra.n_env * kp / (time.perf_counter() - t0p))
+        ra.set_pipelined(False)
         pipe_report = {"serial_env_steps_per_s": rates[0], "pipelined_env_steps_per_s": rates[1], "steps": kp,
-                       "note": "this rank, after the timed window, in the state the window ended in (contact): the same steps with the rasterisation of "
-                               "env step t on a second stream next to the substeps of step t+1; results are bit-identical (tested).  Valid when the "
-                               "next action does not depend on this step's observation (inside an action chunk); `value` above is the closed loop"}
+                       "note": "this rank, after the synchronised window, in the state it ended in (contact), ENQUEUE-ONLY: the same steps serially and with the "
+                               "rasterisation of env step t on a second stream next to the substeps of step t+1; results are bit-identical (tested).  Valid when the "
+                               "next action does not depend on this step's observation (inside an action chunk); never what `value` reports"}
 
-    # closed-loop accounting (outside the timed region): the timed loop above only ENQUEUES steps — a policy in the
-    # loop reads an observation before it picks the next action.  Here every step ends in get_obs(): wait for the render, poll the
-    # sync-free raster batch for overflow, re-render a lossy one.  Same state, same number of steps, first enqueue-only, then with
-    # get_obs(): the ratio is what the read costs; `re_rendered` counts lossy batches that get_obs() had to render again.
+    # closed-loop accounting (outside the timed region): the same state, the same number of steps, first enqueue-only, then with get_obs() after
+    # every step — the ratio is what the policy's read costs (`value` is measured WITH it)
     closed_report = None
     if not args.stub:
         kc = max(4, min(args.steps, 10))
@@ -325,46 +370,23 @@ def main():
         lossy0 = 0
         for with_obs in (False, True):
             for _ in range(2):
-                ro.step()
-            ro.get_obs()
+                ra.step()
+            ra.get_obs()
             torch.cuda.synchronize(dev)
-            lossy0 = ro.lossy_batches
+            lossy0 = ra.lossy_batches
             t0c = time.perf_counter()
             for _ in range(kc):
-                ro.step()
+                ra.step()
                 if with_obs:
-                    ro.get_obs()
+                    ra.get_obs()
             torch.cuda.synchronize(dev)
-            rates.append(ro.n_env * kc / (time.perf_counter() - t0c))
+            rates.append(ra.n_env * kc / (time.perf_counter() - t0c))
         closed_report = {"env_steps_per_s": rates[1], "enqueue_only_env_steps_per_s": rates[0], "ratio": rates[1] / rates[0], "steps": kc,
-                         "re_rendered_batches": int(ro.lossy_batches - lossy0),
-                         "note": "this rank, after the timed window, in the state it ended in (contact): the same steps enqueue-only and with "
+                         "re_rendered_batches": int(ra.lossy_batches - lossy0),
+                         "note": "this rank, after the synchronised window, in the state it ended in (contact): the same steps enqueue-only and with "
                                  "get_obs() after every step (host waits for the frame, validates the sync-free raster batch, re-renders a lossy one)"}
-
-    # de-phased window (outside the timed region): same workload, same number of steps, the same half of the env-steps in
-    # contact — but the environments enter contact one after the other instead of together, so every step of the window runs
-    # the contact flavour for SOME environments (the graph flavour is picked per handle, not per environment)
-    dephase_report = None
-    K = args.steps if args.dephase < 0 else args.dephase
-    if K > 1 and not args.stub and ro.with_gripper and ro.schedule == "grasp":
-        ro2 = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=args.warmup, res=res)
-        ro2.set_dephase(K)
-        for _ in range(args.warmup):
-            ro2.step()
-        torch.cuda.synchronize(dev)
-        ro2.start_log(args.steps)
-        t0d = time.perf_counter()
-        for _ in range(args.steps):
-            ro2.step()
-        torch.cuda.synchronize(dev)
-        el = time.perf_counter() - t0d
-        lg2 = ro2.read_log()
-        dephase_report = {"env_steps_per_s": ro2.n_env * args.steps / el, "ms_per_step": el / args.steps * 1e3, "K": K,
-                          "substep_us_per_step": [round(m / args.substeps * 1e3, 2) for m in lg2["phys_ms"]], "grasped_envs_per_step": lg2["grasped"],
-                          "mesh_contacts_per_step": lg2["mesh_hits"],
-                          "note": "this rank; environment e closes its gripper at timed step (e % K): over the window the same share of env-steps is in "
-                                  "contact as in the synchronised window above (whose environments all close at its middle)"}
-        del ro2
+    if ra is not ro:
+        del ra
 
     # cross-check for the roofline (untimed): the same env step captured as ONE kernel per batched substep, so that the
     # HIP-event time / 667 is a per-kernel duration that rocprofv3's per-kernel average can be compared with directly
@@ -434,20 +456,20 @@ def main():
         comp_bytes = ro.composite_algorithmic_bytes()
         comp_gbs = comp_bytes / (stages["composite"] * 1e-3) / 1e9 if stages["composite"] > 0 else 0.0
 
-        def phase(sel):
+        def phase(sel):   # of the SYNCHRONISED window (the timed one itself when it was not de-phased)
             idx = [i for i in range(args.steps) if sel(i)]
             if not idx:
                 return None
-            return {"steps": len(idx), "ms_per_step": sum(log["step_ms"][i] for i in idx) / len(idx),
-                    "physics_ms_per_step": sum(log["phys_ms"][i] for i in idx) / len(idx),
-                    "substep_us": sum(log["phys_ms"][i] for i in idx) / len(idx) / n_sub * 1e3,
-                    "self_collision_candidates": int(max(log["candidates"][i] for i in idx)),
-                    "mesh_contacts": int(max(log["mesh_hits"][i] for i in idx)),
-                    "grasped_envs": int(max(log["grasped"][i] for i in idx)),
-                    "kernel_flavours": sorted({log["flavour"][i] for i in idx})}
+            return {"steps": len(idx), "ms_per_step": sum(plog["step_ms"][i] for i in idx) / len(idx),
+                    "physics_ms_per_step": sum(plog["phys_ms"][i] for i in idx) / len(idx),
+                    "substep_us": sum(plog["phys_ms"][i] for i in idx) / len(idx) / n_sub * 1e3,
+                    "self_collision_candidates": int(max(plog["candidates"][i] for i in idx)),
+                    "mesh_contacts": int(max(plog["mesh_hits"][i] for i in idx)),
+                    "grasped_envs": int(max(plog["grasped"][i] for i in idx)),
+                    "kernel_flavours": sorted({plog["flavour"][i] for i in idx})}
 
         resident_steps = sum("k_steps_resident" in f for f in log["flavour"])   # env steps of the window that ran as one resident launch
-        first_contact = ro.close_at - args.warmup  # index in the timed window of the step in which the fingers close / rod arrives
+        first_contact = (close_sync if dephased else ro.close_at) - args.warmup  # index in the synchronised window of the step in which the fingers close / rod arrives
         (pmc_sub, src), (pmc_comp, _) = pmc_summary("k_substep", args.config), pmc_summary("k_composite", args.config)
         shared_bytes = 16 * ro.S + 48 * ro.N * ro.n_env        # the topology once (it is shared by the environments and L2-resident) + every environment's state
         traffic = pmc_sub["hbm_bytes_per_launch"] if pmc_sub and ro.n_env == 32 and n_sub == 667 else None
@@ -486,9 +508,19 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {ro.N} particles / {ro.S} springs / {ro.P} Gaussians per env, "
                                    f"{ro.n_env} envs per GPU, {args.substeps} substeps + {ro.views} frames {ro.W}x{ro.H} per env step; "
-                                   f"action trace '{ro.schedule}': free motion, contact from timed step {first_contact}",
+                                   f"action trace '{ro.schedule}'" + (f", environment e {('closes its gripper' if ro.schedule == 'grasp' else 'reaches the block')} at timed step (e * {K_dephase}) // {ro.n_env} "
+                                                                        f"(de-phased episodes); " if dephased else f": free motion, contact from timed step {first_contact}; ")
+                                   + ("every step ends in get_obs() (closed loop)" if closed_loop else "steps only enqueued (--open-loop)"),
                        "envs_per_gpu": ro.n_env, "parallelism": f"envs sharded over {world} GPU(s), no data-path collective"},
+            "window": {"closed_loop_get_obs_every_step": closed_loop, "dephased": bool(dephased), "K": int(K_dephase) if dephased else 0,
+                       "re_rendered_batches": re_rendered,
+                       "substep_us_per_step": [round(m / n_sub * 1e3, 2) for m in log["phys_ms"]], "mesh_contacts_per_step": log["mesh_hits"],
+                       "grasped_envs_per_step": log["grasped"], "kernel_flavours": sorted(set(log["flavour"])),
+                       "note": "what `value` was timed over: K steps, each followed by get_obs() (the host waits for the step's frames, validates the sync-free "
+                               "raster batch, re-renders a lossy one) before the next step is applied; environment e runs the action trace (e K) // E steps late, so "
+                               "half of the window's env-steps are free motion and half are in the grasp, and every step runs the contact flavour for some environments"},
             "phases": {"free": phase(lambda i: i < first_contact), "contact": phase(lambda i: i >= first_contact),
+                       "window": "synchronised_window" if dephased else "the timed window",
                        "note": "free = the end effector moves, nothing touches; contact = fingers closed on the toy's arms / rod against the block "
                                "(mesh_contacts = particles inside a collision margin in the last substep, self_collision_candidates = particles "
                                "with live candidates, maxima over the phase's steps)"},
@@ -520,11 +552,11 @@ def main():
             out["closed_loop_get_obs"] = closed_report
         if ro.lossy_batches:
             out["lossy_batches_in_run"] = int(ro.lossy_batches)
-            out["note_lossy"] = ("sync-free raster batches overflowed their capacity during this run: frames read without get_obs() / observations() "
-                                 "were incomplete; `value` counts those steps (see raster.lossy_batches)")
-        if dephase_report is not None:
-            dephase_report["vs_synchronised_window"] = dephase_report["env_steps_per_s"] / (ro.n_env * args.steps / elapsed) if world == 1 else None
-            out["dephased_window"] = dephase_report
+            out["note_lossy"] = ("sync-free raster batches overflowed their capacity during this run; get_obs() rendered those steps again before handing "
+                                 "the frames out (window.re_rendered_batches of them inside the timed window: their cost is in `value`)")
+        if sync_report is not None:
+            sync_report["value_over_this"] = (ro.n_env * args.steps / elapsed) / sync_report["env_steps_per_s"] if world == 1 else None
+            out["synchronised_window"] = sync_report
         if gate is not None and not gate.get("passed"):
             out["value_withheld"] = out["value"]
             out["value"] = None

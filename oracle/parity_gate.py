@@ -100,9 +100,11 @@ def run(config="sloth_32env", device="cuda:0", seed=0, num_substeps=667, n_compa
         # gripper scenes: the first env step after the closing step whose candidate rebuild finds live pairs (the arms pressed
         # together; the rope in the fingers has none and is taken as it is); pusher scene: the first env step that STARTS with the rod
         # against the block
-        # (+ 2: the flavour of an env step follows from the counters of the step TWO before it — r2s_phys_step's fixed lag — so the step
-        # after next of the closing step is the first that runs the steady contact flavour, the one a timed window is spent in)
-        if t >= close_at + 2 and not compared:
+        # (the flavour of an env step follows from the counters of the step TWO before it — r2s_phys_step's fixed lag.  A large batch defers
+        # its queries as soon as anything is NEAR a mesh — the descent raises that long before the closing step — so the step after the
+        # closing step already runs the steady contact flavour, the one a timed window is spent in; a small batch defers once a query was
+        # NEEDED — the closing step — and runs it from the step after next)
+        if t >= close_at + (1 if ph.layout_stats()["lds_bytes"] == 1024 * 24 else 2) and not compared:
             x, v = ph.sync_state()
             n_cand = 0
             for e in envs:

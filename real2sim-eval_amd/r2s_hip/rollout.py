@@ -322,7 +322,7 @@ class BatchedRollout:
     def synthetic_action(self, step):
         """The synthetic action trace as a CALLER of ``step``: the end-effector motion of env step ``step`` for every environment,
         device tensors (the whole trace lives on the device: no per-step upload).  ``dephase`` (set by ``set_dephase``) delays
-        environment e by ``e % dephase`` steps along the same trace, so that the environments are not all in the same phase of
+        environment e by ``(e * dephase) // n_env`` steps along the same trace, so that the environments are not all in the same phase of
         their episode (episodes of eval_policy_parallel.py are independent: they do not share a phase)."""
         E = self.n_env
         if self._vel_trace is None or step >= len(self._vel_trace) - self._dephase:   # (a restarted episode only looks further back)
@@ -335,7 +335,7 @@ class BatchedRollout:
         if self._dephase > 1 or self._restarted:
             idx = step - self._env_t0                             # an environment's episode starts at its last reset ...
             if self._dephase > 1:
-                idx = idx - self._env_delay                       # ... and environment e replays the trace (e % dephase) steps late
+                idx = idx - self._env_delay                       # ... and environment e replays the trace (e * dephase) // n_env steps late
             act, idc = idx >= 0, idx.clamp(min=0)
             vel = torch.where(act[:, None], self._vel_trace[idc], torch.zeros(E, 3, device=self.device))
             openness = torch.where(act, self._open_cmd[idc], torch.ones(E, device=self.device))
@@ -346,10 +346,11 @@ class BatchedRollout:
                     gripper_openness=None if self.use_pusher else openness, eef_rot_next=self.eef_rot)   # the traces do not rotate
 
     def set_dephase(self, k: int):
-        """Stagger the synthetic episodes: environment e starts its trace ``e % k`` env steps late (it waits, gripper open, at the
-        start pose).  k <= 1: all environments in phase (the default)."""
+        """Stagger the synthetic episodes over a window of ``k`` env steps: environment e starts its trace ``(e * k) // n_env`` steps late
+        (it waits, gripper open, at the start pose) — the delays cover 0 .. k - 1 evenly whatever the number of environments, so over
+        the window the same share of env-steps is in contact as when all environments close at its middle.  k <= 1: all in phase."""
         self._dephase = max(1, int(k))
-        self._env_delay = (torch.arange(self.n_env, device=self.device) % self._dephase)
+        self._env_delay = (torch.arange(self.n_env, device=self.device) * self._dephase) // self.n_env
         self._vel_trace = None
 
     def action13_to_motion(self, action, fps=None):

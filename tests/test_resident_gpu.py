@@ -366,3 +366,31 @@ def test_more_particles_in_contact_than_server_pairs_takes_the_step_off_the_resi
     assert np.isfinite(xc).all() and max(zc[4:9]) > zc[0] + 0.004, zc
     assert np.abs(xc - xf).max() < 2e-3, float(np.abs(xc - xf).max())   # 14 env steps of a grasp: a chaotic system summed in three different orders
     record("rope grasp with the server pairs capped below the contact count", x_max_abs_vs_uncapped=float(np.abs(xc - xf).max()), steps_off_the_resident_launch=len(off), tol=2e-3)
+
+
+@pytest.mark.gpu
+def test_a_cu_budget_too_small_for_the_resident_launch_is_refused_at_create_time(monkeypatch):
+    """the resident launch needs all its workgroups on the chip at once, and r2s_phys_create ASKS
+    (hipOccupancyMaxActiveBlocksPerMultiprocessor for k_steps_resident, the device's CU count, R2S_RES_CU_BUDGET for a partition / a shared
+    device) instead of assuming.  With a budget of 64 CUs the 130 work items of the one-environment rope do not fit: the handle must pick the
+    per-substep kernels of the same layout at create time, say why, and step through a grasp without a fault word."""
+    import torch
+    from r2s_hip import _lib
+    from r2s_hip.rollout import BatchedRollout
+
+    monkeypatch.setenv("R2S_RES_CU_BUDGET", "64")
+    ro = BatchedRollout("rope_1env", close_at=2, seed=2, settle_steps=2)
+    flav = []
+    for _ in range(5):
+        ro.step()
+        flav.append(ro.phys.last_flavour())
+    torch.cuda.synchronize()
+    ro.phys.step(0, 0)                    # a sticky fault would raise here
+    torch.cuda.synchronize()
+    assert not any(f["resident"] for f in flav), [f["kernel"] for f in flav]
+    assert all("x 1 substep" in f["kernel"] for f in flav), [f["kernel"] for f in flav]   # the small-batch layout, one launch per substep
+    assert bool(torch.isfinite(ro.phys.x).all())
+    monkeypatch.delenv("R2S_RES_CU_BUDGET")
+    ro2 = BatchedRollout("rope_1env", close_at=2, seed=2, settle_steps=2)
+    ro2.step()
+    assert ro2.phys.last_flavour()["resident"], "the same scene on the whole chip runs the resident launch"
