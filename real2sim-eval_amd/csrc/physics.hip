@@ -115,6 +115,8 @@ struct PhysDev {
                                // finishing workgroup knows its environment from blockIdx, so count + record + the mesh's rigid
                                // transform are ONE round trip before the query (the chain-wide list costs two: entry, then state)
     int* rec_cnt;
+    int* mq_hint;              // large-mesh scenes: [E,N] the cluster of a particle's closest face in its last query (-1 none; null: no hints) — where its
+                               // next substep's first query looks first (round 5).  Plain loads and stores: a stale hint costs time, never the answer
     int* cand_mark;            // [E,N] = substep + 1 when a particle with candidates was handed to the mesh list in that substep
     const int2* cand_list;     // [E][N] per ENVIRONMENT: (env | candidate count << 12, particle) of its particles with candidates, cand_cnt_env[e] of them
     const int* cand_count;     // all of them
@@ -138,6 +140,10 @@ struct PhysDev {
                                // coalesced (nine 36-byte-strided dword loads per lane cost the texture path 18 cache lines each)
     const int4* cl_info;       // [n_cl] {mesh, kind | (transform slot + 1) << 2 | faces << 8, transform slot of the mesh (-1 none), first stored face}: the whole cluster record in one load
     int n_sup, n_small;        // super-clusters (eight consecutive clusters of a large mesh); small meshes of a scene that has a large one
+    // the FIRST large mesh's clusters [lm_c0, lm_c0 + lm_nc) are runs of 64 stored faces from lm_f0 (the last one shorter: up to lm_f1): their
+    // cl_info record is arithmetic, not a load — the round trip between a hint and its cluster's triangles (cl_info_of)
+    int lm_c0, lm_nc, lm_f0, lm_f1, lm_y;  // lm_y: the record's .y without the face count (mesh kind | (transform slot + 1) << 2), lm_nc = 0: none
+    int lm_mesh, lm_slot;
     const float* sup_box;      // [6][n_sup] rest-frame boxes, component-major
     const int4* sup_info;      // [n_sup] {first cluster, clusters, transform slot (-1 none), mesh kind}
     const int* small_mesh;     // [n_small] mesh ids
@@ -447,7 +453,48 @@ __device__ __forceinline__ void pair_barrier(QShare& sm, int& parity)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, f3 q, int e, bool want, int hint, QShare& sm, int& parity, const Xf& X0 R2S_QP_PARAM)
+// What the two queries of a particle's substep (mesh_collision's query and the gripper / pusher branch's re-query, :322-324, :397) share,
+// and what does not depend on the particle at all — so that neither is a dependent round trip inside a query (round 5: the pusher's
+// finishing launch spent ~2.5 of a query's ~6.5 us waiting for cluster records and triangle corners it had just had in registers):
+__device__ __forceinline__ int4 cl_info_of(const PhysDev& p, int c) // p.cl_info[c], computed where the layout allows it
+{
+    const int k = c - p.lm_c0;
+    if (k >= 0 && k < p.lm_nc) {
+        const int f0 = p.lm_f0 + 64 * k;
+        return make_int4(p.lm_mesh, p.lm_y | (min(64, p.lm_f1 - f0) << 8), p.lm_slot, f0);
+    }
+    return p.cl_info[c];
+}
+struct FaceRegs { f3 a, b, c; int forig; };   // this lane's face of a cluster: rest-frame corners, original (caller) face id
+struct BlkAux {
+    Xf X;              // rigid transform of the first large dynamic mesh at (env, substep): loaded with the particle's record
+    int hint;          // the cluster to look at first in the substep's FIRST query: the particle's closest cluster one substep ago (-1: search)
+    int c0;            // the cluster whose faces are in `fr` (-1 none): a re-query a few micrometres away starts there without a load
+    int4 c0_info;      // its cl_info record
+    FaceRegs fr;
+    bool sup_ok;       // n_sup <= 64: this lane's super-cluster record and rest-frame box, loaded at kernel entry (they depend on the lane only)
+    int4 si;
+    float sbox[6];
+};
+__device__ __forceinline__ void blk_aux_init(const PhysDev& p, BlkAux& A, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 9; ++j) A.X.r[j] = (j % 4 == 0) ? 1.f : 0.f;
+    A.X.t[0] = A.X.t[1] = A.X.t[2] = 0.f;
+    A.hint = -1; A.c0 = -1; A.c0_info = make_int4(0, 0, -1, 0);
+    A.fr.a = A.fr.b = A.fr.c = mk(0.f, 0.f, 0.f); A.fr.forig = 0;
+    A.sup_ok = p.n_sup > 0 && p.n_sup <= 64;
+    A.si = make_int4(0, 0, -1, 0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) A.sbox[k] = 0.f;
+    if (A.sup_ok) {
+        const int s = min(lane, p.n_sup - 1);
+        A.si = p.sup_info[s];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) A.sbox[k] = p.sup_box[k * p.n_sup + s];
+    }
+}
+__device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, f3 q, int e, bool want, int hint, QShare& sm, int& parity, BlkAux& A R2S_QP_PARAM)
 {
     MeshHit out = {false, 0.f, 0, mk(0.f, 0.f, 0.f), 0, 0, -1};
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
@@ -456,6 +503,7 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
     unsigned long long bestkey = ~0ull;
     f3 bcp = mk(0.f, 0.f, 0.f), bdl = mk(0.f, 0.f, 0.f); // closest point and q - p, both in the mesh's frame
     int bstored = 0, bregion = 0, bkind = 0, bxf = -1, bcl = -1;
+    const Xf& X0 = A.X;
     // X0: the first large dynamic mesh's transform of this (env, substep), loaded by the caller together with the particle's
     // state (one load for both queries of a particle); further ones (rare) are fetched where needed
     if (want) {
@@ -482,21 +530,26 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
                 bkind = kind; bxf = slot; bcl = cluster;
             }
         };
-        auto visit = [&](int cluster, int f0, int nf, int kind, int slot) { // a cluster of a large mesh: rest-frame triangle records
+        auto load_faces = [&](int4 ci) -> FaceRegs { // this lane's face of the cluster with record `ci` (lanes beyond its face count: its first face)
+            const int f = ci.w + (lane < (ci.y >> 8) ? lane : 0);
+            const float* t9 = tri_ptr(p, f);
+            FaceRegs r;
+            r.a = mk(t9[0], t9[64], t9[128]); r.b = mk(t9[192], t9[256], t9[320]); r.c = mk(t9[384], t9[448], t9[512]);
+            r.forig = p.face_orig[f];
+            return r;
+        };
+        auto visit = [&](int cluster, int4 ci, const FaceRegs& fr) { // a cluster of a large mesh: rest-frame triangle records
+            const int nf = ci.y >> 8, kind = ci.y & 3, slot = ci.z;
             const f3 qq = rest_point(slot);
             const bool act = lane < nf;
-            const int f = act ? f0 + lane : f0;
-            const float* t9 = tri_ptr(p, f);
-            const f3 a = mk(t9[0], t9[64], t9[128]), b = mk(t9[192], t9[256], t9[320]), c3 = mk(t9[384], t9[448], t9[512]);
-            const int forig = p.face_orig[f];
             float u, v;
             int region;
-            closest_bary(a, b, c3, qq, u, v, region);
-            const f3 cp = a * u + b * v + c3 * (1.f - u - v);
+            closest_bary(fr.a, fr.b, fr.c, qq, u, v, region);
+            const f3 cp = fr.a * u + fr.b * v + fr.c * (1.f - u - v);
             const f3 d = cp - qq;
             const float d2 = dot(d, d);
-            const unsigned long long key = (act && d2 < MAXD2) ? (((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)forig) : ~0ull;
-            reduce(key, cp, qq, region, f, kind, slot, cluster);
+            const unsigned long long key = (act && d2 < MAXD2) ? (((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)fr.forig) : ~0ull;
+            reduce(key, cp, qq, region, ci.w + (act ? lane : 0), kind, slot, cluster);
         };
         // ---- small meshes of the scene (gripper fingers next to a large obstacle): world frame, through the face table
         for (int k = 0; k < p.n_small; ++k) {
@@ -531,28 +584,39 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
         // a wavefront's own visits.  (Round 2 numbered with the diverging bound: a cluster could get a different rank in
         // different wavefronts and be visited by none — more than eight super-clusters in reach, or more than 64 in total.)
         float best0 = best;
-        if (hint >= 0) { // a re-query next to the previous answer: its cluster first, no search for the nearest box
+        if (hint >= 0) { // a query next to a previous answer: its cluster first, no search for the nearest box — and no load when its faces are still here
             C0 = hint;
-            const int4 ci = p.cl_info[C0];
-            visit(C0, ci.w, ci.y >> 8, ci.y & 3, ci.z);
+            if (A.c0 != C0) { A.c0_info = cl_info_of(p, C0); A.fr = load_faces(A.c0_info); A.c0 = C0; }
+            visit(C0, A.c0_info, A.fr);
             R2S_QSTAMP(); // nearest cluster done
         }
         for (int sb = 0; sb < p.n_sup; sb += 64) {
             const int s = min(sb + lane, p.n_sup - 1);
-            const int4 si = p.sup_info[s]; // {first cluster, clusters, transform slot, mesh kind}
-            float d2s = box6(p.sup_box, p.n_sup, s, rest_point(si.z));
+            const bool pre = sb == 0 && A.sup_ok;
+            const int4 si = pre ? A.si : p.sup_info[s]; // {first cluster, clusters, transform slot, mesh kind}
+            float d2s;
+            if (pre) {
+                const f3 qq = rest_point(si.z);
+                const float dx = fmaxf(fmaxf(A.sbox[0] - qq.x, qq.x - A.sbox[3]), 0.f), dy = fmaxf(fmaxf(A.sbox[1] - qq.y, qq.y - A.sbox[4]), 0.f),
+                            dz = fmaxf(fmaxf(A.sbox[2] - qq.z, qq.z - A.sbox[5]), 0.f);
+                d2s = dx * dx + dy * dy + dz * dz;
+            } else
+                d2s = box6(p.sup_box, p.n_sup, s, rest_point(si.z));
             if (sb + lane >= p.n_sup) d2s = 3.0e38f;
             if (sb == 0 && bestkey == ~0ull && hint < 0) { // step 1: nearest first
                 const unsigned long long near = wave_min_u64(((unsigned long long)__float_as_uint(d2s) << 32) | (unsigned)lane);
                 if (__uint_as_float((unsigned)(near >> 32)) < best * 1.0001f + 1e-12f) {
                     const int L = (int)(near & 63);
-                    const int c0 = bcasti(si.x, L), ncl = bcasti(si.y, L), slot = bcasti(si.z, L), kind = bcasti(si.w, L);
+                    const int c0 = bcasti(si.x, L), ncl = bcasti(si.y, L), slot = bcasti(si.z, L);
+                    const int4 cil = p.cl_info[c0 + min(lane, max(ncl - 1, 0))];   // every lane its cluster's record, with the boxes: no round trip behind the choice
                     const float d2c = lane < ncl ? box6(p.cl_box, p.n_cl, c0 + lane, rest_point(slot)) : 3.0e38f;
                     const unsigned long long nc = wave_min_u64(((unsigned long long)__float_as_uint(d2c) << 32) | (unsigned)lane);
                     if (__uint_as_float((unsigned)(nc >> 32)) < best * 1.0001f + 1e-12f) {
-                        C0 = c0 + (int)(nc & 63);
-                        const int4 ci = p.cl_info[C0];
-                        visit(C0, ci.w, ci.y >> 8, kind, slot);
+                        const int Lc = (int)(nc & 63);
+                        C0 = c0 + Lc;
+                        A.c0_info = make_int4(bcasti(cil.x, Lc), bcasti(cil.y, Lc), bcasti(cil.z, Lc), bcasti(cil.w, Lc));
+                        A.fr = load_faces(A.c0_info); A.c0 = C0;
+                        visit(C0, A.c0_info, A.fr);
                     }
                 }
                 R2S_QSTAMP(); // nearest cluster done
@@ -568,9 +632,10 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
                 for (int k = 0; k < cnt; ++k) smask &= smask - 1;
                 const int idx = lane >> 3, j = lane & 7;
                 const int owner = sm.sup[wave][idx];
-                const int c0 = __shfl(si.x, owner), ncl = __shfl(si.y, owner), slot = __shfl(si.z, owner), kind = __shfl(si.w, owner);
+                const int c0 = __shfl(si.x, owner), ncl = __shfl(si.y, owner), slot = __shfl(si.z, owner);
                 const bool valid = idx < cnt && j < ncl;
                 const int c = valid ? c0 + j : 0;
+                const int4 cil = p.cl_info[c];                              // with the box (same round trip): a candidate's record is a readlane away
                 const float d2c = valid ? box6(p.cl_box, p.n_cl, c, rest_point(slot)) : 3.0e38f;
                 unsigned long long cm = __builtin_amdgcn_ballot_w64(d2c < best0 * 1.0001f + 1e-12f && c != C0);
                 while (cm) { // step 3: this wavefront's share of the candidates
@@ -579,8 +644,8 @@ __device__ __forceinline__ MeshHit mesh_query_block(const PhysDev& p, int step, 
                     if ((r++ % QWPB) != wave) continue;
                     if (!(bcast(d2c, L) < best * 1.0001f + 1e-12f)) continue; // cannot beat this wavefront's best any more
                     const int cc = bcasti(c, L);
-                    const int4 ci = p.cl_info[cc];
-                    visit(cc, ci.w, ci.y >> 8, bcasti(kind, L), bcasti(slot, L));
+                    const int4 ci = make_int4(bcasti(cil.x, L), bcasti(cil.y, L), bcasti(cil.z, L), bcasti(cil.w, L));
+                    visit(cc, ci, load_faces(ci));
                 }
             }
         }
@@ -1063,7 +1128,8 @@ __device__ __forceinline__ bool mesh_rec_push(const PhysDev& p, int e, int step,
     const int slot = atomicAdd(p.rec_cnt + (size_t)e * p.n_sub + step, 1);
     if (slot >= p.N) return false;
     int4* r = p.mesh_rec + 2 * (par_off(p, step) + (size_t)e * p.N + slot);
-    r[0] = make_int4(ncand, ncand > 0 ? (i | (int)0x80000000) : i, __float_as_int(x0.x), __float_as_int(x0.y));
+    const int hint = p.mq_hint ? p.mq_hint[(size_t)e * p.N + i] : -1; // the cluster of its closest face one substep ago rides in the record (bits 19..30)
+    r[0] = make_int4(ncand | ((hint + 1) << 19), ncand > 0 ? (i | (int)0x80000000) : i, __float_as_int(x0.x), __float_as_int(x0.y));
     r[1] = make_int4(__float_as_int(x0.z), __float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z));
     return true;
 }
@@ -1086,7 +1152,7 @@ __device__ __forceinline__ bool mesh_rec_push(const PhysDev& p, int e, int step,
 // instead of the state array.  Returns whether THIS call finished (and stored / kept) the lane's particle.
 template <int MESH, bool MAIN = false, int NEED = 0, bool KEEP = false, bool QUAD = false, bool PFOUT = false>
 __device__ __forceinline__ bool finish_wave(const PhysDev& p, int e, int i, size_t eb, int step, int write_forces, f3 x0, f3 v, bool fin,
-                                            const StateM xv_out, const TriRegs* tr, QShare* qs, int* qpar, const Xf* xf0, bool store, ResidentIO* keep R2S_QP_PARAM)
+                                            const StateM xv_out, const TriRegs* tr, QShare* qs, int* qpar, BlkAux* xf0, bool store, ResidentIO* keep R2S_QP_PARAM)
 {
     f3 x = x0;
     // mesh_collision, :295-421 — advances x by v*dt for EVERY particle (:321, :420)
@@ -1137,7 +1203,7 @@ __device__ __forceinline__ bool finish_wave(const PhysDev& p, int e, int i, size
         if (IN_PLACE)
             q = MESH == 3 ? mesh_query_regs<QUAD>(*tr, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), bcasti((int)need, 0) != 0, *qs, *qpar)
               : MESH == 2 ? mesh_query_block(p, step, mk(bcast(next_x.x, 0), bcast(next_x.y, 0), bcast(next_x.z, 0)), e,
-                                             bcasti((int)need, 0) != 0, -1, *qs, *qpar, *xf0 R2S_QP_ARG) // workgroup-cooperative, call site 1
+                                             bcasti((int)need, 0) != 0, xf0->hint, *qs, *qpar, *xf0 R2S_QP_ARG) // workgroup-cooperative, call site 1
                           : mesh_query_lane(p, e, step, next_x, need);
         R2S_QSTAMP(); // first query back
         // per-lane response; lanes that must re-query (gripper branch, :394-408) park their state and meet again below
@@ -1204,6 +1270,8 @@ __device__ __forceinline__ bool finish_wave(const PhysDev& p, int e, int i, size
             }
             q = q2; // face of the LAST query (0 if the re-query missed)
         }
+        // large-mesh scenes: where this particle's next substep should look first (the finishing workgroup's storing lane)
+        if (MESH == 2 && IN_PLACE && !MAIN && fin && store && p.mq_hint) p.mq_hint[eb + i] = q.hint;
         if (hit && write_forces && store) {
             const f3 fo = (v_normal_new - v_normal) / p.dt;
             float* cf3 = p.coll_forces + ((size_t)e * p.nF + (MESH >= 2 ? q.fm : p.face_map[q.face])) * 3;
@@ -1601,10 +1669,6 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
     const unsigned base = ei * (unsigned)SRV_REC;
     const TriIds tids = load_tri_ids(p, lane, r & 1);
     int qpar = QPAIR | (p.srv_quad ? QQUAD : 0);
-    Xf X0;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) X0.r[j] = (j % 4 == 0) ? 1.f : 0.f;
-    X0.t[0] = X0.t[1] = X0.t[2] = 0.f;
     ResidentIO io;
     io.srv_on = false; io.srv_need = false; io.boxes = nullptr; io.step_boxes = nullptr;
     io.x = mk(0.f, 0.f, 0.f); io.v = io.x;
@@ -1726,10 +1790,10 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
         R2S_QP_DECL(r == 0 ? g : -1); // (probe builds: the stamps of the pair's last substep — before, first query back, second back, after)
         R2S_QSTAMP();
         if (p.srv_quad)
-            finish_wave<3, false, 1, true, true>(p, e, i, eb, first + (int)k, last ? write_forces_last : 0, x0, v, lane == 0, none, &tr, &qsrv[pair], &qpar, &X0,
+            finish_wave<3, false, 1, true, true>(p, e, i, eb, first + (int)k, last ? write_forces_last : 0, x0, v, lane == 0, none, &tr, &qsrv[pair], &qpar, nullptr,
                                                  r == 0, &io R2S_QP_ARG);
         else
-            finish_wave<3, false, 1, true>(p, e, i, eb, first + (int)k, last ? write_forces_last : 0, x0, v, lane == 0, none, &tr, &qsrv[pair], &qpar, &X0,
+            finish_wave<3, false, 1, true>(p, e, i, eb, first + (int)k, last ? write_forces_last : 0, x0, v, lane == 0, none, &tr, &qsrv[pair], &qpar, nullptr,
                                            r == 0, &io R2S_QP_ARG);
         R2S_QSTAMP();
         if (qpar & QFAIL) { // the pair's other wavefront did not reach a barrier of this substep
@@ -2268,10 +2332,14 @@ __device__ __forceinline__ void contact_finish_body(const PhysDev& p, const Stat
     else ei = p.mesh_list[po + min(t0, p.mesh_cap - 1)];
     TriIds tid = {0, 0, 0, 0, 0, 0, false};
     if (MESHQ == 3) tid = load_tri_ids(p, lane, wave);
-    Xf Xw; // MESHQ 2: the substep's rigid transform of the first large dynamic mesh of this workgroup's environment
+    BlkAux aux; // MESHQ 2: what a particle's queries share and what does not depend on the particle (super-cluster boxes), loaded with the first record
+    if (MESHQ == 2) blk_aux_init(p, aux, lane);
+    Xf Xw = aux.X; // the substep's rigid transform of the first large dynamic mesh of this workgroup's environment (identity without one)
+    if (MESHQ != 2) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j) Xw.r[j] = (j % 4 == 0) ? 1.f : 0.f;
-    Xw.t[0] = Xw.t[1] = Xw.t[2] = 0.f;
+        for (int j = 0; j < 9; ++j) Xw.r[j] = (j % 4 == 0) ? 1.f : 0.f;
+        Xw.t[0] = Xw.t[1] = Xw.t[2] = 0.f;
+    }
     if (per_env && p.n_xf > 0) Xw = xf_load_slot(p, __builtin_amdgcn_readfirstlane(e_wg), step, 0);
     const int n_mesh = !in_grid ? 0 : per_env ? min(p.rec_cnt[(size_t)e_wg * p.n_sub + step], p.N) : min(p.mesh_cnt[step], p.mesh_cap);
     for (int t = t0; t < n_mesh; t += t_stride) { // a workgroup-uniform trip count (barriers inside)
@@ -2279,7 +2347,7 @@ __device__ __forceinline__ void contact_finish_body(const PhysDev& p, const Stat
         int e, i, cnt;
         if (per_env) {
             if (t != t0) { ra = rec[2 * t]; rc = rec[2 * t + 1]; }
-            tagged = ra.y < 0; e = e_wg; i = ra.y & 0x7fffffff; cnt = ra.x;
+            tagged = ra.y < 0; e = e_wg; i = ra.y & 0x7fffffff; cnt = ra.x & 0x7ffff; aux.hint = (ra.x >> 19) - 1;
         } else {
             if (t != t0) ei = p.mesh_list[po + t];
             tagged = ei.y < 0; e = ei.x & 0xfff; i = ei.y & 0x7fffffff; cnt = ei.x >> 12;
@@ -2287,8 +2355,9 @@ __device__ __forceinline__ void contact_finish_body(const PhysDev& p, const Stat
         const size_t eb = (size_t)e * p.N;
         TriRegs tr;
         if (MESHQ == 3) tr = load_tris(p, e, step, tid); // in flight while the impulses are summed
-        Xf X0 = Xw;
-        if (MESHQ == 2 && !per_env && p.n_xf > 0) X0 = xf_load_slot(p, __builtin_amdgcn_readfirstlane(e), step, 0);
+        aux.X = Xw;
+        if (MESHQ == 2 && !per_env && p.n_xf > 0) aux.X = xf_load_slot(p, __builtin_amdgcn_readfirstlane(e), step, 0);
+        if (!per_env) aux.hint = -1;
         f3 x0, v;
         if (per_env) {
             x0 = mk(__int_as_float(ra.z), __int_as_float(ra.w), __int_as_float(rc.x));
@@ -2303,7 +2372,7 @@ __device__ __forceinline__ void contact_finish_body(const PhysDev& p, const Stat
         if (lane == 0 && qp.wave >= 0 && qp.wave < 1024) g_query_probe[qp.wave * 32 + 31] = probe_entry;
 #endif
         R2S_QSTAMP(); // entry loaded, x0 / v (and the impulses) done
-        finish_wave<MESHQ, false, 1, false, false, PFOUT>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr, &qshare, &qpar, &X0, wave == 0, nullptr R2S_QP_ARG);
+        finish_wave<MESHQ, false, 1, false, false, PFOUT>(p, e, i, eb, step, write_forces, x0, v, lane == 0, xv_out, &tr, &qshare, &qpar, &aux, wave == 0, nullptr R2S_QP_ARG);
         R2S_QSTAMP(); // stored
     }
     if (WITH_SELF) {
@@ -2951,6 +3020,8 @@ struct R2SPhys {
     int pf_pref = 1;            // R2S_PF=0 / r2s_phys_set_pf(h, 0): keep the two-launch contact flavours (A/B measurements, the bit-identity test)
     int2* d_mesh_list = nullptr; int* d_mesh_cnt = nullptr; int mesh_cap = 0; // deferred mesh queries: [E * N] (a chain's slice starts at its first env), [chains][n_sub + 1]
     float4* d_vdef = nullptr;
+    int* d_mq_hint = nullptr;
+    int lm[7] = {0, 0, 0, 0, 0, 0, -1}; // PhysDev::lm_c0, lm_nc, lm_f0, lm_f1, lm_y, lm_mesh, lm_slot
     int4* d_mesh_rec = nullptr; int* d_rec_cnt = nullptr; // large-mesh scenes: per-environment records [E][N][2] and their counters [E][n_sub]
     int* d_cand_mark = nullptr;
     // Counters of an env step ([0] particles near a mesh, [1] sticky fault word, [2] a query was needed, [3] server pairs ran out, [4..15] fault
@@ -3060,7 +3131,8 @@ struct R2SPhys {
         p.coll_num = d_coll_num; p.coll_idx = d_coll_idx; p.coll_cap = coll_cap;
         p.vbc = d_vbc; p.xbc = d_xbc; p.par_stride = (size_t)E * N; p.cand_list = d_cand_list; p.cand_count = d_cand_count; p.cand_cnt_env = d_cand_count ? d_cand_count + 4 : nullptr;
         p.pf = 0; p.pf_nfin = 0; p.pf_res = d_pf_res;
-        p.mesh_list = d_mesh_list; p.mesh_cnt = d_mesh_cnt; p.mesh_cap = mesh_cap; p.mesh_defer = mesh_defer; p.vdef = d_vdef; p.cand_mark = d_cand_mark; p.mesh_rec = d_mesh_rec; p.rec_cnt = d_rec_cnt;
+        p.mesh_list = d_mesh_list; p.mesh_cnt = d_mesh_cnt; p.mesh_cap = mesh_cap; p.mesh_defer = mesh_defer; p.vdef = d_vdef; p.cand_mark = d_cand_mark; p.mesh_rec = d_mesh_rec; p.rec_cnt = d_rec_cnt; p.mq_hint = d_mq_hint;
+        p.lm_c0 = lm[0]; p.lm_nc = lm[1]; p.lm_f0 = lm[2]; p.lm_f1 = lm[3]; p.lm_y = lm[4]; p.lm_mesh = lm[5]; p.lm_slot = lm[6];
         p.n_mesh = n_mesh; p.n_dyn_mesh = n_dyn_mesh; p.nF = nF; p.nV = nV; p.n_dyn_pts = n_dyn_pts;
         p.faces = d_faces; p.mesh_map = d_mesh_map; p.face_map = d_face_map; p.mesh_face_off = d_mesh_face_off;
         p.face_orig = d_face_orig; p.n_cl = n_cl; p.n_xf = n_xf;
@@ -3910,6 +3982,21 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
                     for (int k = 0; k < 3; ++k) tri[((size_t)(f >> 6) * 9 + c * 3 + k) * 64 + (f & 63)] = d->mesh_vertices[3 * (size_t)stored[3 * f + c] + k];
             std::vector<int4> info(h->n_cl);
             for (int c = 0; c < h->n_cl; ++c) info[c] = make_int4(cl_mesh[c], mesh_kind[cl_mesh[c]] | ((mesh_xf[cl_mesh[c]] + 1) << 2) | ((cl_f1[c] - cl_f0[c]) << 8), mesh_xf[cl_mesh[c]], cl_f0[c]);
+            for (int c = 0; c < h->n_cl && h->lm[1] == 0; ++c) // the first large mesh: its cluster records as arithmetic (PhysDev::lm_*), checked against the table
+                if (mesh_kind[cl_mesh[c]] & 1) {
+                    const int m = cl_mesh[c];
+                    int nc = 0;
+                    while (c + nc < h->n_cl && cl_mesh[c + nc] == m) ++nc;
+                    int lm[7] = {c, nc, cl_f0[c], cl_f1[c + nc - 1], mesh_kind[m] | ((mesh_xf[m] + 1) << 2), m, mesh_xf[m]};
+                    bool ok = true;
+                    for (int k = 0; k < nc && ok; ++k) {
+                        const int f0 = lm[2] + 64 * k;
+                        const int4 want = info[c + k];
+                        ok = want.x == m && want.y == (lm[4] | (std::min(64, lm[3] - f0) << 8)) && want.z == mesh_xf[m] && want.w == f0;
+                    }
+                    if (ok) std::copy(lm, lm + 7, h->lm);
+                    break;
+                }
             TRY(dev_alloc(&h->d_tri_rest, tri.size())); TRY(upload(h->d_tri_rest, tri.data(), tri.size(), s));
             TRY(dev_alloc(&h->d_cl_info, info.size())); TRY(upload(h->d_cl_info, info.data(), info.size(), s));
             // super-clusters: runs of eight consecutive clusters of one large mesh (Morton order keeps them compact)
@@ -3992,6 +4079,10 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         if (h->any_large) {
             TRY(dev_alloc(&h->d_mesh_rec, (size_t)4 * E * N));
             R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_rec, 0, sizeof(int4) * (size_t)4 * E * N, s));
+            if (h->n_cl < 4094 && getenv("R2S_NO_MQ_HINT") == nullptr) { // the hint rides in 12 bits of a record word
+                TRY(dev_alloc(&h->d_mq_hint, (size_t)E * N));
+                R2S_HIP_TRY(hipMemsetAsync(h->d_mq_hint, 0xFF, sizeof(int) * (size_t)E * N, s)); // -1: no hint
+            }
             TRY(dev_alloc(&h->d_rec_cnt, (size_t)E * h->prm.num_substeps));
             R2S_HIP_TRY(hipMemsetAsync(h->d_rec_cnt, 0, sizeof(int) * (size_t)E * h->prm.num_substeps, s));
         }
@@ -4114,7 +4205,7 @@ void r2s_phys_destroy(R2SPhys* h)
     (void)hipDeviceSynchronize();
     drop_graph(h);
     void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_slice_int, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
-                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_xbc, h->d_pf_res, h->d_mesh_list, h->d_mesh_cnt, h->d_vdef, h->d_mesh_rec, h->d_rec_cnt, h->d_cand_mark, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
+                    h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_xbc, h->d_pf_res, h->d_mesh_list, h->d_mesh_cnt, h->d_vdef, h->d_mesh_rec, h->d_mq_hint, h->d_rec_cnt, h->d_cand_mark, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
                     h->d_faces, h->d_face_orig, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
                     h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_sup_info, h->d_sup_box, h->d_small_mesh, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
