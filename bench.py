@@ -35,8 +35,8 @@ for p in (ROOT, os.path.join(ROOT, "real2sim-eval_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = next((f for f in (os.path.join("profiles", "r4_pmc_summary.json"), os.path.join("profiles", "r3_pmc_summary.json")) if os.path.exists(os.path.join(ROOT, f))),
-                os.path.join("profiles", "r4_pmc_summary.json"))   # the newest committed counter summary (labelled STALE when collected on other kernel sources)
+PMC_FILE = next((f for f in (os.path.join("profiles", "r5_pmc_summary.json"), os.path.join("profiles", "r4_pmc_summary.json")) if os.path.exists(os.path.join(ROOT, f))),
+                os.path.join("profiles", "r5_pmc_summary.json"))   # the newest committed counter summary (labelled STALE when collected on other kernel sources)
 
 
 def pmc_summary(kernel, config):
@@ -332,7 +332,20 @@ def main():
         torch.cuda.synchronize(dev)
         els = time.perf_counter() - t0s
         plog = ra.read_log()
+        # ... and once more as round 4 timed its `value`: the same synchronised schedule, steps only ENQUEUED (comparable with BENCH_r04.json)
+        rb = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=close_sync, res=res)
+        for _ in range(args.warmup):
+            rb.step()
+        torch.cuda.synchronize(dev)
+        t0e = time.perf_counter()
+        for _ in range(args.steps):
+            rb.step()
+        torch.cuda.synchronize(dev)
+        enq_rate = rb.n_env * args.steps / (time.perf_counter() - t0e)
+        del rb
         sync_report = {"env_steps_per_s": ra.n_env * args.steps / els, "ms_per_step": els / args.steps * 1e3, "closed_loop": closed_loop,
+                       "enqueue_only_env_steps_per_s": enq_rate,
+                       "note_enqueue_only": "the round-4 definition of `value` (synchronised schedule, steps enqueued back to back, no get_obs()): for comparison with BENCH_r04.json only",
                        "note": "this rank; the same workload with all environments in phase (every gripper closes at the window's middle): the window's "
                                "first half runs the free flavour, its second half the contact flavour — see `phases`"}
 

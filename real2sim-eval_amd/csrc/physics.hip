@@ -1346,6 +1346,9 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
     const int xcd = bid & 7, q = bid >> 3;
     const int item = xcd * p.cb + q;
     if (q >= p.cb || item >= p.nb * p.ne) return; // whole workgroup
+    // (round 5, measured and removed: XCD x owning the blocks b = x mod 8 instead of a contiguous range — so that the blocks of a contact
+    // region, neighbours in Morton order, and with them the blocks that wait for a finisher in k_substep_pf, spread over all eight XCDs:
+    // 22.8 vs 22.2 us per contact substep of the headline, 17.8 vs 17.0 free: the halo locality of contiguous ranges is worth more)
     const int b = item / p.ne, e = p.e0 + (item - b * p.ne);
     R2S_STAMP(0);
     const int tid = threadIdx.x;
@@ -2332,16 +2335,16 @@ __device__ __forceinline__ void contact_finish_body(const PhysDev& p, const Stat
     else ei = p.mesh_list[po + min(t0, p.mesh_cap - 1)];
     TriIds tid = {0, 0, 0, 0, 0, 0, false};
     if (MESHQ == 3) tid = load_tri_ids(p, lane, wave);
-    BlkAux aux; // MESHQ 2: what a particle's queries share and what does not depend on the particle (super-cluster boxes), loaded with the first record
-    if (MESHQ == 2) blk_aux_init(p, aux, lane);
-    Xf Xw = aux.X; // the substep's rigid transform of the first large dynamic mesh of this workgroup's environment (identity without one)
-    if (MESHQ != 2) {
+    Xf Xw; // the substep's rigid transform of the first large dynamic mesh of this workgroup's environment (identity without one)
 #pragma unroll
-        for (int j = 0; j < 9; ++j) Xw.r[j] = (j % 4 == 0) ? 1.f : 0.f;
-        Xw.t[0] = Xw.t[1] = Xw.t[2] = 0.f;
-    }
+    for (int j = 0; j < 9; ++j) Xw.r[j] = (j % 4 == 0) ? 1.f : 0.f;
+    Xw.t[0] = Xw.t[1] = Xw.t[2] = 0.f;
     if (per_env && p.n_xf > 0) Xw = xf_load_slot(p, __builtin_amdgcn_readfirstlane(e_wg), step, 0);
     const int n_mesh = !in_grid ? 0 : per_env ? min(p.rec_cnt[(size_t)e_wg * p.n_sub + step], p.N) : min(p.mesh_cnt[step], p.mesh_cap);
+    // MESHQ 2: what a particle's queries share and what does not depend on the particle (super-cluster records and boxes) — issued BEHIND the
+    // record and the count (memory operations return in order: the first query's point must not wait for these; they are needed after its first cluster)
+    BlkAux aux;
+    if (MESHQ == 2) blk_aux_init(p, aux, lane);
     for (int t = t0; t < n_mesh; t += t_stride) { // a workgroup-uniform trip count (barriers inside)
         bool tagged;
         int e, i, cnt;
