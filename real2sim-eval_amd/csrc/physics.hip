@@ -2447,8 +2447,11 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
 #ifndef R2S_PF_WAVES3
 #define R2S_PF_WAVES3 5
 #endif
+#ifndef R2S_PF_WAVES3_NOSELF
+#define R2S_PF_WAVES3_NOSELF R2S_PF_WAVES3
+#endif
 template <int B, int RCAP, bool SELF, int MESH, int MESHQ>
-__global__ void __launch_bounds__(B, (MESHQ == 3 ? R2S_PF_WAVES3 : 1)) k_substep_pf(const PhysDev p, const StateC xv_in, const StateM xv_out, int step, int write_forces, int fin_skip)
+__global__ void __launch_bounds__(B, (MESHQ == 3 ? (SELF ? R2S_PF_WAVES3 : R2S_PF_WAVES3_NOSELF) : 1)) k_substep_pf(const PhysDev p, const StateC xv_in, const StateM xv_out, int step, int write_forces, int fin_skip)
 {
     if ((int)blockIdx.x < p.pf_nfin) {
         constexpr int NTHR = MESHQ == 3 ? 128 : 256;
@@ -3290,10 +3293,12 @@ bool pf_flavour(const R2SPhys* h, const PhysDev& p) { return h->pf_ok && h->pf_p
 // finishing workgroups at the head of a launch: enough for the lists of a batch in contact without a second round (a workgroup strides
 // over its list if there is more), few enough not to stand between the launch and its fused blocks — every workgroup of the launch
 // holds the fused role's LDS window, so an idle finisher costs a block's slot for the microsecond it takes to read an empty list
-int pf_head_size(const R2SPhys* h, int ne)
+int pf_head_size(const R2SPhys* h, int ne, bool with_self)
 {
     const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
-    int n = mesh == 2 ? ne * std::max(16, 256 / std::max(1, ne)) : std::min(1024, 32 * ne);
+    // small scenes: 32 workgroups per environment (deferred queries from the front, candidate particles — eight to a workgroup — from the back;
+    // 16 and 24 ran a second round in the headline's grasp: 25.8 / 24.4 vs 22.8 us), 16 while no particle has candidates
+    int n = mesh == 2 ? ne * std::max(16, 256 / std::max(1, ne)) : std::min(1024, (with_self ? 32 : 16) * ne);
     if (const char* ev = getenv("R2S_PF_HEAD")) n = std::max(8, atoi(ev) * ne); // tuning: finishing workgroups per environment
     return (n + 7) & ~7;
 }
@@ -3385,7 +3390,7 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
     int buf = start_buf;
     const bool pf = pf_flavour(h, p);
     if (pf) { // the finishers of substep k ride at the head of substep k + 1's launch; the last substep's are the stand-alone launch
-        p.pf = 1; p.pf_nfin = pf_head_size(h, ne);
+        p.pf = 1; p.pf_nfin = pf_head_size(h, ne, with_self);
         const size_t words = (size_t)(PF_LINE / 4) * ne * h->N; // this chain's result lines: tags of the previous env step must not match
         hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_pf_res + (size_t)(PF_LINE / 4) * e0 * h->N, words);
     }
