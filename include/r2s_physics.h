@@ -134,6 +134,11 @@ int r2s_phys_set_state_envs(R2SPhys* h, const float* x, const float* v, const in
  * builds a new stepper per reset, whose resting-pair set comes from the new initial positions — and depends on them through the
  * hash-grid cells) while the other environments keep theirs. */
 int r2s_phys_create_resting_case_envs(R2SPhys* h, const int32_t* env_mask, r2s_stream_t stream);
+/* Episode reset into another scene pose (gs_renderer.py:353-390: load_scaniverse re-poses every mesh with a grid_randomization entry by
+ * the episode index before PhysTwinDynamics is rebuilt from it): the vertices of the STATIC collision meshes of the environments whose
+ * env_mask[e] != 0 (null = all), DEVICE float [n_env, n_static_vertices, 3] in the order of R2SPhysDesc::mesh_vertices behind the dynamic
+ * ones; their boxes are rebuilt.  R2S_ERR_INVALID for a static mesh with more than 256 faces (its triangle table is built at create). */
+int r2s_phys_set_static_mesh_points(R2SPhys* h, const float* pts, const int32_t* env_mask, r2s_stream_t stream);
 int r2s_phys_mesh_motion(R2SPhys* h, float** interp_points, float** interp_center, float** dynamic_velocity,
                          float** dynamic_omega);
 

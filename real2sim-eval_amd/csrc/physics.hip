@@ -4259,6 +4259,31 @@ int r2s_phys_set_state_envs(R2SPhys* h, const float* x, const float* v, const in
     return R2S_OK;
 }
 
+__global__ void k_set_static_pts(int E, int n, int nV, int n_dyn_pts, const int* __restrict__ mask, const float* __restrict__ src, float* __restrict__ mesh_pts)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
+    if (t >= 3 * n || (mask && mask[e] == 0)) return;
+    mesh_pts[((size_t)e * nV + n_dyn_pts) * 3 + t] = src[(size_t)e * 3 * n + t];
+}
+
+int r2s_phys_set_static_mesh_points(R2SPhys* h, const float* pts, const int32_t* env_mask, r2s_stream_t stream_)
+{
+    if (!h || !pts || h->nF == 0) return R2S_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream_;
+    const int n = h->nV - h->n_dyn_pts;
+    if (n <= 0) return R2S_ERR_INVALID;
+    for (int m = h->n_dyn_mesh; m < h->n_mesh; ++m)
+        if (h->h_mesh_kind[m] & 1) { // its triangles live in a rest-frame table with a box hierarchy built at create: it cannot move per environment
+            r2s::set_last_error_msg("r2s_phys_set_static_mesh_points: a static collision mesh with more than 256 faces cannot be re-posed (unsupported)");
+            return R2S_ERR_INVALID;
+        }
+    hipLaunchKernelGGL(k_set_static_pts, dim3((unsigned)((3 * n + 255) / 256), (unsigned)h->E), dim3(256), 0, s, h->E, n, h->nV, h->n_dyn_pts, env_mask, pts, h->d_mesh_pts);
+    const int ns = h->n_mesh - h->n_dyn_mesh, tot = h->E * ns;
+    hipLaunchKernelGGL(k_mesh_aabb_static, dim3((tot + 255) / 256), dim3(256), 0, s, h->E, ns, h->n_dyn_mesh, h->nV, h->d_mesh_vert_off, h->d_mesh_pts, h->d_aabb_static);
+    R2S_HIP_TRY(hipGetLastError());
+    return R2S_OK;
+}
+
 int r2s_phys_get_state(R2SPhys* h, float* x, float* v, r2s_stream_t stream_)
 {
     if (!h) return R2S_ERR_INVALID;

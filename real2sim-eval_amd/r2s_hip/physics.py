@@ -55,7 +55,7 @@ def _bind():
         r2s_phys_set_eef_table=[vp, C.c_int32, vp, vp, C.c_float, vp], r2s_phys_set_eef_motion=[vp, vp, vp, vp, vp, vp, vp],
         r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_reset_envs=[vp, vp, vp], r2s_phys_set_state_envs=[vp, vp, vp, vp, vp], r2s_phys_create_resting_case_envs=[vp, vp, vp], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
         r2s_phys_set_collision_lists=[vp, vp, vp, vp], r2s_phys_contact_stats=[vp, C.POINTER(C.c_int32), C.POINTER(vp)],
-        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32], r2s_phys_set_resident=[vp, i32], r2s_phys_set_pf=[vp, i32], r2s_phys_side_stream=[i32, C.POINTER(vp)],
+        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32], r2s_phys_set_resident=[vp, i32], r2s_phys_set_pf=[vp, i32], r2s_phys_set_static_mesh_points=[vp, vp, vp, vp], r2s_phys_side_stream=[i32, C.POINTER(vp)],
         r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
     ).items():
         fn = getattr(L, name)
@@ -205,6 +205,14 @@ class PhysBatch:
         self.sync_state()
 
     # -- per-env-step protocol (phystwin.py:362-521) ------------------------------------------------------
+    def set_static_mesh_points(self, pts: torch.Tensor, mask: Optional[torch.Tensor] = None):
+        """Re-pose the static collision meshes of some environments (an episode reset into another scene pose; r2s_physics.h):
+        ``pts`` float32 [n_env, n_static_vertices, 3] on the device, ``mask`` bool / int [n_env] or None = all."""
+        pts = pts.to(self.device, torch.float32).contiguous()
+        m = None if mask is None else mask.to(self.device, torch.int32).contiguous()
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_set_static_mesh_points(self._h, pts.data_ptr(), 0 if m is None else m.data_ptr(), self._s()), "r2s_phys_set_static_mesh_points")
+
     def create_resting_case(self):
         with torch.cuda.device(self.device):
             check(_bind().r2s_phys_create_resting_case(self._h, self._s()), "r2s_phys_create_resting_case")

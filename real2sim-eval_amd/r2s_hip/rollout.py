@@ -189,6 +189,12 @@ class BatchedRollout:
         self._springs_dev = torch.from_numpy(np.ascontiguousarray(ob["springs"], np.int32)).to(self.device)
         self._target_dev = torch.from_numpy(np.ascontiguousarray(pts + np.array([0.10, 0.0, 0.0], np.float32))).to(self.device)  # push-T goal: 10 cm along +x
         self._box = (np.array([c[0] + 0.25, c[1] + 0.2, 0.135]), 0.5 * np.array([0.2, 0.13, 0.27]))
+        # per-environment pose of the box obstacle (an episode reset with `randomize` may re-pose it: episode_mesh_poses)
+        self._static_v0 = torch.from_numpy(np.ascontiguousarray(sta[0][0], np.float32)).to(self.device) if sta else None
+        self._static_c0 = torch.tensor([float(c[0] + 0.25), float(c[1] + 0.2), 0.0], device=self.device)   # its origin: turned about, in the table plane
+        self._box_c = torch.tensor(self._box[0], dtype=torch.float32, device=self.device)[None].repeat(E, 1)
+        self._box_R = torch.eye(3, device=self.device)[None].repeat(E, 1, 1)
+        self._box_posed = False
         # Gaussians: object splats ride on particles, table splats are static; configs[4] adds 60k splats on the robot's links
         self.with_robot = "multicam" in config
         n_scene = n_gauss - 60000 if self.with_robot else n_gauss
@@ -216,6 +222,7 @@ class BatchedRollout:
         self.rot_env = None
         self.randomize = bool(randomize)
         self.random_variables = {}                                # episode id -> [x, y, z, angle] as the reference records them (gs_renderer.py:637)
+        self.random_mesh_variables = {}                           # episode id -> [[x, y, z, angle] per static mesh with a grid] (gs_renderer.py:390)
         if self.randomize and not self.with_robot:
             self.rot_env = torch.nn.functional.normalize(self.g["rotations"], dim=-1)[None].repeat(E, 1, 1).contiguous()
         if self.with_robot:
@@ -417,22 +424,44 @@ class BatchedRollout:
 
     # ---- episode reset of some environments ------------------------------------------------------------------------
     # grid randomisation of the object pose per scene: cfg/gs/{rope,sloth,T}.yaml `object.grid_randomization` (xy in m, theta in degrees)
+    # `meshes`: the grid of every static mesh that has one (cfg/gs/sloth.yaml `meshes[0].grid_randomization`: the box obstacle; the rope's clip
+    # and the T scene have none), in the order of the config
     GRIDS = {"rope": dict(xy=[(-0.05, -0.05), (-0.05, 0.0), (-0.05, 0.05), (0.0, -0.05), (0.0, 0.0), (0.0, 0.05), (0.05, -0.05), (0.05, 0.0), (0.05, 0.05)],
-                          theta=[-10, 0, 10], one_to_one=False),
-             "sloth": dict(xy=[(0, 0), (-0.05, 0), (0.05, 0), (0, -0.05), (0, 0.03)], theta=[0, -5, 5, -5, 5], one_to_one=True),
-             "T": dict(xy=[(-0.05, -0.05), (-0.05, 0.05), (0.05, -0.05), (0.05, 0.05)], theta=[45, 135, 225, 315], one_to_one=False)}
+                          theta=[-10, 0, 10], one_to_one=False, meshes=[]),
+             "sloth": dict(xy=[(0, 0), (-0.05, 0), (0.05, 0), (0, -0.05), (0, 0.03)], theta=[0, -5, 5, -5, 5], one_to_one=True,
+                           meshes=[dict(xy=[(0, 0), (-0.05, 0), (0.05, 0), (0, 0.05)], theta=[0, -5, 5, 5], one_to_one=True)]),
+             "T": dict(xy=[(-0.05, -0.05), (-0.05, 0.05), (0.05, -0.05), (0.05, 0.05)], theta=[45, 135, 225, 315], one_to_one=False, meshes=[])}
 
-    def episode_pose(self, episode_id: int):
-        """(x, y, z = 0, angle in radians) of episode ``episode_id``: the reference's grid arithmetic (gs_renderer.py:340-347, :614-637:
-        index = episode_id mod n_object_rand; one_to_one: xy[i], theta[i]; else xy[i // n_theta], theta[i % n_theta])."""
-        g = self.GRIDS[self.ob_shape]
-        n = len(g["xy"]) if g["one_to_one"] else len(g["xy"]) * len(g["theta"])
-        i = int(episode_id) % n
+    @staticmethod
+    def _grid_entry(g, i):
         if g["one_to_one"]:
             xy, th = g["xy"][i], g["theta"][i]
         else:
             xy, th = g["xy"][i // len(g["theta"])], g["theta"][i % len(g["theta"])]
         return float(xy[0]), float(xy[1]), 0.0, float(th) * np.pi / 180.0
+
+    @staticmethod
+    def _grid_size(g):
+        return len(g["xy"]) if g["one_to_one"] else len(g["xy"]) * len(g["theta"])
+
+    def episode_pose(self, episode_id: int):
+        """(x, y, z = 0, angle in radians) of the OBJECT in episode ``episode_id``: the reference's grid arithmetic (gs_renderer.py:340-348,
+        :600-637: true_index = episode_id mod n_object_rand; one_to_one: xy[i], theta[i]; else xy[i // n_theta], theta[i % n_theta])."""
+        g = self.GRIDS[self.ob_shape]
+        return self._grid_entry(g, int(episode_id) % self._grid_size(g))
+
+    def episode_mesh_poses(self, episode_id: int):
+        """[(x, y, z = 0, angle)] of every static mesh with a grid in episode ``episode_id``: what is left of the index above the object's
+        grid is peeled mesh by mesh (gs_renderer.py:347, :365-383: true_index_mesh = index // n_object_rand; per mesh: this = true_index_mesh
+        mod n_this_mesh, true_index_mesh //= n_this_mesh) — the sloth scene: 5 object poses x 4 box poses = 20 scenes."""
+        g = self.GRIDS[self.ob_shape]
+        rest = int(episode_id) // self._grid_size(g)
+        out = []
+        for m in g["meshes"]:
+            n = self._grid_size(m)
+            out.append(self._grid_entry(m, rest % n))
+            rest //= n
+        return out
 
     def reset(self, env_ids=None, episode_ids=None):
         """BaseEnv.reset (env.py:30-51) for some environments of the batch (``env_ids``: indices, a bool mask [n_env], or None =
@@ -493,11 +522,30 @@ class BatchedRollout:
                 src = torch.as_tensor(env_ids).cpu()
                 mask_host = src.reshape(E).tolist() if src.dtype == torch.bool else [e in set(src.long().reshape(-1).tolist()) for e in range(E)]
             pose = np.zeros((E, 4), np.float32)
+            mesh_pose = np.zeros((E, 4), np.float32)          # the box obstacle (the only static mesh of these scenes with a grid)
             for e in range(E):
                 if mask_host[e]:
                     pose[e] = self.episode_pose(eids[e])
                     self.random_variables[eids[e]] = [float(a) for a in pose[e]]
+                    mp = self.episode_mesh_poses(eids[e])
+                    if mp:
+                        mesh_pose[e] = mp[0]
+                        self.random_mesh_variables[eids[e]] = [[float(a) for a in q] for q in mp]
             pose_t = torch.from_numpy(pose).to(dev)
+            if self.GRIDS[self.ob_shape]["meshes"] and self._static_v0 is not None:
+                # the box turns about its own origin and shifts (gs_renderer.py:385-388: pose[:3, 3] += t, pose[:3, :3] = Rz pose[:3, :3])
+                mp_t = torch.from_numpy(mesh_pose).to(dev)
+                cb, sb = torch.cos(mp_t[:, 3]), torch.sin(mp_t[:, 3])
+                Rb = torch.zeros(E, 3, 3, device=dev)
+                Rb[:, 0, 0], Rb[:, 0, 1], Rb[:, 1, 0], Rb[:, 1, 1], Rb[:, 2, 2] = cb, -sb, sb, cb, 1.0
+                cbox = self._static_c0
+                shift_b = torch.cat([mp_t[:, :2], torch.zeros(E, 1, device=dev)], 1)
+                v_new_box = (self._static_v0[None] - cbox).matmul(Rb.transpose(1, 2)) + cbox + shift_b[:, None]
+                self.phys.set_static_mesh_points(v_new_box, torch.tensor(mask_host, device=dev))
+                mh = torch.tensor(mask_host, device=dev)
+                self._box_posed = True
+                self._box_c = torch.where(mh[:, None], torch.tensor(self._box[0], dtype=torch.float32, device=dev)[None] + shift_b, self._box_c)
+                self._box_R = torch.where(mh[:, None, None], Rb, self._box_R)
             ca, sa = torch.cos(pose_t[:, 3]), torch.sin(pose_t[:, 3])
             Rz = torch.zeros(E, 3, 3, device=dev)
             Rz[:, 0, 0], Rz[:, 0, 1], Rz[:, 1, 0], Rz[:, 1, 1], Rz[:, 2, 2] = ca, -sa, sa, ca, 1.0
@@ -516,7 +564,15 @@ class BatchedRollout:
             if self.with_gripper:
                 e0 = self._init["eef_xyz"][0][None].expand(E, -1)
                 if self.use_pusher:
-                    eef_xyz_new, eef_rot_new = e0 + shift, self._init["eef_rot"]
+                    # the rod starts in front of the TURNED block's -x face, at the height of its start pose and the distance the trace
+                    # covers until `close_at` (as the constructor places it for the unturned block): the face is wherever the turned
+                    # particles reach furthest in -x — a rod start that was only shifted could sit inside a block turned by 45 .. 315 degrees
+                    xmin = x_new[:, :, 0].min(1).values
+                    near = x_new[:, :, 0] < (xmin[:, None] + 0.01)
+                    y_face = torch.where(near, x_new[:, :, 1], torch.full_like(x_new[:, :, 1], float("nan"))).nanmedian(1).values
+                    d0 = float(self._init["eef_xyz"][0, 0] - self._init["x"][0, :, 0].min())       # (negative: the rod starts on the -x side)
+                    eef_xyz_new = torch.stack([xmin + d0, y_face, e0[:, 2]], 1)
+                    eef_rot_new = self._init["eef_rot"]
                 else:
                     eef_xyz_new = (e0 - c)[:, None].matmul(Rz.transpose(1, 2))[:, 0] + c + shift
                     eef_rot_new = Rz.bmm(self._init["eef_rot"][0][None].expand(E, -1, -1))
@@ -761,7 +817,12 @@ class BatchedRollout:
             return metrics.pusht_success(x, self._target_dev)
         # sloth: >= 3050 of ~15k particles (the same fraction here) inside the box obstacle's OBB scaled by 1.05
         c, half = self._box
-        return metrics.points_in_obb(x, c, np.eye(3), 1.05 * half) >= int(round(3050 / 15000 * self.N))
+        need = int(round(3050 / 15000 * self.N))
+        if self._box_posed:     # boxes re-posed per environment by posed resets: the same count against each environment's own box
+            loc = (x - self._box_c[:, None]).matmul(self._box_R)          # box axes = columns of R
+            inside = (loc.abs() <= torch.tensor(1.05 * half, dtype=torch.float32, device=x.device)).all(-1)
+            return inside.sum(1) >= need
+        return metrics.points_in_obb(x, c, np.eye(3), 1.05 * half) >= need
 
     # ---- accounting -------------------------------------------------------------------------------
     def physics_algorithmic_bytes_per_substep(self):

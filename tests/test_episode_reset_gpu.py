@@ -263,3 +263,51 @@ def test_episode_ids_place_the_object_at_the_grid_pose_of_the_episode():
     ro.reset([0], episode_ids=[13, 0])
     torch.cuda.synchronize()
     assert float((ro2.phys.x[1] - ro.phys.x[0]).abs().max()) < 2e-6
+
+
+def test_episode_index_above_the_object_grid_reposes_the_box_obstacle_and_the_rod_starts_clear_of_the_turned_block():
+    """ADVICE r4: load_scaniverse peels the episode index — object pose = index mod n_object_rand, then mesh by mesh from index //
+    n_object_rand (gs_renderer.py:340-383): the sloth scene has 5 object poses x 4 box poses = 20 start scenes, and episodes 0 and 5 differ
+    (in the box).  A posed reset re-poses the static box of the stepper (r2s_phys_set_static_mesh_points) and the success predicate's box;
+    the pusher's rod starts in front of the TURNED block, never inside it."""
+    import torch
+    from r2s_hip.rollout import BatchedRollout
+
+    ro = BatchedRollout("sloth_32env", n_env=2, num_substeps=20, seed=3, randomize=True, settle_steps=0)
+    # the index arithmetic, against the reference's loops restated literally
+    n_obj, box = 5, BatchedRollout.GRIDS["sloth"]["meshes"][0]
+    for idx in range(0, 23):
+        true_index, true_index_mesh = idx % n_obj, idx // n_obj
+        this = true_index_mesh % len(box["xy"])
+        assert ro.episode_pose(idx)[:2] == tuple(float(v) for v in BatchedRollout.GRIDS["sloth"]["xy"][true_index])
+        (mx, my, mz, ma), = ro.episode_mesh_poses(idx)
+        assert (mx, my) == tuple(float(v) for v in box["xy"][this]) and abs(ma - box["theta"][this] * np.pi / 180) < 1e-12
+    assert ro.episode_pose(0) == ro.episode_pose(5) and ro.episode_mesh_poses(0) != ro.episode_mesh_poses(5)
+    assert ro.episode_mesh_poses(20) == ro.episode_mesh_poses(0)
+    c0 = ro._box_c.clone()
+    ro.reset([0, 1], episode_ids=[5, 12])            # box poses 1 (-5 cm in x, -5 deg) and 2 (+5 cm, +5 deg)
+    torch.cuda.synchronize()
+    assert torch.allclose(ro._box_c[0] - c0[0], torch.tensor([-0.05, 0.0, 0.0], device=ro.device), atol=1e-7)
+    assert torch.allclose(ro._box_c[1] - c0[1], torch.tensor([0.05, 0.0, 0.0], device=ro.device), atol=1e-7)
+    assert ro.random_mesh_variables[5][0][:2] == [-0.05, 0.0] and ro.random_mesh_variables[12][0][:2] == [0.05, 0.0]
+    # the predicate follows the box: particles gathered inside environment 0's RE-POSED box satisfy it, inside the old pose they do not
+    half = torch.tensor(ro._box[1], dtype=torch.float32, device=ro.device)
+    x = ro.phys.x.clone()
+    x[0] = ro._box_c[0] + (torch.rand(ro.N, 3, device=ro.device) - 0.5) * half
+    x[1] = c0[1] + torch.tensor([-0.12, 0.0, 0.0], device=ro.device) + (torch.rand(ro.N, 3, device=ro.device) - 0.5) * 0.01   # 7 cm outside the box moved to +5 cm
+    ro.phys.set_state(x)
+    assert ro.success_flags().tolist() == [True, False]
+    for _ in range(2):
+        ro.step()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ro.phys.x).all())
+    # pusher: the rod's start pose is derived from the turned block's extent
+    rp = BatchedRollout("T_pusher_32env", n_env=9, num_substeps=20, seed=3, randomize=True, close_at=3)
+    rp.reset(list(range(9)), episode_ids=list(range(9)))       # 4 xy x 4 theta: angles 45 .. 315 degrees
+    torch.cuda.synchronize()
+    x = rp.phys.x
+    gap = x[:, :, 0].min(1).values - rp.eef_xyz[:, 0]
+    assert float(gap.min()) > 0.005 + 0.001, ("the rod (radius 5 mm, margin 1 mm) must start clear of the block's -x extent", gap.tolist())
+    assert float((gap - gap[0]).abs().max()) < 1e-5, "the same clearance for every pose"
+    rp.step(); rp.get_obs()
+    assert rp.contact_stats()["mesh_contacts"] == 0, "no penetration at the start of a posed episode"
