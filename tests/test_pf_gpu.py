@@ -13,7 +13,7 @@ from util_parity import record
 pytestmark = pytest.mark.gpu
 
 
-def _rollout(cfg, n_env, pf, steps, close_at=2, sync_every_step=False, **kw):
+def _rollout(cfg, n_env, pf, steps, close_at=2, sync_every_step=False, busy=False, **kw):
     import torch
     from r2s_hip.rollout import BatchedRollout
 
@@ -21,7 +21,13 @@ def _rollout(cfg, n_env, pf, steps, close_at=2, sync_every_step=False, **kw):
     assert ro.phys.layout_stats()["lds_bytes"] == 1024 * 24, "the large-batch layout"
     ro.phys.set_pf(pf)
     xs, vs, fl = [], [], []
+    side = torch.cuda.Stream() if busy else None
+    big = torch.empty(1 << 27, dtype=torch.float32, device="cuda") if busy else None      # 512 MiB
     for _ in range(steps):
+        if busy:                     # a second stream keeps every CU streaming through HBM next to the hand-offs (uneven load)
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    big.mul_(1.0001)
         ro.physics_step()
         ro.t += 1
         if sync_every_step:
@@ -94,3 +100,16 @@ def _rollout_small(cfg, steps, sync_every_step):
         xs.append(ro.phys.x.clone()); vs.append(ro.phys.v.clone()); fl.append(ro.phys.last_flavour())
     torch.cuda.synchronize()
     return [x.cpu().numpy() for x in xs], [v.cpu().numpy() for v in vs], fl
+
+
+def test_hand_offs_under_uneven_load_a_second_stream_streaming_through_hbm():
+    """The result lines are a cross-workgroup (cross-XCD) hand-off inside a launch: tested where such hand-offs fail — under uneven load,
+    with the pollers' lines warm (cdna_hip_programming.md, Guideline 16).  The same 9-environment grasp on a quiet chip and next to a stream
+    that keeps rewriting 512 MiB: every word of every state equal, no poll ran into its limit."""
+    steps = 6
+    xa, va, fa, sa, *_ = _rollout("sloth_32env", 9, True, steps)
+    xb, vb, fb, sb, *_ = _rollout("sloth_32env", 9, True, steps, busy=True)
+    assert [f["kernel"] for f in fa] == [f["kernel"] for f in fb] and fa[-1]["finishers_at_head_of_next_launch"]
+    assert sa["mesh_contacts"] > 0 and sa["self_collision_candidates"] > 0
+    for k in range(steps):
+        assert np.array_equal(xa[k], xb[k]) and np.array_equal(va[k], vb[k]), (k, float(np.abs(xa[k] - xb[k]).max()))
