@@ -35,6 +35,11 @@ int r2s_wrist_camera(int32_t n_env, const float* eef_xyz, const float* eef_rot, 
                      int32_t height, double near_plane, double far_plane, float* viewmatrix, float* projmatrix, float* campos,
                      r2s_stream_t stream);
 
+/* obs['robot']['eef_quat'] of BaseEnv.get_obs (sim/envs/env.py:62-66; phystwin.py:117: kornia rotation_matrix_to_quaternion of the current
+ * end-effector rotation) for a batch, on the device in ONE launch: rot [n,3,3] row-major -> quat [n,4] (w, x, y, z), DEVICE float32.
+ * (The torch restatement of the same branch scheme is ~40 small launches per observation: 0.2 ms of host time in a closed loop.) */
+int r2s_rot_to_quat(int32_t n, const float* rot, float* quat, r2s_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

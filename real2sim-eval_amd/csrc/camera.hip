@@ -68,7 +68,44 @@ __global__ void k_wrist_camera(int E, const float* __restrict__ eef_xyz, const f
         }
 }
 
+// kornia.geometry.conversions.rotation_matrix_to_quaternion (>= 0.7: w, x, y, z) as r2s_hip.rollout.rotation_matrix_to_quaternion states it,
+// float32, one lane per matrix: the published branch scheme — trace > 0: sq = 2 sqrt(trace + 1 + eps), else the largest diagonal entry
+// picks the component the square root computes — the sign the scheme yields, not canonicalised; a division by max(sq, FLT_MIN).
+__global__ void k_rot_to_quat(int n, const float* __restrict__ R, float eps, float* __restrict__ q)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float* m = R + 9 * (size_t)e;
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
+    const float tr = m00 + m11 + m22;
+    const float tiny = 1.17549435e-38f;
+    float w, x, y, z;
+    if (tr > 0.f) {
+        const float s = sqrtf(tr + 1.0f + eps) * 2.0f, d = fmaxf(s, tiny);
+        w = 0.25f * s; x = (m21 - m12) / d; y = (m02 - m20) / d; z = (m10 - m01) / d;
+    } else if (m00 > m11 && m00 > m22) {
+        const float s = sqrtf(1.0f + m00 - m11 - m22 + eps) * 2.0f, d = fmaxf(s, tiny);
+        w = (m21 - m12) / d; x = 0.25f * s; y = (m01 + m10) / d; z = (m02 + m20) / d;
+    } else if (m11 > m22) {
+        const float s = sqrtf(1.0f + m11 - m00 - m22 + eps) * 2.0f, d = fmaxf(s, tiny);
+        w = (m02 - m20) / d; x = (m01 + m10) / d; y = 0.25f * s; z = (m12 + m21) / d;
+    } else {
+        const float s = sqrtf(1.0f + m22 - m00 - m11 + eps) * 2.0f, d = fmaxf(s, tiny);
+        w = (m10 - m01) / d; x = (m02 + m20) / d; y = (m12 + m21) / d; z = 0.25f * s;
+    }
+    float* o = q + 4 * (size_t)e;
+    o[0] = w; o[1] = x; o[2] = y; o[3] = z;
+}
+
 } // namespace
+
+extern "C" int r2s_rot_to_quat(int32_t n, const float* rot, float* quat, r2s_stream_t stream)
+{
+    if (n <= 0 || !rot || !quat) return R2S_ERR_INVALID;
+    hipLaunchKernelGGL(k_rot_to_quat, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, rot, 1e-8f, quat);
+    R2S_HIP_TRY(hipGetLastError());
+    return R2S_OK;
+}
 
 extern "C" int r2s_wrist_camera(int32_t n_env, const float* eef_xyz, const float* eef_rot, const double* eef2c, const double* K, int32_t width,
                                 int32_t height, double near_plane, double far_plane, float* viewmatrix, float* projmatrix, float* campos,

@@ -20,8 +20,19 @@ def _bind():
         vp = C.c_void_p
         L.r2s_wrist_camera.restype = C.c_int
         L.r2s_wrist_camera.argtypes = [C.c_int32, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_double, C.c_double, vp, vp, vp, vp]
+        L.r2s_rot_to_quat.restype = C.c_int
+        L.r2s_rot_to_quat.argtypes = [C.c_int32, vp, vp, vp]
         _bound = True
     return L
+
+
+def rot_to_quat(rot: torch.Tensor) -> torch.Tensor:
+    """[n,3,3] device rotation matrices -> [n,4] (w, x, y, z): r2s_rot_to_quat, one launch (r2s_camera.h)."""
+    r = rot.to(torch.float32).contiguous().reshape(-1, 9)
+    q = torch.empty(r.shape[0], 4, dtype=torch.float32, device=r.device)
+    with torch.cuda.device(r.device):
+        check(_bind().r2s_rot_to_quat(r.shape[0], r.data_ptr(), q.data_ptr(), cur_stream(r.device)), "r2s_rot_to_quat")
+    return q
 
 
 class WristCamera:

@@ -711,7 +711,12 @@ class BatchedRollout:
         """obs['robot'] of BaseEnv.get_obs (env.py:62-66) for every environment, device tensors: eef_xyz [E,3], eef_quat [E,4]
         (w, x, y, z of the current end-effector rotation, phystwin.py:117), eef_gripper [E,1] (the opening commanded by the last
         action; 1 = open)."""
-        return dict(eef_xyz=self.eef_xyz, eef_quat=rotation_matrix_to_quaternion(self.eef_rot), eef_gripper=self.eef_gripper[:, None])
+        if self.eef_rot.is_cuda:      # one launch (r2s_rot_to_quat) instead of the ~40 of the torch restatement: 0.2 ms of host time per observation
+            from .camera import rot_to_quat
+            quat = rot_to_quat(self.eef_rot)
+        else:
+            quat = rotation_matrix_to_quaternion(self.eef_rot)
+        return dict(eef_xyz=self.eef_xyz, eef_quat=quat, eef_gripper=self.eef_gripper[:, None])
 
     def get_obs(self):
         """BaseEnv.get_obs (env.py:53-74) for the batch: the fixed-camera and wrist-camera images of the last step — complete and

@@ -141,3 +141,24 @@ def test_observations_rerenders_a_sync_free_batch_that_overflowed():
     ro.step(action(top + 1.5))
     ro.observations()
     assert ro.lossy_batches == 1, counts
+
+
+@pytest.mark.gpu
+def test_rot_to_quat_kernel_equals_the_torch_restatement_of_the_kornia_branch_scheme():
+    """obs['robot']['eef_quat'] (env.py:62-66, phystwin.py:117): r2s_rot_to_quat against r2s_hip.rollout.rotation_matrix_to_quaternion (pinned against
+    scipy up to the sign in tests/test_host_logic.py) on random rotations that hit all four branches, and on the identity."""
+    import torch
+    from scipy.spatial.transform import Rotation
+    from r2s_hip.camera import rot_to_quat
+    from r2s_hip.rollout import rotation_matrix_to_quaternion
+
+    R = np.concatenate([Rotation.random(4000, random_state=3).as_matrix(), np.eye(3)[None],
+                        Rotation.from_euler("xyz", [[179.9, 0, 0], [0, 179.9, 0], [0, 0, 179.9], [120, 120, 0]], degrees=True).as_matrix()]).astype(np.float32)
+    Rt = torch.from_numpy(R).cuda()
+    q_ref = rotation_matrix_to_quaternion(Rt)
+    q = rot_to_quat(Rt)
+    torch.cuda.synchronize()
+    tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    assert (tr > 0).any() and (tr <= 0).sum() > 100, "every branch must be exercised"
+    assert float((q - q_ref).abs().max()) < 2e-6, float((q - q_ref).abs().max())
+    assert float((q.norm(dim=1) - 1).abs().max()) < 1e-5
