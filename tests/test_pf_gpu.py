@@ -1,5 +1,5 @@
 """Round 5: the contact flavours of a large batch with the finishing code of substep k at the HEAD of substep k + 1's launch
-(k_substep_pf; csrc/physics.hip "finishing at the HEAD of the next launch") against the two-launch form (k_substep + k_contact_finish
+(k_substep_pf; csrc/physics_substep.h "finishing at the HEAD of the next launch", csrc/physics_finish.h) against the two-launch form (k_substep + k_contact_finish
 per substep, r2s_phys_set_pf(h, 0)).  Same arithmetic on the same inputs in the same order, another transport (a tagged write-through
 result line per particle instead of the state array + a launch boundary): the states must agree BIT FOR BIT, every env step, with
 deferred mesh queries, tagged entries and live self-collision candidates in play — and two runs of the same rollout, enqueued without
