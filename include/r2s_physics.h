@@ -149,8 +149,14 @@ int r2s_phys_mesh_motion(R2SPhys* h, float** interp_points, float** interp_cente
  * the step in which they occurred has finished on the device (a word copied to pinned memory, read without waiting) — (1) a
  * self-collision impulse changed a particle's velocity by more than 40 m/s in one substep, so the "no mesh within reach"
  * decision taken before the impulse (test widened by 2 mm) may have skipped a mesh response the reference applies; (2) a
- * workgroup of the resident small-batch launch waited for its neighbour beyond the poll limit (see r2s_phys_set_resident).
- * The word is sticky — every later r2s_phys_step fails — until r2s_phys_set_state hands in a new state. */
+ * workgroup of the resident small-batch launch waited for its neighbour beyond the poll limit (see r2s_phys_set_resident), or a
+ * block of a large batch for a particle the head of its launch finishes (see r2s_phys_set_pf).
+ * The word is sticky — every later r2s_phys_step fails — until r2s_phys_set_state hands in a new state.
+ * Which captured flavour a step runs (finishing code in the graph or mesh queries in place; r2s_phys_last_flavour) follows from
+ * counters of the step TWO before it — copied to pinned memory behind that step and WAITED for here if they have not landed (they
+ * have, in any loop that reads its observations; an open loop is held to two steps of run-ahead) — never from whatever copy happens
+ * to have arrived: two runs of the same calls end in the same bits.  r2s_phys_set_state starts a new history (two steps of the default
+ * flavour: queries in place — always correct, slower in contact). */
 int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t stream);
 
 /* collision_forces (:690-695): device pointer to [n_env, n_faces, 3]; holds the LAST substep's
