@@ -157,10 +157,18 @@ __device__ __forceinline__ void spring_group(const PhysDev& p, const AdjGroup& g
     const float a[GROUP] = {g.a.x, g.a.y, g.a.z, g.a.w};
 #pragma unroll
     for (int u = 0; u < GROUP; ++u) {
+#ifdef R2S_WIN16 // experiment: a 16-byte {x, y, z, vz} plane + an 8-byte {vx, vy} plane: ds_read_b128 + ds_read_b64 per slot instead of three ds_read_b64
+        typedef float v4f_ __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const v4f_ lds_f4;
+        const v4f_ xz = *(lds_f4*)(win + 2u * off[u]);
+        const v2f vxy = *(lds_f2*)(win + off[u] + 2 * (RCAP * 8 + 8));
+        spring_term((v2f){xz.x, xz.y}, xz.z, vxy, xz.w, xi, vi, k[u], a[u], p.dashpot, fxy, fz);
+#else
         const v2f xy = *(lds_f2*)(win + off[u]);
         const v2f zz = *(lds_f2*)(win + off[u] + PLANE1<RCAP>());
         const v2f vxy = *(lds_f2*)(win + off[u] + PLANE2<RCAP>());
         spring_term(xy, zz.x, vxy, zz.y, xi, vi, k[u], a[u], p.dashpot, fxy, fz);
+#endif
     }
 }
 
@@ -544,9 +552,15 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
         for (int k = 0; k < KB; ++k) {
             const int r = tid + (k0 + k) * B;
             if (r < RCAP && part[k] < p.N) {
+#ifdef R2S_WIN16
+                win_s[2 * r] = qa[k];
+                win_s[2 * r + 1] = qb[k];
+                win_s[2 * (RCAP + 1) + r] = qc[k];
+#else
                 win_s[r] = qa[k];
                 win_s[RCAP + 1 + r] = qb[k];
                 win_s[2 * (RCAP + 1) + r] = qc[k];
+#endif
             }
         }
         if (k0 == 0) { own_a = qa[0]; own_b = qb[0]; own_c = qc[0]; }
