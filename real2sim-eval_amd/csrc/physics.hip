@@ -167,6 +167,8 @@ struct PhysDev {
     int* fault;                // [0] sticky: 1 = a self-collision impulse exceeded the bound the "no mesh in reach" decision relies on; 2 = a
                                // hand-off of the resident stepper timed out; [1] a particle needed a mesh query since the host last looked
     void* xch;                 // resident stepper: exchange array [E][2 buffers][3 planes][N] x 16 B {value, tag, value, tag}
+    void* vx;                  // resident stepper, self-collision flavour: [E][N padded to 8] x 64 B — {x0, post-force v} of a particle with candidates, three
+                               // granules tagged with the substep, written by its block's wavefront 0, polled by its candidates' blocks
     // resident stepper, mesh-query SERVERS (small scenes; see k_steps_resident): workgroups of the same launch beyond the blocks' own,
     // two wavefronts per served particle
     int srv_slots;             // server wavefront pairs of this launch (0: none — queries in place)
@@ -289,6 +291,8 @@ struct R2SPhys {
     hipEvent_t ring_ev[RING] = {}; bool ring_pending[RING] = {}, ring_stale_fault[RING] = {};
     uint64_t step_no = 0; // env steps enqueued since the last full set_state
     void* d_xch = nullptr;    // resident stepper: exchange array (96 B per particle)
+    void* d_vx = nullptr;     // resident stepper, self-collision flavour: {x0, post-force v} of the particles with candidates, laid out like d_xch
+    int res_self = 1;         // R2S_RES_SELF=0: a small batch with live candidates takes the per-substep kernels (rounds 3-4)
     void* d_srv_claim = nullptr; void* d_srv_rr = nullptr; // resident stepper's mesh-query servers: a 128-byte line per claim, one of control words, one per pair of fault-report state; a line of request and a line of result granules per particle
     bool srv_exhausted = false; // a launch ran out of server pairs: per-substep kernels + finishing launch until the contact is over
     bool srv_ok = false;      // small scene (every mesh small, <= 128 faces in total): a resident launch may carry query servers
@@ -397,7 +401,7 @@ struct R2SPhys {
         p.mesh_pts = d_mesh_pts; p.interp_pts = d_interp; p.interp_center = d_center; p.dyn_vel = d_dyn_vel; p.dyn_omega = d_dyn_omega;
         p.aabb_dyn = d_aabb_dyn; p.aabb_static = d_aabb_static; p.coll_forces = d_coll_forces; p.hit_cnt = d_hit_cnt;
         p.fault = d_mesh_total ? d_mesh_total + 1 : nullptr;
-        p.xch = d_xch;
+        p.xch = d_xch; p.vx = d_vx;
         p.spin_limit = spin_limit;
         p.srv_own = srv_own; p.srv_quad = 0; p.srv_slots = 0; p.srv_claim = d_srv_claim; p.srv_rr = d_srv_rr; p.srv_ctl = d_srv_claim ? (int*)((char*)d_srv_claim + SRV_CTL_OFF) : nullptr;
         return p;
@@ -577,7 +581,7 @@ __global__ void k_zero_f32(float* __restrict__ p, size_t n)
 // The env step's flavour that runs as one resident launch: no particle with self-collision candidates, nothing near a mesh.
 bool resident_flavour(const R2SPhys* h, bool with_self, int mesh_defer)
 {
-    return h->resident_ok && h->resident_pref != 0 && !with_self && !(h->nF > 0 && mesh_defer);
+    return h->resident_ok && h->resident_pref != 0 && !(with_self && !(h->res_self && h->d_vx)) && !(h->nF > 0 && mesh_defer);
 }
 constexpr int RES_MAX_ITEMS = 256; // (block, env) work items of a resident launch: one 512-thread workgroup per CU (two wavefronts per SIMD, each
                                    // with its 2 + 2 adjacency groups in registers), all on the chip at once
@@ -616,7 +620,7 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
         hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_xch + (size_t)24 * e0 * xn, words);
         // mesh-query servers: workgroups beyond the blocks' own, as many as the chip has CUs left (the whole launch is resident at once)
         int n_srv = 0;
-        if (h->srv_ok && n > 1) {
+        if (h->srv_ok && n > 1 && !with_self) {
             // workgroups go to the XCDs round-robin and every XCD must hold its share at once: the grid (8 * cb block workgroups — up to 7
             // of them idle, but their CUs may be on other XCDs than the servers that would need them — plus the servers) <= CUs
             n_srv = std::min(h->n_cu - 8 * p.cb, h->srv_wg_cap);
@@ -632,7 +636,11 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
         const StateC in = h->state(start_buf);
         const StateM out = h->state(start_buf ^ 1);
         const bool with_mesh = h->nF > 0;
-        if (with_mesh) hipLaunchKernelGGL((k_steps_resident<512, false, 1>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
+        if (with_self) { // candidates' {x0, v} records: tags of the previous launch must not match
+            hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_vx + (size_t)24 * e0 * xn, words);
+            if (with_mesh) hipLaunchKernelGGL((k_steps_resident<512, true, 1>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
+            else hipLaunchKernelGGL((k_steps_resident<512, true, 0>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
+        } else if (with_mesh) hipLaunchKernelGGL((k_steps_resident<512, false, 1>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
         else hipLaunchKernelGGL((k_steps_resident<512, false, 0>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
         return R2S_OK;
     }
@@ -1382,8 +1390,11 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         int occ_min = 1 << 30;
         {
             int occ = 0;
-            const void* kernels[2] = {(const void*)k_steps_resident<512, false, 0>, (const void*)k_steps_resident<512, false, 1>};
-            for (int k = 0; k < (h->nF > 0 ? 2 : 1); ++k) {
+            const void* kernels[4] = {(const void*)k_steps_resident<512, false, 0>, (const void*)k_steps_resident<512, false, 1>,
+                                      (const void*)k_steps_resident<512, true, 0>, (const void*)k_steps_resident<512, true, 1>};
+            for (int k = 0; k < 4; ++k) {
+                if ((k & 1) && h->nF == 0) continue;                 // (the mesh templates of a scene without meshes are never launched)
+                if ((k & 2) && !h->prm.self_collision) continue;     // (nor the self-collision flavour of a handle without it)
                 R2S_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernels[k], RES_THREADS, 0));
                 occ_min = std::min(occ_min, occ);
             }
@@ -1400,6 +1411,11 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             const size_t xn = ((size_t)N + 7) & ~(size_t)7;
             TRY(dev_alloc((char**)&h->d_xch, (size_t)96 * E * xn));
             R2S_HIP_TRY(hipMemsetAsync(h->d_xch, 0, (size_t)96 * E * xn, s));
+            if (const char* ev = getenv("R2S_RES_SELF")) h->res_self = atoi(ev) != 0;
+            if (h->prm.self_collision) {
+                TRY(dev_alloc((char**)&h->d_vx, (size_t)96 * E * xn));
+                R2S_HIP_TRY(hipMemsetAsync(h->d_vx, 0, (size_t)96 * E * xn, s));
+            }
             // query servers ride in the launch when every mesh is small enough for k_contact_finish<3>'s code (triangles in registers, one per
             // lane in two wavefronts) and the blocks leave CUs free; R2S_RES_SERVERS=0: queries in place / per-substep flavour as in round 3
             bool pref = true;
@@ -1466,7 +1482,7 @@ void r2s_phys_destroy(R2SPhys* h)
                     h->d_faces, h->d_face_orig, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
                     h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_sup_info, h->d_sup_box, h->d_small_mesh, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
-                    h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta, h->d_hit_cnt, h->d_xch,
+                    h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta, h->d_hit_cnt, h->d_xch, h->d_vx,
                     h->d_srv_claim, h->d_srv_rr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_cand_count) (void)hipHostFree(h->h_cand_count);
@@ -1778,12 +1794,12 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         if (!h->ring_pending[k] && !h->ring_stale_fault[k] && h->h_ring[16 * k + 1] != 0) { cnt[1] = h->h_ring[16 * k + 1]; memcpy(cnt + 4, h->h_ring + 16 * k + 4, 12 * sizeof(int)); }
     }
     if (cnt[1] != 0) { // the sticky fault word of an earlier step
-        if (cnt[1] >= 2 && cnt[1] <= 6) {
+        if (cnt[1] >= 2 && cnt[1] <= 7) {
             char buf[640];
             const int* w = cnt + 4;
             snprintf(buf, sizeof buf, "resident stepper: a workgroup waited for %s beyond the poll limit (the launch was not resident at once, or the device "
                      "is shared with a kernel that never ends); the state is invalid [first fault: code %d, work item %d, substep %d of the launch, context %d %d %d %d %d %d]",
-                     cnt[1] == 2 ? "a neighbour block's substep" : cnt[1] == 5 ? "a neighbour's record (server pair)" : cnt[1] == 6 ? "a particle finished by the head of its launch" : "a mesh-query server's result", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+                     cnt[1] == 2 ? "a neighbour block's substep" : cnt[1] == 5 ? "a neighbour's record (server pair)" : cnt[1] == 6 ? "a particle finished by the head of its launch" : cnt[1] == 7 ? "a self-collision partner's record" : "a mesh-query server's result", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
             r2s::set_last_error_msg(buf);
         }
         else
@@ -1813,7 +1829,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     const bool resident = resident_flavour(h, variant == 1, h->mesh_defer);
     if (resident) {
         h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)
-        int n_srv = h->srv_ok && n > 1 ? std::min(h->n_cu - 8 * ((h->nb * h->E + 7) / 8), h->srv_wg_cap) : 0; // as enqueue_steps sizes the grid
+        int n_srv = h->srv_ok && n > 1 && variant == 0 ? std::min(h->n_cu - 8 * ((h->nb * h->E + 7) / 8), h->srv_wg_cap) : 0; // as enqueue_steps sizes the grid
         if (n_srv < SRV_MIN_WG) n_srv = 0;
         h->last_flavour[3] = 1 | (n_srv << 8) | ((h->srv_own ? 1 : 0) << 20) | ((n_srv > 0 && h->srv_quad_for(n_srv) ? 1 : 0) << 21);
     }

@@ -353,7 +353,7 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
 
 // The same kernel is the small-batch layout's PER-SUBSTEP kernel (n_steps = 1: no hand-off at all, the window comes from the state
 // arrays, wavefront 0 alone finishes and owns every side effect): the contact flavours — deferred mesh queries, self-collision
-// candidates (SELF; only ever with n_steps = 1) — keep their finishing kernels and a launch per substep, but a block's springs are
+// candidates (SELF with n_steps = 1; with n_steps > 1 see `self_res` below) — keep their finishing kernels and a launch per substep, but a block's springs are
 // still shared by eight wavefronts instead of walked by one (k_substep<64,512,..>: 8.0 us per substep of the rope, this: see DESIGN §4).
 template <int RCAP, bool SELF, int MESH>
 __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev p, const StateC xv_in, const StateM xv_out, int first, int n_steps,
@@ -424,6 +424,14 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     io.x = mk(0.f, 0.f, 0.f); io.v = io.x;
     const bool srv_on = MESH == 1 && !SELF && p.srv_slots > 0 && n_steps > 1;
     io.srv_on = srv_on; io.srv_need = false;
+    // SELF with more than one substep per launch (round 5: the resident stepper's self-collision flavour): a particle with candidates
+    // publishes {x0, post-force v} of every substep in its own tagged write-through record (p.vx, three granules, tag = k + 1), wavefront 0
+    // of its block polls the records of its candidates — in list order, the reference's own summation order (:150-191) —, applies the
+    // averaged impulse and finishes it; the candidate lists are constant over the env step
+    const bool self_res = SELF && n_steps > 1;
+    const int ncand_l = (SELF && valid) ? p.coll_num[eb + i] : 0;
+    const __amdgpu_buffer_rsrc_t rvx = __builtin_amdgcn_make_buffer_rsrc(p.vx, 0, 0x7fffffff, 0x00020000);
+    const unsigned vxe = (unsigned)e * 6u * xn; // laid out like the exchange array: [env][substep parity][plane][particle, padded to 8] x 16 B
     constexpr int RES_STAGE_MESH = 8;        // meshes whose per-substep boxes are staged in LDS at the top of every substep (more: loaded where they are used)
     __shared__ float sbox_s[6 * RES_STAGE_MESH];
     const bool stage_boxes = MESH != 0 && n_steps > 1 && p.n_mesh <= RES_STAGE_MESH;
@@ -588,8 +596,18 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             if (!last) out.p = nullptr;
             io.x = x0; io.v = v0;
             bool fin = valid && !(srv_own && srv_ever); // (a particle a server pair owns is not finished here — wavefront 0 takes its state from the pair)
-            if (SELF) { // as in substep_body: particles with candidates publish v_before_collision and are finished by k_self_finish / k_contact_finish
-                const int ncand = valid ? p.coll_num[eb + i] : 0;
+            if (SELF && self_res) {
+                if (ncand_l > 0) {
+                    fin = false; // finished by wavefront 0 below, once its candidates' records of this substep are in
+                    if (wave == 0) {
+                        const unsigned tag = (unsigned)(k + 1), o = (vxe + (unsigned)(k & 1) * 3u * xn + (unsigned)i) * 16u;
+                        srv_store(rvx, o, __float_as_uint(x0.x), __float_as_uint(x0.y), tag);
+                        srv_store(rvx, o + xn * 16u, __float_as_uint(x0.z), __float_as_uint(v.x), tag);
+                        srv_store(rvx, o + 2u * xn * 16u, __float_as_uint(v.y), __float_as_uint(v.z), tag);
+                    }
+                }
+            } else if (SELF) { // as in substep_body: particles with candidates publish v_before_collision and are finished by k_self_finish / k_contact_finish
+                const int ncand = ncand_l;
                 if (ncand > 0) {
                     const size_t po = par_off(p, step);
                     p.vbc[po + eb + i] = make_float4(v.x, v.y, v.z, 0.f);
@@ -621,6 +639,51 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             // for their results — the other two finishing wavefronts leave those lanes to it (three wavefronts polling the same granules
             // tripled the poll traffic on the hand-offs of a block with twenty particles in a finger's reach) — and publishes all three planes
             bool sneed = false, early_pub = false; // early_pub: wavefront 0 has published its finished lanes already (wave-uniform)
+            if (SELF && self_res) {
+                sneed = ncand_l > 0; // wavefront 0 finishes these lanes and publishes all three planes of them (the other finishers skip them)
+                if (wave == 0 && __builtin_amdgcn_ballot_w64(sneed) != 0ull) {
+                    // object_collision (:132-193, :230-268) for this lane's particle: its candidates one after the other, each partner's
+                    // {x0, post-force v} of THIS substep from the partner's record (polled: the partner's block may still be in its gather)
+                    float validc = 0.f;
+                    f3 Jsum = mk(0.f, 0.f, 0.f);
+                    const int mask1 = p.masks[ic];
+                    const unsigned tag = (unsigned)(k + 1);
+                    bool stuck = false;
+                    for (int c = 0; c < ncand_l; ++c) {
+                        const int j = p.coll_idx[(eb + i) * (size_t)p.coll_cap + c];
+                        const unsigned o = (vxe + (unsigned)(k & 1) * 3u * xn + (unsigned)j) * 16u;
+                        v4u d0, d1, d2;
+                        for (unsigned spins = 0;; ++spins) {
+                            d0 = srv_load(rvx, o); d1 = srv_load(rvx, o + xn * 16u); d2 = srv_load(rvx, o + 2u * xn * 16u);
+                            asm volatile("" ::: "memory");
+                            if (d0.y == tag && d0.w == tag && d1.y == tag && d1.w == tag && d2.y == tag && d2.w == tag) break;
+                            if (spins >= p.spin_limit) { stuck = true; break; }
+                        }
+                        if (stuck) { resident_fault(p, 7, item, k, (unsigned)i, (unsigned)j, d0.y, d1.y, d2.y, (unsigned)c); fail_s = 1; break; }
+                        const f3 x2 = mk(__uint_as_float(d0.x), __uint_as_float(d0.z), __uint_as_float(d1.x));
+                        const f3 v2 = mk(__uint_as_float(d1.z), __uint_as_float(d2.x), __uint_as_float(d2.z));
+                        const float m2 = p.masses[j];
+                        const f3 dis = x2 - x0;
+                        const float dis_len = len(dis);
+                        const f3 rv = v2 - v;
+                        if (mask1 != p.masks[j] && dis_len < p.cd && dot(dis, rv) < -1e-4f) {
+                            validc += 1.f;
+                            const f3 nrm = dis / fmaxf(dis_len, 1e-6f);
+                            const f3 v_rel_n = nrm * dot(rv, nrm);
+                            const float inv = 1.f / m1 + 1.f / m2;
+                            const f3 impulse_n = (v_rel_n * (-(1.f + p.cse))) / inv;
+                            const float vnl = len(v_rel_n);
+                            const f3 v_rel_t = rv - v_rel_n;
+                            const float vtl = fmaxf(len(v_rel_t), 1e-6f);
+                            const float a = fmaxf(0.f, 1.f - p.csf * (1.f + p.cse) * vnl / vtl);
+                            const f3 impulse_t = (v_rel_t * (a - 1.f)) / inv;
+                            Jsum = Jsum + (impulse_n + impulse_t);
+                        }
+                    }
+                    const f3 vi = (sneed && validc > 0.f) ? v - (Jsum / validc) / m1 : v;
+                    finish_wave<MESH, MESH != 0, 0, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, vi, sneed, out, nullptr, nullptr, nullptr, nullptr, true, &io R2S_QP_ARG);
+                }
+            }
             if (MESH == 1 && !SELF && srv_on) {
                 const bool need_now = io.srv_need; // the same in the three finishing wavefronts (same inputs, same instructions)
                 srv_ever = srv_ever || need_now;

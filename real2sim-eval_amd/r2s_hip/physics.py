@@ -379,9 +379,10 @@ class PhysBatch:
         rcap = self.layout_stats()["lds_bytes"] // 24
         if a[2] == 2:       # the env step as one resident launch (small batches; with query servers in the launch also through mesh contact)
             srv, own, quad = (int(a[3]) >> 8) & 0xfff, bool((int(a[3]) >> 20) & 1), bool((int(a[3]) >> 21) & 1)
-            return dict(self_collision_kernel=False, mesh_template=int(a[1]), deferred_mesh_queries=False, chains=1, resident=True, query_server_workgroups=srv,
+            scr = bool(a[0] & 1)      # live candidates: the resident launch's self-collision flavour (round 5)
+            return dict(self_collision_kernel=scr, mesh_template=int(a[1]), deferred_mesh_queries=False, chains=1, resident=True, query_server_workgroups=srv,
                         servers_own_their_particle=own and srv > 0, wavefronts_per_served_particle=(4 if quad else 2) if srv else 0,
-                        kernel=f"k_steps_resident<{rcap},false,{int(a[1])}>" + (f" + {srv} query-server workgroups in the launch"
+                        kernel=f"k_steps_resident<{rcap},{'true' if scr else 'false'},{int(a[1])}>" + (f" + {srv} query-server workgroups in the launch"
                                                                                   + (f" ({'a quad' if quad else 'a pair'} of wavefronts owns its particle from the claim on)" if own else " (a request per substep)") if srv else ""))
         sc, split, pf = bool(a[0] & 1), bool(a[0] & 2), a[2] == 3
         fused = "k_substep_pf" if pf else "k_substep"
