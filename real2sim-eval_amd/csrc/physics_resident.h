@@ -425,12 +425,53 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     const bool srv_on = MESH == 1 && !SELF && p.srv_slots > 0 && n_steps > 1;
     io.srv_on = srv_on; io.srv_need = false;
     // SELF with more than one substep per launch (round 5: the resident stepper's self-collision flavour): a particle with candidates
-    // publishes {x0, post-force v} of every substep in its own tagged write-through record (p.vx, three granules, tag = k + 1), wavefront 0
-    // of its block polls the records of its candidates — in list order, the reference's own summation order (:150-191) —, applies the
-    // averaged impulse and finishes it; the candidate lists are constant over the env step
+    // publishes {x0, post-force v} of every substep in tagged write-through records (p.vx, laid out like the exchange array, tag = k + 1).
+    // The (particle, candidate) pairs of the block are TASKS spread over all eight wavefronts — the five that do not finish particles
+    // first: they ask for the partners' records right behind barrier C, while the finishing wavefronts still sum the forces —; a task's
+    // impulse goes to LDS and wavefront 0 sums its lane's impulses in list order, the reference's own summation order (:150-191), applies
+    // the average and finishes the particle.  (Wavefront 0 alone, candidate after candidate: 4.2 us of finishing per substep on the rope
+    // folded onto itself — up to six dependent hand-offs and the arithmetic of six impulses in one wavefront.)  The candidate lists are
+    // constant over the env step: tasks, partners' masses and mask tests are set up once per launch.
     const bool self_res = SELF && n_steps > 1;
     const int ncand_l = (SELF && valid) ? p.coll_num[eb + i] : 0;
     const __amdgpu_buffer_rsrc_t rvx = __builtin_amdgcn_make_buffer_rsrc(p.vx, 0, 0x7fffffff, 0x00020000);
+    constexpr int RES_CB = 1;        // the tail (tasks beyond the LDS table: a block with more than RES_TCAP pairs): candidates wavefront 0 asks for together
+    constexpr int RES_KS = 2;        // tasks per thread
+    constexpr int RES_TCAP = SELF ? RES_THREADS * RES_KS : 1; // tasks with a slot in the LDS table
+    __shared__ float4 contrib_s[RES_TCAP];       // per task: impulse (xyz), 1 if the pair collides (w)
+    __shared__ float4 selfx_s[SELF ? B : 1], selfv_s[SELF ? B : 1]; // wavefront 0's particles: (x0, mass), post-force velocity
+    __shared__ int coff_s[SELF ? B + 1 : 1];     // first task of each lane of wavefront 0; [B]: the block's task count
+    const int mask1 = SELF ? p.masks[ic] : 0;
+    int t_blk = 0;
+    int tk_j[RES_KS], tk_li[RES_KS];
+    float tk_m2[RES_KS];             // partner's mass; < 0: same mask (:155: never collides)
+#pragma unroll
+    for (int m = 0; m < RES_KS; ++m) { tk_j[m] = -1; tk_li[m] = 0; tk_m2[m] = 1.f; }
+    if (SELF && self_res) {
+        if (wave == 0) {
+            int incl = ncand_l;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+            coff_s[lane] = incl - ncand_l;
+            if (lane == 63) coff_s[B] = incl;
+        }
+        __syncthreads();
+        t_blk = __builtin_amdgcn_readfirstlane(coff_s[B]);
+#pragma unroll
+        for (int m = 0; m < RES_KS; ++m) {
+            // the five wavefronts that finish nothing take the first tasks
+            const int t = (tid >= 192 ? tid - 192 : tid + (RES_THREADS - 192)) + RES_THREADS * m;
+            if (t < min(t_blk, RES_TCAP)) {
+                int lo = 0, hi = B - 1; // the last lane whose first task is <= t and that has tasks
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (coff_s[mid] <= t) lo = mid; else hi = mid - 1; }
+                const int il = b * B + lo, j = p.coll_idx[(eb + il) * (size_t)p.coll_cap + (t - coff_s[lo])];
+                tk_j[m] = j; tk_li[m] = lo;
+                tk_m2[m] = p.masks[il] != p.masks[j] ? p.masses[j] : -1.f;
+            }
+        }
+    }
+    const bool self_blk = SELF && self_res && t_blk > 0; // (the same in every wavefront of the block)
+    const int my_coff = (SELF && self_res && wave == 0) ? coff_s[lane] : 0; // wavefront 0: this lane's first task
     const unsigned vxe = (unsigned)e * 6u * xn; // laid out like the exchange array: [env][substep parity][plane][particle, padded to 8] x 16 B
     constexpr int RES_STAGE_MESH = 8;        // meshes whose per-substep boxes are staged in LDS at the top of every substep (more: loaded where they are used)
     __shared__ float sbox_s[6 * RES_STAGE_MESH];
@@ -498,9 +539,17 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
 #ifdef R2S_PHASE_PROBE // wall clock (100 MHz) spent per phase by wavefront 0, summed over the launch: own gather + poll | halo gather + reduce | finish | publish; [4] poll passes
     long long pr_acc[5] = {0, 0, 0, 0, 0}, pr_t = (long long)wall_clock64();
     const long long pr_w0 = pr_t, pr_c0 = (long long)__builtin_readcyclecounter(); // shader clock = cycles / wall ticks x 100 MHz
-#define R2S_RSTAMP(kk) do { const long long now_ = (long long)wall_clock64(); pr_acc[kk] += now_ - pr_t; pr_t = now_; } while (0)
+#define R2S_RSTAMP_(kk) do { const long long now_ = (long long)wall_clock64(); pr_acc[kk] += now_ - pr_t; pr_t = now_; } while (0)
+#ifdef R2S_SELF_STAMP2 // the tail of the self-collision flavour: everything up to barrier E | impulse sum | second finish_wave | publish
+#define R2S_RSTAMP(kk) do { } while (0)
+#define R2S_RSTAMP2(kk) R2S_RSTAMP_(kk)
+#else
+#define R2S_RSTAMP(kk) R2S_RSTAMP_(kk)
+#define R2S_RSTAMP2(kk) do { } while (0)
+#endif
 #else
 #define R2S_RSTAMP(kk) do { } while (0)
+#define R2S_RSTAMP2(kk) do { } while (0)
 #endif
 
     for (int k = 0; k < n_steps; ++k) {
@@ -573,6 +622,13 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
         spring_groups_n<RCAP>(p, n_halo, ag_halo, win, x0, v0, fxy, fz);
         part_s[wave][lane] = make_float4(fxy.x, fxy.y, fz, 0.f);
         __syncthreads(); // C
+        f3 v = v0;
+        StateM out = xv_out;
+        if (!last) out.p = nullptr;
+        bool sneed = false, early_pub = false; // early_pub: this wavefront has published its finished lanes already (wave-uniform)
+        bool fin = false;
+        v4u td[RES_KS][3];   // self-collision tasks: the partners' records
+        unsigned pendc = 0;
         if (finisher) {
             f3 f;
             {
@@ -591,19 +647,19 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
 
             // update_vel_from_force, mesh_collision, integrate_ground_collision — the same in the three finishing wavefronts; wavefront 0
             // stores / accumulates
-            const f3 v = vel_update_rcp(p, v0, f, m1, inv_m1);
-            StateM out = xv_out;
-            if (!last) out.p = nullptr;
+            v = vel_update_rcp(p, v0, f, m1, inv_m1);
             io.x = x0; io.v = v0;
-            bool fin = valid && !(srv_own && srv_ever); // (a particle a server pair owns is not finished here — wavefront 0 takes its state from the pair)
+            fin = valid && !(srv_own && srv_ever); // (a particle a server pair owns is not finished here — wavefront 0 takes its state from the pair)
             if (SELF && self_res) {
                 if (ncand_l > 0) {
-                    fin = false; // finished by wavefront 0 below, once its candidates' records of this substep are in
+                    fin = false; // finished by wavefront 0 below, once the impulses of its candidates are in
                     if (wave == 0) {
                         const unsigned tag = (unsigned)(k + 1), o = (vxe + (unsigned)(k & 1) * 3u * xn + (unsigned)i) * 16u;
                         srv_store(rvx, o, __float_as_uint(x0.x), __float_as_uint(x0.y), tag);
                         srv_store(rvx, o + xn * 16u, __float_as_uint(x0.z), __float_as_uint(v.x), tag);
                         srv_store(rvx, o + 2u * xn * 16u, __float_as_uint(v.y), __float_as_uint(v.z), tag);
+                        selfx_s[lane] = make_float4(x0.x, x0.y, x0.z, m1);
+                        selfv_s[lane] = make_float4(v.x, v.y, v.z, 0.f);
                     }
                 }
             } else if (SELF) { // as in substep_body: particles with candidates publish v_before_collision and are finished by k_self_finish / k_contact_finish
@@ -632,52 +688,179 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                     }
                 }
             }
+        }
+        if (SELF && self_res) sneed = ncand_l > 0; // wavefront 0 finishes these lanes behind barrier E and publishes all three planes of them
+        if (self_blk) {
+            // ---- the block's (particle, candidate) tasks: partner's record of THIS substep (polled: its block may still be in its gather) ----
+            const unsigned tag = (unsigned)(k + 1), pbase = (vxe + (unsigned)(k & 1) * 3u * xn) * 16u;
+#pragma unroll
+            for (int m = 0; m < RES_KS; ++m)
+                if (tk_j[m] >= 0 && tk_m2[m] >= 0.f) pendc |= 1u << m;
+            for (unsigned spins = 0; pendc != 0u; ++spins) {
+#pragma unroll
+                for (int m = 0; m < RES_KS; ++m)
+                    if (pendc & (1u << m)) {
+                        const unsigned o = pbase + (unsigned)tk_j[m] * 16u;
+                        td[m][0] = srv_load(rvx, o); td[m][1] = srv_load(rvx, o + xn * 16u); td[m][2] = srv_load(rvx, o + 2u * xn * 16u);
+                    }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int m = 0; m < RES_KS; ++m)
+                    if ((pendc & (1u << m)) && td[m][0].y == tag && td[m][0].w == tag && td[m][1].y == tag && td[m][1].w == tag && td[m][2].y == tag && td[m][2].w == tag)
+                        pendc &= ~(1u << m);
+                if (pendc != 0u && spins >= p.spin_limit) {
+                    resident_fault(p, 7, item, k, (unsigned)tid, (unsigned)tk_j[0], (unsigned)tk_j[1], td[0][0].y, pendc, (unsigned)t_blk);
+                    fail_s = 1;
+                    break;
+                }
+            }
+            __syncthreads(); // D: wavefront 0's {x0, post-force v} of this substep are in LDS
+        }
+        // everything after the velocity update for the lanes WITHOUT candidates, behind barrier D: a block that is late — the one the others
+        // wait for — finds its partners' records in already, and its impulses must not queue behind work that can run beside them.
+        // In a block with tasks wavefronts 1 and 2 do this (1 stores and publishes planes 0 and 1, 2 plane 2); wavefront 0 only finishes
+        // the lanes with candidates, behind barrier E
+        if (finisher && !(self_blk && wave == 0)) {
             R2S_QP_DECL(-1);
             io.srv_need = false;
-            finish_wave<MESH, MESH != 0, 0, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, v, fin, out, nullptr, nullptr, nullptr, nullptr, wave == 0, &io R2S_QP_ARG);
+            finish_wave<MESH, MESH != 0, 0, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, v, fin, out, nullptr, nullptr, nullptr, nullptr,
+                                                  wave == (self_blk ? 1 : 0), &io R2S_QP_ARG);
+            if (self_blk && !last) {
+                // the lanes that are finished publish BEFORE the impulses are in: their records are what the neighbour blocks need for the
+                // next substep
+                early_pub = true;
+                if (!sneed) {
+                    const unsigned tag = (unsigned)(k + 1), pub = (xe + (unsigned)i) * 16u + (unsigned)((k + 1) & 1) * xb;
+                    if (wave == 1) {
+                        if (valid) {
+                            const v4u w0 = {__float_as_uint(io.x.x), tag, __float_as_uint(io.x.y), tag}, w1 = {__float_as_uint(io.x.z), tag, __float_as_uint(io.v.z), tag};
+                            __builtin_amdgcn_raw_buffer_store_b128(w0, rx, pub, 0, RES_AUX_SC1);
+                            __builtin_amdgcn_raw_buffer_store_b128(w1, rx, pub + xn * 16u, 0, RES_AUX_SC1);
+                        }
+                        win_s[lane] = (v2f){io.x.x, io.x.y};
+                        win_s[(RCAP + 1) + lane] = (v2f){io.x.z, io.v.z};
+                    } else {
+                        if (valid) {
+                            const v4u w2 = {__float_as_uint(io.v.x), tag, __float_as_uint(io.v.y), tag};
+                            __builtin_amdgcn_raw_buffer_store_b128(w2, rx, pub + 2u * xn * 16u, 0, RES_AUX_SC1);
+                        }
+                        win_s[2 * (RCAP + 1) + lane] = (v2f){io.v.x, io.v.y};
+                    }
+                }
+            }
+        }
+        if (self_blk && wave == 0) early_pub = !last; // (its lanes without candidates were published by wavefronts 1 and 2)
+        if (self_blk) {
+#pragma unroll
+            for (int m = 0; m < RES_KS; ++m) {
+                if (tk_j[m] < 0) continue;
+                const int t = (tid >= 192 ? tid - 192 : tid + (RES_THREADS - 192)) + RES_THREADS * m;
+                float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (tk_m2[m] >= 0.f && !(pendc & (1u << m))) {
+                    const float4 sx = selfx_s[tk_li[m]], sv = selfv_s[tk_li[m]];
+                    const f3 xa = mk(sx.x, sx.y, sx.z), va = mk(sv.x, sv.y, sv.z);
+                    const float ma = sx.w, m2 = tk_m2[m];
+                    const f3 x2 = mk(__uint_as_float(td[m][0].x), __uint_as_float(td[m][0].z), __uint_as_float(td[m][1].x));
+                    const f3 v2 = mk(__uint_as_float(td[m][1].z), __uint_as_float(td[m][2].x), __uint_as_float(td[m][2].z));
+                    const f3 dis = x2 - xa;
+                    const float dis_len = len(dis);
+                    const f3 rv = v2 - va;
+                    if (dis_len < p.cd && dot(dis, rv) < -1e-4f) {
+                        const f3 nrm = dis / fmaxf(dis_len, 1e-6f);
+                        const f3 v_rel_n = nrm * dot(rv, nrm);
+                        const float inv = 1.f / ma + 1.f / m2;
+                        const f3 impulse_n = (v_rel_n * (-(1.f + p.cse))) / inv;
+                        const float vnl = len(v_rel_n);
+                        const f3 v_rel_t = rv - v_rel_n;
+                        const float vtl = fmaxf(len(v_rel_t), 1e-6f);
+                        const float a = fmaxf(0.f, 1.f - p.csf * (1.f + p.cse) * vnl / vtl);
+                        const f3 impulse_t = (v_rel_t * (a - 1.f)) / inv;
+                        const f3 J = impulse_n + impulse_t;
+                        c4 = make_float4(J.x, J.y, J.z, 1.f);
+                    }
+                }
+                contrib_s[t] = c4;
+            }
+            __syncthreads(); // E: the impulses are in LDS
+#ifdef R2S_SELF_STAMP
+            R2S_RSTAMP(2); // (probe: phase 2 = force sum .. E, phase 3 = the rest of the substep)
+#endif
+            R2S_RSTAMP2(0);
+        }
+        if (finisher) {
+            R2S_QP_DECL(-1);
             // particles that need a mesh query were handed to a server pair (resident_server), not finished above.  Wavefront 0 alone waits
             // for their results — the other two finishing wavefronts leave those lanes to it (three wavefronts polling the same granules
             // tripled the poll traffic on the hand-offs of a block with twenty particles in a finger's reach) — and publishes all three planes
-            bool sneed = false, early_pub = false; // early_pub: wavefront 0 has published its finished lanes already (wave-uniform)
             if (SELF && self_res) {
-                sneed = ncand_l > 0; // wavefront 0 finishes these lanes and publishes all three planes of them (the other finishers skip them)
                 if (wave == 0 && __builtin_amdgcn_ballot_w64(sneed) != 0ull) {
-                    // object_collision (:132-193, :230-268) for this lane's particle: its candidates one after the other, each partner's
-                    // {x0, post-force v} of THIS substep from the partner's record (polled: the partner's block may still be in its gather)
+                    // object_collision (:132-193, :230-268) for this lane's particle: the impulses of its candidates in list order
                     float validc = 0.f;
                     f3 Jsum = mk(0.f, 0.f, 0.f);
-                    const int mask1 = p.masks[ic];
-                    const unsigned tag = (unsigned)(k + 1);
+                    // (the contributions are read four at a time — independent LDS reads — and added one after the other: a read per
+                    // candidate, each behind the previous add, was 0.6 us of the 1.4 us between barrier E and the block's publish)
+                    const int c_lds = sneed ? min(ncand_l, max(RES_TCAP - my_coff, 0)) : 0;
+                    for (int c = 0; c < c_lds; c += 4) {
+                        float4 c4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) c4[u] = contrib_s[min(my_coff + c + u, RES_TCAP - 1)];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (c + u < c_lds && c4[u].w != 0.f) { validc += 1.f; Jsum = Jsum + mk(c4[u].x, c4[u].y, c4[u].z); }
+                    }
+                    R2S_RSTAMP2(1);
+                    // the tail: candidates without a slot in the task table (a block with more than RES_TCAP pairs), by this lane itself,
+                    // RES_CB records asked for together
+                    const unsigned tag = (unsigned)(k + 1), pbase = (vxe + (unsigned)(k & 1) * 3u * xn) * 16u;
                     bool stuck = false;
-                    for (int c = 0; c < ncand_l; ++c) {
-                        const int j = p.coll_idx[(eb + i) * (size_t)p.coll_cap + c];
-                        const unsigned o = (vxe + (unsigned)(k & 1) * 3u * xn + (unsigned)j) * 16u;
-                        v4u d0, d1, d2;
+                    for (int c0 = c_lds; c0 < ncand_l && !stuck; c0 += RES_CB) {
+                        int jj[RES_CB];
+                        v4u d[RES_CB][3];
+                        unsigned pendc = 0;
+#pragma unroll
+                        for (int c = 0; c < RES_CB; ++c) {
+                            jj[c] = c0 + c < ncand_l ? p.coll_idx[(eb + i) * (size_t)p.coll_cap + c0 + c] : 0;
+                            if (c0 + c < ncand_l) pendc |= 1u << c;
+                        }
                         for (unsigned spins = 0;; ++spins) {
-                            d0 = srv_load(rvx, o); d1 = srv_load(rvx, o + xn * 16u); d2 = srv_load(rvx, o + 2u * xn * 16u);
+#pragma unroll
+                            for (int c = 0; c < RES_CB; ++c)
+                                if (pendc & (1u << c)) {
+                                    const unsigned o = pbase + (unsigned)jj[c] * 16u;
+                                    d[c][0] = srv_load(rvx, o); d[c][1] = srv_load(rvx, o + xn * 16u); d[c][2] = srv_load(rvx, o + 2u * xn * 16u);
+                                }
                             asm volatile("" ::: "memory");
-                            if (d0.y == tag && d0.w == tag && d1.y == tag && d1.w == tag && d2.y == tag && d2.w == tag) break;
+#pragma unroll
+                            for (int c = 0; c < RES_CB; ++c)
+                                if ((pendc & (1u << c)) && d[c][0].y == tag && d[c][0].w == tag && d[c][1].y == tag && d[c][1].w == tag && d[c][2].y == tag && d[c][2].w == tag)
+                                    pendc &= ~(1u << c);
+                            if (pendc == 0u) break;
                             if (spins >= p.spin_limit) { stuck = true; break; }
                         }
-                        if (stuck) { resident_fault(p, 7, item, k, (unsigned)i, (unsigned)j, d0.y, d1.y, d2.y, (unsigned)c); fail_s = 1; break; }
-                        const f3 x2 = mk(__uint_as_float(d0.x), __uint_as_float(d0.z), __uint_as_float(d1.x));
-                        const f3 v2 = mk(__uint_as_float(d1.z), __uint_as_float(d2.x), __uint_as_float(d2.z));
-                        const float m2 = p.masses[j];
-                        const f3 dis = x2 - x0;
-                        const float dis_len = len(dis);
-                        const f3 rv = v2 - v;
-                        if (mask1 != p.masks[j] && dis_len < p.cd && dot(dis, rv) < -1e-4f) {
-                            validc += 1.f;
-                            const f3 nrm = dis / fmaxf(dis_len, 1e-6f);
-                            const f3 v_rel_n = nrm * dot(rv, nrm);
-                            const float inv = 1.f / m1 + 1.f / m2;
-                            const f3 impulse_n = (v_rel_n * (-(1.f + p.cse))) / inv;
-                            const float vnl = len(v_rel_n);
-                            const f3 v_rel_t = rv - v_rel_n;
-                            const float vtl = fmaxf(len(v_rel_t), 1e-6f);
-                            const float a = fmaxf(0.f, 1.f - p.csf * (1.f + p.cse) * vnl / vtl);
-                            const f3 impulse_t = (v_rel_t * (a - 1.f)) / inv;
-                            Jsum = Jsum + (impulse_n + impulse_t);
+                        if (stuck) { resident_fault(p, 7, item, k, (unsigned)i, (unsigned)jj[0], d[0][0].y, (unsigned)c0, pendc, (unsigned)ncand_l); fail_s = 1; break; }
+#pragma unroll
+                        for (int c = 0; c < RES_CB; ++c) {
+                            if (c0 + c >= ncand_l) continue;
+                            const int j = jj[c];
+                            const f3 x2 = mk(__uint_as_float(d[c][0].x), __uint_as_float(d[c][0].z), __uint_as_float(d[c][1].x));
+                            const f3 v2 = mk(__uint_as_float(d[c][1].z), __uint_as_float(d[c][2].x), __uint_as_float(d[c][2].z));
+                            const float m2 = p.masses[j];
+                            const f3 dis = x2 - x0;
+                            const float dis_len = len(dis);
+                            const f3 rv = v2 - v;
+                            if (mask1 != p.masks[j] && dis_len < p.cd && dot(dis, rv) < -1e-4f) {
+                                validc += 1.f;
+                                const f3 nrm = dis / fmaxf(dis_len, 1e-6f);
+                                const f3 v_rel_n = nrm * dot(rv, nrm);
+                                const float inv = 1.f / m1 + 1.f / m2;
+                                const f3 impulse_n = (v_rel_n * (-(1.f + p.cse))) / inv;
+                                const float vnl = len(v_rel_n);
+                                const f3 v_rel_t = rv - v_rel_n;
+                                const float vtl = fmaxf(len(v_rel_t), 1e-6f);
+                                const float a = fmaxf(0.f, 1.f - p.csf * (1.f + p.cse) * vnl / vtl);
+                                const f3 impulse_t = (v_rel_t * (a - 1.f)) / inv;
+                                Jsum = Jsum + (impulse_n + impulse_t);
+                            }
                         }
                     }
                     const f3 vi = (sneed && validc > 0.f) ? v - (Jsum / validc) / m1 : v;
@@ -761,7 +944,10 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
 #ifdef R2S_PHASE_PROBE
             if (io.x.x == 1.2345e33f) return;
 #endif
+#ifndef R2S_SELF_STAMP
             R2S_RSTAMP(2);
+#endif
+            R2S_RSTAMP2(2);
 
             if (!last) { // publish version k + 1 (plane `wave`; wavefront 0: all three planes of its served lanes) and refresh the block's own records in the window
                 const unsigned tag = (unsigned)(k + 1);
@@ -783,6 +969,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                 }
             }
             R2S_RSTAMP(3);
+            R2S_RSTAMP2(3);
         }
     }
     if (MESH == 1 && !SELF && srv_on) { // end this block's server pairs, then count the block out (pairs nobody claimed leave when every block has)

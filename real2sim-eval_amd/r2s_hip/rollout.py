@@ -28,6 +28,10 @@ from .skinning import Skinning, knn_relations, knn_weights
 CONFIGS = {
     # name: (object shape, particles, gaussians per env, envs, W, H)  — BASELINE.json configs[1..3]
     "rope_1env": ("rope", 8000, 40000, 1, 640, 480),
+    # the same rope folded onto itself (rest shape a hairpin, the upper leg sags onto the lower one): live self-collision candidates
+    # through the window, the gripper hovering — the resident stepper's self-collision flavour
+    "rope_fold_1env": ("rope_fold", 8000, 40000, 1, 640, 480),
+    "rope_tip_fold_1env": ("rope_tip_fold", 2000, 10000, 1, 320, 240),   # a test scene: 8 cm of the rope's end folded back onto it
     "sloth_32env": ("sloth_arms", 15000, 80000, 32, 640, 480),   # configs[2]: the headline workload
     "T_32env": ("T", 2229, 40000, 32, 640, 480),
     "T_pusher_32env": ("T", 2229, 40000, 32, 640, 480),   # configs[3] per GPU: T block pushed by the ~25k-face pusher rod

@@ -83,7 +83,7 @@ def lattice_points(shape: str, n_target: int, seed: int, spacing: float = 0.006)
     """Jittered cubic lattice carved to a shape, resting 1 mm above z=0."""
     rng = np.random.default_rng(seed)
     h = spacing
-    if shape == "rope":
+    if shape in ("rope", "rope_fold", "rope_tip_fold", "rope_cross"):
         r = 0.012
         per_len = np.pi * r * r / h**3  # particles per metre
         length = n_target / per_len
@@ -140,8 +140,74 @@ def lattice_points(shape: str, n_target: int, seed: int, spacing: float = 0.006)
     g = np.stack(np.meshgrid(*ax, indexing="ij"), -1).reshape(-1, 3)
     g = g[inside(g)]
     g = g + rng.uniform(-0.1 * h, 0.1 * h, g.shape)
+    if shape == "rope_fold":
+        g = _fold_over(g, r)
+    if shape == "rope_tip_fold":
+        g = _fold_over(g, r, upper_len=0.08)
+    if shape == "rope_cross":
+        g = _lay_in_a_loop(g, r)
     g[:, 2] += -g[:, 2].min() + 0.001
     return g.astype(np.float32)
+
+
+def _fold_over(g: np.ndarray, r: float, leg_gap: float = 0.026, upper_len: float | None = None):
+    """The straight rope (axis x) laid out as a hairpin in the vertical plane: the first half along +x on the table, a half circle,
+    the second half back along -x above the first, `leg_gap` between the two surfaces — more than the 25 mm within which the reference
+    marks particle pairs as resting neighbours (spring_mass_warp.py:272-291), so every pair of particles of the two legs may become a
+    collision candidate.  This is the REST shape (the springs are built on it: no strain); gravity lays the upper leg onto the lower
+    one within a few env steps: a rope folded onto itself, with live self-collision candidates (:196-227) from then on.
+    `upper_len`: the length of the upper leg (default: half of what the bend leaves); 8 cm ("rope_tip_fold") is a tip folded back that
+    touches down with a handful of candidates — few enough contact decisions in its first env step of contact for a comparison with
+    the oracle at round-off level (thousands of pairs in sustained contact are not: tests/test_physics_oracle_kat.py)."""
+    Rb = r + 0.5 * leg_gap                      # radius of the centre line in the bend
+    s = g[:, 0] - g[:, 0].min()
+    L = float(s.max())
+    La = 0.5 * (L - np.pi * Rb) if upper_len is None else L - np.pi * Rb - upper_len
+    u, w = g[:, 1], g[:, 2]
+    out = np.empty_like(g)
+    lo, hi = s <= La, s >= La + np.pi * Rb
+    be = ~(lo | hi)
+    out[lo] = np.stack([s[lo], u[lo], w[lo]], 1)
+    phi = (s[be] - La) / Rb
+    out[be] = np.stack([La + (Rb - w[be]) * np.sin(phi), u[be], Rb - (Rb - w[be]) * np.cos(phi)], 1)
+    t = s[hi] - La - np.pi * Rb
+    out[hi] = np.stack([La - t, u[hi], 2.0 * Rb - w[hi]], 1)
+    return out
+
+
+def _lay_in_a_loop(g: np.ndarray, r: float, loop_radius: float = 0.06, lift: float = 0.05, bump: float = 0.09):
+    """The straight rope (axis x) laid out on the table in a loop that crosses over itself ONCE: a straight leg along +x, three quarters
+    of a circle to the left, then straight back across the first leg at a right angle, lifted over it by `lift` (centre line; more than
+    the 25 mm of the resting-pair radius plus the rope's thickness) along a smooth bump of half-length `bump`.  The REST shape (springs are
+    built on it); gravity lays the lifted stretch onto the leg below it: self-contact in the few square centimetres of the crossing —
+    a handful of candidates instead of the thousands of `rope_fold`, few enough decisions per env step for a comparison with the oracle
+    at round-off level."""
+    s = g[:, 0] - g[:, 0].min()
+    L = float(s.max())
+    arc = 1.5 * np.pi * loop_radius
+    la = 0.5 * (L - arc) + 0.5 * loop_radius      # first leg; the rest after the arc is the tail that crosses it
+    n = 4096
+    ss = np.linspace(0.0, L, n)
+    c = np.zeros((n, 3))
+    th = np.clip((ss - la) / loop_radius, 0.0, 1.5 * np.pi)
+    on_a, on_arc = ss <= la, (ss > la) & (ss < la + arc)
+    c[on_a, 0] = ss[on_a]
+    c[on_arc, 0] = la + loop_radius * np.sin(th[on_arc]); c[on_arc, 1] = loop_radius * (1.0 - np.cos(th[on_arc]))
+    tail = ~(on_a | on_arc)
+    c[tail, 0] = la - loop_radius; c[tail, 1] = loop_radius - (ss[tail] - la - arc)
+    s_cross = la + arc + loop_radius                # the tail passes y = 0 here
+    d = np.clip(np.abs(ss - s_cross) / bump, 0.0, 1.0)
+    c[:, 2] = lift * 0.5 * (1.0 + np.cos(np.pi * d))
+    t = np.gradient(c, ss, axis=0)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    up = np.array([0.0, 0.0, 1.0])
+    n2 = up[None] - t * (t @ up)[:, None]
+    n2 /= np.linalg.norm(n2, axis=1, keepdims=True)
+    n1 = np.cross(n2, t)
+    out = np.empty_like(g)
+    for k in range(3):
+        out[:, k] = (np.interp(s, ss, c[:, k]) + g[:, 1] * np.interp(s, ss, n1[:, k]) + g[:, 2] * np.interp(s, ss, n2[:, k])).astype(g.dtype)
+    return out
 
 
 def build_springs(pts: np.ndarray, radius: float = 0.02, max_neighbours: int = 30):

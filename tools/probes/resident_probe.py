@@ -9,7 +9,7 @@ from r2s_hip import _lib
 cfg = os.environ.get("VB_CONFIG", "rope_1env")
 ro = BatchedRollout(cfg, num_substeps=667, n_env=int(os.environ.get("N_ENV", "1")))
 ro.phys.set_timing(True)
-for _ in range(3):
+for _ in range(int(os.environ.get("STEPS", "3"))):
     ro.physics_step(); ro.t += 1
 torch.cuda.synchronize()
 ms, k = ro.phys.last_step_ms()
@@ -24,3 +24,6 @@ us = a[:, :4] * 0.01 / 667
 print("per substep, us: poll %.2f  gather+reduce %.2f  finish %.2f  publish %.2f   (mean over %d workgroups); poll passes per substep %.2f" % (*us.mean(0), n, a[:, 4].mean() / 666))
 print("max over workgroups:", us.max(0), "min:", us.min(0))
 print("shader clock over the launch: %.0f MHz (cycle counter / 100 MHz wall clock)" % (a[:, 5].sum() / a[:, 6].sum() * 100))
+act = us[:, 0] > 0
+if act.any() and (~act).any():
+    print("workgroups with a stamp in phase 0: %d of %d; their medians: %s" % (act.sum(), n, np.median(us[act], 0)))
