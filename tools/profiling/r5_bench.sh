@@ -4,9 +4,11 @@ R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/r5_bench; mkdir -p $out
 cd $R
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_sloth_32env.json 2> $out/bench.err; tail -c 400 $out/bench.err
 : > $out/bench_other_configs.jsonl
-for cfg in rope_1env T_pusher_32env sloth_multicam_8env; do
+for cfg in rope_1env T_pusher_32env sloth_multicam_8env rope_fold_1env; do
   timeout 400 python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 >> $out/bench_other_configs.jsonl
 done
+# the folded rope with the per-substep kernels (what a small batch with live candidates ran until round 4)
+R2S_RES_SELF=0 timeout 400 python bench.py --config rope_fold_1env --steps 20 --warmup 5 --no-cpu-baseline --no-pipelined 2>/dev/null | tail -1 > $out/bench_rope_fold_per_substep_kernels.json
 python - <<'PY'
 import json
 rows = [json.loads(open('gpurun_out/r5_bench/bench_sloth_32env.json').read().strip().splitlines()[-1])] + [json.loads(l) for l in open('gpurun_out/r5_bench/bench_other_configs.jsonl')]
