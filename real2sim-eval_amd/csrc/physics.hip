@@ -578,10 +578,12 @@ __global__ void k_zero_f32(float* __restrict__ p, size_t n)
     if (i < n) p[i] = 0.f;
 }
 
-// The env step's flavour that runs as one resident launch: no particle with self-collision candidates, nothing near a mesh.
-bool resident_flavour(const R2SPhys* h, bool with_self, int mesh_defer)
+// The env step's flavour that runs as one resident launch: a small batch, no deferred mesh queries (candidates: the SELF templates, round 5).
+bool resident_flavour(const R2SPhys* h, bool with_self, int mesh_defer, int n)
 {
-    return h->resident_ok && h->resident_pref != 0 && !(with_self && !(h->res_self && h->d_vx)) && !(h->nF > 0 && mesh_defer);
+    // (the self-collision flavour of the one-launch stepper needs more than one substep in the launch: a single substep with candidates
+    // is the per-substep form, k_steps_resident x 1 + k_self_finish)
+    return h->resident_ok && h->resident_pref != 0 && !(with_self && !(h->res_self && h->d_vx && n > 1)) && !(h->nF > 0 && mesh_defer);
 }
 constexpr int RES_MAX_ITEMS = 256; // (block, env) work items of a resident launch: one 512-thread workgroup per CU (two wavefronts per SIMD, each
                                    // with its 2 + 2 adjacency groups in registers), all on the chip at once
@@ -607,7 +609,7 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
                 hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (float*)(h->d_cand_mark + (size_t)par * h->E * h->N + (size_t)e0 * h->N), cnt);
         }
     }
-    if (resident_flavour(h, with_self, p.mesh_defer)) {
+    if (resident_flavour(h, with_self, p.mesh_defer, n)) {
         // one launch for all n substeps: the final state goes to the OTHER buffer whatever n is (a late workgroup may still be reading
         // its substep-0 window from the input buffer while an early one stores its last substep) — r2s_phys_step flips accordingly
         if (h->nF > 0 && zero_forces) {
@@ -1826,7 +1828,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     h->last_flavour[0] = variant | (h->split_ok ? 2 : 0); h->last_flavour[1] = h->nF > 0 ? (h->any_large ? 2 : 1) : 0; h->last_flavour[2] = h->mesh_defer;
     h->last_flavour[3] = use_graph ? h->chains() : 1;
     if (h->nF > 0 && h->pf_ok && h->pf_pref != 0 && h->pb == 256 && (h->mesh_defer || h->any_large)) h->last_flavour[2] = 3; // 3 = deferred, finishers at the head of the next launch
-    const bool resident = resident_flavour(h, variant == 1, h->mesh_defer);
+    const bool resident = resident_flavour(h, variant == 1, h->mesh_defer, n);
     if (resident) {
         h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)
         int n_srv = h->srv_ok && n > 1 && variant == 0 ? std::min(h->n_cu - 8 * ((h->nb * h->E + 7) / 8), h->srv_wg_cap) : 0; // as enqueue_steps sizes the grid
