@@ -1,6 +1,8 @@
 """Soak of the hand-offs inside k_substep_pf (finishers at the head of the next launch): the same rollout through a grasp N times — the
 headline batch (32 environments, four chains) or the pusher's — each time next to a second stream that keeps the chip streaming through
 HBM; every run must end in the same bits as the first and none may run a poll into its limit (a sticky fault raises at the next step).
+`rope_fold_1env` puts the same soak on the resident stepper's self-collision flavour (two tagged hand-offs per substep, 3 000 particles
+with candidates).
 usage: soak_pf.py [config] [runs] [steps]"""
 import hashlib
 import os
@@ -37,7 +39,7 @@ for r in range(runs):
         ref = h
         st = ro.contact_stats()
         print("flavour", ro.phys.last_flavour()["kernel"], {k: st[k] for k in ("self_collision_candidates", "mesh_contacts", "grasped_envs")})
-        assert st["mesh_contacts"] > 0, "the soak must run in contact"
+        assert st["mesh_contacts"] > 0 or st["self_collision_candidates"] > 0, "the soak must run in contact"
     bad += h != ref
     if h != ref:
         print("run", r, "differs:", h, "vs", ref)
