@@ -167,8 +167,8 @@ struct PhysDev {
     int* fault;                // [0] sticky: 1 = a self-collision impulse exceeded the bound the "no mesh in reach" decision relies on; 2 = a
                                // hand-off of the resident stepper timed out; [1] a particle needed a mesh query since the host last looked
     void* xch;                 // resident stepper: exchange array [E][2 buffers][3 planes][N] x 16 B {value, tag, value, tag}
-    void* vx;                  // resident stepper, self-collision flavour: [E][N padded to 8] x 64 B — {x0, post-force v} of a particle with candidates, three
-                               // granules tagged with the substep, written by its block's wavefront 0, polled by its candidates' blocks
+    void* vx;                  // resident stepper, self-collision flavour: {x0, post-force v} of the particles with candidates, laid out like xch
+                               // ([E][2 substep parities][3 planes][N padded to 8] x 16 B), written by their block's wavefront 0, polled by their candidates' blocks
     // resident stepper, mesh-query SERVERS (small scenes; see k_steps_resident): workgroups of the same launch beyond the blocks' own,
     // two wavefronts per served particle
     int srv_slots;             // server wavefront pairs of this launch (0: none — queries in place)
@@ -1816,7 +1816,8 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         // motion — the step in which the first particle enters a margin pays for its in-place queries once
         h->mesh_defer = (h->resident_ok && h->resident_pref ? cnt[2] : cnt[0]) > 0 ? 1 : 0;
         // ... and with query servers in the launch (round 4) a small batch stays resident THROUGH contact: a particle that needs a query is
-        // answered by a server pair of the same launch (resident_server); only the self-collision flavour still takes the per-substep path
+        // answered by a server pair of the same launch (resident_server).  (The self-collision flavour of the resident launch, round 5, has no
+        // servers: with live candidates a needed query still sends the following steps to the per-substep kernels + finishing kernel)
         if (have_cnt) { // (more particles in contact than the launch has pairs: answered in place — correct, and 20 x slower than the finishing launch)
             if (cnt[3] > 0) h->srv_exhausted = true;
             else if (cnt[2] == 0) h->srv_exhausted = false;
