@@ -81,3 +81,32 @@ def test_counter_summaries_are_keyed_by_the_kernel_sources_and_stale_ones_are_la
     ent, src = bench.pmc_summary("k_substep", "sloth_32env")
     assert ent["stale"] is True and "STALE" in src
     assert bench.pmc_summary("no_such_kernel", "sloth_32env") == (None, None)
+
+
+def test_folded_rope_scenes_rest_without_strain_and_without_resting_pairs_between_the_legs():
+    """`rope_fold` / `rope_tip_fold` (r2s_hip/synth.py: the scenes of the resident stepper's self-collision flavour): the hairpin is the
+    REST shape — springs are built on it, none joins the two legs — and the legs are about as far apart as the reference's resting-pair
+    marking reaches (spring_mass_warp.py:272-291), so nearly every pair of particles of the two legs may become a candidate once gravity
+    has laid the upper leg on the lower one (tests/test_physics_oracle_kat.py counts them: more than 500 of 2 080 particles)."""
+    from scipy.spatial import cKDTree
+    from r2s_hip import synth
+    from r2s_hip.rollout import CONFIGS
+
+    assert CONFIGS["rope_fold_1env"][0] == "rope_fold" and CONFIGS["rope_tip_fold_1env"][0] == "rope_tip_fold"
+    for shape, upper_min, upper_max in (("rope_fold", 0.3, 0.6), ("rope_tip_fold", 0.05, 0.11)):
+        ob = synth.phystwin_object(shape, 2000, 0)
+        p = ob["points"].astype(np.float64)
+        rest = np.linalg.norm(p[ob["springs"][:, 0]] - p[ob["springs"][:, 1]], axis=1)
+        assert np.abs(rest - ob["rest"]).max() < 1e-6                          # no strain at rest
+        z_mid = 0.5 * (p[:, 2].min() + p[:, 2].max())
+        x_bend = p[:, 0].max() - 0.03                                          # the half circle: the last 2.5 cm in x
+        lower = (p[:, 2] < z_mid) & (p[:, 0] < x_bend)
+        upper = (p[:, 2] > z_mid) & (p[:, 0] < x_bend)
+        assert lower.sum() > 500 and upper.sum() > 50
+        span = p[upper, 0].max() - p[upper, 0].min()
+        assert upper_min < span < upper_max, span
+        d, _ = cKDTree(p[lower]).query(p[upper])
+        assert d.min() > 0.022, d.min()                                        # 26 mm between the surfaces less the lattice's jitter: about the
+                                                                               # resting-pair reach (5 x collision_dist; cell-granular, :287-291)
+        s = ob["springs"]
+        assert not ((lower[s[:, 0]] & upper[s[:, 1]]) | (upper[s[:, 0]] & lower[s[:, 1]])).any()
