@@ -293,6 +293,8 @@ struct R2SPhys {
     void* d_xch = nullptr;    // resident stepper: exchange array (96 B per particle)
     void* d_vx = nullptr;     // resident stepper, self-collision flavour: {x0, post-force v} of the particles with candidates, laid out like d_xch
     int res_self = 1;         // R2S_RES_SELF=0: a small batch with live candidates takes the per-substep kernels (rounds 3-4)
+    int self_srv = 0;         // this env step: query servers in the resident launch of the self-collision flavour (a query was needed two steps ago)
+    int res_self_srv = 1;     // R2S_RES_SELF_SRV=0: no query servers next to the self-collision flavour (a needed query then sends the next steps to the per-substep kernels); 2: always
     void* d_srv_claim = nullptr; void* d_srv_rr = nullptr; // resident stepper's mesh-query servers: a 128-byte line per claim, one of control words, one per pair of fault-report state; a line of request and a line of result granules per particle
     bool srv_exhausted = false; // a launch ran out of server pairs: per-substep kernels + finishing launch until the contact is over
     bool srv_ok = false;      // small scene (every mesh small, <= 128 faces in total): a resident launch may carry query servers
@@ -363,8 +365,8 @@ struct R2SPhys {
     // launch / in contact, against 19.1 / 19.8 / 26.0 as separate graphs on four streams — a branch of a hipGraph is not a
     // hardware queue of its own, a stream is).
     static constexpr int MAX_CHAINS = 8;
-    hipGraph_t graph[MAX_CHAINS][8] = {};
-    hipGraphExec_t graph_exec[MAX_CHAINS][8] = {};
+    hipGraph_t graph[MAX_CHAINS][12] = {};      // [mesh_defer * 4 + variant * 2 + parity]; [8 + 2 + parity]: the resident self-collision flavour WITH servers (self_srv)
+    hipGraphExec_t graph_exec[MAX_CHAINS][12] = {};
     hipEvent_t chain_fork = nullptr, chain_join[MAX_CHAINS] = {};
     // timing
     bool timing = false;
@@ -622,13 +624,15 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
         hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_xch + (size_t)24 * e0 * xn, words);
         // mesh-query servers: workgroups beyond the blocks' own, as many as the chip has CUs left (the whole launch is resident at once)
         int n_srv = 0;
-        if (h->srv_ok && n > 1 && !with_self) {
+        if (h->srv_ok && n > 1 && h->chains() == 1 && (!with_self || (h->res_self_srv && h->self_srv))) { // (the claim lines are the handle's: one resident launch at a time — a forced second chain runs without servers)
             // workgroups go to the XCDs round-robin and every XCD must hold its share at once: the grid (8 * cb block workgroups — up to 7
             // of them idle, but their CUs may be on other XCDs than the servers that would need them — plus the servers) <= CUs
             n_srv = std::min(h->n_cu - 8 * p.cb, h->srv_wg_cap);
             if (n_srv < SRV_MIN_WG) n_srv = 0;
         }
         if (n_srv > 0) {
+            if (with_self) p.srv_own = 0; // next to the self-collision flavour the pairs only ANSWER queries (a request per particle and substep, carrying
+                                          // the velocity after the impulses): an owned particle would have to take part in the candidates' hand-off itself
             p.srv_quad = h->srv_quad_for(n_srv); p.srv_slots = (p.srv_quad ? 2 : 4) * n_srv;
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((SRV_DBG_OFF / 4 + 255) / 256)), dim3(256), 0, s, (float*)h->d_srv_claim, (size_t)SRV_DBG_OFF / 4); // claims and control words
             const size_t rw = (size_t)(SRV_REC / 4) * ne * h->N;
@@ -640,7 +644,8 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
         const bool with_mesh = h->nF > 0;
         if (with_self) { // candidates' {x0, v} records: tags of the previous launch must not match
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_vx + (size_t)24 * e0 * xn, words);
-            if (with_mesh) hipLaunchKernelGGL((k_steps_resident<512, true, 1>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
+            if (with_mesh && n_srv > 0) hipLaunchKernelGGL((k_steps_resident<512, true, 1, true>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
+            else if (with_mesh) hipLaunchKernelGGL((k_steps_resident<512, true, 1, false>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
             else hipLaunchKernelGGL((k_steps_resident<512, true, 0>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
         } else if (with_mesh) hipLaunchKernelGGL((k_steps_resident<512, false, 1>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
         else hipLaunchKernelGGL((k_steps_resident<512, false, 0>), grid, dim3(RES_THREADS), 0, s, p, in, out, first, n, 1);
@@ -675,7 +680,7 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
 void drop_graph(R2SPhys* h)
 {
     for (int c = 0; c < R2SPhys::MAX_CHAINS; ++c)
-        for (int v = 0; v < 8; ++v) {
+        for (int v = 0; v < 12; ++v) {
             if (h->graph_exec[c][v]) (void)hipGraphExecDestroy(h->graph_exec[c][v]);
             if (h->graph[c][v]) (void)hipGraphDestroy(h->graph[c][v]);
             h->graph_exec[c][v] = nullptr; h->graph[c][v] = nullptr;
@@ -688,9 +693,17 @@ void drop_graph_fwd(R2SPhys* h) { drop_graph(h); }
 // while one chain's workgroups stage their windows (memory phase, VALU idle) or sit in the launch gap between two substeps,
 // another chain's are in the gather (VALU phase), and one chain's finishing kernel runs next to the others' fused kernels.
 // Each chain is captured into its own graph.
+// The captured flavours: {no candidates, candidates} x {queries in place / resident, deferred} x parity of the state buffer, and the
+// resident self-collision flavour with query servers in the launch (self_srv: only while queries are being needed — idle servers and
+// their hand-off code cost that flavour 0.5 us per substep)
+int graph_slot(const R2SPhys* h, int variant, int start_buf)
+{
+    return (variant == 1 && !h->mesh_defer && h->self_srv ? 8 : h->mesh_defer * 4) + variant * 2 + (start_buf & 1);
+}
+
 int capture_graph(R2SPhys* h, int variant, int start_buf)
 {
-    const int slot = h->mesh_defer * 4 + variant * 2 + (start_buf & 1);
+    const int slot = graph_slot(h, variant, start_buf);
     const int chains = h->chains();
     for (int c = 0; c < chains; ++c) {
         if (h->graph_exec[c][slot]) (void)hipGraphExecDestroy(h->graph_exec[c][slot]);
@@ -1392,11 +1405,12 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         int occ_min = 1 << 30;
         {
             int occ = 0;
-            const void* kernels[4] = {(const void*)k_steps_resident<512, false, 0>, (const void*)k_steps_resident<512, false, 1>,
-                                      (const void*)k_steps_resident<512, true, 0>, (const void*)k_steps_resident<512, true, 1>};
-            for (int k = 0; k < 4; ++k) {
-                if ((k & 1) && h->nF == 0) continue;                 // (the mesh templates of a scene without meshes are never launched)
-                if ((k & 2) && !h->prm.self_collision) continue;     // (nor the self-collision flavour of a handle without it)
+            const void* kernels[5] = {(const void*)k_steps_resident<512, false, 0>, (const void*)k_steps_resident<512, false, 1>,
+                                      (const void*)k_steps_resident<512, true, 0>, (const void*)k_steps_resident<512, true, 1, false>,
+                                      (const void*)k_steps_resident<512, true, 1, true>};
+            for (int k = 0; k < 5; ++k) {
+                if ((k == 1 || k >= 3) && h->nF == 0) continue;                 // (the mesh templates of a scene without meshes are never launched)
+                if (k >= 2 && !h->prm.self_collision) continue;     // (nor the self-collision flavour of a handle without it)
                 R2S_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernels[k], RES_THREADS, 0));
                 occ_min = std::min(occ_min, occ);
             }
@@ -1414,6 +1428,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             TRY(dev_alloc((char**)&h->d_xch, (size_t)96 * E * xn));
             R2S_HIP_TRY(hipMemsetAsync(h->d_xch, 0, (size_t)96 * E * xn, s));
             if (const char* ev = getenv("R2S_RES_SELF")) h->res_self = atoi(ev) != 0;
+            if (const char* ev = getenv("R2S_RES_SELF_SRV")) h->res_self_srv = std::max(0, std::min(2, atoi(ev))); // 2: servers in every launch of the flavour (tests)
             if (h->prm.self_collision) {
                 TRY(dev_alloc((char**)&h->d_vx, (size_t)96 * E * xn));
                 R2S_HIP_TRY(hipMemsetAsync(h->d_vx, 0, (size_t)96 * E * xn, s));
@@ -1467,6 +1482,11 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             for (int par = 0; par < ((h->prm.num_substeps & 1) ? 2 : 1); ++par) {
                 h->mesh_defer = defer;
                 TRY(capture_graph(h, variant, par));
+                if (variant == 1 && defer == 0 && h->resident_ok && h->srv_ok && h->res_self && h->res_self_srv && h->d_vx && h->chains() == 1) {
+                    h->self_srv = 1; // ... and the resident self-collision flavour with query servers in the launch
+                    TRY(capture_graph(h, variant, par));
+                    h->self_srv = 0;
+                }
             }
     h->mesh_defer = h->any_large ? 1 : 0;
 #undef TRY
@@ -1809,6 +1829,7 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
                                     "test (widened by 2 mm) may have been skipped where the reference applies it (unsupported)");
         return R2S_ERR_INVALID;
     }
+    h->self_srv = 0;
     if (h->nF > 0) { // defer the mesh queries to k_contact_finish when the last finished step saw particles near a mesh
         // an unfinished count keeps the previous flavour.  Large batches defer as soon as anything is NEAR a mesh (an idle finishing launch
         // costs them ~0.7 us per substep, an in-place query in the fused kernel up to 190); small batches only once a query was NEEDED:
@@ -1822,7 +1843,11 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
             if (cnt[3] > 0) h->srv_exhausted = true;
             else if (cnt[2] == 0) h->srv_exhausted = false;
         }
-        if (h->resident_ok && h->resident_pref && h->srv_ok && variant == 0 && !h->srv_exhausted) h->mesh_defer = 0;
+        // (the self-collision flavour of the resident launch, round 5, gets its servers — answering, not owning — only while queries are
+        // being needed: the step in which the first particle enters a margin, and the one after it, answer in place as ever)
+        const bool self_srv_ok = h->res_self && h->res_self_srv && h->d_vx && n > 1;
+        h->self_srv = variant == 1 && self_srv_ok && (h->mesh_defer || h->res_self_srv == 2) && h->resident_ok && h->resident_pref && h->srv_ok && h->chains() == 1 && !h->srv_exhausted ? 1 : 0;
+        if (h->resident_ok && h->resident_pref && h->srv_ok && h->chains() == 1 && (variant == 0 || self_srv_ok) && !h->srv_exhausted) h->mesh_defer = 0;
         if (h->force_defer >= 0) h->mesh_defer = h->force_defer; // test / tuning: force a flavour
         if (h->any_large) h->mesh_defer = 1;
     }
@@ -1832,16 +1857,16 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     const bool resident = resident_flavour(h, variant == 1, h->mesh_defer, n);
     if (resident) {
         h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)
-        int n_srv = h->srv_ok && n > 1 && variant == 0 ? std::min(h->n_cu - 8 * ((h->nb * h->E + 7) / 8), h->srv_wg_cap) : 0; // as enqueue_steps sizes the grid
+        int n_srv = h->srv_ok && n > 1 && h->chains() == 1 && (variant == 0 || (h->res_self_srv && h->self_srv)) ? std::min(h->n_cu - 8 * ((h->nb * h->E + 7) / 8), h->srv_wg_cap) : 0; // as enqueue_steps sizes the grid
         if (n_srv < SRV_MIN_WG) n_srv = 0;
-        h->last_flavour[3] = 1 | (n_srv << 8) | ((h->srv_own ? 1 : 0) << 20) | ((n_srv > 0 && h->srv_quad_for(n_srv) ? 1 : 0) << 21);
+        h->last_flavour[3] = 1 | (n_srv << 8) | ((h->srv_own && variant == 0 ? 1 : 0) << 20) | ((n_srv > 0 && h->srv_quad_for(n_srv) ? 1 : 0) << 21);
     }
     int gate_dev = -1;
     if (resident) { int rcg = resident_enter(s, &gate_dev); if (rcg) return rcg; }
     struct GateLeave { hipStream_t s; int dev; ~GateLeave() { if (dev >= 0) (void)resident_leave(s, dev); } } gate_leave{s, gate_dev};
     if (use_graph) {
         // every flavour was captured at construction (capture_all); only set_params / set_tuning drop them
-        const int slot = h->mesh_defer * 4 + variant * 2 + (h->cur & 1);
+        const int slot = graph_slot(h, variant, h->cur);
         if (!h->graph_exec[0][slot]) {
             const int keep = h->mesh_defer;
             int rc = capture_graph(h, variant, h->cur);

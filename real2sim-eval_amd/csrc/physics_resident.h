@@ -355,7 +355,9 @@ __device__ void resident_server(const PhysDev& p, int first, int n_steps, int wr
 // arrays, wavefront 0 alone finishes and owns every side effect): the contact flavours — deferred mesh queries, self-collision
 // candidates (SELF with n_steps = 1; with n_steps > 1 see `self_res` below) — keep their finishing kernels and a launch per substep, but a block's springs are
 // still shared by eight wavefronts instead of walked by one (k_substep<64,512,..>: 8.0 us per substep of the rope, this: see DESIGN §4).
-template <int RCAP, bool SELF, int MESH>
+// SRV: the launch may carry mesh-query servers (small scenes).  The self-collision flavour has both forms: the servers' hand-off code costs
+// it a spilled register and 0.3 us per substep (rope folded onto itself: 5.55 vs 5.85), so it only pays for them while queries are needed.
+template <int RCAP, bool SELF, int MESH, bool SRV = (MESH == 1 && !SELF)>
 __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev p, const StateC xv_in, const StateM xv_out, int first, int n_steps,
                                                                     int write_forces_last)
 {
@@ -366,7 +368,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     __shared__ float4 part_s[NW][B]; // partial forces of the eight wavefronts: one 16-byte write per lane, eight 16-byte reads per finishing lane
     __shared__ volatile int fail_s;
     if ((int)blockIdx.x >= 8 * p.cb) { // workgroups beyond the blocks' own: mesh-query servers (small scenes only)
-        if (MESH == 1 && !SELF) resident_server(p, first, n_steps, write_forces_last);
+        if (SRV) resident_server(p, first, n_steps, write_forces_last);
         return;
     }
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -422,7 +424,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
     const float inv_m1 = 1.0f / m1;
     ResidentIO io;
     io.x = mk(0.f, 0.f, 0.f); io.v = io.x;
-    const bool srv_on = MESH == 1 && !SELF && p.srv_slots > 0 && n_steps > 1;
+    const bool srv_on = SRV && p.srv_slots > 0 && n_steps > 1; // (SELF: only when the host put servers into the launch — answering, not owning: p.srv_own = 0)
     io.srv_on = srv_on; io.srv_need = false;
     // SELF with more than one substep per launch (round 5: the resident stepper's self-collision flavour): a particle with candidates
     // publishes {x0, post-force v} of every substep in tagged write-through records (p.vx, laid out like the exchange array, tag = k + 1).
@@ -720,17 +722,26 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
         // wait for — finds its partners' records in already, and its impulses must not queue behind work that can run beside them.
         // In a block with tasks wavefronts 1 and 2 do this (1 stores and publishes planes 0 and 1, 2 plane 2); wavefront 0 only finishes
         // the lanes with candidates, behind barrier E
-        if (finisher && !(self_blk && wave == 0)) {
+        if (finisher && !(self_blk && wave == 0 && !srv_on)) {
             R2S_QP_DECL(-1);
             io.srv_need = false;
-            finish_wave<MESH, MESH != 0, 0, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, v, fin, out, nullptr, nullptr, nullptr, nullptr,
-                                                  wave == (self_blk ? 1 : 0), &io R2S_QP_ARG);
+            const bool done1 = finish_wave<MESH, MESH != 0, 0, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, v, fin, out, nullptr, nullptr, nullptr, nullptr,
+                                                                     wave == ((self_blk && !srv_on) ? 1 : 0), &io R2S_QP_ARG);
             if (self_blk && !last) {
                 // the lanes that are finished publish BEFORE the impulses are in: their records are what the neighbour blocks need for the
                 // next substep
                 early_pub = true;
-                if (!sneed) {
-                    const unsigned tag = (unsigned)(k + 1), pub = (xe + (unsigned)i) * 16u + (unsigned)((k + 1) & 1) * xb;
+                const unsigned tag = (unsigned)(k + 1), pub = (xe + (unsigned)i) * 16u + (unsigned)((k + 1) & 1) * xb;
+                if (srv_on) { // servers in the launch: the three finishing wavefronts as in a launch without candidates, each its plane
+                    if (done1) {
+                        const float va = wave == 0 ? io.x.x : (wave == 1 ? io.x.z : io.v.x), vb = wave == 0 ? io.x.y : (wave == 1 ? io.v.z : io.v.y);
+                        if (valid) {
+                            const v4u w = {__float_as_uint(va), tag, __float_as_uint(vb), tag};
+                            __builtin_amdgcn_raw_buffer_store_b128(w, rx, pub + (unsigned)wave * xn * 16u, 0, RES_AUX_SC1);
+                        }
+                        win_s[wave * (RCAP + 1) + lane] = (v2f){va, vb};
+                    }
+                } else if (!sneed) {
                     if (wave == 1) {
                         if (valid) {
                             const v4u w0 = {__float_as_uint(io.x.x), tag, __float_as_uint(io.x.y), tag}, w1 = {__float_as_uint(io.x.z), tag, __float_as_uint(io.v.z), tag};
@@ -749,7 +760,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                 }
             }
         }
-        if (self_blk && wave == 0) early_pub = !last; // (its lanes without candidates were published by wavefronts 1 and 2)
+        if (self_blk && wave == 0 && !srv_on) early_pub = !last; // (its lanes without candidates were published by wavefronts 1 and 2)
         if (self_blk) {
 #pragma unroll
             for (int m = 0; m < RES_KS; ++m) {
@@ -865,12 +876,14 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                     }
                     const f3 vi = (sneed && validc > 0.f) ? v - (Jsum / validc) / m1 : v;
                     finish_wave<MESH, MESH != 0, 0, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, vi, sneed, out, nullptr, nullptr, nullptr, nullptr, true, &io R2S_QP_ARG);
+                    if (srv_on && sneed) v = vi; // (a lane that needs a mesh query on top: the request below carries the velocity AFTER the impulses)
                 }
             }
-            if (MESH == 1 && !SELF && srv_on) {
+            if (SRV && srv_on) {
                 const bool need_now = io.srv_need; // the same in the three finishing wavefronts (same inputs, same instructions)
                 srv_ever = srv_ever || need_now;
-                sneed = srv_own ? srv_ever : need_now;
+                const bool sself = sneed;                          // (SELF: lanes with candidates — wavefront 0 has finished them above unless they need a query)
+                const bool ssrv = srv_own ? srv_ever : need_now;   // lanes whose state comes from a server pair
                 const unsigned uk = (unsigned)k;
                 if (wave == 0) {
                     bool inplace = srv_own && srv_ever && !srv_mine && !need_now; // owning servers, no pair was left at its first need: in place from then on
@@ -896,14 +909,14 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                             srv_store(rsv, sbase, 0u, 0u, 2u * (uk + 1u)); // nothing in reach in this substep: the pair skips it
                     }
                     if (__builtin_amdgcn_ballot_w64(inplace) != 0ull) // (wave-uniform branch: finish_wave's queries are per lane here)
-                        finish_wave<MESH, false, 1, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, v, sneed && inplace, out, nullptr, nullptr, nullptr, nullptr,
+                        finish_wave<MESH, false, 1, true>(p, e, i, eb, step, last ? write_forces_last : 0, x0, v, ssrv && inplace, out, nullptr, nullptr, nullptr, nullptr,
                                                           true, &io R2S_QP_ARG);
-                    if (__builtin_amdgcn_ballot_w64(sneed && !inplace) != 0ull) {
+                    if (__builtin_amdgcn_ballot_w64(ssrv && !inplace) != 0ull) {
                         // the lanes that are finished publish BEFORE the wait: their records are what the pairs (and the neighbour blocks) need
                         // for the next substep — behind the wait, every substep of a particle in contact paid a second hand-off for them
                         if (!last) {
                             early_pub = true;
-                            if (!sneed) {
+                            if (!ssrv && !sself) {
                                 if (valid) {
                                     const v4u w = {__float_as_uint(io.x.x), (unsigned)(k + 1), __float_as_uint(io.x.y), (unsigned)(k + 1)};
                                     __builtin_amdgcn_raw_buffer_store_b128(w, rx, (xe + (unsigned)i) * 16u + (unsigned)((k + 1) & 1) * xb, 0, RES_AUX_SC1);
@@ -913,7 +926,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                         }
                         for (unsigned spins = 0;; ++spins) {
                             bool ok = true;
-                            if (sneed && !inplace) {
+                            if (ssrv && !inplace) {
                                 const unsigned ro = sbase + (unsigned)SRV_RES + ((uk + 1u) & 1u) * 64u;
                                 const v4u d0 = srv_load(rsv, ro), d1 = srv_load(rsv, ro + 16u), d2 = srv_load(rsv, ro + 32u);
                                 if (d0.y == uk + 1u && d0.w == uk + 1u && d1.y == uk + 1u && d1.w == uk + 1u && d2.y == uk + 1u && d2.w == uk + 1u) {
@@ -937,9 +950,10 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                                 break;
                             }
                         }
-                        if (last && sneed && !inplace && xv_out.p != nullptr) st_store(xv_out, eb + i, io.x, io.v);
+                        if (last && ssrv && !inplace && xv_out.p != nullptr) st_store(xv_out, eb + i, io.x, io.v);
                     }
                 }
+                sneed = ssrv || sself;
             }
 #ifdef R2S_PHASE_PROBE
             if (io.x.x == 1.2345e33f) return;
@@ -972,7 +986,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             R2S_RSTAMP2(3);
         }
     }
-    if (MESH == 1 && !SELF && srv_on) { // end this block's server pairs, then count the block out (pairs nobody claimed leave when every block has)
+    if (SRV && srv_on) { // end this block's server pairs, then count the block out (pairs nobody claimed leave when every block has)
         if (wave == 0 && srv_mine) srv_store(rsv, sbase, 0u, 0u, SRV_END);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -38,7 +38,7 @@ def _sheets_between_fingers(n_sub, closing=1.0):
     return ob, nA, [fl, fr], motion
 
 
-@pytest.mark.parametrize("n_env", [1, 9], ids=["1 env", "9 envs, two chains"])
+@pytest.mark.parametrize("n_env", [1, 5, 9], ids=["1 env", "5 envs, one chain", "9 envs, two chains"])
 @pytest.mark.parametrize("defer", ["0", "1"], ids=["queries in place (k_self_finish)", "finishing kernel (k_contact_finish<3,true>)"])
 def test_two_sheets_squeezed_between_closing_fingers(defer, n_env, monkeypatch):
     """Every particle under the pads has a live self-collision candidate (the sheet opposite, 4 mm away) and is inside the 5 mm
@@ -47,7 +47,8 @@ def test_two_sheets_squeezed_between_closing_fingers(defer, n_env, monkeypatch):
     import torch
 
     monkeypatch.setenv("R2S_MESH_DEFER", defer)
-    if n_env > 1:
+    monkeypatch.setenv("R2S_RES_SELF_SRV", "2")       # servers from the first step on (default: once a query was needed, two steps later)
+    if n_env == 9:
         monkeypatch.setenv("R2S_CHAINS", "2")
     n_sub = 36   # the float64 shadow of the oracle agrees with its float32 run to 3e-8 over 40 substeps of this scene; past ~42 a
     #              contact decision flips between the two and they part by 0.1 mm (scratch run recorded in DESIGN.md §2)
@@ -56,7 +57,7 @@ def test_two_sheets_squeezed_between_closing_fingers(defer, n_env, monkeypatch):
     kw = dict(num_substeps=n_sub, dynamic_meshes=fingers, self_collision=True)
     o = oracle_env(far, **kw)
     h = hip_env(far, n_env=n_env, **kw)
-    if n_env > 1:
+    if n_env == 9:
         assert h.layout_stats()["chains"] == 2
     o.x[:] = ob["points"]
     h.set_state(torch.from_numpy(ob["points"])[None].repeat(n_env, 1, 1))
@@ -69,6 +70,13 @@ def test_two_sheets_squeezed_between_closing_fingers(defer, n_env, monkeypatch):
     o.step(); h.step()
     fl = h.last_flavour()
     assert fl["self_collision_kernel"] and fl["mesh_template"] == 1 and fl["deferred_mesh_queries"] == (defer == "1"), fl
+    if defer == "0" and n_env < 9:
+        # round 5: a small batch stays ONE resident launch through this — the candidates' hand-off AND query servers that answer (a request
+        # per particle and substep, carrying the velocity after the impulses); a forced second chain (the 9-environment case) runs without
+        # servers: their claim lines are the handle's
+        assert fl["resident"] and fl.get("query_server_workgroups", 0) > 0 and not fl.get("servers_own_their_particle", True), fl
+    if defer == "0" and n_env == 9:
+        assert fl["resident"] and fl.get("query_server_workgroups", 0) == 0, fl
     tagged = h.tagged_count()
     if defer == "1":
         assert tagged >= 20 * n_env, tagged      # ~50 particles per environment sit under the pads with a candidate
@@ -229,18 +237,25 @@ def test_an_impulse_beyond_the_reach_bound_is_reported_by_a_later_step_and_a_new
     assert bool(torch.isfinite(h.x).all())
 
 
-def test_bench_scene_one_env_20_substeps_in_the_grasp_vs_oracle_driven_through_eef_oracle():
+@pytest.mark.parametrize("servers", ["1", "0"], ids=["resident launch: candidates' hand-off + query servers", "per-substep kernels + k_contact_finish"])
+def test_bench_scene_one_env_20_substeps_in_the_grasp_vs_oracle_driven_through_eef_oracle(servers, monkeypatch):
     """ONE environment of bench.py's own workload (sloth_arms, 15 066 particles, grasp trace) through the
     product path; in the first env step after the fingers closed — arms pressed together, finger contact, the flavour the
     headline's contact phase times — 20 substeps against PhysOracle driven by EefOracle, and the side-camera frame against the
-    raster oracle.  The same routine is bench.py's --parity-gate."""
+    raster oracle.  The same routine is bench.py's --parity-gate.  Round 5: one environment stays in the resident launch through this —
+    the self-collision flavour with query servers that answer (a request per particle and substep, carrying the velocity after the
+    impulses); `R2S_RES_SELF_SRV=0` is the form of rounds 3-4, two launches per substep."""
     from oracle import parity_gate
 
+    monkeypatch.setenv("R2S_RES_SELF_SRV", servers)
     r = parity_gate.run("sloth_32env", num_substeps=667, n_compare=20, close_at=2)
-    record("bench scene (sloth_arms, grasp), 20 substeps in contact", **{k: v for k, v in r.items() if isinstance(v, (int, float)) and not isinstance(v, bool)}, tol=1e-5)
+    record(f"bench scene (sloth_arms, grasp), 20 substeps in contact, R2S_RES_SELF_SRV={servers}", **{k: v for k, v in r.items() if isinstance(v, (int, float)) and not isinstance(v, bool)}, tol=1e-5)
     assert r["mesh_contact"] and r["particles_with_candidates"] > 0, r
-    assert "true,1>" in r["flavour"] and "k_contact_finish" in r["flavour"], r["flavour"]   # (one environment: the small-batch layout, two launches per substep)
-    assert r["tagged_entries"] >= 0 and r["deferred_per_substep_max"] > 0, r
+    if servers == "1":
+        assert r["flavour"].startswith("k_steps_resident<512,true,1> + ") and "a request per substep" in r["flavour"], r["flavour"]
+    else:
+        assert "true,1>" in r["flavour"] and "k_contact_finish" in r["flavour"], r["flavour"]   # (the small-batch layout, two launches per substep)
+        assert r["tagged_entries"] >= 0 and r["deferred_per_substep_max"] > 0, r
     assert r["eef_pts_max_abs"] < 2e-6 and r["eef_center_max_abs"] < 5e-7, r
     assert r["x_max_abs"] < 1e-5, r
     assert r["hard_rgb_mismatch_pixels"] == 0 and r["hard_depth_mismatch_pixels"] == 0, r
