@@ -12,13 +12,21 @@ collective (weak scaling); the only collective is the final all-gather of per-ra
 
 The timed window is what a POLICY IN THE LOOP sees (round 5; eval_policy.py:124-213): every step ends in get_obs() — the host
 waits for the frames, validates the sync-free raster batch, re-renders a lossy one — before the next action is applied, and the
-environments are DE-PHASED: environment e runs the action trace (e K) // E steps late, so the grippers close one after the other
-across the window instead of all at its middle (episodes of eval_policy_parallel.py do not share a phase) and every step runs the
-contact flavour for some environments.  Over the window half of the env-steps are free motion (the open gripper comes down over
-the toy's raised arms) and half are in the grasp (finger contact, the arms pressed together: live self-collision candidates, grasp
-detection, lift).  `value` is the mean over that window.  Reported next to it, never as `value`: the same K steps with all
-environments in phase (`synchronised_window`: free first half, contact second half, `phases` splits it), enqueue-only, and
-with the rasterisation of step t next to the substeps of step t+1.
+environments are DE-PHASED: environment e runs the action trace (e K/2) // E steps late, so the grippers close one after the other
+(episodes of eval_policy_parallel.py do not share a phase).  Round 6: the gripper CLOSES LIKE A POLICY CLOSES IT — the commanded opening
+ramps down by --close-rate per env step (default 0.1) towards 0 instead of jumping — so the reference's grasp state machine
+(phystwin.py:383-412) runs as it does in an episode: the pads load up step by step, both filtered pad forces exceed 3e4, `grasped`
+latches, the opening freezes (or creeps by 0.05 per step while a force sags), and the object is LIFTED in the grasp.  Until round 5 the
+command jumped to its closed value within one env step, after which it can never again be below the current opening — the condition
+under which the reference establishes a grasp — and `grasped_envs` was 0 in every bench line of rounds 3-5.  The window starts with
+the first grippers already closing (the trace's closing step is `warmup - 4`) and the delays cover K/2 steps: over the K timed steps
+some environments are still coming down or closing (free motion, first finger contact) and from about two thirds of the window on all
+of them hold the toy's arms and lift (`window.grasped_envs_per_step` ends at the batch size) — finger contact on every pad, the arms
+pressed together (live self-collision candidates), the state machine in its hold / creep branches.  `value` is the mean over that
+window; `window.step_latency_ms` says what a single step of it costs at most.  Reported next to it, never as `value`: the same K steps
+with all environments in phase (`synchronised_window`; `phases` splits it into free motion and contact), enqueue-only, with the
+rasterisation of step t next to the substeps of step t+1, and SUSTAINED full episodes (`episodes`: reset -> 30 settling steps ->
+450 policy steps on every slot, observation sink on; eval_policy.py:65-267).
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the fused physics substep) and `cpu_baseline`
 (the oracle — a CPU restatement of the reference algorithm, kind "port" — on a bounded sample).
@@ -142,6 +150,85 @@ def cpu_baseline(ro, budget_s=20.0):
     }
 
 
+def _pct(v, q):
+    v = sorted(v)
+    return float(v[min(len(v) - 1, int(round(q * (len(v) - 1))))]) if v else None
+
+
+def latency_stats(ms):
+    return {"p50": _pct(ms, 0.5), "p99": _pct(ms, 0.99), "max": max(ms) if ms else None, "mean": sum(ms) / len(ms) if ms else None, "steps": len(ms)}
+
+
+EPISODE_STEPS = {"sloth": 450, "rope": 900, "T": 1800}   # env.sim.duration x 30 fps: scripts/eval_policy/sloth_act.sh (15 s), cfg/env/xarm_gripper.yaml:3 (30 s), xarm_pusher.yaml:3 (60 s)
+
+
+def sustained_episodes(config, dev, seed, n_env, substeps, res, per_slot, steps, close_rate, sink_dir):
+    """FULL episodes on every environment slot through the episode scheduler (r2s_hip/evaluate.run_episodes: eval_policy.py:65-267 for a
+    batch): per-slot reset into the episode's randomised start pose -> 30 settling steps -> `steps` steps of the scene's action trace
+    (approach, closing ramp, grasp, lift, hold / the rod pushing the block), get_obs() before every step, the observation sink writing
+    every frame and state (JPEG + pickle per environment and step, worker processes).  Never `value`: the sustained figure NEXT to the
+    20-step window — tails a short mean hides (flavour switches, resets, re-rendered batches, sink stalls) show up here."""
+    import shutil
+    import tempfile
+
+    import torch
+    from r2s_hip.evaluate import run_episodes, summarize
+    from r2s_hip.rollout import BatchedRollout
+    from r2s_hip.sink import ObservationSink
+
+    settle = 30
+    kw = dict(device=dev, seed=seed, n_env=n_env, num_substeps=substeps, res=res, close_at=settle + 15, randomize="multicam" not in config)
+    if close_rate and "pusher" not in config:
+        kw.update(close_rate=close_rate, lift_steps=60)
+    ro = BatchedRollout(config, **kw)
+    steps = int(steps or EPISODE_STEPS.get(ro.ob_shape, 450))
+    E = ro.n_env
+    tmp = sink_dir or tempfile.mkdtemp(prefix="r2s_sink_")
+    sink = ObservationSink(tmp, E, ro.views, ro.H, ro.W, device=dev, slots=6, state_bytes=2 * E * ro.N * 12 + 4096)
+    lat, grasped_trace, flav = [], [], set()
+    last = [time.perf_counter()]
+    cnt = [0]
+    gdev = torch.zeros(steps + settle + 2, 3, dtype=torch.int32, device=dev)
+
+    def on_step(r, slot_episode, step_t):
+        sink.submit(cnt[0] % (steps + settle), r.out_color, state=dict(x=r.phys.x, v=r.phys.v))
+        if cnt[0] < gdev.shape[0]:
+            r.phys.log_contacts(gdev[cnt[0]])          # {candidates, mesh hits, grasped environments} of this step, kept on the device
+        if cnt[0] % 16 == 0:
+            flav.add(r.phys.last_flavour()["kernel"])
+        cnt[0] += 1
+        now = time.perf_counter()
+        lat.append((now - last[0]) * 1e3)
+        last[0] = now
+
+    lossy0 = ro.lossy_batches
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    last[0] = t0
+    rec = run_episodes(ro, list(range(per_slot * E)), policy=None, max_steps=steps, settle_steps=settle, on_step=on_step)
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    sink.close()
+    drain = time.perf_counter() - t1
+    g = gdev[: min(cnt[0], gdev.shape[0])].cpu().numpy()
+    out = {"config": config, "envs": E, "episodes": int(rec.shape[0]), "steps_per_episode": steps, "settle_steps": settle, "env_steps": int(E * cnt[0]),
+           "sustained_env_steps_per_s": E * cnt[0] / wall, "wall_s": wall, "step_latency_ms": latency_stats(lat[1:]),
+           "slowest_steps": sorted(((round(m, 2), k) for k, m in enumerate(lat)), reverse=True)[:5],
+           "re_rendered_batches": int(ro.lossy_batches - lossy0), "sink": {"frames_written": sink.frames_written, "steps_written": sink.steps_written,
+                                                                          "producer_stalls": sink.stalls, "drain_after_run_s": drain, "format": sink.ext},
+           "grasped_envs_max": int(g[:, 2].max()) if len(g) else 0, "grasped_env_steps_share_first_episode": float(g[:, 2].sum() / max(1, E * len(g))) if len(g) else 0.0,
+           "mesh_contacts_max": int(g[:, 1].max()) if len(g) else 0, "candidates_max": int(g[:, 0].max()) if len(g) else 0,
+           "kernel_flavours_sampled": sorted(flav), "records": summarize(rec),
+           "note": "run_episodes on every slot: randomised per-slot resets (episode id -> grid pose), 30 settling steps + the episode's steps of the synthetic action "
+                   "trace (closing ramp -> grasp -> lift 60 steps -> hold), get_obs() before every step (closed loop), sink on (every frame + state written by worker "
+                   "processes); step_latency_ms = host wall clock between consecutive steps (the first step, which pays the first render, is left out)"}
+    del ro
+    if not sink_dir:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 class StubRollout:
     """CPU stand-in for BatchedRollout: the launcher / barrier / MAX / all-gather / JSON path of this file without a GPU
     (tests/test_distributed_gloo.py drives `bench.py --stub --gpus 2` through the same self-launch as the real bench)."""
@@ -208,6 +295,12 @@ def main():
                                                             "in phase (the round-4 window; then no second, synchronised window is timed)")
     ap.add_argument("--open-loop", action="store_true", help="the timed window only ENQUEUES steps (no get_obs() per step): the round-4 definition of `value`; "
                                                              "for profiling runs (a kernel trace of back-to-back steps), never for a reported number")
+    ap.add_argument("--close-rate", type=float, default=0.1, help="gripper scenes: the commanded opening falls by this much per env step once the gripper closes "
+                                                                     "(towards 0: where the fingers stop is the grasp state machine's decision, phystwin.py:399-405); 0: the "
+                                                                     "command jumps to its closed value within one env step (rounds 1-5: no grasp can ever be detected)")
+    ap.add_argument("--episodes", type=int, default=-1, help="full episodes per environment slot of the sustained measurement that follows the timed window "
+                                                              "(reset -> 30 settling steps -> the scene's episode length, sink on; -1: 2 on one GPU, 0 on several; 0: skip)")
+    ap.add_argument("--episode-steps", type=int, default=0, help="policy steps per episode of the sustained measurement (0: the reference's: sloth 450, rope 900, T 1800)")
     ap.add_argument("--sink", default=None, help="directory: also run the observation sink (row f4) every step — packed 8-bit frames + state "
                                                  "to pinned ring buffers, JPEG / pickle written by a host thread; not part of the headline")
     args = ap.parse_args()
@@ -246,22 +339,29 @@ def main():
         try:
             n_bench = args.envs if args.envs is not None else CONFIGS[args.config][3]
             gate = parity_gate.run(args.config, device=dev, seed=rank, num_substeps=args.substeps, n_compare=20, close_at=2,
-                                   n_env=9 if n_bench >= 9 else n_bench, res=res)
+                                   n_env=9 if n_bench >= 9 else n_bench, res=res,
+                                   close_rate=args.close_rate if args.close_rate > 0 and "pusher" not in args.config else None)
         except Exception as e:  # a gate that cannot run is a failed gate
             gate = {"passed": False, "error": f"{type(e).__name__}: {e}"}
 
-    close_sync = args.warmup + args.steps // 2   # all environments in phase: the window is half free motion, half contact (grasp schedule / pusher)
-    K_dephase = args.steps if args.dephase < 0 else args.dephase
+    # Gripper scenes close at --close-rate per env step (a ramp of ~10 steps; the grasp latches ~8 steps after the closing starts): the
+    # timed window begins with the first environments 4 steps into their closing and the delays cover HALF the window, so that every
+    # environment is in the grasp — holding, lifting — for the window's last third.  The pusher scene has no ramp: the rod reaches the
+    # block at the window's start + the environment's delay, delays over the whole window (as in round 5).
+    ramp = args.close_rate > 0 and "pusher" not in args.config
+    kw_ro = dict(device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, res=res)
+    if ramp:
+        kw_ro.update(close_rate=args.close_rate, lift_steps=60)
+    lead = 4 if ramp else 0                      # env steps of closing before the window starts
+    close_sync = args.warmup + (max(0, args.steps // 2 - 6) if ramp else args.steps // 2)   # all environments in phase: free motion, then closing -> contact -> grasp -> lift
+    K_dephase = (max(2, args.steps // 2) if ramp else args.steps) if args.dephase < 0 else args.dephase
     tc0 = time.perf_counter()
-    # the timed rollout: environment e closes its gripper / reaches the block at timed step (e K) // E — over the window the same share of
-    # env-steps is in contact as in the synchronised window
-    ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule,
-                        close_at=args.warmup if K_dephase > 1 else close_sync, res=res)
+    ro = BatchedRollout(args.config, close_at=max(0, args.warmup - lead) if K_dephase > 1 else close_sync, **kw_ro)
     dephased = K_dephase > 1 and ro.with_gripper and ro.schedule in ("grasp", "push") and ro.n_env > 1   # (one environment: its contact event at the window's middle)
     if dephased:
         ro.set_dephase(K_dephase)
-    elif K_dephase > 1:   # a trace without a contact event (the small test scenes' lissajous path): nothing to de-phase
-        ro = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=close_sync, res=res)
+    elif K_dephase > 1:   # a trace without a contact event (the small test scenes' lissajous path), or one environment: nothing to de-phase
+        ro = BatchedRollout(args.config, close_at=close_sync, **kw_ro)
 
     torch.cuda.synchronize(dev)
     construct_s = time.perf_counter() - tc0            # scene synthesis, topology upload, graph capture of every flavour, settling
@@ -288,12 +388,15 @@ def main():
     ro.start_log(args.steps)
     lossy_before = ro.lossy_batches
     t0 = time.perf_counter()
+    lat = []
     for k in range(args.steps):
+        ts = time.perf_counter()
         ro.step()
         if closed_loop:
             ro.get_obs()          # the policy's read: wait for the frames of THIS step, validate the batch, re-render a lossy one
         if sink is not None:
             sink.submit(k, ro.out_color, state=dict(x=ro.phys.x, v=ro.phys.v), ready=getattr(ro, "_render_done", None))
+        lat.append((time.perf_counter() - ts) * 1e3)   # (closed loop: action -> observation, host wall clock; open loop: enqueue time only)
     barrier()
     elapsed = time.perf_counter() - t0
     re_rendered = int(ro.lossy_batches - lossy_before)
@@ -317,7 +420,7 @@ def main():
     # timed this one, enqueue-only, as `value`) — on a rollout of its own; the accounting runs below continue from the state it ends in
     sync_report, plog, ra = None, log, ro
     if dephased and not args.stub:
-        ra = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=close_sync, res=res)
+        ra = BatchedRollout(args.config, close_at=close_sync, **kw_ro)
         for _ in range(args.warmup):
             ra.step()
             if closed_loop:
@@ -333,7 +436,7 @@ def main():
         els = time.perf_counter() - t0s
         plog = ra.read_log()
         # ... and once more as round 4 timed its `value`: the same synchronised schedule, steps only ENQUEUED (comparable with BENCH_r04.json)
-        rb = BatchedRollout(args.config, device=dev, seed=rank, n_env=args.envs, num_substeps=args.substeps, schedule=args.schedule, close_at=close_sync, res=res)
+        rb = BatchedRollout(args.config, close_at=close_sync, **kw_ro)
         for _ in range(args.warmup):
             rb.step()
         torch.cuda.synchronize(dev)
@@ -482,7 +585,7 @@ def main():
                     "kernel_flavours": sorted({plog["flavour"][i] for i in idx})}
 
         resident_steps = sum("k_steps_resident" in f for f in log["flavour"])   # env steps of the window that ran as one resident launch
-        first_contact = (close_sync if dephased else ro.close_at) - args.warmup  # index in the synchronised window of the step in which the fingers close / rod arrives
+        first_contact = (close_sync if dephased else ro.close_at) - args.warmup + (2 if ramp else 0)  # index in the synchronised window of the step in which the pads reach the object (two steps into the ramp) / the fingers snap shut / the rod arrives
         (pmc_sub, src), (pmc_comp, _) = pmc_summary("k_substep", args.config), pmc_summary("k_composite", args.config)
         shared_bytes = 16 * ro.S + 48 * ro.N * ro.n_env        # the topology once (it is shared by the environments and L2-resident) + every environment's state
         traffic = pmc_sub["hbm_bytes_per_launch"] if pmc_sub and ro.n_env == 32 and n_sub == 667 else None
@@ -526,12 +629,14 @@ def main():
                                    + ("every step ends in get_obs() (closed loop)" if closed_loop else "steps only enqueued (--open-loop)"),
                        "envs_per_gpu": ro.n_env, "parallelism": f"envs sharded over {world} GPU(s), no data-path collective"},
             "window": {"closed_loop_get_obs_every_step": closed_loop, "dephased": bool(dephased), "K": int(K_dephase) if dephased else 0,
-                       "re_rendered_batches": re_rendered,
+                       "re_rendered_batches": re_rendered, "step_latency_ms": dict(latency_stats(lat), per_step=[round(m, 3) for m in lat]),
+                       "close_rate": args.close_rate if ramp else None,
                        "substep_us_per_step": [round(m / n_sub * 1e3, 2) for m in log["phys_ms"]], "mesh_contacts_per_step": log["mesh_hits"],
                        "grasped_envs_per_step": log["grasped"], "kernel_flavours": sorted(set(log["flavour"])),
-                       "note": "what `value` was timed over: K steps, each followed by get_obs() (the host waits for the step's frames, validates the sync-free "
-                               "raster batch, re-renders a lossy one) before the next step is applied; environment e runs the action trace (e K) // E steps late, so "
-                               "half of the window's env-steps are free motion and half are in the grasp, and every step runs the contact flavour for some environments"},
+                       "note": "what `value` was timed over: `steps` steps, each followed by get_obs() (the host waits for the step's frames, validates the sync-free "
+                               "raster batch, re-renders a lossy one) before the next step is applied; environment e runs the action trace (e K) // E steps late.  Gripper "
+                               "scenes: the commanded opening ramps down by close_rate per step from 4 steps before the window on, the pads load up, the grasp state machine "
+                               "latches from the stepper's own forces (grasped_envs_per_step) and the object is lifted in the grasp; step_latency_ms = host wall clock per step"},
             "phases": {"free": phase(lambda i: i < first_contact), "contact": phase(lambda i: i >= first_contact),
                        "window": "synchronised_window" if dephased else "the timed window",
                        "note": "free = the end effector moves, nothing touches; contact = fingers closed on the toy's arms / rod against the block "
@@ -579,6 +684,19 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(ro, args.cpu_budget)
             except Exception as e:  # the baseline is a report, never the product
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        n_epi = args.episodes if args.episodes >= 0 else (2 if world == 1 else 0)
+        if n_epi > 0 and not args.stub:
+            ro = None
+            torch.cuda.empty_cache()
+            epi = []
+            for cfg_e, per_slot in ((args.config, n_epi),) + ((("T_pusher_32env", 1),) if args.config == "sloth_32env" and args.episode_steps == 0 else ()):
+                try:
+                    epi.append(sustained_episodes(cfg_e, dev, rank, args.envs if cfg_e == args.config else None, args.substeps, res if cfg_e == args.config else None,
+                                                  per_slot, args.episode_steps, args.close_rate, args.sink))
+                except Exception as e:   # reported, never fatal for the line
+                    epi.append({"config": cfg_e, "error": f"{type(e).__name__}: {e}"})
+            out["episodes"] = {"runs": epi, "sustained_over_value": (epi[0].get("sustained_env_steps_per_s") or 0.0) / value if epi and value else None,
+                               "note": "sustained full-episode figures NEXT to the timed window (never `value`); the first run is this config's"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

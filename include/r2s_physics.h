@@ -137,8 +137,9 @@ int r2s_phys_create_resting_case_envs(R2SPhys* h, const int32_t* env_mask, r2s_s
 /* Episode reset into another scene pose (gs_renderer.py:353-390: load_scaniverse re-poses every mesh with a grid_randomization entry by
  * the episode index before PhysTwinDynamics is rebuilt from it): the vertices of the STATIC collision meshes of the environments whose
  * env_mask[e] != 0 (null = all), DEVICE float [n_env, n_static_vertices, 3] in the order of R2SPhysDesc::mesh_vertices behind the dynamic
- * ones; their boxes are rebuilt.  R2S_ERR_INVALID for a static mesh with more than 256 faces (its triangle table is built at create). */
-int r2s_phys_set_static_mesh_points(R2SPhys* h, const float* pts, const int32_t* env_mask, r2s_stream_t stream);
+ * ones — ALL static meshes, n_static_vertices = their vertex count (checked: R2S_ERR_INVALID otherwise); their boxes are rebuilt.
+ * R2S_ERR_INVALID for a static mesh with more than 256 faces (its triangle table is built at create). */
+int r2s_phys_set_static_mesh_points(R2SPhys* h, const float* pts, int32_t n_static_vertices, const int32_t* env_mask, r2s_stream_t stream);
 int r2s_phys_mesh_motion(R2SPhys* h, float** interp_points, float** interp_center, float** dynamic_velocity,
                          float** dynamic_omega);
 
@@ -203,6 +204,64 @@ int r2s_phys_tagged_count(R2SPhys* h, int32_t* out, r2s_stream_t stream);
  * launch, see r2s_phys_set_resident; 3 = like 1 with the finishers of substep k at the head of substep k + 1's launch, see
  * r2s_phys_set_pf), out[3] kernel chains. */
 int r2s_phys_last_flavour(R2SPhys* h, int32_t* out);
+/* Flavour selection as a PURE function (round 6): everything r2s_phys_step decides before it launches — which captured graph, which
+ * kernels, how many chains, how many query-server workgroups — from (a) the counters the env step TWO before this one left, (b) what the
+ * handle can do, fixed at create, (c) the switches.  Host only: no handle, no device, no state; r2s_phys_step fills the input from its
+ * handle and calls the same function, tests/test_flavour_matrix.py enumerates it without a GPU.  The reference has one flavour
+ * (spring_mass_warp.py:823-943 launches the same nine kernels every substep); the flavours here run the same arithmetic with
+ * different work splits, and which pairs are bit-identical is stated in `R2SFlavourOut::sum_class` (same class = same bits). */
+typedef struct R2SFlavourIn {
+    /* (a) counters of env step t - 2 (have_counters = 0: a new history — they read as zero and the default flavour runs) */
+    int32_t have_counters;
+    int32_t near_mesh;          /* a particle was within margin + 3 cm of a collision mesh's box                         */
+    int32_t query_needed;       /* a particle was inside a mesh's reach (a query had to be answered)                     */
+    int32_t servers_ran_out;    /* a resident launch had more particles in contact than server units                     */
+    int32_t srv_exhausted;      /* the handle's sticky copy of that (cleared once no query is needed any more)           */
+    int32_t n_candidates;       /* particles with self-collision candidates after the last update_collision_graph        */
+    int32_t n_substeps;         /* substeps of this call                                                                 */
+    int32_t full_step;          /* the call replays the captured env step (all substeps from 0)                          */
+    /* (b) capabilities */
+    int32_t n_faces;            /* faces of the combined collision mesh (0: no meshes)                                   */
+    int32_t any_large;          /* some mesh has more than 256 faces                                                     */
+    int32_t block;              /* particles per workgroup of the layout: 256, 128 or 64                                 */
+    int32_t split_ok;           /* 64-particle layout whose slices fit k_steps_resident's registers                      */
+    int32_t resident_ok;        /* the env step can run as ONE resident launch                                           */
+    int32_t srv_ok;             /* a resident launch may carry query servers (small scene, CUs to spare)                 */
+    int32_t pf_ok;              /* the contact flavours can run with the finishers at the head of the next launch        */
+    int32_t has_vx;             /* the resident self-collision flavour's record array exists                             */
+    int32_t self_collision;     /* cfg.self_collision                                                                    */
+    int32_t n_blocks, n_env;    /* particle blocks per environment, environments                                         */
+    int32_t n_cu, srv_wg_cap;   /* CUs a resident launch may fill, cap on its server workgroups                          */
+    /* (c) switches (environment variables at create, r2s_phys_set_* later) */
+    int32_t resident_pref, res_self, res_self_srv, pf_pref, force_defer /* -1 auto */, chains_override /* 0 auto */, srv_own, srv_quad /* -1 auto */;
+} R2SFlavourIn;
+typedef struct R2SFlavourOut {
+    int32_t variant;            /* 1: the SELF templates (some particle has candidates)                                  */
+    int32_t mesh;               /* mesh template: 0 none, 1 small meshes, 2 a large mesh is present                      */
+    int32_t mesh_defer;         /* needy particles are listed and finished by the finishing code (else queried in place) */
+    int32_t resident;           /* the env step runs as one k_steps_resident launch                                      */
+    int32_t self_srv;           /* ... the self-collision flavour of it, with (answering) query servers                  */
+    int32_t pf;                 /* finishing code of substep k at the head of substep k + 1's launch (k_substep_pf)      */
+    int32_t contact_finish;     /* the flavour carries k_contact_finish (pf: only behind the last substep)               */
+    int32_t chains;             /* concurrent kernel chains                                                              */
+    int32_t n_srv, srv_quad, srv_own; /* server workgroups of a resident launch, units of four wavefronts, units own their particle */
+    int32_t srv_exhausted;      /* the sticky word after this decision                                                   */
+    int32_t graph_slot;         /* index of the captured graph (without the state buffer's parity bit)                   */
+    int32_t sum_class;          /* flavours of one scene with the same class end in the same bits                        */
+    char kernel[192];           /* what runs, as r2s_phys_last_flavour's callers print it                                */
+} R2SFlavourOut;
+int r2s_phys_debug_pick_flavour(const R2SFlavourIn* in, R2SFlavourOut* out);
+/* The input r2s_phys_step would build for the handle's NEXT full env step (counters as they are known to the host now). */
+int r2s_phys_debug_flavour_input(R2SPhys* h, R2SFlavourIn* out);
+
+/* What the last r2s_phys_step decided (the full record; r2s_phys_last_flavour is its four-word summary). */
+int r2s_phys_last_flavour_ex(R2SPhys* h, R2SFlavourOut* out);
+/* The sticky fault word of r2s_phys_step, read NOW: waits for everything enqueued on `stream`, returns R2S_ERR_INVALID with the step's
+ * message in r2s_last_error() if a fault is pending (R2S_OK otherwise).  r2s_phys_step reports a fault with a lag of up to two env steps
+ * and a full r2s_phys_set_state clears it: a caller that ends episodes and resets every environment at once (evaluate.run_episodes)
+ * asks here before it records their outcome. */
+int r2s_phys_check_fault(R2SPhys* h, r2s_stream_t stream);
+
 /* Tuning (not part of the reference surface): chains > 0 overrides the number of concurrent kernel chains of the captured
  * env step (0 = default), mesh_defer 0/1 forces the deferred large-mesh-query flavour (-1 = automatic).  The environment
  * variables R2S_CHAINS / R2S_MESH_DEFER / R2S_LAYOUT / R2S_HALO_CAP are read ONCE, by r2s_phys_create. */

@@ -33,13 +33,21 @@ def _eef_pts_func(table):
 
 
 def run(config="sloth_32env", device="cuda:0", seed=0, num_substeps=667, n_compare=20, close_at=2, max_steps=None, render=True,
-        settle_steps=None, n_env=1, res=None):
+        settle_steps=None, n_env=1, res=None, close_rate=None):
     """Returns a dict: x_max_abs, v_max_abs, rgb / depth mismatch classes, ... and ``passed``.
 
     ``n_env`` > 1 runs the gate on a BATCH of that many environments — the large-batch layout and, from 256 work items on, several
     concurrent kernel chains: the flavour a multi-environment bench window times (bench.py passes 9: two chains) — and checks the
     first and the last environment (they sit in different chains) against an oracle each; ``flavour`` / ``chains`` / ``layout`` in
-    the result name what ran.  ``res``: (W, H) override of the config's frame size."""
+    the result name what ran.  ``res``: (W, H) override of the config's frame size.  ``close_rate`` (round 6; bench.py passes its own): the
+    gripper closes like a policy closes it — the commanded opening ramps down, the grasp state machine latches from the stepper's own
+    forces — and the substeps compared are those of the first env step that STARTS in the grasp (opening frozen, both pads loaded,
+    the arms pressed together): the state a real episode spends its time in.
+
+    ``x_ulp_spread``: the same ``n_compare`` substeps by the ORACLE from a start state one ulp away (every coordinate moved to the next
+    float) against the oracle itself — how far apart two correct float32 runs of this scene are after the compared substeps.  A scene in
+    sustained contact amplifies round-off through its contact decisions (tests/test_physics_oracle_kat.py); ``x_max_abs`` is to be read
+    against this figure, not against zero."""
     import torch
 
     from . import PhysOracle, raster_forward
@@ -49,7 +57,10 @@ def run(config="sloth_32env", device="cuda:0", seed=0, num_substeps=667, n_compa
 
     t_start = time.perf_counter()
     kw = {} if res is None else dict(res=res)
+    if close_rate:
+        kw["close_rate"] = float(close_rate)
     ro = BatchedRollout(config, device=device, seed=seed, n_env=n_env, num_substeps=num_substeps, close_at=close_at, settle_steps=settle_steps, **kw)
+    ramp = bool(close_rate) and ro.schedule == "grasp"
     ph = ro.phys
     E = ro.n_env
     envs = sorted({0, E - 1})
@@ -65,7 +76,7 @@ def run(config="sloth_32env", device="cuda:0", seed=0, num_substeps=667, n_compa
     assert all(np.array_equal(o.mesh_map, ph.mesh_map) for o in os_.values())
     out = dict(config=config, particles=int(ro.N), envs_in_batch=int(E), envs_checked=envs, substeps_compared=int(n_compare),
                eef_pts_max_abs=0.0, eef_center_max_abs=0.0, eef_vel_max_abs=0.0)
-    max_steps = max_steps if max_steps is not None else close_at + 6
+    max_steps = max_steps if max_steps is not None else close_at + (16 if ramp else 6)
     # "lissajous" traces (the gripper hovers above the object) never touch inside a short window: the gate then compares the
     # flavour such a window times — free motion next to the gripper meshes — and does not ask for contact
     expects_contact = ro.schedule in ("grasp", "push")
@@ -115,14 +126,23 @@ def run(config="sloth_32env", device="cuda:0", seed=0, num_substeps=667, n_compa
                     n_cand = max(n_cand, int((o.coll_num > 0).sum()))
             last_chance = t == max_steps - 1
             wants_cand = ph.self_collision and not ro.use_pusher and ro.ob_shape == "sloth"
-            if ro.use_pusher or n_cand > 0 or last_chance or not expects_contact or not wants_cand:
+            in_grasp = (not ramp) or all(eos[e].grasped for e in envs)       # (ramp: wait for the step that starts in the grasp)
+            if (ro.use_pusher or n_cand > 0 or not expects_contact or not wants_cand) and in_grasp or last_chance:
                 saved = {e: (os_[e].x.copy(), os_[e].v.copy()) for e in envs}
                 hit = False
+                spread = 0.0
                 for e in envs:
                     ref = refs[e]
-                    os_[e].set_mesh_interactive(ref["interp_points"], ref["interp_center"], ref["dynamic_velocity"], ref["dynamic_omega"])
-                    os_[e].step(n_compare, 0)
-                    hit = hit or float(np.abs(os_[e].collision_forces).max()) > 0
+                    o = os_[e]
+                    o.set_mesh_interactive(ref["interp_points"], ref["interp_center"], ref["dynamic_velocity"], ref["dynamic_omega"])
+                    # the oracle one ulp away from itself (same lists, same mesh motion): what round-off alone does to this scene in n_compare substeps
+                    o.x[:] = np.nextafter(saved[e][0], np.float32(np.inf)).astype(o.x.dtype)
+                    o.step(n_compare, 0)
+                    x_nb = o.x.copy()
+                    o.x[:], o.v[:] = saved[e]
+                    o.step(n_compare, 0)
+                    spread = max(spread, float(np.abs(x_nb - o.x).max()))
+                    hit = hit or float(np.abs(o.collision_forces).max()) > 0
                 if expects_contact and not hit and not last_chance:
                     for e in envs:                                  # nothing touches yet (the rod has not reached the block, the fingers
                         os_[e].x[:], os_[e].v[:] = saved[e]         # are still closing): try the next env step
@@ -132,6 +152,7 @@ def run(config="sloth_32env", device="cuda:0", seed=0, num_substeps=667, n_compa
                     xs, vs = ph.x.cpu().numpy(), ph.v.cpu().numpy()
                     out.update(x_max_abs=max(float(np.abs(xs[e] - os_[e].x).max()) for e in envs),
                                v_max_abs=max(float(np.abs(vs[e] - os_[e].v).max()) for e in envs),
+                               x_ulp_spread=spread, grasped_at_compare=[bool(eos[e].grasped) for e in envs] if not ro.use_pusher else None,
                                particles_with_candidates=n_cand, tagged_entries=int(ph.tagged_count()), mesh_contact=bool(hit),
                                deferred_per_substep_max=int(ph.deferred_counts()[:n_compare].max()), flavour=fl["kernel"],
                                chains=int(ph.layout_stats()["chains"]),

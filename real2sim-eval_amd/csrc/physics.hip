@@ -51,6 +51,7 @@
 #include "r2s_common.h"
 #include <rocprim/rocprim.hpp>
 #include "../../include/r2s_physics.h"
+#include "physics_flavour.h"
 #include <algorithm>
 #include <array>
 #include <climits>
@@ -302,7 +303,7 @@ struct R2SPhys {
     int n_cu = 256;
     unsigned spin_limit = RES_SPIN_LIMIT;
     int srv_quad = -1;        // R2S_RES_SRV_QUAD=0 / 1: pairs / quads whatever the launch has room for (-1: quads when it has >= 64 server workgroups)
-    int srv_quad_for(int n_srv) const { return srv_quad >= 0 ? srv_quad : (n_srv >= 64 ? 1 : 0); }
+    int srv_quad_for(int n_srv) const { return r2s_flavour::fl_srv_quad(flavour_caps(), n_srv); }
     int srv_own = 1;          // R2S_RES_SRV_OWN=0: one request per substep instead of pairs that own their particle
     bool split_ok = false;    // 64-particle layout whose slices fit k_steps_resident's registers (no remote neighbours, <= 64 interior / halo slots)
     bool resident_ok = false; // the handle can run the env step as ONE resident launch (k_steps_resident) in its free flavour
@@ -320,19 +321,19 @@ struct R2SPhys {
     hipEvent_t cand_event = nullptr;
     bool cand_pending = false;
     int n_cand = 0;              // particles with candidates after the last update (host view)
-    int chains() const // parallel kernel chains of the captured env step
+    // capabilities + switches of this handle as the flavour functions read them (physics_flavour.h); the counters are the caller's to fill
+    R2SFlavourIn flavour_caps() const
     {
-        // chains are separate graphs on separate streams (hardware queues; more than four lose: 26 / 42 us per substep with six).
-        // Measured per batched substep, free / contact (tools/profiling/variant_bench.py, round 3): 32 sloth envs (1888 work items)
-        // 1 chain 23.7 / 25.7, 2 chains 20.8 / 26.8, 4 chains 19.1 / 26.0 us; 8 sloth envs x 4 views (472 items) 10.6 / 17.3,
-        // 9.5 / 17.2, 10.6 / 19.3; 32 T-block envs with the 25k-face rod (288 items) 10.4 / 25.9, 10.5 / 24.4, 12.7 / 26.3.
-        const int64_t items = (int64_t)nb * E;
-        int c = items >= 1536 ? 4 : (items >= 256 ? 2 : 1);
-        if (pb == 64) c = 1; // small batches (the resident layout): one chain
-        c = std::min(c, E);
-        if (chains_override > 0) c = std::max(1, std::min(chains_override, std::min(E, 8)));
+        R2SFlavourIn c{};
+        c.n_faces = nF; c.any_large = any_large; c.block = pb; c.split_ok = split_ok; c.resident_ok = resident_ok; c.srv_ok = srv_ok;
+        c.pf_ok = pf_ok; c.has_vx = d_vx != nullptr; c.self_collision = prm.self_collision; c.n_blocks = nb; c.n_env = E; c.n_cu = n_cu;
+        c.srv_wg_cap = srv_wg_cap; c.resident_pref = resident_pref; c.res_self = res_self; c.res_self_srv = res_self_srv; c.pf_pref = pf_pref;
+        c.force_defer = force_defer; c.chains_override = chains_override; c.srv_own = srv_own; c.srv_quad = srv_quad;
+        c.srv_exhausted = srv_exhausted; c.n_candidates = n_cand; c.n_substeps = prm.num_substeps; c.full_step = 1;
         return c;
     }
+    int chains() const { return r2s_flavour::fl_chains(flavour_caps()); } // parallel kernel chains of the captured env step
+    R2SFlavourOut last_pick{};   // what the last r2s_phys_step decided
     uint32_t *d_bits = nullptr, *d_keys[2] = {nullptr, nullptr}, *d_ids[2] = {nullptr, nullptr};
     int2* d_cell_tab = nullptr;  // [E << 21] direct cell table (null when it would exceed 4 GiB: binary search instead)
     float4* d_cell_xs = nullptr; // [E,N] sorted positions + internal index
@@ -488,11 +489,7 @@ void launch_substep_layout(const PhysDev& p, dim3 grid, const StateC in, const S
 }
 
 // true when the env step's flavour carries k_contact_finish (deferred mesh queries + self-collision impulses in one launch)
-bool has_contact_finish(const R2SPhys* h, const PhysDev& p)
-{
-    const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
-    return mesh != 0 && (p.mesh_defer || mesh == 2);
-}
+bool has_contact_finish(const R2SPhys* h, const PhysDev& p) { return r2s_flavour::fl_contact_finish(h->flavour_caps(), p.mesh_defer); }
 
 void launch_fused(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_forces, bool with_self, hipStream_t s)
 {
@@ -544,7 +541,7 @@ int launch_substep(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
 }
 
 // The contact flavours of a large batch with the finishers at the head of the next launch (k_substep_pf; PhysDev::pf)
-bool pf_flavour(const R2SPhys* h, const PhysDev& p) { return h->pf_ok && h->pf_pref != 0 && h->pb == 256 && has_contact_finish(h, p); }
+bool pf_flavour(const R2SPhys* h, const PhysDev& p) { return r2s_flavour::fl_pf(h->flavour_caps(), p.mesh_defer); }
 // finishing workgroups at the head of a launch: enough for the lists of a batch in contact without a second round (a workgroup strides
 // over its list if there is more), few enough not to stand between the launch and its fused blocks — every workgroup of the launch
 // holds the fused role's LDS window, so an idle finisher costs a block's slot for the microsecond it takes to read an empty list
@@ -581,12 +578,7 @@ __global__ void k_zero_f32(float* __restrict__ p, size_t n)
 }
 
 // The env step's flavour that runs as one resident launch: a small batch, no deferred mesh queries (candidates: the SELF templates, round 5).
-bool resident_flavour(const R2SPhys* h, bool with_self, int mesh_defer, int n)
-{
-    // (the self-collision flavour of the one-launch stepper needs more than one substep in the launch: a single substep with candidates
-    // is the per-substep form, k_steps_resident x 1 + k_self_finish)
-    return h->resident_ok && h->resident_pref != 0 && !(with_self && !(h->res_self && h->d_vx && n > 1)) && !(h->nF > 0 && mesh_defer);
-}
+bool resident_flavour(const R2SPhys* h, bool with_self, int mesh_defer, int n) { return r2s_flavour::fl_resident(h->flavour_caps(), with_self, mesh_defer, n); }
 constexpr int RES_MAX_ITEMS = 256; // (block, env) work items of a resident launch: one 512-thread workgroup per CU (two wavefronts per SIMD, each
                                    // with its 2 + 2 adjacency groups in registers), all on the chip at once
 
@@ -623,13 +615,9 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
         const size_t words = (size_t)24 * ne * xn; // this chain's environments: 2 buffers x 3 planes x 16 B per particle
         hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (float*)h->d_xch + (size_t)24 * e0 * xn, words);
         // mesh-query servers: workgroups beyond the blocks' own, as many as the chip has CUs left (the whole launch is resident at once)
-        int n_srv = 0;
-        if (h->srv_ok && n > 1 && h->chains() == 1 && (!with_self || (h->res_self_srv && h->self_srv))) { // (the claim lines are the handle's: one resident launch at a time — a forced second chain runs without servers)
-            // workgroups go to the XCDs round-robin and every XCD must hold its share at once: the grid (8 * cb block workgroups — up to 7
-            // of them idle, but their CUs may be on other XCDs than the servers that would need them — plus the servers) <= CUs
-            n_srv = std::min(h->n_cu - 8 * p.cb, h->srv_wg_cap);
-            if (n_srv < SRV_MIN_WG) n_srv = 0;
-        }
+        // (the claim lines are the handle's: one resident launch at a time — a forced second chain runs without servers; workgroups go to
+        // the XCDs round-robin and every XCD must hold its share at once: 8 * cb block workgroups + the servers <= CUs: fl_n_srv)
+        const int n_srv = r2s_flavour::fl_n_srv(h->flavour_caps(), with_self, h->self_srv, n);
         if (n_srv > 0) {
             if (with_self) p.srv_own = 0; // next to the self-collision flavour the pairs only ANSWER queries (a request per particle and substep, carrying
                                           // the velocity after the impulses): an owned particle would have to take part in the candidates' hand-off itself
@@ -698,7 +686,7 @@ void drop_graph_fwd(R2SPhys* h) { drop_graph(h); }
 // their hand-off code cost that flavour 0.5 us per substep)
 int graph_slot(const R2SPhys* h, int variant, int start_buf)
 {
-    return (variant == 1 && !h->mesh_defer && h->self_srv ? 8 : h->mesh_defer * 4) + variant * 2 + (start_buf & 1);
+    return r2s_flavour::fl_graph_slot(variant, h->mesh_defer, h->self_srv) + (start_buf & 1);
 }
 
 int capture_graph(R2SPhys* h, int variant, int start_buf)
@@ -840,6 +828,21 @@ int grid_sort(R2SPhys* h, hipStream_t s, const uint32_t** keys, const uint32_t**
     *keys = dk.current();
     *ids = dv.current();
     return R2S_OK;
+}
+
+// The sticky fault word of an earlier env step as r2s_last_error() text (cnt: the 16 words of the step's ring slot).
+void report_fault(const int* cnt)
+{
+    if (cnt[1] >= 2 && cnt[1] <= 7) {
+        char buf[640];
+        const int* w = cnt + 4;
+        snprintf(buf, sizeof buf, "resident stepper: a workgroup waited for %s beyond the poll limit (the launch was not resident at once, or the device "
+                 "is shared with a kernel that never ends); the state is invalid [first fault: code %d, work item %d, substep %d of the launch, context %d %d %d %d %d %d]",
+                 cnt[1] == 2 ? "a neighbour block's substep" : cnt[1] == 5 ? "a neighbour's record (server pair)" : cnt[1] == 6 ? "a particle finished by the head of its launch" : cnt[1] == 7 ? "a self-collision partner's record" : "a mesh-query server's result", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+        r2s::set_last_error_msg(buf);
+    } else
+        r2s::set_last_error_msg("a self-collision impulse changed a particle's velocity by more than 40 m/s within one substep: its mesh-contact "
+                                "test (widened by 2 mm) may have been skipped where the reference applies it (unsupported)");
 }
 
 } // namespace
@@ -1553,12 +1556,19 @@ __global__ void k_set_static_pts(int E, int n, int nV, int n_dyn_pts, const int*
     mesh_pts[((size_t)e * nV + n_dyn_pts) * 3 + t] = src[(size_t)e * 3 * n + t];
 }
 
-int r2s_phys_set_static_mesh_points(R2SPhys* h, const float* pts, const int32_t* env_mask, r2s_stream_t stream_)
+int r2s_phys_set_static_mesh_points(R2SPhys* h, const float* pts, int32_t n_static_vertices, const int32_t* env_mask, r2s_stream_t stream_)
 {
+    r2s::set_last_error_msg("");
     if (!h || !pts || h->nF == 0) return R2S_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream_;
     const int n = h->nV - h->n_dyn_pts;
     if (n <= 0) return R2S_ERR_INVALID;
+    if (n_static_vertices != n) { // the array covers EVERY static mesh, in the order of the constructor: anything else would be read past its end
+        char buf[200];
+        snprintf(buf, sizeof buf, "r2s_phys_set_static_mesh_points: %d vertices per environment handed in, the static meshes have %d", (int)n_static_vertices, n);
+        r2s::set_last_error_msg(buf);
+        return R2S_ERR_INVALID;
+    }
     for (int m = h->n_dyn_mesh; m < h->n_mesh; ++m)
         if (h->h_mesh_kind[m] & 1) { // its triangles live in a rest-frame table with a box hierarchy built at create: it cannot move per environment
             r2s::set_last_error_msg("r2s_phys_set_static_mesh_points: a static collision mesh with more than 256 faces cannot be re-posed (unsupported)");
@@ -1798,7 +1808,6 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
             return R2S_ERR_INVALID;
         }
     }
-    const int variant = (h->prm.self_collision && h->n_cand > 0) ? 1 : 0;
     // the counters this step's flavour follows from: those of step (step_no - LAG), waited for (long landed in any real loop)
     int cnt[16] = {0};
     bool have_cnt = false;
@@ -1816,51 +1825,22 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
         if (!h->ring_pending[k] && !h->ring_stale_fault[k] && h->h_ring[16 * k + 1] != 0) { cnt[1] = h->h_ring[16 * k + 1]; memcpy(cnt + 4, h->h_ring + 16 * k + 4, 12 * sizeof(int)); }
     }
     if (cnt[1] != 0) { // the sticky fault word of an earlier step
-        if (cnt[1] >= 2 && cnt[1] <= 7) {
-            char buf[640];
-            const int* w = cnt + 4;
-            snprintf(buf, sizeof buf, "resident stepper: a workgroup waited for %s beyond the poll limit (the launch was not resident at once, or the device "
-                     "is shared with a kernel that never ends); the state is invalid [first fault: code %d, work item %d, substep %d of the launch, context %d %d %d %d %d %d]",
-                     cnt[1] == 2 ? "a neighbour block's substep" : cnt[1] == 5 ? "a neighbour's record (server pair)" : cnt[1] == 6 ? "a particle finished by the head of its launch" : cnt[1] == 7 ? "a self-collision partner's record" : "a mesh-query server's result", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
-            r2s::set_last_error_msg(buf);
-        }
-        else
-            r2s::set_last_error_msg("a self-collision impulse changed a particle's velocity by more than 40 m/s within one substep: its mesh-contact "
-                                    "test (widened by 2 mm) may have been skipped where the reference applies it (unsupported)");
+        report_fault(cnt);
         return R2S_ERR_INVALID;
     }
-    h->self_srv = 0;
-    if (h->nF > 0) { // defer the mesh queries to k_contact_finish when the last finished step saw particles near a mesh
-        // an unfinished count keeps the previous flavour.  Large batches defer as soon as anything is NEAR a mesh (an idle finishing launch
-        // costs them ~0.7 us per substep, an in-place query in the fused kernel up to 190); small batches only once a query was NEEDED:
-        // their free flavour is the resident launch (2.3 vs 7.2 us per substep for the rope), and a gripper hovering within 3 cm is free
-        // motion — the step in which the first particle enters a margin pays for its in-place queries once
-        h->mesh_defer = (h->resident_ok && h->resident_pref ? cnt[2] : cnt[0]) > 0 ? 1 : 0;
-        // ... and with query servers in the launch (round 4) a small batch stays resident THROUGH contact: a particle that needs a query is
-        // answered by a server pair of the same launch (resident_server).  (The self-collision flavour of the resident launch, round 5, has no
-        // servers: with live candidates a needed query still sends the following steps to the per-substep kernels + finishing kernel)
-        if (have_cnt) { // (more particles in contact than the launch has pairs: answered in place — correct, and 20 x slower than the finishing launch)
-            if (cnt[3] > 0) h->srv_exhausted = true;
-            else if (cnt[2] == 0) h->srv_exhausted = false;
-        }
-        // (the self-collision flavour of the resident launch, round 5, gets its servers — answering, not owning — only while queries are
-        // being needed: the step in which the first particle enters a margin, and the one after it, answer in place as ever)
-        const bool self_srv_ok = h->res_self && h->res_self_srv && h->d_vx && n > 1;
-        h->self_srv = variant == 1 && self_srv_ok && (h->mesh_defer || h->res_self_srv == 2) && h->resident_ok && h->resident_pref && h->srv_ok && h->chains() == 1 && !h->srv_exhausted ? 1 : 0;
-        if (h->resident_ok && h->resident_pref && h->srv_ok && h->chains() == 1 && (variant == 0 || self_srv_ok) && !h->srv_exhausted) h->mesh_defer = 0;
-        if (h->force_defer >= 0) h->mesh_defer = h->force_defer; // test / tuning: force a flavour
-        if (h->any_large) h->mesh_defer = 1;
-    }
-    h->last_flavour[0] = variant | (h->split_ok ? 2 : 0); h->last_flavour[1] = h->nF > 0 ? (h->any_large ? 2 : 1) : 0; h->last_flavour[2] = h->mesh_defer;
-    h->last_flavour[3] = use_graph ? h->chains() : 1;
-    if (h->nF > 0 && h->pf_ok && h->pf_pref != 0 && h->pb == 256 && (h->mesh_defer || h->any_large)) h->last_flavour[2] = 3; // 3 = deferred, finishers at the head of the next launch
-    const bool resident = resident_flavour(h, variant == 1, h->mesh_defer, n);
-    if (resident) {
-        h->last_flavour[2] = 2; // 2 = the resident launch (never with deferred queries)
-        int n_srv = h->srv_ok && n > 1 && h->chains() == 1 && (variant == 0 || (h->res_self_srv && h->self_srv)) ? std::min(h->n_cu - 8 * ((h->nb * h->E + 7) / 8), h->srv_wg_cap) : 0; // as enqueue_steps sizes the grid
-        if (n_srv < SRV_MIN_WG) n_srv = 0;
-        h->last_flavour[3] = 1 | (n_srv << 8) | ((h->srv_own && variant == 0 ? 1 : 0) << 20) | ((n_srv > 0 && h->srv_quad_for(n_srv) ? 1 : 0) << 21);
-    }
+    // Which flavour: a pure function of those counters, the handle's capabilities and the switches (physics_flavour.h: the rules are
+    // written out there; tests/test_flavour_matrix.py enumerates them).  Nothing below decides anything.
+    R2SFlavourIn fin = h->flavour_caps();
+    fin.have_counters = have_cnt; fin.near_mesh = cnt[0]; fin.query_needed = cnt[2]; fin.servers_ran_out = cnt[3];
+    fin.n_substeps = n; fin.full_step = use_graph;
+    R2SFlavourOut& fl = h->last_pick;
+    r2s_flavour::pick_flavour(fin, fl);
+    const int variant = fl.variant;
+    h->mesh_defer = fl.mesh_defer; h->self_srv = fl.self_srv; h->srv_exhausted = fl.srv_exhausted != 0;
+    h->last_flavour[0] = variant | (h->split_ok ? 2 : 0); h->last_flavour[1] = fl.mesh;
+    h->last_flavour[2] = fl.resident ? 2 : (fl.pf ? 3 : fl.mesh_defer); // 2 = the resident launch (never with deferred queries), 3 = deferred, finishers at the head of the next launch
+    h->last_flavour[3] = fl.resident ? (1 | (fl.n_srv << 8) | (fl.srv_own << 20) | (fl.srv_quad << 21)) : fl.chains;
+    const bool resident = fl.resident != 0;
     int gate_dev = -1;
     if (resident) { int rcg = resident_enter(s, &gate_dev); if (rcg) return rcg; }
     struct GateLeave { hipStream_t s; int dev; ~GateLeave() { if (dev >= 0) (void)resident_leave(s, dev); } } gate_leave{s, gate_dev};
@@ -1997,6 +1977,40 @@ int r2s_phys_last_flavour(R2SPhys* h, int32_t* out /* [4] */)
     if (!h || !out) return R2S_ERR_INVALID;
     for (int k = 0; k < 4; ++k) out[k] = h->last_flavour[k];
     return R2S_OK;
+}
+
+int r2s_phys_debug_pick_flavour(const R2SFlavourIn* in, R2SFlavourOut* out)
+{
+    if (!in || !out) return R2S_ERR_INVALID;
+    r2s_flavour::pick_flavour(*in, *out);
+    return R2S_OK;
+}
+
+int r2s_phys_debug_flavour_input(R2SPhys* h, R2SFlavourIn* out)
+{
+    if (!h || !out) return R2S_ERR_INVALID;
+    *out = h->flavour_caps();
+    return R2S_OK;
+}
+
+int r2s_phys_last_flavour_ex(R2SPhys* h, R2SFlavourOut* out)
+{
+    if (!h || !out) return R2S_ERR_INVALID;
+    *out = h->last_pick;
+    return R2S_OK;
+}
+
+int r2s_phys_check_fault(R2SPhys* h, r2s_stream_t stream_)
+{
+    r2s::set_last_error_msg("");
+    if (!h) return R2S_ERR_INVALID;
+    if (!h->d_mesh_total) return R2S_OK;
+    int cnt[16] = {0};
+    R2S_HIP_TRY(hipMemcpyAsync(cnt, h->d_mesh_total, sizeof cnt, hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    R2S_HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    if (cnt[1] == 0) return R2S_OK;
+    report_fault(cnt);
+    return R2S_ERR_INVALID;
 }
 
 int r2s_phys_log_contacts(R2SPhys* h, int32_t* out3_dev, r2s_stream_t stream_)

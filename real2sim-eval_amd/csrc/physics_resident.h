@@ -535,6 +535,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
             for (int c = 0; c < 6; ++c) box_s[c] = ub[c];
             const float r = mgmax + RES_RANGE_PAD;
             box_s[6] = r * r * 1.0001f;
+            box_s[7] = (mgmax + NEAR_PAD) * (mgmax + NEAR_PAD); // "near": within margin + 3 cm of where any mesh is during this launch (below)
         }
         // visible to the finishing wavefronts after barrier A of the first substep
     }
@@ -566,6 +567,15 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
         }
         const v2f oa = win_s[lane], ob = win_s[RCAP + 1 + lane], oc = win_s[2 * (RCAP + 1) + lane];
         const f3 x0 = mk(oa.x, oa.y, ob.x), v0 = mk(oc.x, oc.y, ob.y);
+        // Once per launch (round 6): is any particle within margin + NEAR_PAD of the union of the mesh boxes over the launch's substeps?  The
+        // per-substep tests of a resident launch only look RES_RANGE_PAD (2 mm) beyond a margin — by design: a hovering gripper must not cost
+        // them anything —, so until round 5 the host's "near" counter of a small batch rose at most one env step before the first query: too
+        // late for a flavour that is picked from the counters of the step TWO before it (the answering servers of the self-collision
+        // flavour, physics_flavour.h).  One box test per particle and LAUNCH costs nothing and gives the host its 3 cm of warning.
+        if (MESH != 0 && n_steps > 1 && k == 0 && wave == 0) {
+            const unsigned long long nm = __builtin_amdgcn_ballot_w64(valid && box_dist2(x0, box_s) < box_s[7]);
+            if (nm && lane == __builtin_ctzll(nm)) p.mesh_cnt[p.n_sub] = 1;
+        }
 
         // the halo of version k (the state after k substeps of this launch) comes from buffer k & 1.  The interior springs go first — the
         // neighbours' records are still on their way anyway — then the first poll pass (RES_PRE = RES_NG; issuing it before or between the

@@ -102,6 +102,13 @@ def run_episodes(ro, episode_ids: Sequence[int], policy: Optional[Callable] = No
             host = flags.cpu().tolist()                                  # the one read per step of this mode
             ended = sorted(set(ended) | {s for s in range(E) if slot_row[s] >= 0 and slot_step[s] > 0 and host[s]})
         if ended:
+            # Every running episode ends with this step: what follows is a FULL reset (which hands the stepper a whole new state and with it
+            # clears its sticky fault word) or the end of the run — and the stepper reports a fault with a lag of up to two env steps.  A
+            # fault raised in the last steps of these episodes (a hand-off that timed out, an impulse beyond the bound a skipped mesh test
+            # relies on: the state is invalid) would never surface and their outcome would be recorded from an invalid state.  Ask now
+            # (one host synchronisation per wave of episodes; the rollout raises): nothing is recorded from such a state.
+            if len(ended) == sum(r >= 0 for r in slot_row) and hasattr(ro, "check_fault"):
+                ro.check_fault()
             if flags is None:
                 flags = ro.success_flags()
             now = time.perf_counter()

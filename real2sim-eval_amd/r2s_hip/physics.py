@@ -33,6 +33,36 @@ class R2SPhysDesc(C.Structure):
     ]
 
 
+class R2SFlavourIn(C.Structure):
+    """include/r2s_physics.h: the input of the flavour selection (counters of env step t - 2, capabilities, switches)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "have_counters", "near_mesh", "query_needed", "servers_ran_out", "srv_exhausted", "n_candidates", "n_substeps", "full_step",
+        "n_faces", "any_large", "block", "split_ok", "resident_ok", "srv_ok", "pf_ok", "has_vx", "self_collision", "n_blocks", "n_env",
+        "n_cu", "srv_wg_cap", "resident_pref", "res_self", "res_self_srv", "pf_pref", "force_defer", "chains_override", "srv_own", "srv_quad")]
+
+
+class R2SFlavourOut(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "variant", "mesh", "mesh_defer", "resident", "self_srv", "pf", "contact_finish", "chains", "n_srv", "srv_quad", "srv_own",
+        "srv_exhausted", "graph_slot", "sum_class")] + [("kernel", C.c_char * 192)]
+
+
+def pick_flavour(**fields):
+    """The flavour selection as the pure function it is (r2s_phys_debug_pick_flavour; no GPU, no handle): keyword arguments are the
+    fields of ``R2SFlavourIn`` (unset: 0, ``force_defer`` / ``srv_quad``: -1 = automatic); returns the fields of ``R2SFlavourOut``."""
+    fin = R2SFlavourIn()
+    fin.force_defer, fin.srv_quad = -1, -1
+    for k, v in fields.items():
+        if not hasattr(fin, k):
+            raise KeyError(k)
+        setattr(fin, k, int(v))
+    out = R2SFlavourOut()
+    check(_bind().r2s_phys_debug_pick_flavour(C.byref(fin), C.byref(out)), "r2s_phys_debug_pick_flavour")
+    d = {n: int(getattr(out, n)) for n, _ in R2SFlavourOut._fields_ if n != "kernel"}
+    d["kernel"] = out.kernel.decode()
+    return d
+
+
 _bound = False
 
 
@@ -55,8 +85,8 @@ def _bind():
         r2s_phys_set_eef_table=[vp, C.c_int32, vp, vp, C.c_float, vp], r2s_phys_set_eef_motion=[vp, vp, vp, vp, vp, vp, vp],
         r2s_phys_eef_state=[vp, C.POINTER(vp), C.POINTER(vp)], r2s_phys_reset_envs=[vp, vp, vp], r2s_phys_set_state_envs=[vp, vp, vp, vp, vp], r2s_phys_create_resting_case_envs=[vp, vp, vp], r2s_phys_mesh_motion=[vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
         r2s_phys_set_collision_lists=[vp, vp, vp, vp], r2s_phys_contact_stats=[vp, C.POINTER(C.c_int32), C.POINTER(vp)],
-        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32], r2s_phys_set_resident=[vp, i32], r2s_phys_set_pf=[vp, i32], r2s_phys_set_static_mesh_points=[vp, vp, vp, vp], r2s_phys_side_stream=[i32, C.POINTER(vp)],
-        r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
+        r2s_phys_last_flavour=[vp, C.POINTER(C.c_int32)], r2s_phys_deferred_counts=[vp, vp, vp], r2s_phys_tagged_count=[vp, C.POINTER(C.c_int32), vp], r2s_phys_log_contacts=[vp, vp, vp], r2s_phys_set_tuning=[vp, i32, i32], r2s_phys_set_resident=[vp, i32], r2s_phys_set_pf=[vp, i32], r2s_phys_set_static_mesh_points=[vp, vp, C.c_int32, vp, vp], r2s_phys_side_stream=[i32, C.POINTER(vp)],
+        r2s_phys_set_params=[vp, C.POINTER(R2SPhysParams), vp], r2s_phys_debug_pick_flavour=[C.POINTER(R2SFlavourIn), C.POINTER(R2SFlavourOut)], r2s_phys_debug_flavour_input=[vp, C.POINTER(R2SFlavourIn)], r2s_phys_last_flavour_ex=[vp, C.POINTER(R2SFlavourOut)], r2s_phys_check_fault=[vp, vp], r2s_phys_layout_stats=[vp, C.POINTER(C.c_int64)], r2s_phys_last_step_ms=[vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
     ).items():
         fn = getattr(L, name)
         fn.restype = i32
@@ -132,6 +162,8 @@ class PhysBatch:
         d.init_masses = masses.ctypes.data
         d.init_collision_mask = masks.ctypes.data if masks is not None else None
         d.n_dynamic_meshes, d.n_static_meshes = len(dyn), len(sta)
+        self.n_dynamic_meshes = len(dyn)
+        self.mesh_vertex_counts = np.array([len(v) for v, _ in meshes], np.int64)
         self.n_dyn_pts = int(sum(len(v) for v, _ in dyn))
         self.n_faces = int(sum(len(t) for _, t in meshes))
         if meshes:
@@ -209,9 +241,11 @@ class PhysBatch:
         """Re-pose the static collision meshes of some environments (an episode reset into another scene pose; r2s_physics.h):
         ``pts`` float32 [n_env, n_static_vertices, 3] on the device, ``mask`` bool / int [n_env] or None = all."""
         pts = pts.to(self.device, torch.float32).contiguous()
+        n_static = int((self.mesh_vertex_counts[self.n_dynamic_meshes:]).sum())
+        assert tuple(pts.shape) == (self.n_env, n_static, 3), f"static mesh points must be [n_env, {n_static}, 3] (every static mesh, in order), got {tuple(pts.shape)}"
         m = None if mask is None else mask.to(self.device, torch.int32).contiguous()
         with torch.cuda.device(self.device):
-            check(_bind().r2s_phys_set_static_mesh_points(self._h, pts.data_ptr(), 0 if m is None else m.data_ptr(), self._s()), "r2s_phys_set_static_mesh_points")
+            check(_bind().r2s_phys_set_static_mesh_points(self._h, pts.data_ptr(), n_static, 0 if m is None else m.data_ptr(), self._s()), "r2s_phys_set_static_mesh_points", reason=True)
 
     def create_resting_case(self):
         with torch.cuda.device(self.device):
@@ -374,23 +408,27 @@ class PhysBatch:
         return int(n.value)
 
     def last_flavour(self):
-        a = (C.c_int32 * 4)()
-        check(_bind().r2s_phys_last_flavour(self._h, a), "r2s_phys_last_flavour")
-        rcap = self.layout_stats()["lds_bytes"] // 24
-        if a[2] == 2:       # the env step as one resident launch (small batches; with query servers in the launch also through mesh contact)
-            srv, own, quad = (int(a[3]) >> 8) & 0xfff, bool((int(a[3]) >> 20) & 1), bool((int(a[3]) >> 21) & 1)
-            scr = bool(a[0] & 1)      # live candidates: the resident launch's self-collision flavour (round 5)
-            return dict(self_collision_kernel=scr, mesh_template=int(a[1]), deferred_mesh_queries=False, chains=1, resident=True, query_server_workgroups=srv,
-                        servers_own_their_particle=own and srv > 0, wavefronts_per_served_particle=(4 if quad else 2) if srv else 0,
-                        kernel=f"k_steps_resident<{rcap},{'true' if scr else 'false'},{int(a[1])}>" + (f" + {srv} query-server workgroups in the launch"
-                                                                                  + (f" ({'a quad' if quad else 'a pair'} of wavefronts owns its particle from the claim on)" if own else " (a request per substep)") if srv else ""))
-        sc, split, pf = bool(a[0] & 1), bool(a[0] & 2), a[2] == 3
-        fused = "k_substep_pf" if pf else "k_substep"
-        return dict(self_collision_kernel=sc, mesh_template=int(a[1]), deferred_mesh_queries=bool(a[2]), finishers_at_head_of_next_launch=pf,
-                    chains=int(a[3]) & 0xff, resident=False,
-                    kernel=(f"k_steps_resident<{rcap},{'true' if sc else 'false'},{int(a[1])}> x 1 substep" if split else
-                            f"{fused}<{ {1024: 256, 768: 128}.get(rcap, 64)},{rcap},{'true' if sc else 'false'},{int(a[1])}>")
-                           + (" (finishers of substep k at the head of substep k+1's launch)" if pf else " + k_contact_finish" if a[2] else (" + k_self_finish" if sc else "")))
+        """What the last ``step`` ran (r2s_phys_last_flavour_ex: the record of the pure flavour function, physics_flavour.h)."""
+        o = R2SFlavourOut()
+        check(_bind().r2s_phys_last_flavour_ex(self._h, C.byref(o)), "r2s_phys_last_flavour_ex")
+        srv = int(o.n_srv)
+        return dict(self_collision_kernel=bool(o.variant), mesh_template=int(o.mesh), deferred_mesh_queries=bool(o.mesh_defer) and not o.resident,
+                    finishers_at_head_of_next_launch=bool(o.pf), chains=int(o.chains), resident=bool(o.resident), query_server_workgroups=srv,
+                    servers_own_their_particle=bool(o.srv_own) and srv > 0, wavefronts_per_served_particle=(4 if o.srv_quad else 2) if srv else 0,
+                    self_collision_servers=bool(o.self_srv), sum_class=int(o.sum_class), kernel=o.kernel.decode())
+
+    def flavour_input(self):
+        """The capabilities + switches of this handle as the flavour function reads them (a dict of R2SFlavourIn's fields)."""
+        fin = R2SFlavourIn()
+        check(_bind().r2s_phys_debug_flavour_input(self._h, C.byref(fin)), "r2s_phys_debug_flavour_input")
+        return {n: int(getattr(fin, n)) for n, _ in R2SFlavourIn._fields_}
+
+    def check_fault(self):
+        """Raise NOW if a kernel of an earlier ``step`` flagged the state as invalid (a timed-out hand-off, an impulse beyond the bound a
+        skipped mesh test relies on): waits for the stream.  ``step`` itself reports such a fault with a lag of up to two env steps, and a
+        full ``set_state`` clears it — a caller that ends episodes and resets everything at once asks here first (r2s_phys_check_fault)."""
+        with torch.cuda.device(self.device):
+            check(_bind().r2s_phys_check_fault(self._h, self._s()), "r2s_phys_check_fault", reason=True)
 
     def set_tuning(self, chains: int = 0, mesh_defer: int = -1):
         check(_bind().r2s_phys_set_tuning(self._h, int(chains), int(mesh_defer)), "r2s_phys_set_tuning")

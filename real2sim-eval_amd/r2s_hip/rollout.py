@@ -107,10 +107,120 @@ def quaternion_to_rotation_matrix(q: torch.Tensor) -> torch.Tensor:
                         tx * z - ty * w, ty * z + tx * w, 1.0 - tx * x - ty * y], 1).reshape(-1, 3, 3)
 
 
+def env_shifts(n_env, seed):
+    """Per-environment planar shift of the object (a few cm; environment 0 unshifted): the stand-in for the grid randomisation of
+    cfg/gs/*.yaml when a rollout is built without episode ids."""
+    rng = np.random.default_rng(seed + 1)
+    sh = np.zeros((n_env, 3), np.float32)
+    sh[:, :2] = rng.uniform(-0.03, 0.03, (n_env, 2))
+    sh[0] = 0
+    return sh
+
+
+def scene_setup(config, seed=0, num_substeps=667, schedule=None, close_at=15, open_at=10**9, with_gripper=True, with_static=True,
+                close_rate=None, lift_steps=None):
+    """The synthetic scene of a config as plain numpy: the PhysTwin object, the collision meshes (two finger meshes or
+    the pusher rod, the box obstacle), the end effector's table of finger vertices and start pose, and the parameters of the synthetic
+    action trace (``eef_velocity`` / ``open_command``).  No device is touched: ``BatchedRollout`` builds its batch from it, and the
+    checker's closed loop (oracle/closed_loop.py) the same scene on the CPU.
+
+    ``close_rate``: how fast the commanded opening falls once the gripper closes, per env step.  None (the class default, what every
+    scenario test of rounds 1-5 was written against): the command JUMPS to its closed value in env step ``close_at`` — a gripper that
+    snaps shut within 1/30 s, and one that can never detect a grasp: the reference only establishes a grasp while the command is still
+    BELOW the current opening (phystwin.py:399-405), and after a jump the two are equal from the next step on.  A rate (bench.py and
+    evaluate use 0.1: the stroke from open to the closed value in ~7 env steps, like a gripper driven by a policy at 30 Hz) ramps the
+    command down, the pads load up step by step, and the state machine runs as it does in an episode: closing -> grasped (both pads'
+    filtered forces > 3e4) -> opening frozen / creeping 0.05 per step -> held through the lift."""
+    shape, n_particles = CONFIGS[config][0], CONFIGS[config][1]
+    ob = synth.phystwin_object(shape, n_particles, seed)
+    pts = ob["points"]
+    c, top = pts.mean(0), pts[:, 2].max()
+    ob_shape = "sloth" if shape == "sloth_arms" else ("rope" if shape.startswith("rope") else shape)
+    use_pusher = "pusher" in config
+    scn = dict(config=config, ob=ob, ob_shape=ob_shape, use_pusher=use_pusher, schedule="push", close_at=0, open_at=10**9, v_down=0.1,
+               eef_table=None, eef_init=None, eef0=None, dyn=[], sta=[], num_substeps=int(num_substeps), dt=5e-5,
+               close_rate=None if close_rate is None else float(close_rate), faces_left=None, faces_right=None,
+               lift_steps=None if lift_steps is None else int(lift_steps))
+    # commanded opening while closed.  With a closing rate: 0 — "close", as a policy commands it; where the fingers stop is the grasp
+    # state machine's business (phystwin.py:399-405: the opening freezes once both pads' forces exceed the threshold).  Without one
+    # (the command jumps): 0.3 (34 mm between the pads) squeezes the toy's 61 mm pair of arms; the 24 mm rope needs 0.08 (18 mm): with
+    # 0.3 the pads stop at the rope's 5 mm contact margin, brush it and lift nothing
+    scn["closed_cmd"] = 0.0 if close_rate is not None else (0.08 if ob_shape == "rope" else 0.3)
+    if with_gripper and use_pusher:
+        # vertical pusher rod next to the block's -x face (assets/.../pusher_20cm.stl has 25 368 faces)
+        scn["eef_init"] = np.array([0.3, 0.0, 0.4], np.float32)
+        rod_v, rod_f = synth.cylinder_mesh((0.0, 0.0, -0.1), radius=0.005, length=0.2)
+        rel = rod_v.astype(np.float64)
+        rel[:, 1] *= -1
+        rel[:, 2] *= -1
+        scn["eef_table"] = np.repeat((scn["eef_init"].astype(np.float64) + rel)[None], 2, axis=0)   # rigid: two equal knots
+        # the rod (radius 5 mm, 1 mm contact margin) pushes along +x at 5 cm/s and reaches the block's -x face at env step `close_at`
+        scn["schedule"], scn["close_at"] = "push", int(close_at)
+        ys = np.sort(pts[pts[:, 0] < pts[:, 0].min() + 0.01, 1])
+        y_face = float(ys[(len(ys) - 1) // 2])   # the T's bar: the part that reaches furthest in -x (the LOWER median: torch.nanmedian's, which a posed reset uses)
+        scn["eef0"] = np.array([pts[:, 0].min() - 0.006 - 0.05 * scn["close_at"] * num_substeps * 5e-5, y_face, 0.2], np.float32)
+        scn["rod_offset_x"] = float(scn["eef0"][0] - pts[:, 0].min())   # (negative: the rod starts on the -x side) — a posed reset keeps this distance to the turned block
+        scn["dyn"] = [(synth.eef_world_points(scn["eef_table"][-1], scn["eef_init"], scn["eef0"]), rod_f)]
+    elif with_gripper:
+        scn["eef_table"], scn["eef_init"], fl, fr = synth.gripper_eef_table()
+        scn["faces_left"], scn["faces_right"] = fl, fr
+        scn["schedule"] = schedule or ("grasp" if shape == "sloth_arms" or config == "rope_1env" else "lissajous")
+        scn["close_at"], scn["open_at"] = (int(close_at), int(open_at)) if scn["schedule"] == "grasp" else (100, 300)
+        if scn["schedule"] == "grasp":
+            # fingers (5 cm tall, centred 6 cm below the eef) end up centred on the arms' upper 8 cm: eef = top + 2 cm at
+            # `close_at`, reached by a straight descent at 0.1 m/s (3.3 mm per env step); for a flat object (rope, T block) the
+            # finger tips stop 2 mm above the table instead of going through it
+            z_close = max(top + 0.02, 0.002 + 0.025 + 0.06)
+            scn["eef0"] = np.array([c[0], c[1], z_close + scn["v_down"] * scn["close_at"] * num_substeps * 5e-5], np.float32)
+        else:
+            scn["eef0"] = np.array([c[0], c[1], top + 0.1], np.float32)
+        w0 = synth.eef_world_points(scn["eef_table"][-1], scn["eef_init"], scn["eef0"])
+        scn["dyn"] = [(w0[: len(w0) // 2], fl), (w0[len(w0) // 2:], fr)]
+    if with_static:
+        scn["sta"] = [synth.box_mesh((c[0] + 0.25, c[1] + 0.2, 0.135), (0.2, 0.13, 0.27))]
+    return scn
+
+
+def eef_velocity(scn, step):
+    """End-effector velocity of env step ``step`` of the scene's synthetic action trace (m/s, float32 [3])."""
+    w = 2 * np.pi * 0.25
+    tt = step / 30.0
+    if scn["use_pusher"]:  # push along +x at 5 cm/s with a slow lateral weave
+        return np.array([0.05, 0.02 * np.cos(w * tt), 0.0], np.float32)
+    if scn["schedule"] == "grasp":
+        if step < scn["close_at"]:      # free motion: straight down over the arms, fingers open
+            return np.array([0.0, 0.0, -scn["v_down"]], np.float32)
+        if step < scn["close_at"] + close_steps(scn):     # the fingers close during these env steps (one, without a closing rate)
+            return np.zeros(3, np.float32)
+        # lift, with a slow sway along the fingers; after `lift_steps` env steps (None: never) the end effector keeps its height (a full
+        # episode is 450+ steps: an unbounded lift would carry the object out of every camera's view)
+        lift = scn.get("lift_steps")
+        up = 0.05 if lift is None or step < scn["close_at"] + close_steps(scn) + lift else 0.0
+        return np.array([0.02 * np.cos(w * tt), 0.0, up], np.float32)
+    return np.array([0.05 * w * np.cos(w * tt) * 0.6, 0.05 * w * np.cos(2 * w * tt + 0.5) * 0.6, -0.01 * np.sin(w * tt)], np.float32)
+
+
+def close_steps(scn):
+    """Env steps the commanded opening takes from 1 to the scene's closed value."""
+    if scn["close_rate"] is None:
+        return 1
+    return int(np.ceil((1.0 - scn["closed_cmd"]) / scn["close_rate"] - 1e-9))
+
+
+def open_command(scn, step):
+    """Commanded gripper opening (1 = open) of env step ``step``: closed between ``close_at`` and ``open_at`` — at once, or ramped down
+    by ``close_rate`` per env step (``scene_setup``)."""
+    if not (scn["close_at"] <= step < scn["open_at"]):
+        return 1.0
+    if scn["close_rate"] is None:
+        return float(scn["closed_cmd"])
+    return float(max(scn["closed_cmd"], 1.0 - scn["close_rate"] * (step - scn["close_at"] + 1)))
+
+
 class BatchedRollout:
     def __init__(self, config="sloth_32env", device="cuda:0", seed=0, n_env=None, num_substeps=667, views=2,
                  self_collision=True, with_gripper=True, with_static=True, tile_culling=True, schedule=None, close_at=15, open_at=10**9,
-                 settle_steps=None, randomize=False, res=None):
+                 settle_steps=None, randomize=False, res=None, close_rate=None, lift_steps=None):
         """``schedule``: the synthetic action trace.  "grasp" (default for the sloth scenes and rope_1env): the open gripper comes down over
         the object (free motion) — the toy's raised arms, the middle of the rope —, closes on it at env step
         ``close_at`` — finger contact, for the toy the two arms pressed together (live self-collision candidates), grasp detection —
@@ -118,7 +228,10 @@ class BatchedRollout:
         contact half.  "lissajous" (the default of the small test scenes and of T_32env — a gripper over the push-T block is
         not a scene of the reference, which pushes it with the rod: T_pusher_32env): the gripper hovers 10 cm above the object on a Lissajous path, closes at
         step 100, opens at 300 — no contact inside a short window.  The pusher scene pushes along +x and reaches the block at
-        ``close_at``.  ``res``: (W, H) instead of the config's frame size (the reference's default frame is 848x480,
+        ``close_at``.  ``close_rate`` / ``lift_steps``: see ``scene_setup`` — None (the default here) JUMPS the commanded opening to its
+        closed value within env step ``close_at`` (every scenario test of rounds 1-5 was written against that; such a gripper can never
+        detect a grasp); bench.py and the grasp tests pass a rate, the opening ramps down and the grasp state machine runs as in an episode.
+        ``res``: (W, H) instead of the config's frame size (the reference's default frame is 848x480,
         cfg/env/xarm_gripper.yaml:21-49).  ``settle_steps`` (default 40 for "grasp"): env steps run
         inside the constructor with the gripper parked 15 cm higher, so that the toy is AT REST when the rollout starts
         (SURVEY.md §8d places the objects resting on the table; a jittered lattice with random stiffness is not in equilibrium
@@ -137,54 +250,25 @@ class BatchedRollout:
         self.num_substeps = int(num_substeps)
         self.dt = 5e-5
         E = self.n_env
-        ob = synth.phystwin_object(shape, n_particles, seed)
-        self.ob = ob
-        self.ob_shape = "sloth" if shape == "sloth_arms" else shape
-        self.schedule, self.close_at, self.open_at = "push", 0, 10**9
+        # the scene itself — object, collision meshes, the end effector's start pose and action trace — is plain numpy and shared with the
+        # checker's closed loop (oracle/closed_loop.py builds the same scene without a GPU)
+        scn = self.scene = scene_setup(config, seed=seed, num_substeps=num_substeps, schedule=schedule, close_at=close_at, open_at=open_at,
+                                       with_gripper=with_gripper, with_static=with_static, close_rate=close_rate, lift_steps=lift_steps)
+        ob = self.ob = scn["ob"]
+        self.ob_shape = scn["ob_shape"]
+        self.schedule, self.close_at, self.open_at = scn["schedule"], scn["close_at"], scn["open_at"]
         pts = ob["points"]
         self.N, self.S = len(pts), len(ob["springs"])
         # per-env pose: grid randomisation stand-in — planar shifts of a few cm (cfg/gs/*.yaml patterns)
-        rng = np.random.default_rng(seed + 1)
-        self.env_shift = np.zeros((E, 3), np.float32)
-        self.env_shift[:, :2] = rng.uniform(-0.03, 0.03, (E, 2))
-        self.env_shift[0] = 0
+        self.env_shift = env_shifts(E, seed)
         x0 = pts[None] + self.env_shift[:, None]
         c = pts.mean(0)
         top = pts[:, 2].max()
-        dyn, sta = [], []
-        self.use_pusher = "pusher" in config
-        self.eef_table = None
-        if with_gripper and self.use_pusher:
-            # vertical pusher rod next to the block's -x face (assets/.../pusher_20cm.stl has 25 368 faces)
-            self.eef_init = np.array([0.3, 0.0, 0.4], np.float32)
-            rod_v, rod_f = synth.cylinder_mesh((0.0, 0.0, -0.1), radius=0.005, length=0.2)
-            rel = rod_v.astype(np.float64)
-            rel[:, 1] *= -1
-            rel[:, 2] *= -1
-            self.eef_table = np.repeat((self.eef_init.astype(np.float64) + rel)[None], 2, axis=0)   # rigid: two equal knots
-            # the rod (radius 5 mm, 1 mm contact margin) pushes along +x at 5 cm/s and reaches the block's -x face at env step `close_at`
-            self.schedule, self.close_at = "push", int(close_at)
-            y_face = float(np.median(pts[pts[:, 0] < pts[:, 0].min() + 0.01, 1]))   # the T's bar: the part that reaches furthest in -x
-            self.eef0 = np.array([pts[:, 0].min() - 0.006 - 0.05 * self.close_at * num_substeps * 5e-5, y_face, 0.2], np.float32)
-            dyn = [(synth.eef_world_points(self.eef_table[-1], self.eef_init, self.eef0), rod_f)]
-        elif with_gripper:
-            self.eef_table, self.eef_init, fl, fr = synth.gripper_eef_table()
-            self.schedule = schedule or ("grasp" if shape == "sloth_arms" or config == "rope_1env" else "lissajous")
-            self.close_at, self.open_at = (int(close_at), int(open_at)) if self.schedule == "grasp" else (100, 300)
-            if self.schedule == "grasp":
-                # fingers (5 cm tall, centred 6 cm below the eef) end up centred on the arms' upper 8 cm: eef = top + 2 cm at
-                # `close_at`, reached by a straight descent at 0.1 m/s (3.3 mm per env step); for a flat object (rope, T block) the
-                # finger tips stop 2 mm above the table instead of going through it
-                self.v_down = 0.1
-                z_close = max(top + 0.02, 0.002 + 0.025 + 0.06)
-                self.eef0 = np.array([c[0], c[1], z_close + self.v_down * self.close_at * num_substeps * 5e-5], np.float32)
-            else:
-                self.eef0 = np.array([c[0], c[1], top + 0.1], np.float32)
-            w0 = synth.eef_world_points(self.eef_table[-1], self.eef_init, self.eef0)
-            dyn = [(w0[: len(w0) // 2], fl), (w0[len(w0) // 2:], fr)]
+        self.use_pusher = scn["use_pusher"]
+        self.eef_table, self.eef_init, self.eef0 = scn["eef_table"], scn["eef_init"], scn["eef0"]
+        self.v_down = scn["v_down"]
+        dyn, sta = scn["dyn"], scn["sta"]
         self.fingers = dyn
-        if with_static:
-            sta = [synth.box_mesh((c[0] + 0.25, c[1] + 0.2, 0.135), (0.2, 0.13, 0.27))]
         self.phys = PhysBatch(init_vertices=x0, init_springs=ob["springs"], init_rest_lengths=ob["rest"],
                               init_masses=np.ones(self.N, np.float32), init_spring_Y=ob["log_Y"], num_substeps=num_substeps,
                               self_collision=self_collision, dynamic_meshes=dyn, static_meshes=sta, use_pusher=self.use_pusher,
@@ -194,7 +278,9 @@ class BatchedRollout:
         self._target_dev = torch.from_numpy(np.ascontiguousarray(pts + np.array([0.10, 0.0, 0.0], np.float32))).to(self.device)  # push-T goal: 10 cm along +x
         self._box = (np.array([c[0] + 0.25, c[1] + 0.2, 0.135]), 0.5 * np.array([0.2, 0.13, 0.27]))
         # per-environment pose of the box obstacle (an episode reset with `randomize` may re-pose it: episode_mesh_poses)
-        self._static_v0 = torch.from_numpy(np.ascontiguousarray(sta[0][0], np.float32)).to(self.device) if sta else None
+        # vertices of EVERY static mesh, in the constructor's order (r2s_phys_set_static_mesh_points takes them all), and which mesh each belongs to
+        self._static_v0 = torch.from_numpy(np.ascontiguousarray(np.concatenate([v for v, _ in sta]), np.float32)).to(self.device) if sta else None
+        self._static_mesh_of = torch.from_numpy(np.concatenate([np.full(len(v), k, np.int64) for k, (v, _) in enumerate(sta)])).to(self.device) if sta else None
         self._static_c0 = torch.tensor([float(c[0] + 0.25), float(c[1] + 0.2), 0.0], device=self.device)   # its origin: turned about, in the table plane
         self._box_c = torch.tensor(self._box[0], dtype=torch.float32, device=self.device)[None].repeat(E, 1)
         self._box_R = torch.eye(3, device=self.device)[None].repeat(E, 1, 1)
@@ -318,17 +404,7 @@ class BatchedRollout:
         self.eef_gripper = torch.ones(E, device=self.device)      # commanded opening of the last step (state['eef_gripper'], phystwin.py:165)
 
     def _eef_velocity(self, step):
-        w = 2 * np.pi * 0.25
-        tt = step / 30.0
-        if self.use_pusher:  # push along +x at 5 cm/s with a slow lateral weave
-            return np.array([0.05, 0.02 * np.cos(w * tt), 0.0], np.float32)
-        if self.schedule == "grasp":
-            if step < self.close_at:      # free motion: straight down over the arms, fingers open
-                return np.array([0.0, 0.0, -self.v_down], np.float32)
-            if step == self.close_at:     # the fingers close during this env step
-                return np.zeros(3, np.float32)
-            return np.array([0.02 * np.cos(w * tt), 0.0, 0.05], np.float32)   # lift, with a slow sway along the fingers
-        return np.array([0.05 * w * np.cos(w * tt) * 0.6, 0.05 * w * np.cos(2 * w * tt + 0.5) * 0.6, -0.01 * np.sin(w * tt)], np.float32)
+        return eef_velocity(self.scene, step)
 
     def synthetic_action(self, step):
         """The synthetic action trace as a CALLER of ``step``: the end-effector motion of env step ``step`` for every environment,
@@ -339,10 +415,7 @@ class BatchedRollout:
         if self._vel_trace is None or step >= len(self._vel_trace) - self._dephase:   # (a restarted episode only looks further back)
             n = max(1024, 2 * (step + 1 + self._dephase))
             self._vel_trace = torch.from_numpy(np.stack([self._eef_velocity(k) for k in range(n)])).to(self.device)
-            # commanded opening while closed: 0.3 (34 mm between the pads) squeezes the toy's 61 mm pair of arms; the 24 mm rope needs 0.08
-            # (18 mm): with 0.3 the pads stop at the rope's 5 mm contact margin, brush it and lift nothing
-            closed = 0.08 if self.ob_shape == "rope" else 0.3
-            self._open_cmd = torch.tensor([closed if self.close_at <= k < self.open_at else 1.0 for k in range(n)], dtype=torch.float32, device=self.device)
+            self._open_cmd = torch.tensor([open_command(self.scene, k) for k in range(n)], dtype=torch.float32, device=self.device)
         if self._dephase > 1 or self._restarted:
             idx = step - self._env_t0                             # an environment's episode starts at its last reset ...
             if self._dephase > 1:
@@ -467,6 +540,30 @@ class BatchedRollout:
             rest //= n
         return out
 
+    def _pose_static_meshes(self, mesh_pose, mask):
+        """Re-pose the static collision meshes of the environments in ``mask`` (device bool [n_env]): ``mesh_pose`` [n_env, G, 4] = (x, y, z, angle)
+        of the first G static meshes (those with a grid; the rest keep their loaded pose).  A mesh turns about the scene's mesh origin and
+        shifts (gs_renderer.py:385-388: pose[:3, 3] += t, pose[:3, :3] = Rz pose[:3, :3]); the stepper gets ALL static vertices of those
+        environments (r2s_phys_set_static_mesh_points), the success predicate's box follows mesh 0."""
+        E, dev = self.n_env, self.device
+        G = mesh_pose.shape[1]
+        per_v = mesh_pose[:, self._static_mesh_of.clamp(max=G - 1)]                               # [E, V, 4]: every vertex' mesh pose ...
+        per_v = torch.where((self._static_mesh_of < G)[None, :, None], per_v, torch.zeros_like(per_v))   # ... identity for meshes without a grid
+        ca, sa = torch.cos(per_v[..., 3]), torch.sin(per_v[..., 3])
+        d = self._static_v0[None] - self._static_c0
+        v_new = torch.stack([ca * d[..., 0] - sa * d[..., 1], sa * d[..., 0] + ca * d[..., 1], d[..., 2]], -1) + self._static_c0
+        v_new = v_new + torch.cat([per_v[..., :2], torch.zeros_like(per_v[..., :1])], -1)
+        m = mask.to(dev).bool().reshape(E)
+        self.phys.set_static_mesh_points(v_new, m)
+        mp0 = mesh_pose[:, 0]
+        cb, sb = torch.cos(mp0[:, 3]), torch.sin(mp0[:, 3])
+        Rb = torch.zeros(E, 3, 3, device=dev)
+        Rb[:, 0, 0], Rb[:, 0, 1], Rb[:, 1, 0], Rb[:, 1, 1], Rb[:, 2, 2] = cb, -sb, sb, cb, 1.0
+        shift_b = torch.cat([mp0[:, :2], torch.zeros(E, 1, device=dev)], 1)
+        self._box_posed = True
+        self._box_c = torch.where(m[:, None], torch.tensor(self._box[0], dtype=torch.float32, device=dev)[None] + shift_b, self._box_c)
+        self._box_R = torch.where(m[:, None, None], Rb, self._box_R)
+
     def reset(self, env_ids=None, episode_ids=None):
         """BaseEnv.reset (env.py:30-51) for some environments of the batch (``env_ids``: indices, a bool mask [n_env], or None =
         all) while the others keep running — episodes are independent and end at different steps (eval_policy_parallel.py:
@@ -526,30 +623,19 @@ class BatchedRollout:
                 src = torch.as_tensor(env_ids).cpu()
                 mask_host = src.reshape(E).tolist() if src.dtype == torch.bool else [e in set(src.long().reshape(-1).tolist()) for e in range(E)]
             pose = np.zeros((E, 4), np.float32)
-            mesh_pose = np.zeros((E, 4), np.float32)          # the box obstacle (the only static mesh of these scenes with a grid)
+            n_grid_meshes = len(self.GRIDS[self.ob_shape]["meshes"])
+            mesh_pose = np.zeros((E, max(n_grid_meshes, 1), 4), np.float32)   # one grid pose per static mesh that has a grid (the k-th grid = the k-th static mesh)
             for e in range(E):
                 if mask_host[e]:
                     pose[e] = self.episode_pose(eids[e])
                     self.random_variables[eids[e]] = [float(a) for a in pose[e]]
                     mp = self.episode_mesh_poses(eids[e])
                     if mp:
-                        mesh_pose[e] = mp[0]
+                        mesh_pose[e, : len(mp)] = mp
                         self.random_mesh_variables[eids[e]] = [[float(a) for a in q] for q in mp]
             pose_t = torch.from_numpy(pose).to(dev)
-            if self.GRIDS[self.ob_shape]["meshes"] and self._static_v0 is not None:
-                # the box turns about its own origin and shifts (gs_renderer.py:385-388: pose[:3, 3] += t, pose[:3, :3] = Rz pose[:3, :3])
-                mp_t = torch.from_numpy(mesh_pose).to(dev)
-                cb, sb = torch.cos(mp_t[:, 3]), torch.sin(mp_t[:, 3])
-                Rb = torch.zeros(E, 3, 3, device=dev)
-                Rb[:, 0, 0], Rb[:, 0, 1], Rb[:, 1, 0], Rb[:, 1, 1], Rb[:, 2, 2] = cb, -sb, sb, cb, 1.0
-                cbox = self._static_c0
-                shift_b = torch.cat([mp_t[:, :2], torch.zeros(E, 1, device=dev)], 1)
-                v_new_box = (self._static_v0[None] - cbox).matmul(Rb.transpose(1, 2)) + cbox + shift_b[:, None]
-                self.phys.set_static_mesh_points(v_new_box, torch.tensor(mask_host, device=dev))
-                mh = torch.tensor(mask_host, device=dev)
-                self._box_posed = True
-                self._box_c = torch.where(mh[:, None], torch.tensor(self._box[0], dtype=torch.float32, device=dev)[None] + shift_b, self._box_c)
-                self._box_R = torch.where(mh[:, None, None], Rb, self._box_R)
+            if n_grid_meshes and self._static_v0 is not None:
+                self._pose_static_meshes(torch.from_numpy(mesh_pose).to(dev), torch.tensor(mask_host, device=dev))
             ca, sa = torch.cos(pose_t[:, 3]), torch.sin(pose_t[:, 3])
             Rz = torch.zeros(E, 3, 3, device=dev)
             Rz[:, 0, 0], Rz[:, 0, 1], Rz[:, 1, 0], Rz[:, 1, 1], Rz[:, 2, 2] = ca, -sa, sa, ca, 1.0
@@ -574,18 +660,27 @@ class BatchedRollout:
                     xmin = x_new[:, :, 0].min(1).values
                     near = x_new[:, :, 0] < (xmin[:, None] + 0.01)
                     y_face = torch.where(near, x_new[:, :, 1], torch.full_like(x_new[:, :, 1], float("nan"))).nanmedian(1).values
-                    d0 = float(self._init["eef_xyz"][0, 0] - self._init["x"][0, :, 0].min())       # (negative: the rod starts on the -x side)
+                    d0 = self.scene["rod_offset_x"]       # host data of the constructor: nothing is read back from the device here
                     eef_xyz_new = torch.stack([xmin + d0, y_face, e0[:, 2]], 1)
                     eef_rot_new = self._init["eef_rot"]
                 else:
                     eef_xyz_new = (e0 - c)[:, None].matmul(Rz.transpose(1, 2))[:, 0] + c + shift
                     eef_rot_new = Rz.bmm(self._init["eef_rot"][0][None].expand(E, -1, -1))
+        # an UNPOSED reset of environments that an earlier posed reset had re-posed puts object AND obstacle back where the scene was loaded
+        # (the reference reloads the default mesh poses with every reset): the box, its boxes in the stepper, the success predicate's
+        # box — and the resting-pair set, which belongs to the start positions
+        unpose = (not posed) and self._box_posed
+        if unpose and self._static_v0 is not None:
+            self._pose_static_meshes(torch.zeros(E, 1, 4, device=dev), mask)
+        repair = posed or (unpose and getattr(self, "_obj_posed", False))
+        if posed:
+            self._obj_posed = True
         if everything:
             self.phys.set_state(x_new, v_new)   # a whole new state: clears a sticky fault
-            if posed and self.phys.self_collision:
+            if repair and self.phys.self_collision:
                 self.phys.create_resting_case()
         else:
-            self.phys.set_state_envs(x_new, v_new, mask, resting_case=posed)
+            self.phys.set_state_envs(x_new, v_new, mask, resting_case=repair)
         self.phys.reset_envs(mask)
         obj = self.means[:, : self.n_obj]
         obj.copy_(torch.where(m3, means_new, obj))     # in place: the prepared raster sets point at this storage
@@ -643,6 +738,11 @@ class BatchedRollout:
                 self._cand_done = torch.cuda.Event()
                 self._cand_done.record(self._cand_stream)
             self._cand_fresh = True
+
+    def check_fault(self):
+        """Raise now if a kernel of an earlier step declared the state invalid (PhysBatch.check_fault: waits for the stream) — what the
+        episode scheduler asks before it records episodes whose end is followed by a full reset (evaluate.run_episodes)."""
+        self.phys.check_fault()
 
     # ---- per-step log of a timed window: stamps on the launch stream + contact counters kept on the device ------------
     def start_log(self, n_steps):

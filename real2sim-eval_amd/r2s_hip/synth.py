@@ -306,11 +306,85 @@ def sphere_mesh(center, radius=0.015, n_seg=160, n_rings=110):
     return (np.asarray(v, np.float64) + np.asarray(center, np.float64)).astype(np.float32), np.asarray(f, np.int32)
 
 
-def finger_mesh(center, size=(0.02, 0.01, 0.05), n_faces=44, pad_normal=None):
-    """A closed box re-tessellated to ``n_faces`` triangles (the real finger collision meshes have 44,
-    assets/robots/xarm/xarm7_with_gripper_collision.urdf:425,519): the two large side faces are split
-    into strips.  ``pad_normal``: outward normal of the finger's gripping side; the three largest triangles of that side
-    are moved to face indices 1, 18 and 19 — the faces whose forces the grasp test sums (phystwin.py:386-391)."""
+def chamfered_box_mesh(center, size, chamfer=0.001, pad_normal=None):
+    """A box with every edge chamfered and every corner cut: 6 flats (2 triangles each) + 12 edge chamfers (2 each) + 8 corner
+    triangles = 44 faces on 24 vertices, a closed, consistently oriented manifold — the topology of the reference's finger collision
+    meshes (assets/robots/xarm/xarm_gripper/meshes/{left,right}_finger_large_2.stl: 44 faces, 24 welded vertices, every edge shared by
+    two faces).  In those meshes the faces the grasp test sums (phystwin.py:386-391) are the two triangles of the gripping flat
+    (faces 18 and 19: the whole pad) and one triangle of a chamfer next to it (face 1).  ``pad_normal``: outward axis direction of
+    the gripping side; its flat goes to face indices 18 and 19, a triangle of the chamfer between it and the next axis' + flat to 1."""
+    import itertools
+
+    c, h, d = np.asarray(center, np.float64), np.asarray(size, np.float64) / 2, float(chamfer)
+    V, vid = [], {}
+    for a in range(3):                                  # the four corners of the flat (axis a, sign s), pulled in by the chamfer
+        o = [k for k in range(3) if k != a]
+        for s in (-1, 1):
+            for sb in (-1, 1):
+                for sc in (-1, 1):
+                    p = np.zeros(3)
+                    p[a], p[o[0]], p[o[1]] = s * h[a], sb * (h[o[0]] - d), sc * (h[o[1]] - d)
+                    vid[(a, s, sb, sc)] = len(V)
+                    V.append(p)
+    V = np.asarray(V)
+    F, kind = [], []
+
+    def tri(i, j, k, what):
+        n = np.cross(V[j] - V[i], V[k] - V[i])
+        F.append([i, j, k] if n @ (V[i] + V[j] + V[k]) > 0 else [i, k, j])   # outward (the solid is convex about the origin)
+        kind.append(what)
+
+    def at_corner(a, sg):                               # the vertex of flat (a, sg[a]) at the corner with signs sg
+        o = [k for k in range(3) if k != a]
+        return vid[(a, sg[a], sg[o[0]], sg[o[1]])]
+
+    for a in range(3):
+        for s in (-1, 1):
+            q = [vid[(a, s, -1, -1)], vid[(a, s, 1, -1)], vid[(a, s, 1, 1)], vid[(a, s, -1, 1)]]
+            tri(q[0], q[1], q[2], ("flat", a, s)); tri(q[0], q[2], q[3], ("flat", a, s))
+    for a, b in ((0, 1), (0, 2), (1, 2)):               # the chamfer between flats (a, sa) and (b, sb), along the third axis
+        t = 3 - a - b
+        for sa in (-1, 1):
+            for sb in (-1, 1):
+                q = []
+                for st in (-1, 1):
+                    sg = [0, 0, 0]
+                    sg[a], sg[b], sg[t] = sa, sb, st
+                    q.append((at_corner(a, sg), at_corner(b, sg)))
+                tri(q[0][0], q[0][1], q[1][1], ("chamfer", a, sa, b, sb)); tri(q[0][0], q[1][1], q[1][0], ("chamfer", a, sa, b, sb))
+    for sg in itertools.product((-1, 1), repeat=3):
+        tri(at_corner(0, sg), at_corner(1, sg), at_corner(2, sg), ("corner",))
+    F = np.asarray(F, np.int32)
+    if pad_normal is not None:
+        pn = np.asarray(pad_normal, np.float64)
+        a = int(np.argmax(np.abs(pn)))
+        s = 1 if pn[a] > 0 else -1
+        pads = [k for k, w in enumerate(kind) if w == ("flat", a, s)]
+        b = (a + 2) % 3 if a == 1 else (a + 1) % 3                                  # y pads: the chamfer towards +x, like the reference's face 1
+        key = ("chamfer", min(a, b), s if a < b else 1, max(a, b), 1 if a < b else s)
+        ch = [k for k, w in enumerate(kind) if w == key]
+        order = list(range(len(F)))
+        for slot, src in zip((18, 19, 1), (pads[0], pads[1], ch[1])):
+            k = order.index(src)
+            order[slot], order[k] = order[k], order[slot]
+        F = F[order]
+    return (V + c).astype(np.float32), F
+
+
+def finger_mesh(center, size=(0.02, 0.01, 0.05), n_faces=44, pad_normal=None, closed=None):
+    """The stand-in for a finger collision mesh (assets/robots/xarm/xarm7_with_gripper_collision.urdf:425,519; 44 faces).
+    ``closed`` (default for 44 faces): ``chamfered_box_mesh`` — a closed manifold with the reference meshes' topology, the gripping
+    flat at face indices 18, 19 (+ a chamfer triangle at 1: the faces whose forces the grasp test sums, phystwin.py:386-391).
+    Until round 5 the stand-in was a box whose triangles were bisected without splitting their neighbours — T-junctions: NOT a closed
+    manifold, so the stepper gave it the open-mesh treatment (sign by winding number, no "outside the box is outside the mesh"
+    early-out: every particle within 2 cm of a finger asked for a query instead of every particle within its 5 mm margin) and only
+    3 of the pad's ~16 triangles fed the grasp test.  That form is kept as ``closed=False`` (and for other face counts): the open-mesh
+    code path still needs a test scene.  ``pad_normal``: outward normal of the finger's gripping side."""
+    if closed is None:
+        closed = n_faces == 44
+    if closed:
+        assert n_faces == 44, "the closed stand-in is the 44-face chamfered box"
+        return chamfered_box_mesh(center, size, pad_normal=pad_normal)
     v, f = box_mesh(center, size)
     v, f = list(map(list, v)), [list(t) for t in f]
     # split triangles (longest edge midpoint) until the face count is reached

@@ -46,6 +46,7 @@ def test_struct_layouts_match_headers():
     assert ctypes.sizeof(_lib.R2SRasterFrame) == 2 * 4 + 3 * 4 + 4 + 7 * 8  # 4 bytes of padding before the pointers
     assert ctypes.sizeof(_lib.R2SRasterDebug) == 2 * 8 + 8 * 8
     assert ctypes.sizeof(physics.R2SPhysParams) == 16 * 4
+    assert ctypes.sizeof(physics.R2SFlavourIn) == 29 * 4 and ctypes.sizeof(physics.R2SFlavourOut) == 14 * 4 + 192   # include/r2s_physics.h: R2SFlavourIn / R2SFlavourOut
     assert ctypes.sizeof(physics.R2SPhysDesc) == 64 + 3 * 4 + 4 + 7 * 8 + 2 * 4 + 4 * 8 + 8
 
 

@@ -167,3 +167,30 @@ def test_eval_batched_cli_two_ranks_stub():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["episodes"] == 13 and d["episode_ids_seen"] == 13 and d["episodes_per_rank"] == [7, 6]
     assert d["success_rate"] == 1.0 and 3.0 <= d["mean_steps"] <= 4.0 and d["env_steps_per_s"] > 0
+
+
+def test_a_fault_pending_when_a_whole_wave_of_episodes_ends_is_raised_not_recorded():
+    """the stepper reports a fault with a lag of two env steps and a full reset clears it — when every slot ends on
+    the same step the scheduler must ask (check_fault) BEFORE it records the wave and resets everything."""
+    from r2s_hip.evaluate import run_episodes
+
+    class Faulty(FakeRollout):
+        def __init__(self, n_env, fault_at_check):
+            super().__init__(n_env)
+            self.checks, self.fault_at_check = 0, fault_at_check
+
+        def check_fault(self):
+            self.checks += 1
+            if self.checks == self.fault_at_check:
+                raise RuntimeError("r2s_phys_check_fault: invalid argument a workgroup waited beyond the poll limit; the state is invalid")
+
+    ok = Faulty(2, fault_at_check=0)
+    rec = run_episodes(ok, [0, 1, 2, 3], policy=_policy, max_steps=3, settle_steps=1)
+    assert ok.checks == 2 and rec[:, 2].tolist() == [3.0] * 4          # asked once per wave that ends together
+    bad = Faulty(2, fault_at_check=2)
+    with pytest.raises(RuntimeError, match="state is invalid"):
+        run_episodes(bad, [0, 1, 2, 3], policy=_policy, max_steps=3, settle_steps=1)
+    # slots that end at different steps: a partial reset keeps the fault word, the stepper's own lagged report is enough — no extra syncs
+    stag = Faulty(2, fault_at_check=0)
+    run_episodes(stag, [0, 1, 2], policy=_policy, max_steps=3, settle_steps=1, stop_on_success=True)
+    assert stag.checks <= 2
