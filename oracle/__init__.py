@@ -427,7 +427,7 @@ def phys_step_batch(envs, n_substeps=None):
     lib().r2s_oracle_phys_step_batch_f32(arr, xs, vs, C.c_int(n), C.c_int(0), C.c_int(ns))
 
 
-def phys_step_batch_par(envs, n_substeps=None, threads_per_env=1):
+def phys_step_batch_par(envs, n_substeps=None, threads_per_env=1, first_substep=0):
     """``phys_step_batch`` with every environment's per-particle loops split over ``threads_per_env`` threads (environments x
     particle chunks; r2s_oracle_phys_step_batch_par_f32).  Positions / velocities equal the sequential stepper's bit for bit under
     the checker build (per-face force sums are atomic adds: equal up to their order).  Returns the threads that ran."""
@@ -437,7 +437,7 @@ def phys_step_batch_par(envs, n_substeps=None, threads_per_env=1):
     xs = (C.c_void_p * n)(*[e.x.ctypes.data for e in envs])
     vs = (C.c_void_p * n)(*[e.v.ctypes.data for e in envs])
     ns = envs[0].num_substeps if n_substeps is None else int(n_substeps)
-    return int(lib().r2s_oracle_phys_step_batch_par_f32(arr, xs, vs, C.c_int(n), C.c_int(0), C.c_int(ns), C.c_int(int(threads_per_env))))
+    return int(lib().r2s_oracle_phys_step_batch_par_f32(arr, xs, vs, C.c_int(n), C.c_int(int(first_substep)), C.c_int(ns), C.c_int(int(threads_per_env))))
 
 
 def mesh_query(pts, faces, p, max_dist=0.02, threshold=0.6, f64=False):

@@ -58,28 +58,45 @@ class OracleRollout:
             out.append(float(np.linalg.norm(f[18] + f[19] + f[1])) if len(f) > 19 else 0.0)
         return out
 
-    def step(self, vel=None, openness=None, n_substeps=None):
-        """One env step of the scene's action trace (or of the given end-effector velocity [3] / commanded opening)."""
-        from . import phys_step_batch_par
+    def begin_step(self, vel=None, openness=None, forces=None):
+        """The caller side of one env step (phystwin.py:362-460): candidate rebuild, grasp state machine on the forces the PREVIOUS step's
+        last substep left (``forces``: another stepper's instead of this one's own — a test that wants both state machines on equal
+        input), finger kinematics, set_mesh_interactive.  Returns what was handed to the stepper."""
         from r2s_hip.rollout import eef_velocity, open_command
 
         scn, ph = self.scn, self.phys
         if ph.self_collision:
             ph.update_collision_graph()
-        vel = eef_velocity(scn, self.t) if vel is None else np.asarray(vel, np.float32)
+        self._vel = eef_velocity(scn, self.t) if vel is None else np.asarray(vel, np.float32)
         op = None if scn["use_pusher"] else (open_command(scn, self.t) if openness is None else float(openness))
-        norms = self.filtered_forces() if not scn["use_pusher"] else [0.0, 0.0]
-        ref = self.eef.step(self.eef_xyz, vel[None], self.eef_rot, self.eef_rot_vel, op, self.fn, scn["eef_init"],
-                            np.asarray(ph.collision_forces, np.float32), ph.mesh_map)
+        F = np.asarray(ph.collision_forces if forces is None else forces, np.float32)
+        self._norms = self.filtered_forces() if not scn["use_pusher"] else [0.0, 0.0]
+        self._op = op
+        ref = self.eef.step(self.eef_xyz, self._vel[None], self.eef_rot, self.eef_rot_vel, op, self.fn, scn["eef_init"], F, ph.mesh_map)
         ph.set_mesh_interactive(ref["interp_points"], ref["interp_center"], ref["dynamic_velocity"], ref["dynamic_omega"])
-        n = ph.num_substeps if n_substeps is None else int(n_substeps)
-        if self.threads > 1 and not ph.f64:
-            phys_step_batch_par([ph], n, self.threads)
+        return ref
+
+    def run(self, n_substeps, first_substep=0):
+        """Substeps [first, first + n) of the env step begun with ``begin_step``."""
+        from . import phys_step_batch_par
+
+        ph = self.phys
+        if self.threads > 1 and not ph.f64:   # (positions / velocities equal the sequential stepper's bit for bit under the checker build)
+            phys_step_batch_par([ph], int(n_substeps), self.threads, first_substep=int(first_substep))
         else:
-            ph.step(n, 0)
-        self.eef_xyz = (self.eef_xyz + vel[None] * np.float32(scn["num_substeps"] * scn["dt"])).astype(np.float32)
-        self.log.append(dict(t=self.t, command=op, openness=self.eef.current_openness, grasped=bool(self.eef.grasped), force_in=norms,
+            ph.step(int(n_substeps), int(first_substep))
+
+    def end_step(self):
+        scn, ph = self.scn, self.phys
+        self.eef_xyz = (self.eef_xyz + self._vel[None] * np.float32(scn["num_substeps"] * scn["dt"])).astype(np.float32)
+        self.log.append(dict(t=self.t, command=self._op, openness=self.eef.current_openness, grasped=bool(self.eef.grasped), force_in=self._norms,
                              candidates=int((ph.coll_num > 0).sum()) if ph.self_collision else 0,
                              hits=int((np.abs(ph.collision_forces).sum(1) > 0).sum())))
         self.t += 1
+
+    def step(self, vel=None, openness=None):
+        """One env step of the scene's action trace (or of the given end-effector velocity [3] / commanded opening)."""
+        ref = self.begin_step(vel, openness)
+        self.run(self.phys.num_substeps, 0)
+        self.end_step()
         return ref

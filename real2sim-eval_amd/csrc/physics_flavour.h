@@ -120,7 +120,7 @@ inline void pick_flavour(const R2SFlavourIn& c, R2SFlavourOut& o)
     // which flavours of one scene end in the same bits: chains and pf never change them (same kernels' arithmetic on the same inputs in the
     // same order); everything else sums in another order (in-place vs listed queries, 16 vs 64 lanes over a candidate list, the resident
     // launch's eight partial force sums, a server unit's fixed trees)
-    o.sum_class = resident ? 100 + 10 * variant + (o.n_srv > 0 ? (o.srv_own ? 2 : 1) : 0) : (c.split_ok ? 50 : 0) + 2 * variant + mesh_defer;
+    o.sum_class = resident ? 100 + 10 * variant + (o.n_srv > 0 ? (o.srv_own ? 2 : 1) : 0) : (c.split_ok ? 50 : (c.block == 256 ? 0 : (c.block == 128 ? 20 : 30))) + 2 * variant + mesh_defer; // (per layout: a block's window decides which neighbours are gathered from LDS and which from memory — the same sums, but nothing holds them to the same bits)
     const int rcap = c.block == 256 ? 1024 : (c.block == 128 ? 768 : 512);
     const char* sc = variant ? "true" : "false";
     char* k = o.kernel;

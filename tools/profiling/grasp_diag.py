@@ -1,5 +1,5 @@
 """Per-step trace of the 'grasp' action schedule (bench.py's timed window): contact counters, grasp state, finger forces,
-physics time.  usage: grasp_diag.py [config] [envs] [close_at] [steps]"""
+physics time.  usage: grasp_diag.py [config] [envs] [close_at] [steps] [close_rate: 0 = the command jumps]"""
 import os
 import sys
 
@@ -14,7 +14,8 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "sloth_32env"
 envs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 close_at = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 14
-ro = BatchedRollout(cfg, n_env=envs, close_at=close_at)
+rate = float(sys.argv[5]) if len(sys.argv) > 5 else 0.1
+ro = BatchedRollout(cfg, n_env=envs, close_at=close_at, close_rate=rate if rate > 0 else None)
 print("N", ro.N, "S", ro.S, "schedule", ro.schedule, "close_at", ro.close_at, "layout", ro.phys.layout_stats())
 ro.phys.set_timing(True)
 x0 = ro.phys.x.clone()
@@ -33,6 +34,10 @@ for t in range(steps):
     if os.environ.get("R2S_DIAG_DEFER"):
         dc = ro.phys.deferred_counts()
         print(f"   deferred mesh queries per substep: mean {dc[:-1].mean():.1f} max {int(dc[:-1].max())} last {int(dc[-2])}; near flag {int(dc[-1])}")
+    if not ro.use_pusher:
+        mm = ro.phys.mesh_map
+        pads = [float(torch.linalg.norm(f[0][torch.from_numpy(mm == m).to(f.device)][[18, 19, 1]].sum(0))) for m in (0, 1)]
+        print(f"   pad forces (faces 18 + 19 + 1) env 0: {pads[0]:9.1f} {pads[1]:9.1f}  grasped per env {gr.tolist()}")
     print(f"step {t:2d}: phys {ms:7.3f} ms ({ms / k * 1e3:6.2f} us/substep) cand {st['self_collision_candidates']:6d} hits {st['mesh_contacts']:5d} "
           f"grasped {st['grasped_envs']} open {float(op[0]):.3f} |F|max {float(f.abs().max()):9.1f} eef_z {float(ro.eef_xyz[0, 2]):.4f} "
           f"top_z {float(x[0, :, 2].max()):.4f} max|dx| {float((x - x0).abs().max()):.4f} finite {bool(torch.isfinite(x).all())} {st['flavour']['kernel']}")
