@@ -585,7 +585,7 @@ def main():
                     "kernel_flavours": sorted({plog["flavour"][i] for i in idx})}
 
         resident_steps = sum("k_steps_resident" in f for f in log["flavour"])   # env steps of the window that ran as one resident launch
-        first_contact = (close_sync if dephased else ro.close_at) - args.warmup + (2 if ramp else 0)  # index in the synchronised window of the step in which the pads reach the object (two steps into the ramp) / the fingers snap shut / the rod arrives
+        first_contact = (close_sync if dephased else ro.close_at) - args.warmup + (1 if ramp else 0)  # index in the synchronised window of the step in which the pads reach the object (the ramp's second step: the first particles enter the pads' margins) / the fingers snap shut / the rod arrives
         (pmc_sub, src), (pmc_comp, _) = pmc_summary("k_substep", args.config), pmc_summary("k_composite", args.config)
         shared_bytes = 16 * ro.S + 48 * ro.N * ro.n_env        # the topology once (it is shared by the environments and L2-resident) + every environment's state
         traffic = pmc_sub["hbm_bytes_per_launch"] if pmc_sub and ro.n_env == 32 and n_sub == 667 else None

@@ -215,7 +215,7 @@ typedef struct R2SFlavourIn {
     int32_t have_counters;
     int32_t near_mesh;          /* a particle was within margin + 3 cm of a collision mesh's box                         */
     int32_t query_needed;       /* a particle was inside a mesh's reach (a query had to be answered)                     */
-    int32_t servers_ran_out;    /* a resident launch had more particles in contact than server units                     */
+    int32_t servers_ran_out;    /* a resident launch had more particles in contact than server units, or was running low (> 30 % claimed) */
     int32_t srv_exhausted;      /* the handle's sticky copy of that (cleared once no query is needed any more)           */
     int32_t n_candidates;       /* particles with self-collision candidates after the last update_collision_graph        */
     int32_t n_substeps;         /* substeps of this call                                                                 */

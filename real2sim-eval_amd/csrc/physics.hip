@@ -140,6 +140,8 @@ struct PhysDev {
     const float* cl_box;       // [6][n_cl] rest-frame boxes (clusters of large meshes), component-major: one lane per cluster loads coalesced
     const int* mesh_kind;      // [n_mesh] bit 0: large (> 256 faces: clusters, wave-cooperative); bit 1: not a closed manifold (sign by
                                // exact winding number; closed large meshes use pseudonormals, small meshes always the winding number)
+    const int* mesh_inward;    // [n_mesh] 1: a closed manifold whose faces are oriented INWARD (negative signed volume at construction): its winding number is
+                               // -1 inside, never above the 0.6 threshold — the batched small-scene finisher's plane-side shortcut must not be used for it
     const int* mesh_xf;        // [n_mesh] transform slot of a large dynamic mesh, else -1
     const int* xf_mesh;        // [n_xf] mesh of a transform slot
     const float* xf;           // [E,n_sub,n_xf,12]
@@ -173,6 +175,7 @@ struct PhysDev {
     // resident stepper, mesh-query SERVERS (small scenes; see k_steps_resident): workgroups of the same launch beyond the blocks' own,
     // two wavefronts per served particle
     int srv_slots;             // server wavefront pairs of this launch (0: none — queries in place)
+    int srv_low;               // a claim of slot >= srv_low reports "units running low" (30 % of srv_slots; R2S_RES_SRV_LOW = per cent, 100: only when none is left)
     void* srv_claim;           // [srv_slots] x 128 B, first granule {env * N + particle, 1, first substep of the launch it is served from, 1}; then control words and fault-report state (SRV_CTL_OFF, SRV_DBG_OFF)
     void* srv_rr;              // [E][N] x 256 B of tagged 16-byte granules: line 0 the REQUEST (x0.x x0.y | x0.z v.x | v.y v.z), line 1 the RESULT (xy | z vz | vxy)
     int* srv_ctl;              // [0] next free slot, [1] blocks that have left the launch
@@ -280,14 +283,22 @@ struct R2SPhys {
     float4* d_vdef = nullptr;
     int* d_mq_hint = nullptr;
     int lm[7] = {0, 0, 0, 0, 0, 0, -1}; // PhysDev::lm_c0, lm_nc, lm_f0, lm_f1, lm_y, lm_mesh, lm_slot
-    int4* d_mesh_rec = nullptr; int* d_rec_cnt = nullptr; // large-mesh scenes: per-environment records [E][N][2] and their counters [E][n_sub]
+    int4* d_mesh_rec = nullptr; int* d_rec_cnt = nullptr; // large-mesh scenes and small scenes with batched finishing: per-environment records [E][N][2] and their counters [E][n_sub]
+    bool fin_batch = false;     // small scene (every mesh small, <= 128 faces, <= FB_MAX_MESH meshes): the finishing code takes 16 records of an environment at a time (contact_finish_batch; R2S_FIN_BATCH=0: one workgroup per particle, rounds 2-5)
     int* d_cand_mark = nullptr;
     // Counters of an env step ([0] particles near a mesh, [1] sticky fault word, [2] a query was needed, [3] server pairs ran out, [4..15] fault
     // context) travel to pinned memory behind the step and pick the FLAVOUR of a later step.  Which later step is fixed (round 5): step t
     // runs the flavour that follows from the counters of step t - LAG, waited for if they have not landed (they have: two env steps ago) —
     // never "whatever copy happens to have arrived", which made the bits of a run in contact depend on host timing (the flavours sum in
     // different orders).  A full set_state starts a new history: its first LAG steps run the default flavour (queries in place).
-    static constexpr int LAG = 2, RING = 4;
+    static constexpr int LAG = 2, RING = 4;   // LAG: the default; `lag` below is what the handle uses
+    // Round 6: SMALL batches (the resident layout) use lag 1.  Their contact flavours differ by a factor of ten in cost when the wrong one runs
+    // (a resident launch whose server units run out answers in place: 55 - 140 ms for an env step of the one-environment toy against 8 - 15), and
+    // a closing grasp quadruples its contacts from one env step to the next (24 -> 95 particles in the step the grasp latches) — two steps of
+    // lag cannot see that coming, one can.  The price: r2s_phys_step waits for the PREVIOUS step's counters, i.e. the host no longer runs a step
+    // ahead of the device — nothing in a closed loop (the caller has waited for that step's frames), a few per cent of an enqueue-only loop of
+    // 2 - 4 ms steps.  Large batches (0.8 ms of host time per step for four graph launches) keep 2.  Any FIXED lag keeps runs bit-reproducible.
+    int lag = LAG;
     int* d_mesh_total = nullptr; int* h_ring = nullptr; // pinned [RING][16]
     hipEvent_t ring_ev[RING] = {}; bool ring_pending[RING] = {}, ring_stale_fault[RING] = {};
     uint64_t step_no = 0; // env steps enqueued since the last full set_state
@@ -305,6 +316,7 @@ struct R2SPhys {
     int srv_quad = -1;        // R2S_RES_SRV_QUAD=0 / 1: pairs / quads whatever the launch has room for (-1: quads when it has >= 64 server workgroups)
     int srv_quad_for(int n_srv) const { return r2s_flavour::fl_srv_quad(flavour_caps(), n_srv); }
     int srv_own = 1;          // R2S_RES_SRV_OWN=0: one request per substep instead of pairs that own their particle
+    int srv_low_pct = 30;     // R2S_RES_SRV_LOW: share of a launch's server units whose claim reports "running low" (the host leaves the resident launch before a claim goes unanswered)
     bool split_ok = false;    // 64-particle layout whose slices fit k_steps_resident's registers (no remote neighbours, <= 64 interior / halo slots)
     bool resident_ok = false; // the handle can run the env step as ONE resident launch (k_steps_resident) in its free flavour
     int resident_pref = 1;    // R2S_RESIDENT=0 / r2s_phys_set_tuning: never pick the 64-particle layout / the resident launch
@@ -340,7 +352,7 @@ struct R2SPhys {
     char* d_sort_tmp = nullptr;
     size_t sort_bytes = 0;
     int *d_faces = nullptr, *d_mesh_map = nullptr, *d_face_map = nullptr, *d_mesh_face_off = nullptr, *d_mesh_vert_off = nullptr;
-    int *d_face_orig = nullptr, *d_mesh_kind = nullptr,
+    int *d_face_orig = nullptr, *d_mesh_kind = nullptr, *d_mesh_inward = nullptr,
         *d_mesh_xf = nullptr, *d_xf_mesh = nullptr, *d_xf_ref = nullptr;
     float *d_cl_box = nullptr, *d_xf = nullptr, *d_rest_pts = nullptr, *d_pnorm = nullptr, *d_xf_rest_box = nullptr, *d_tri_rest = nullptr;
     int4* d_cl_info = nullptr; int4* d_sup_info = nullptr; float* d_sup_box = nullptr; int* d_small_mesh = nullptr; int n_sup = 0, n_small = 0;
@@ -398,7 +410,7 @@ struct R2SPhys {
         p.n_mesh = n_mesh; p.n_dyn_mesh = n_dyn_mesh; p.nF = nF; p.nV = nV; p.n_dyn_pts = n_dyn_pts;
         p.faces = d_faces; p.mesh_map = d_mesh_map; p.face_map = d_face_map; p.mesh_face_off = d_mesh_face_off;
         p.face_orig = d_face_orig; p.n_cl = n_cl; p.n_xf = n_xf;
-        p.cl_box = d_cl_box; p.mesh_kind = d_mesh_kind; p.mesh_xf = d_mesh_xf; p.xf_mesh = d_xf_mesh; p.xf = d_xf; p.rest_pts = d_rest_pts;
+        p.cl_box = d_cl_box; p.mesh_kind = d_mesh_kind; p.mesh_inward = d_mesh_inward; p.mesh_xf = d_mesh_xf; p.xf_mesh = d_xf_mesh; p.xf = d_xf; p.rest_pts = d_rest_pts;
         p.pnorm = d_pnorm; p.tri_rest = d_tri_rest; p.cl_info = d_cl_info;
         p.n_sup = n_sup; p.n_small = n_small; p.sup_box = d_sup_box; p.sup_info = d_sup_info; p.small_mesh = d_small_mesh;
         p.mesh_pts = d_mesh_pts; p.interp_pts = d_interp; p.interp_center = d_center; p.dyn_vel = d_dyn_vel; p.dyn_omega = d_dyn_omega;
@@ -508,6 +520,15 @@ void launch_fused(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_
     }
 }
 
+// batched small-scene finishing: workgroups per environment.  Part 1 takes the records 16 at a time from the first slot on (8 slots = 128 listed
+// particles per environment without a second round), part 2 the candidate particles 16 to a workgroup from the last slot back
+int fin_batch_slots(bool with_self)
+{
+    int n = with_self ? 16 : 8;
+    if (const char* ev = getenv("R2S_FIN_SLOTS")) n = std::max(1, atoi(ev));
+    return n;
+}
+
 // What the fused kernel left unfinished: with something near a mesh (mesh_defer) ONE combined finishing kernel per substep —
 // deferred mesh queries, one workgroup per particle, plus the self-collision impulses; otherwise only k_self_finish
 // while candidates exist (mesh queries of the rare needy particle in place).
@@ -516,7 +537,12 @@ void launch_finish(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write
     const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
     const StateC in = h->state(in_buf);
     const StateM out = h->state(in_buf ^ 1);
-    if (has_contact_finish(h, p)) {
+    if (has_contact_finish(h, p) && h->fin_batch) {
+        // batched small-scene finishing: (environments of this chain, slots) workgroups of 256 threads; a slot takes 16 records of ITS environment at a time
+        const dim3 g((unsigned)p.ne, (unsigned)fin_batch_slots(with_self));
+        if (with_self) hipLaunchKernelGGL((k_contact_finish_batch<true>), g, dim3(256), 0, s, p, in, out, step, write_forces);
+        else hipLaunchKernelGGL((k_contact_finish_batch<false>), g, dim3(256), 0, s, p, in, out, step, write_forces);
+    } else if (has_contact_finish(h, p)) {
         const bool small = mesh == 1 && h->nF <= 128; // every mesh small: the substep's triangles fit two per lane
         // 2048 wavefronts (an idle launch costs the same ~2.5 us with 16 workgroups: it is the launch boundary), grid-stride: workgroups of
         // two (small) or four wavefronts; large-mesh scenes: (environments of this chain, slots), a workgroup strides over ITS environment's records
@@ -550,7 +576,7 @@ int pf_head_size(const R2SPhys* h, int ne, bool with_self)
     const int mesh = h->nF > 0 ? (h->any_large ? 2 : 1) : 0;
     // small scenes: 32 workgroups per environment (deferred queries from the front, candidate particles — eight to a workgroup — from the back;
     // 16 and 24 ran a second round in the headline's grasp: 25.8 / 24.4 vs 22.8 us), 16 while no particle has candidates
-    int n = mesh == 2 ? ne * std::max(16, 256 / std::max(1, ne)) : std::min(1024, (with_self ? 32 : 16) * ne);
+    int n = mesh == 2 ? ne * std::max(16, 256 / std::max(1, ne)) : h->fin_batch ? fin_batch_slots(with_self) * ne : std::min(1024, (with_self ? 32 : 16) * ne);
     if (const char* ev = getenv("R2S_PF_HEAD")) n = std::max(8, atoi(ev) * ne); // tuning: finishing workgroups per environment
     return (n + 7) & ~7;
 }
@@ -562,8 +588,8 @@ void launch_fused_pf(R2SPhys* h, const PhysDev& p, int in_buf, int step, int wri
     const StateC in = h->state(in_buf);
     const StateM out = h->state(in_buf ^ 1);
 #define R2S_PF(SELF, MESH, Q) hipLaunchKernelGGL((k_substep_pf<256, 1024, SELF, MESH, Q>), grid, dim3(256), 0, s, p, in, out, step, write_forces, fin_skip)
-    if (with_self) { if (mesh == 2) R2S_PF(true, 2, 2); else if (small) R2S_PF(true, 1, 3); else R2S_PF(true, 1, 2); }
-    else { if (mesh == 2) R2S_PF(false, 2, 2); else if (small) R2S_PF(false, 1, 3); else R2S_PF(false, 1, 2); }
+    if (with_self) { if (mesh == 2) R2S_PF(true, 2, 2); else if (h->fin_batch) R2S_PF(true, 1, 4); else if (small) R2S_PF(true, 1, 3); else R2S_PF(true, 1, 2); }
+    else { if (mesh == 2) R2S_PF(false, 2, 2); else if (h->fin_batch) R2S_PF(false, 1, 4); else if (small) R2S_PF(false, 1, 3); else R2S_PF(false, 1, 2); }
 #undef R2S_PF
 }
 
@@ -622,6 +648,7 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
             if (with_self) p.srv_own = 0; // next to the self-collision flavour the pairs only ANSWER queries (a request per particle and substep, carrying
                                           // the velocity after the impulses): an owned particle would have to take part in the candidates' hand-off itself
             p.srv_quad = h->srv_quad_for(n_srv); p.srv_slots = (p.srv_quad ? 2 : 4) * n_srv;
+            p.srv_low = (int)((int64_t)p.srv_slots * h->srv_low_pct / 100);
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((SRV_DBG_OFF / 4 + 255) / 256)), dim3(256), 0, s, (float*)h->d_srv_claim, (size_t)SRV_DBG_OFF / 4); // claims and control words
             const size_t rw = (size_t)(SRV_REC / 4) * ne * h->N;
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((rw + 255) / 256)), dim3(256), 0, s, (float*)h->d_srv_rr + (size_t)(SRV_REC / 4) * e0 * h->N, rw);
@@ -1256,6 +1283,20 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             TRY(upload(h->d_cl_box, box_t.data(), box_t.size(), s));
         }
         TRY(upload(h->d_mesh_kind, mesh_kind.data(), mesh_kind.size(), s));
+        {   // orientation of each mesh: signed volume of its faces about the origin at construction (rigid motion keeps it)
+            std::vector<int> inward(h->n_mesh, 0);
+            for (int m = 0; m < h->n_mesh; ++m) {
+                double vol = 0.0;
+                for (int f = foff[m]; f < foff[m + 1]; ++f) {
+                    const int ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
+                    const double a[3] = {vtx(ia, 0), vtx(ia, 1), vtx(ia, 2)}, b[3] = {vtx(ib, 0), vtx(ib, 1), vtx(ib, 2)}, c[3] = {vtx(ic, 0), vtx(ic, 1), vtx(ic, 2)};
+                    vol += a[0] * (b[1] * c[2] - b[2] * c[1]) + a[1] * (b[2] * c[0] - b[0] * c[2]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+                }
+                inward[m] = vol < 0.0 ? 1 : 0;
+            }
+            TRY(dev_alloc(&h->d_mesh_inward, h->n_mesh));
+            TRY(upload(h->d_mesh_inward, inward.data(), inward.size(), s));
+        }
         TRY(upload(h->d_mesh_xf, mesh_xf.data(), mesh_xf.size(), s)); TRY(upload(h->d_rest_pts, d->mesh_vertices, 3 * (size_t)h->nV, s));
         TRY(upload(h->d_pnorm, pnorm.data(), pnorm.size(), s)); TRY(upload(h->d_xf_mesh, xf_mesh.data(), xf_mesh.size(), s));
         {
@@ -1359,10 +1400,11 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_list, 0, sizeof(int2) * (size_t)2 * h->mesh_cap, s));
         TRY(dev_alloc(&h->d_mesh_cnt, (size_t)8 * (h->prm.num_substeps + 1)));
         TRY(dev_alloc(&h->d_vdef, (size_t)2 * E * N));
-        if (h->any_large) {
+        h->fin_batch = !h->any_large && h->nF <= FB_MAX_F && h->n_mesh <= FB_MAX_MESH && !(getenv("R2S_FIN_BATCH") && atoi(getenv("R2S_FIN_BATCH")) == 0);
+        if (h->any_large || h->fin_batch) {
             TRY(dev_alloc(&h->d_mesh_rec, (size_t)4 * E * N));
             R2S_HIP_TRY(hipMemsetAsync(h->d_mesh_rec, 0, sizeof(int4) * (size_t)4 * E * N, s));
-            if (h->n_cl < 4094 && getenv("R2S_NO_MQ_HINT") == nullptr) { // the hint rides in 12 bits of a record word
+            if (h->any_large && h->n_cl < 4094 && getenv("R2S_NO_MQ_HINT") == nullptr) { // the hint rides in 12 bits of a record word
                 TRY(dev_alloc(&h->d_mq_hint, (size_t)E * N));
                 R2S_HIP_TRY(hipMemsetAsync(h->d_mq_hint, 0xFF, sizeof(int) * (size_t)E * N, s)); // -1: no hint
             }
@@ -1426,6 +1468,8 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             r2s::set_last_error_msg(buf); // informational: r2s_phys_create still returns R2S_OK
         }
         h->n_cu = n_cu;
+        h->lag = h->resident_ok ? 1 : R2SPhys::LAG;
+        if (const char* ev = getenv("R2S_FLAVOUR_LAG")) h->lag = std::max(1, std::min(R2SPhys::RING - 1, atoi(ev)));
         if (h->resident_ok) {
             const size_t xn = ((size_t)N + 7) & ~(size_t)7;
             TRY(dev_alloc((char**)&h->d_xch, (size_t)96 * E * xn));
@@ -1441,6 +1485,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
             bool pref = true;
             if (const char* ev = getenv("R2S_RES_SERVERS")) pref = atoi(ev) != 0;
             if (const char* ev = getenv("R2S_RES_SPIN_LIMIT")) h->spin_limit = (unsigned)std::max(1024, atoi(ev));
+            if (const char* ev = getenv("R2S_RES_SRV_LOW")) h->srv_low_pct = std::max(1, std::min(100, atoi(ev)));
             if (const char* ev = getenv("R2S_RES_SRV_OWN")) h->srv_own = atoi(ev) != 0;
             if (const char* ev = getenv("R2S_RES_SRV_QUAD")) h->srv_quad = atoi(ev) != 0;
             if (const char* ev = getenv("R2S_RES_SRV_WG")) h->srv_wg_cap = std::max(1, std::min(atoi(ev), SRV_MAX_SLOTS / 4));
@@ -1504,7 +1549,7 @@ void r2s_phys_destroy(R2SPhys* h)
     drop_graph(h);
     void* ptrs[] = {h->xv[0], h->xv[1], h->d_slice_off, h->d_slice_deg, h->d_slice_int, h->d_rslice_off, h->d_rslice_deg, h->d_adj_idx, h->d_adj_k, h->d_adj_ir, h->d_radj, h->d_halo_off, h->d_halo_ids, h->d_perm, h->d_inv, h->d_num_user, h->d_idx_user, h->d_masses, h->d_masks,
                     h->d_coll_num, h->d_coll_idx, h->d_max_count, h->d_vbc, h->d_xbc, h->d_pf_res, h->d_mesh_list, h->d_mesh_cnt, h->d_vdef, h->d_mesh_rec, h->d_mq_hint, h->d_rec_cnt, h->d_cand_mark, h->d_mesh_total, h->d_cand_list, h->d_cand_count, h->d_bits, h->d_keys[0], h->d_keys[1], h->d_ids[0], h->d_ids[1], h->d_sort_tmp, h->d_cell_tab, h->d_cell_xs,
-                    h->d_faces, h->d_face_orig, h->d_cl_box, h->d_mesh_kind, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
+                    h->d_faces, h->d_face_orig, h->d_cl_box, h->d_mesh_kind, h->d_mesh_inward, h->d_mesh_xf, h->d_xf_mesh, h->d_xf_ref,
                     h->d_xf, h->d_rest_pts, h->d_pnorm, h->d_tri_rest, h->d_cl_info, h->d_sup_info, h->d_sup_box, h->d_small_mesh, h->d_xf_rest_box, h->d_rigid_err, h->d_mesh_map, h->d_face_map, h->d_mesh_face_off, h->d_mesh_vert_off, h->d_mesh_pts, h->d_interp, h->d_center,
                     h->d_dyn_vel, h->d_dyn_omega, h->d_aabb_dyn, h->d_aabb_static, h->d_coll_forces,
                     h->d_eef_table, h->d_eef_open, h->d_eef_grasped, h->d_eef_has, h->d_eef_need, h->d_eef_rel0, h->d_eef_delta, h->d_hit_cnt, h->d_xch, h->d_vx,
@@ -1811,15 +1856,15 @@ int r2s_phys_step(R2SPhys* h, int n_substeps, int first_substep, r2s_stream_t st
     // the counters this step's flavour follows from: those of step (step_no - LAG), waited for (long landed in any real loop)
     int cnt[16] = {0};
     bool have_cnt = false;
-    if (h->step_no >= (uint64_t)R2SPhys::LAG) {
-        const int k = (int)((h->step_no - R2SPhys::LAG) % R2SPhys::RING);
+    if (h->step_no >= (uint64_t)h->lag) {
+        const int k = (int)((h->step_no - h->lag) % R2SPhys::RING);
         if (h->ring_pending[k]) { R2S_HIP_TRY(hipEventSynchronize(h->ring_ev[k])); h->ring_pending[k] = false; }
         memcpy(cnt, h->h_ring + 16 * k, sizeof cnt);
         if (h->ring_stale_fault[k]) cnt[1] = 0;
         have_cnt = true;
     }
     // the sticky fault word is looked for in the NEWER copies too when they have landed: it only ends the run, it picks no flavour
-    for (uint64_t back = 1; back < (uint64_t)R2SPhys::LAG && back <= h->step_no && cnt[1] == 0; ++back) {
+    for (uint64_t back = 1; back < (uint64_t)h->lag && back <= h->step_no && cnt[1] == 0; ++back) {
         const int k = (int)((h->step_no - back) % R2SPhys::RING);
         if (h->ring_pending[k] && hipEventQuery(h->ring_ev[k]) == hipSuccess) h->ring_pending[k] = false;
         if (!h->ring_pending[k] && !h->ring_stale_fault[k] && h->h_ring[16 * k + 1] != 0) { cnt[1] = h->h_ring[16 * k + 1]; memcpy(cnt + 4, h->h_ring + 16 * k + 4, 12 * sizeof(int)); }

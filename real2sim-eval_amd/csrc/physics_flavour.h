@@ -23,7 +23,8 @@
 //                the servers are in the launch BEFORE the first particle enters a margin.  Until round 5 this followed "a query was
 //                NEEDED": the first two env steps of a contact on top of live candidates answered in place, 118 ms each on the
 //                one-environment toy against 8.6 (DESIGN §8 item 4 of round 5).  With servers available a small batch never defers;
-//                a launch that ran out of server units (servers_ran_out) sends the following steps to the per-substep kernels + finishing
+//                a launch that ran out of server units — or, round 6, claimed more than 30 % of them: a closing grasp doubles its contacts in the two
+//                steps the counters lag — (servers_ran_out) sends the following steps to the per-substep kernels + finishing
 //                launch until no query is needed any more (srv_exhausted, sticky).
 //   pf           large-batch layout with meshes, preference on, and the flavour carries finishing code: the finishers of substep k ride
 //                at the head of substep k + 1's launch (k_substep_pf), bit-identical to the two-launch form.

@@ -685,7 +685,7 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                         bool near;
                         if (mesh_need(p, e, step, x0 + v * p.dt, 0.002f, near)) {
                             p.fault[1] = 1;
-                            if (MESH == 2) {
+                            if (MESH == 2 || p.mesh_rec) { // (small scenes with batched finishing list per environment too: round 6)
                                 if (mesh_rec_push(p, e, step, i, ncand, x0, v)) p.cand_mark[po + eb + i] = step + 1;
                             } else {
                                 const int slot = atomicAdd(p.mesh_cnt + step, 1);
@@ -900,6 +900,9 @@ __global__ void __launch_bounds__(RES_THREADS, 2) k_steps_resident(const PhysDev
                     bool claimed_now = false;
                     if (need_now && !srv_mine) {
                         const int slot = atomicAdd(p.srv_ctl, 1);
+                        if (slot >= p.srv_low) p.fault[2] = 1; // units running LOW (30 % claimed; round 6) or out: the host takes the following steps off the resident
+                                                                         // launch BEFORE a claim goes unanswered (the flavour follows the counters of an earlier step, and a closing
+                                                                         // grasp doubles its contacts in that time: 12 -> 14 -> 37 -> 61 -> 79 listed particles per env step of the toy)
                         if (slot < p.srv_slots) {
                             srv_mine = true; srv_slot = slot; claimed_now = true;
                             const __amdgpu_buffer_rsrc_t rcl = __builtin_amdgcn_make_buffer_rsrc(p.srv_claim, 0, 0x7fffffff, 0x00020000);

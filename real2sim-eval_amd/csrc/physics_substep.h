@@ -325,6 +325,8 @@ __device__ __forceinline__ bool finish_wave(const PhysDev& p, int e, int i, size
             if (qm && (int)(threadIdx.x & 63) == __builtin_ctzll(qm)) p.fault[1] = 1;
             if (MESH == 2) { // large scenes always defer (the fused kernel carries no query code), through the per-environment records
                 if (need && mesh_rec_push(p, e, step, i, 0, x0, v)) { fin = false; need = false; }
+            } else if (need && p.mesh_defer && p.mesh_rec) { // small scene, batched finishing (round 6): through the per-environment records as well
+                if (mesh_rec_push(p, e, step, i, 0, x0, v)) { fin = false; need = false; }
             } else if (need && p.mesh_defer) {
                 const int slot = atomicAdd(p.mesh_cnt + step, 1);
                 if (slot < p.mesh_cap) {
@@ -483,12 +485,14 @@ extern "C" int r2s_phys_debug_phase_probe(long long* out, int n)
 
 // PF: the launch is a k_substep_pf — `bid` = the workgroup's number among the fused blocks (behind the finishers), records of particles the
 // previous substep left unfinished are PF_SENT and come from the finishers' result lines, particles this substep leaves unfinished get PF_SENT
-template <int B, int RCAP, bool SELF, int MESH, bool PF = false>
+// EXTWIN: the LDS window is the caller's (k_substep_pf with the batched finishers: the two roles of that launch share one allocation)
+template <int B, int RCAP, bool SELF, int MESH, bool PF = false, bool EXTWIN = false>
 __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_in, const StateM xv_out, int step,
-                                             int write_forces, int bid)
+                                             int write_forces, int bid, __attribute__((address_space(3))) v2f* win_ext = nullptr)
 {
     static_assert(B % SLICE == 0 && RCAP >= B && RCAP * 8 <= 65536, "window offsets are u16 bytes");
-    __shared__ __attribute__((aligned(16))) v2f win_s[3 * (RCAP + 1)]; // planes xy | (z, vz) | vxy, 24 B per record (+ 1 pad each)
+    __shared__ __attribute__((aligned(16))) v2f win_own[EXTWIN ? 1 : 3 * (RCAP + 1)]; // planes xy | (z, vz) | vxy, 24 B per record (+ 1 pad each)
+    __attribute__((address_space(3))) v2f* const win_s = EXTWIN ? win_ext : (__attribute__((address_space(3))) v2f*)win_own;
     const int xcd = bid & 7, q = bid >> 3;
     const int item = xcd * p.cb + q;
     if (q >= p.cb || item >= p.nb * p.ne) return; // whole workgroup
@@ -598,7 +602,7 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
                 bool near;
                 if (mesh_need(p, e, step, x0 + v * p.dt, 0.002f, near)) {
                     p.fault[1] = 1;
-                    if (MESH == 2) {
+                    if (MESH == 2 || p.mesh_rec) {
                         if (mesh_rec_push(p, e, step, i, ncand, x0, v)) p.cand_mark[po + eb + i] = step + 1;
                     } else {
                         const int slot = atomicAdd(p.mesh_cnt + step, 1);

@@ -551,7 +551,7 @@ class BatchedRollout:
         per_v = torch.where((self._static_mesh_of < G)[None, :, None], per_v, torch.zeros_like(per_v))   # ... identity for meshes without a grid
         ca, sa = torch.cos(per_v[..., 3]), torch.sin(per_v[..., 3])
         d = self._static_v0[None] - self._static_c0
-        v_new = torch.stack([ca * d[..., 0] - sa * d[..., 1], sa * d[..., 0] + ca * d[..., 1], d[..., 2]], -1) + self._static_c0
+        v_new = torch.stack([ca * d[..., 0] - sa * d[..., 1], sa * d[..., 0] + ca * d[..., 1], d[..., 2].expand_as(ca)], -1) + self._static_c0
         v_new = v_new + torch.cat([per_v[..., :2], torch.zeros_like(per_v[..., :1])], -1)
         m = mask.to(dev).bool().reshape(E)
         self.phys.set_static_mesh_points(v_new, m)

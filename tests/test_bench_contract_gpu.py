@@ -28,7 +28,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "env-steps/s" and isinstance(c["sample"], str) and c["value"] > 0
     assert abs(d["value"] - d["config"]["envs_per_gpu"] * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
-    assert set(d["phases"]) >= {"free", "contact", "note"} and d["phases"]["free"]["steps"] == 2
+    assert set(d["phases"]) >= {"free", "contact", "note"} and d["phases"]["free"]["steps"] >= 1
     for k in ("traffic_source", "hbm_actual_frac", "valu_busy_frac", "algorithmic_bytes_per_launch", "avg_launch_us", "frac_shared_topology",
               "traffic_over_shared", "bound_in_practice"):
         assert k in r, k
@@ -42,15 +42,18 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 
 def test_headline_schedule_contains_free_motion_finger_contact_and_live_self_collision():
     """the timed window of the headline workload must not be a contact-free best case.  A 2-env cut of
-    configs[2] (same object, same 667 substeps, same action trace): the first half of the window is free motion, the second
-    half has particles inside the fingers' collision margin, live self-collision candidates (the toy's arms pressed
-    together) and the graph flavour with the self-collision variant of the fused kernel plus k_contact_finish."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--envs", "2", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"],
+    configs[2] (same object, same 667 substeps, same action trace): the window starts in free motion; from the second step of the
+    closing ramp (round 6: the commanded opening falls by 0.1 per step from six steps before the window's middle, so that the grasp
+    latches from the stepper's own forces inside the window) particles are inside the fingers' collision margin, then live
+    self-collision candidates (the toy's arms pressed together) and the graph flavour with the self-collision variant of the fused
+    kernel plus the finishing code, and the grasp state machine latches: the window's last steps are the held grasp."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--envs", "2", "--steps", "16", "--warmup", "2", "--no-cpu-baseline", "--episodes", "0"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][-1])
     free, contact = d["phases"]["free"], d["phases"]["contact"]
-    assert free["steps"] == 4 and contact["steps"] == 4
+    assert free["steps"] == 3 and contact["steps"] == 13            # the ramp starts at timed step 16 / 2 - 6 = 2, the pads arrive one step later
+    assert contact["grasped_envs"] == 2, contact                    # ... and the grasp latches from the stepper's own forces (VERDICT r5 item 2)
     assert free["mesh_contacts"] == 0 and free["self_collision_candidates"] == 0
     assert contact["mesh_contacts"] > 0 and contact["self_collision_candidates"] > 0, contact
     # SELF=true + finishing code (round 5: at the head of the next substep's launch, k_substep_pf; before: k_contact_finish as a launch of its own)

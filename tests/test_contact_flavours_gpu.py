@@ -248,6 +248,7 @@ def test_bench_scene_one_env_20_substeps_in_the_grasp_vs_oracle_driven_through_e
     from oracle import parity_gate
 
     monkeypatch.setenv("R2S_RES_SELF_SRV", servers)
+    monkeypatch.setenv("R2S_RES_SRV_LOW", "100")     # (round 6: a launch that claimed 30 % of its units sends the next step to the per-substep kernels; this test pins the resident path)
     r = parity_gate.run("sloth_32env", num_substeps=667, n_compare=20, close_at=2)
     record(f"bench scene (sloth_arms, grasp), 20 substeps in contact, R2S_RES_SELF_SRV={servers}", **{k: v for k, v in r.items() if isinstance(v, (int, float)) and not isinstance(v, bool)}, tol=1e-5)
     assert r["mesh_contact"] and r["particles_with_candidates"] > 0, r
