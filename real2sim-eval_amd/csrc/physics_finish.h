@@ -265,16 +265,19 @@ struct __attribute__((aligned(16))) BatchWave {
     unsigned long long key[FB_PW];        // best (distance^2 bits, face) so far
     float cp[FB_PW][4];                   // its closest point; [3] bits: region of the closest feature | side of the face's plane << 8 (1: behind it)
     int meta[FB_PW][4];                   // mesh_map, face_map, mesh of that face
-    unsigned count[4];                    // [0] entries of the queue
+    float st[FB_PW][20];                  // a particle's state between the phases of its substep (the sixteen lanes of a particle hold the same values: parked here,
+                                          // not in sixteen copies of registers — the finishing role's registers are what the merged launch spills)
+    float lb[FB_NJ][64];                  // this lane's lower bounds (distance^2 to the boxes of triangles sl, sl + 16, ...) of the first query
     unsigned short queue[FB_PW * FB_MAX_F]; // surviving (particle << 8 | face) pairs
 };
 struct __attribute__((aligned(16))) BatchShare {
     float4 tri[FB_MAX_F][3];              // {a.x a.y a.z b.x} {b.y b.z c.x c.y} {c.z, bits(mesh_map), bits(face_map), bits(mesh)} of the substep's triangles
-    float4 tbox[FB_MAX_F][2];             // their boxes {lo.x lo.y lo.z hi.x} {hi.y hi.z - -}
-    float box[FB_MAX_MESH][8];            // the substep's world box of mesh m [0..5]; [6] bits: 1 = not a closed manifold, 2 = closed but oriented inward
+    float tbox[FB_MAX_F][6];              // their boxes lo.xyz hi.xyz
+    float4 box[FB_MAX_MESH][2];           // the substep's world box of mesh m {lo.x lo.y lo.z hi.x} {hi.y hi.z, flags, -}; flags bits: 1 = not a closed manifold, 2 = closed but oriented inward
     float eef[12];                        // interp_center, dyn_omega, dyn_vel[0], dyn_vel[1] of the environment
     BatchWave w[4];
 };
+static_assert(sizeof(BatchShare) <= sizeof(v2f) * 3 * (1024 + 1), "the batched finishers share the fused role's LDS window in k_substep_pf");
 
 template <int O> __device__ __forceinline__ unsigned fb_xor_u32(unsigned v) // lane ^ O, O < 16
 {
@@ -342,12 +345,19 @@ __device__ __forceinline__ f3 self_impulse_pre(const PhysDev& p, size_t po, size
 {
     float valid = 0.f;
     f3 Jsum = mk(0.f, 0.f, 0.f);
-    if (q.on) imp_term(p, x0, v, q.m1, q.mask1, xyz(q.x2), xyz(q.v2), q.m2, q.mask2, valid, Jsum);
-    if (tagged)
-        for (int k = sl + 16; k < cnt; k += 16) { // (more than 16 candidates: rare)
+    bool have = q.on;
+    f3 x2 = xyz(q.x2), v2 = xyz(q.v2);
+    float m2 = q.m2;
+    int mask2 = q.mask2;
+    for (int k = sl; __builtin_amdgcn_ballot_w64(have) != 0ull;) { // one copy of the impulse arithmetic: the first trip on the prefetched partner, further trips (more than 16 candidates: rare) load theirs
+        if (have) imp_term(p, x0, v, q.m1, q.mask1, x2, v2, m2, mask2, valid, Jsum);
+        k += 16;
+        have = tagged && k < cnt;
+        if (have) {
             const int j = p.coll_idx[(eb + i) * (size_t)p.coll_cap + k];
-            imp_term(p, x0, v, q.m1, q.mask1, xyz(p.xbc[po + eb + j]), xyz(p.vbc[po + eb + j]), p.masses[j], p.masks[j], valid, Jsum);
+            x2 = xyz(p.xbc[po + eb + j]); v2 = xyz(p.vbc[po + eb + j]); m2 = p.masses[j]; mask2 = p.masks[j];
         }
+    }
     valid += fb_xor_f32<8>(valid); Jsum.x += fb_xor_f32<8>(Jsum.x); Jsum.y += fb_xor_f32<8>(Jsum.y); Jsum.z += fb_xor_f32<8>(Jsum.z);
     valid += fb_xor_f32<4>(valid); Jsum.x += fb_xor_f32<4>(Jsum.x); Jsum.y += fb_xor_f32<4>(Jsum.y); Jsum.z += fb_xor_f32<4>(Jsum.z);
     valid += fb_xor_f32<2>(valid); Jsum.x += fb_xor_f32<2>(Jsum.x); Jsum.y += fb_xor_f32<2>(Jsum.y); Jsum.z += fb_xor_f32<2>(Jsum.z);
@@ -359,10 +369,11 @@ __device__ __forceinline__ f3 self_impulse_pre(const PhysDev& p, size_t po, size
 __device__ __forceinline__ unsigned fb_wn_mask(const PhysDev& p, const BatchShare& sh, f3 q)
 {
     unsigned m = 0u;
-    for (int k = 0; k < p.n_mesh; ++k) {
-        const float* bb = sh.box[k];
-        const bool in = q.x >= bb[0] && q.x <= bb[3] && q.y >= bb[1] && q.y <= bb[4] && q.z >= bb[2] && q.z <= bb[5];
-        if (in || (__float_as_int(bb[6]) & 1) != 0) m |= 1u << k;
+#pragma unroll 1
+    for (int k = 0; k < p.n_mesh; ++k) { // (a loop on purpose: unrolled, the compiler reads every box ahead — 16 more registers per mesh)
+        const float4 b0 = sh.box[k][0], b1 = sh.box[k][1];
+        const bool in = q.x >= b0.x && q.x <= b0.w && q.y >= b0.y && q.y <= b1.x && q.z >= b0.z && q.z <= b1.y;
+        if (in || (__float_as_int(b1.z) & 1) != 0) m |= 1u << k;
     }
     return m;
 }
@@ -438,7 +449,7 @@ struct BProbe { int row, n; bool on; };
 // that close to the new point was within d1 + 2 delta of the old one: the pairs whose FIRST bound is <= `thr` = (d1 + 2 delta)^2 (widened)
 // are the only ones that can win; `lb` still holds those bounds.
 template <bool REQ>
-__device__ __forceinline__ MeshHit batch_query(const PhysDev& p, BatchShare& sh, BatchWave& w, f3 q, bool want, float (&lb)[FB_NJ], float thr_req, float& d2_out R2S_BP_PARAM)
+__device__ __forceinline__ MeshHit batch_query(const PhysDev& p, BatchShare& sh, BatchWave& w, f3 q, bool want, float thr_req, float& d2_out R2S_BP_PARAM)
 {
     const int lane = (int)(threadIdx.x & 63);
     const int sl = lane & (FB_SL - 1), pi = lane / FB_SL;
@@ -453,20 +464,13 @@ __device__ __forceinline__ MeshHit batch_query(const PhysDev& p, BatchShare& sh,
     if (!REQ) {
         // 1. lower bounds: this lane's triangles sl, sl + 16, ...
         float minlb = 3.0e38f;
-#pragma unroll
-        for (int j = 0; j < FB_NJ; ++j) {
-            lb[j] = 3.0e38f;
-            if (j * FB_SL < nF) { // wave-uniform
-                const int f = sl + j * FB_SL;
-                const int fc = f < nF ? f : nF - 1;
-                const float4 b0 = sh.tbox[fc][0], b1 = sh.tbox[fc][1];
-                const float dx = fmaxf(fmaxf(b0.x - q.x, q.x - b0.w), 0.f), dy = fmaxf(fmaxf(b0.y - q.y, q.y - b1.x), 0.f), dz = fmaxf(fmaxf(b0.z - q.z, q.z - b1.y), 0.f);
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                if (want && f < nF) {
-                    lb[j] = d2;
-                    if (d2 < MAXD2 * 1.0001f + 1e-12f && d2 < minlb) { minlb = d2; minf = f; } // (a triangle whose box is beyond max_dist cannot answer)
-                }
-            }
+        for (int j = 0; j * FB_SL < nF; ++j) { // wave-uniform
+            const int f = sl + j * FB_SL;
+            const float* tb = sh.tbox[f < nF ? f : nF - 1];
+            const float dx = fmaxf(fmaxf(tb[0] - q.x, q.x - tb[3]), 0.f), dy = fmaxf(fmaxf(tb[1] - q.y, q.y - tb[4]), 0.f), dz = fmaxf(fmaxf(tb[2] - q.z, q.z - tb[5]), 0.f);
+            const float d2 = (want && f < nF) ? dx * dx + dy * dy + dz * dz : 3.0e38f;
+            w.lb[j][lane] = d2;
+            if (d2 < MAXD2 * 1.0001f + 1e-12f && d2 < minlb) { minlb = d2; minf = f; } // (a triangle whose box is beyond max_dist cannot answer)
         }
         R2S_BP_STAMP(); // bounds done
         // 2. the exact distance of each lane's most promising triangle; the best of the particle's lanes is an upper bound of the answer
@@ -489,27 +493,18 @@ __device__ __forceinline__ MeshHit batch_query(const PhysDev& p, BatchShare& sh,
         R2S_BP_STAMP(); R2S_BP_STAMP();
     }
     // 3. the pairs that can still win (usually none behind step 2), packed; 64 at a time
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < FB_NJ; ++j)
-        if (j * FB_SL < nF) any = any || (want && lb[j] <= thr && sl + j * FB_SL != minf);
     int base = 0;
-    if (__builtin_amdgcn_ballot_w64(any) != 0ull) { // wave-uniform
-#pragma unroll
-        for (int j = 0; j < FB_NJ; ++j) {
-            if (j * FB_SL < nF) {
-                const int f = sl + j * FB_SL;
-                const bool surv = want && lb[j] <= thr && f != minf;
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(surv);
-                if (m != 0ull) {
-                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (surv) w.queue[base + rank] = (unsigned short)((pi << 8) | f);
-                    base += __builtin_popcountll(m);
-                }
-            }
+    for (int j = 0; j * FB_SL < nF; ++j) { // (a loop on purpose: unrolled, with the eight bounds read ahead, the kernel needs 167 instead of 122 VGPRs)
+        const int f = sl + j * FB_SL;
+        const bool surv = want && w.lb[j][lane] <= thr && f != minf;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(surv);
+        if (m != 0ull) {
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (surv) w.queue[base + rank] = (unsigned short)((pi << 8) | f);
+            base += __builtin_popcountll(m);
         }
-        fb_wave_sync();
     }
+    fb_wave_sync();
     R2S_BP_STAMP(); // survivors packed
     R2S_BP_VALUE(base);
     for (int it = 0; it < base; it += 64) { // wave-uniform
@@ -543,7 +538,7 @@ __device__ __forceinline__ MeshHit batch_query(const PhysDev& p, BatchShare& sh,
     // sign (see the header): which meshes can contribute at all?
     const unsigned wmask = found ? fb_wn_mask(p, sh, q) : 0u;
     const int mstar = mt.z, rg = __float_as_int(bc.w);
-    const bool simple = found && (rg & 255) == 0 && __float_as_int(sh.box[found ? mstar : 0][6]) == 0;
+    const bool simple = found && (rg & 255) == 0 && __float_as_int(sh.box[found ? mstar : 0][1].z) == 0;
     const unsigned gmask = !found ? 0u : simple ? (wmask & ~(1u << mstar)) : wmask;
     float sign = (simple && gmask == 0u && ((wmask >> mstar) & 1u) != 0u && (rg & 256) != 0) ? -1.f : 1.f;
     const unsigned long long gen = __builtin_amdgcn_ballot_w64(gmask != 0u);
@@ -621,15 +616,14 @@ __device__ __forceinline__ void contact_finish_batch(const PhysDev& p, const Sta
             sh.tri[tid][0] = make_float4(a.x, a.y, a.z, b.x);
             sh.tri[tid][1] = make_float4(b.y, b.z, c.x, c.y);
             sh.tri[tid][2] = make_float4(c.z, __int_as_float(mm), __int_as_float(fm), __int_as_float(m));
-            sh.tbox[tid][0] = make_float4(fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)), fmaxf(a.x, fmaxf(b.x, c.x)));
-            sh.tbox[tid][1] = make_float4(fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)), 0.f, 0.f);
+            sh.tbox[tid][0] = fminf(a.x, fminf(b.x, c.x)); sh.tbox[tid][1] = fminf(a.y, fminf(b.y, c.y)); sh.tbox[tid][2] = fminf(a.z, fminf(b.z, c.z));
+            sh.tbox[tid][3] = fmaxf(a.x, fmaxf(b.x, c.x)); sh.tbox[tid][4] = fmaxf(a.y, fmaxf(b.y, c.y)); sh.tbox[tid][5] = fmaxf(a.z, fmaxf(b.z, c.z));
         } else if (tid >= 128 && tid < 128 + p.n_mesh) {
             const int m = tid - 128;
             const float* bb = m < p.n_dyn_mesh ? p.aabb_dyn + (((size_t)e * p.n_sub + step) * p.n_dyn_mesh + m) * 6
                                                : p.aabb_static + ((size_t)e * (p.n_mesh - p.n_dyn_mesh) + (m - p.n_dyn_mesh)) * 6;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) sh.box[m][k] = bb[k];
-            sh.box[m][6] = __int_as_float(((p.mesh_kind[m] & 2) ? 1 : 0) | (p.mesh_inward[m] ? 2 : 0));
+            sh.box[m][0] = make_float4(bb[0], bb[1], bb[2], bb[3]);
+            sh.box[m][1] = make_float4(bb[4], bb[5], __int_as_float(((p.mesh_kind[m] & 2) ? 1 : 0) | (p.mesh_inward[m] ? 2 : 0)), 0.f);
         } else if (tid >= 192 && tid < 204) {
             const int k = tid - 192;
             sh.eef[k] = k < 3 ? p.interp_center[((size_t)e * p.n_sub + step) * 3 + k] : k < 6 ? p.dyn_omega[(size_t)e * 3 + (k - 3)] : p.dyn_vel[(size_t)e * 6 + (k - 6)];
@@ -645,92 +639,114 @@ __device__ __forceinline__ void contact_finish_batch(const PhysDev& p, const Sta
                 if (WITH_SELF) { imp_pre1(p, eb, ra.y & 0x7fffffff, act && ra.y < 0, sl, ra.x & 0x7ffff, ip); imp_pre2(p, po, eb, ip); }
             }
             const bool tagged = act && ra.y < 0;
-            const int i = act ? (ra.y & 0x7fffffff) : 0, cnt = ra.x & 0x7ffff;
-            const f3 x0 = mk(__int_as_float(ra.z), __int_as_float(ra.w), __int_as_float(rc.x));
-            f3 v = mk(__int_as_float(rc.y), __int_as_float(rc.z), __int_as_float(rc.w));
-            if (WITH_SELF && __builtin_amdgcn_ballot_w64(tagged) != 0ull) v = self_impulse_pre(p, po, eb, i, tagged, x0, v, sl, cnt, ip);
+            float* st = w.st[pi]; // the particle's parked state: [0..2] x0, [3..5] v, [6] i | [7..9] next_x, [10..12] next_v, [13..15] per-face force, [16] margin, [17] flags, [18] face_map
+            {
+                const int i = act ? (ra.y & 0x7fffffff) : 0, cnt = ra.x & 0x7ffff;
+                const f3 x0 = mk(__int_as_float(ra.z), __int_as_float(ra.w), __int_as_float(rc.x));
+                f3 v = mk(__int_as_float(rc.y), __int_as_float(rc.z), __int_as_float(rc.w));
+                if (WITH_SELF && __builtin_amdgcn_ballot_w64(tagged) != 0ull) v = self_impulse_pre(p, po, eb, i, tagged, x0, v, sl, cnt, ip);
+                if (sl == 0) { st[0] = x0.x; st[1] = x0.y; st[2] = x0.z; st[3] = v.x; st[4] = v.y; st[5] = v.z; st[6] = __int_as_float(i); }
+            }
+            fb_wave_sync();
             R2S_BSTAMP(); // record + impulses done
             // mesh_collision (:295-421) — the arithmetic of finish_wave, expression for expression
-            f3 vin = v;
-            f3 next_x = x0 + vin * p.dt;
-            f3 next_v = vin;
-            float lb[FB_NJ], d2_1, d2_2;
-            const f3 q1x = next_x;
-            const MeshHit q = batch_query<false>(p, sh, w, next_x, act, lb, 0.f, d2_1 R2S_BP_ARG);
+            float d2_1, d2_2;
+            MeshHit q;
+            {
+                const f3 x0 = mk(st[0], st[1], st[2]), vin = mk(st[3], st[4], st[5]);
+                q = batch_query<false>(p, sh, w, x0 + vin * p.dt, act, 0.f, d2_1 R2S_BP_ARG);
+            }
             R2S_BSTAMP(); // first query back
-            bool requery = false, hit = false;
-            f3 normal = mk(0.f, 0.f, 0.f), v_normal = mk(0.f, 0.f, 0.f), v_normal_new = mk(0.f, 0.f, 0.f);
-            float margin = 0.f;
-            int qface_fm = q.fm;
-            if (q.result) {
-                int is_gripper;
-                const int mm = q.mm;
-                if (!p.use_pusher) is_gripper = mm == 0 ? 1 : (mm == 1 ? 2 : 0);
-                else is_gripper = mm >= 0 ? 1 : 0;
-                f3 delta = next_x - q.pt;
-                float dist = len(delta) * q.sign;
-                margin = (is_gripper >= 1 && !p.use_pusher) ? 0.005f : 0.001f;
-                float err = dist - margin;
-                if (err < 0.f) {
-                    hit = true;
-                    normal = normalize0(delta) * q.sign;
-                    f3 rdv = mk(0.f, 0.f, 0.f);
-                    float ce, cf;
-                    if (is_gripper >= 1) {
-                        const f3 ctr = mk(sh.eef[0], sh.eef[1], sh.eef[2]);
-                        const f3 om = mk(sh.eef[3], sh.eef[4], sh.eef[5]);
-                        const f3 dv = is_gripper == 1 ? mk(sh.eef[6], sh.eef[7], sh.eef[8]) : mk(sh.eef[9], sh.eef[10], sh.eef[11]);
-                        rdv = dv + cross(om, x0 - ctr);
-                        vin = vin - rdv;
-                        ce = p.cee; cf = p.cef;
-                    } else {
-                        ce = p.ce; cf = p.cf;
-                    }
-                    v_normal = normal * dot(vin, normal);
-                    const f3 v_tao = vin - v_normal;
-                    const float vnl = len(v_normal);
-                    const float vtl = fmaxf(len(v_tao), 1e-6f);
-                    v_normal_new = v_normal * (-ce);
-                    const float a = fmaxf(0.f, 1.f - cf * (1.f + ce) * vnl / vtl);
-                    next_v = v_normal_new + v_tao * a;
-                    if (is_gripper >= 1) {
-                        next_v = next_v + rdv;
-                        next_x = x0 + next_v * p.dt;
-                        requery = true; // the reference rebinds `query` (:397)
-                    } else {
-                        next_x = next_x - normal * err;
-                    }
-                }
-            }
-            // the re-query's point is `delta` from the first one's: see batch_query<true> (bounds widened for the rounding of delta and of the square root)
-            const float delta = len(next_x - q1x) * 1.0001f + 1e-9f;
-            const float reach = sqrtf(d2_1) * 1.0001f + 2.f * delta;
-            const MeshHit q2 = batch_query<true>(p, sh, w, next_x, requery, lb, reach * reach * 1.0001f + 1e-12f, d2_2 R2S_BP_ARG);
-            R2S_BSTAMP(); // response + second query back
-            if (requery) {
-                if (q2.result) {
-                    const f3 delta = next_x - q2.pt;
-                    const float dist = len(delta) * q2.sign;
-                    const float err = dist - margin;
+            bool requery = false;
+            float thr2 = 0.f;
+            f3 next_x;
+            {
+                const f3 x0 = mk(st[0], st[1], st[2]);
+                f3 vin = mk(st[3], st[4], st[5]);
+                next_x = x0 + vin * p.dt;
+                const f3 q1x = next_x;
+                f3 next_v = vin;
+                bool hit = false;
+                f3 normal = mk(0.f, 0.f, 0.f), v_normal = mk(0.f, 0.f, 0.f), v_normal_new = mk(0.f, 0.f, 0.f);
+                float margin = 0.f;
+                if (q.result) {
+                    int is_gripper;
+                    const int mm = q.mm;
+                    if (!p.use_pusher) is_gripper = mm == 0 ? 1 : (mm == 1 ? 2 : 0);
+                    else is_gripper = mm >= 0 ? 1 : 0;
+                    f3 delta = next_x - q.pt;
+                    float dist = len(delta) * q.sign;
+                    margin = (is_gripper >= 1 && !p.use_pusher) ? 0.005f : 0.001f;
+                    float err = dist - margin;
                     if (err < 0.f) {
-                        normal = normalize0(delta) * q2.sign;
-                        next_x = next_x - normal * err;
+                        hit = true;
+                        normal = normalize0(delta) * q.sign;
+                        f3 rdv = mk(0.f, 0.f, 0.f);
+                        float ce, cf;
+                        if (is_gripper >= 1) {
+                            const f3 ctr = mk(sh.eef[0], sh.eef[1], sh.eef[2]);
+                            const f3 om = mk(sh.eef[3], sh.eef[4], sh.eef[5]);
+                            const f3 dv = is_gripper == 1 ? mk(sh.eef[6], sh.eef[7], sh.eef[8]) : mk(sh.eef[9], sh.eef[10], sh.eef[11]);
+                            rdv = dv + cross(om, x0 - ctr);
+                            vin = vin - rdv;
+                            ce = p.cee; cf = p.cef;
+                        } else {
+                            ce = p.ce; cf = p.cf;
+                        }
+                        v_normal = normal * dot(vin, normal);
+                        const f3 v_tao = vin - v_normal;
+                        const float vnl = len(v_normal);
+                        const float vtl = fmaxf(len(v_tao), 1e-6f);
+                        v_normal_new = v_normal * (-ce);
+                        const float a = fmaxf(0.f, 1.f - cf * (1.f + ce) * vnl / vtl);
+                        next_v = v_normal_new + v_tao * a;
+                        if (is_gripper >= 1) {
+                            next_v = next_v + rdv;
+                            next_x = x0 + next_v * p.dt;
+                            requery = true; // the reference rebinds `query` (:397)
+                        } else {
+                            next_x = next_x - normal * err;
+                        }
                     }
                 }
-                qface_fm = q2.fm; // face of the LAST query (0 if the re-query missed)
+                // the re-query's point is `delta` from the first one's: see batch_query<true> (bounds widened for the rounding of delta and of the square root)
+                const float dq = len(next_x - q1x) * 1.0001f + 1e-9f;
+                const float reach = sqrtf(d2_1) * 1.0001f + 2.f * dq;
+                thr2 = reach * reach * 1.0001f + 1e-12f;
+                if (sl == 0) {
+                    const f3 fo = (v_normal_new - v_normal) / p.dt;
+                    st[7] = next_x.x; st[8] = next_x.y; st[9] = next_x.z; st[10] = next_v.x; st[11] = next_v.y; st[12] = next_v.z;
+                    st[13] = fo.x; st[14] = fo.y; st[15] = fo.z; st[16] = margin; st[17] = __int_as_float((hit ? 1 : 0) | (requery ? 2 : 0)); st[18] = __int_as_float(q.fm);
+                }
             }
-            const bool store = act && sl == 0;
-            if (hit && write_forces && store) {
-                const f3 fo = (v_normal_new - v_normal) / p.dt;
-                float* cf3 = p.coll_forces + ((size_t)e * p.nF + qface_fm) * 3;
-                atomicAdd(cf3, fo.x);
-                atomicAdd(cf3 + 1, fo.y);
-                atomicAdd(cf3 + 2, fo.z);
-                atomicAdd(p.hit_cnt + e, 1);
-            }
-            // integrate_ground_collision, :424-474
-            if (store) {
-                const f3 x = next_x, vv = next_v;
+            fb_wave_sync();
+            const MeshHit q2 = batch_query<true>(p, sh, w, next_x, requery, thr2, d2_2 R2S_BP_ARG);
+            R2S_BSTAMP(); // response + second query back
+            if (act && sl == 0) { // the particle's storing lane
+                f3 x = mk(st[7], st[8], st[9]);
+                const f3 vv = mk(st[10], st[11], st[12]);
+                const int flags = __float_as_int(st[17]);
+                int qface_fm = __float_as_int(st[18]);
+                if (flags & 2) {
+                    if (q2.result) {
+                        const f3 delta = x - q2.pt;
+                        const float dist = len(delta) * q2.sign;
+                        const float err = dist - st[16];
+                        if (err < 0.f) {
+                            const f3 normal = normalize0(delta) * q2.sign;
+                            x = x - normal * err;
+                        }
+                    }
+                    qface_fm = q2.fm; // face of the LAST query (0 if the re-query missed)
+                }
+                if ((flags & 1) && write_forces) {
+                    float* cf3 = p.coll_forces + ((size_t)e * p.nF + qface_fm) * 3;
+                    atomicAdd(cf3, st[13]);
+                    atomicAdd(cf3 + 1, st[14]);
+                    atomicAdd(cf3 + 2, st[15]);
+                    atomicAdd(p.hit_cnt + e, 1);
+                }
+                // integrate_ground_collision, :424-474
                 const f3 gn = mk(0.f, 0.f, 1.f) * p.rf;
                 const float x_z = x.z, v_z = vv.z;
                 const float next_x_z = (x_z + v_z * p.dt) * p.rf;
@@ -750,9 +766,11 @@ __device__ __forceinline__ void contact_finish_batch(const PhysDev& p, const Sta
                     toi = 0.f;
                 }
                 const f3 xn = x + vv * toi + v1 * (p.dt - toi);
+                const int i = __float_as_int(st[6]);
                 if (PFOUT) pf_store(p, eb + (size_t)i, xn, v1, (unsigned)step + 1u);
                 else st_store(xv_out, eb + i, xn, v1);
             }
+            fb_wave_sync();
             R2S_BSTAMP(); // stored
         }
     }
@@ -762,6 +780,7 @@ __device__ __forceinline__ void contact_finish_batch(const PhysDev& p, const Sta
 #endif
 #undef R2S_BSTAMP
 #undef probe_n
+#ifndef R2S_FB_NO_PART2
     if (WITH_SELF) {
 #ifdef R2S_PHASE_PROBE
         finish_candidates<1, PFOUT>(p, xv_out, step, write_forces, L, n_wg, 256, po, lane, wave, probe_entry);
@@ -769,6 +788,7 @@ __device__ __forceinline__ void contact_finish_batch(const PhysDev& p, const Sta
         finish_candidates<1, PFOUT>(p, xv_out, step, write_forces, L, n_wg, 256, po, lane, wave, 0);
 #endif
     }
+#endif
 }
 
 template <bool WITH_SELF>
@@ -803,10 +823,13 @@ __global__ void __launch_bounds__(256) k_contact_finish(const PhysDev p, const S
 // MESHQ 4 (round 6): the batched small-scene finishers (contact_finish_batch) — all four wavefronts of a finishing workgroup work, and the
 // two roles share ONE LDS allocation (the window of the fused role is the larger one).
 #ifndef R2S_PF_WAVES4
-#define R2S_PF_WAVES4 4
+#define R2S_PF_WAVES4 4          // with candidates: the finishing role needs ~125 VGPRs; held to 96 (five wavefronts per SIMD) it spills 17 dwords and the held grasp runs 35.5 instead of 31.0 us per batched substep
+#endif
+#ifndef R2S_PF_WAVES4_NOSELF
+#define R2S_PF_WAVES4_NOSELF 5   // without candidates it fits 96 without a spill: five (a hovering gripper: 19.5 instead of 20.6 us per batched substep)
 #endif
 template <int B, int RCAP, bool SELF, int MESH, int MESHQ>
-__global__ void __launch_bounds__(B, (MESHQ == 3 ? (SELF ? R2S_PF_WAVES3 : R2S_PF_WAVES3_NOSELF) : MESHQ == 4 ? R2S_PF_WAVES4 : 1)) k_substep_pf(const PhysDev p, const StateC xv_in, const StateM xv_out, int step, int write_forces, int fin_skip)
+__global__ void __launch_bounds__(B, (MESHQ == 3 ? (SELF ? R2S_PF_WAVES3 : R2S_PF_WAVES3_NOSELF) : MESHQ == 4 ? (SELF ? R2S_PF_WAVES4 : R2S_PF_WAVES4_NOSELF) : 1)) k_substep_pf(const PhysDev p, const StateC xv_in, const StateM xv_out, int step, int write_forces, int fin_skip)
 {
     if constexpr (MESHQ == 4) {
         static_assert(B == 256, "the batched finishers are 256-thread workgroups");
