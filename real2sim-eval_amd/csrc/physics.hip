@@ -521,10 +521,13 @@ void launch_fused(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_
 }
 
 // batched small-scene finishing: workgroups per environment.  Part 1 takes the records 16 at a time from the first slot on (8 slots = 128 listed
-// particles per environment without a second round), part 2 the candidate particles 16 to a workgroup from the last slot back
+// particles per environment without a second round), part 2 the candidate particles 16 to a workgroup from the last slot back.  With candidates
+// 32: at 16 the two parts met in the middle slots of the environments with the most contacts (~100 listed + ~140 candidate particles), those
+// workgroups ran part 2 behind part 1 and the blocks waiting for them ended the launch 3 us later — 30.4 / 28.2 / 28.4 / 27.6 us per batched
+// substep of the held grasp with 16 / 20 / 24 / 32 slots (hovering: 19.3 / 19.4 / 19.5 / 19.7).
 int fin_batch_slots(bool with_self)
 {
-    int n = with_self ? 16 : 8;
+    int n = with_self ? 32 : 8;
     if (const char* ev = getenv("R2S_FIN_SLOTS")) n = std::max(1, atoi(ev));
     return n;
 }

@@ -449,7 +449,7 @@ struct BProbe { int row, n; bool on; };
 // that close to the new point was within d1 + 2 delta of the old one: the pairs whose FIRST bound is <= `thr` = (d1 + 2 delta)^2 (widened)
 // are the only ones that can win; `lb` still holds those bounds.
 template <bool REQ>
-__device__ __forceinline__ MeshHit batch_query(const PhysDev& p, BatchShare& sh, BatchWave& w, f3 q, bool want, float thr_req, float& d2_out R2S_BP_PARAM)
+__device__ __forceinline__ MeshHit batch_query(const PhysDev& p, BatchShare& sh, BatchWave& w, f3 q, bool want, float thr_req, float& d2_out, float (&lm)[3] R2S_BP_PARAM)
 {
     const int lane = (int)(threadIdx.x & 63);
     const int sl = lane & (FB_SL - 1), pi = lane / FB_SL;
@@ -461,23 +461,28 @@ __device__ __forceinline__ MeshHit batch_query(const PhysDev& p, BatchShare& sh,
     if (sl == 0) *(float4*)w.q[pi] = make_float4(q.x, q.y, q.z, 0.f);
     float thr = thr_req;
     int minf = -1;
+    bool rest = true; // some lane may hold a second pair that can still win: the packed path below
+    f3 cp = mk(0.f, 0.f, 0.f);
+    int region = 0;
+    int4 meta = make_int4(0, 0, 0, 0);
+    unsigned long long key = ~0ull;
     if (!REQ) {
-        // 1. lower bounds: this lane's triangles sl, sl + 16, ...
-        float minlb = 3.0e38f;
+        // 1. lower bounds: this lane's triangles sl, sl + 16, ...; the smallest (its triangle: minf) and the second smallest are kept
+        float minlb = 3.0e38f, min2 = 3.0e38f;
+#pragma unroll 2
         for (int j = 0; j * FB_SL < nF; ++j) { // wave-uniform
             const int f = sl + j * FB_SL;
             const float* tb = sh.tbox[f < nF ? f : nF - 1];
             const float dx = fmaxf(fmaxf(tb[0] - q.x, q.x - tb[3]), 0.f), dy = fmaxf(fmaxf(tb[1] - q.y, q.y - tb[4]), 0.f), dz = fmaxf(fmaxf(tb[2] - q.z, q.z - tb[5]), 0.f);
             const float d2 = (want && f < nF) ? dx * dx + dy * dy + dz * dz : 3.0e38f;
             w.lb[j][lane] = d2;
-            if (d2 < MAXD2 * 1.0001f + 1e-12f && d2 < minlb) { minlb = d2; minf = f; } // (a triangle whose box is beyond max_dist cannot answer)
+            if (d2 < minlb) { min2 = minlb; minlb = d2; minf = f; }
+            else min2 = fminf(min2, d2);
         }
+        lm[0] = minlb; lm[1] = __int_as_float(minf); lm[2] = min2;
+        if (!(minlb < MAXD2 * 1.0001f + 1e-12f)) minf = -1; // (a triangle whose box is beyond max_dist cannot answer)
         R2S_BP_STAMP(); // bounds done
         // 2. the exact distance of each lane's most promising triangle; the best of the particle's lanes is an upper bound of the answer
-        f3 cp = mk(0.f, 0.f, 0.f);
-        int region = 0;
-        int4 meta = make_int4(0, 0, 0, 0);
-        unsigned long long key = ~0ull;
         if (__builtin_amdgcn_ballot_w64(minf >= 0) != 0ull) {
             const unsigned long long k = fb_eval(sh, minf >= 0 ? minf : 0, q, cp, region, meta);
             if (minf >= 0) key = k;
@@ -487,13 +492,28 @@ __device__ __forceinline__ MeshHit batch_query(const PhysDev& p, BatchShare& sh,
         if (key == mn && mn != ~0ull) { *(float4*)w.cp[pi] = make_float4(cp.x, cp.y, cp.z, __int_as_float(region)); *(int4*)w.meta[pi] = meta; }
         const float ub = mn != ~0ull ? __uint_as_float((unsigned)(mn >> 32)) : MAXD2;
         thr = ub * 1.0001f + 1e-12f;
+        rest = __builtin_amdgcn_ballot_w64(want && lm[2] <= thr) != 0ull; // no lane's SECOND bound is in reach: nothing behind step 2 (the common case)
         R2S_BP_STAMP(); // upper bound known
     } else {
-        if (sl == 0) w.key[pi] = ~0ull;
-        R2S_BP_STAMP(); R2S_BP_STAMP();
+        R2S_BP_STAMP();
+        rest = __builtin_amdgcn_ballot_w64(want && lm[2] <= thr) != 0ull;
+        if (!rest) {
+            // the common case of the re-query: no lane holds more than ONE pair in reach, its first query's nearest box — one evaluation per
+            // lane and the row minimum, no packing
+            minf = (want && lm[0] <= thr) ? __float_as_int(lm[1]) : -1;
+            if (__builtin_amdgcn_ballot_w64(minf >= 0) != 0ull) {
+                const unsigned long long k = fb_eval(sh, minf >= 0 ? minf : 0, q, cp, region, meta);
+                if (minf >= 0) key = k;
+            }
+            const unsigned long long mn = fb_row_min_u64(key);
+            if (sl == 0) w.key[pi] = mn;
+            if (key == mn && mn != ~0ull) { *(float4*)w.cp[pi] = make_float4(cp.x, cp.y, cp.z, __int_as_float(region)); *(int4*)w.meta[pi] = meta; }
+        } else if (sl == 0) w.key[pi] = ~0ull;
+        R2S_BP_STAMP();
     }
     // 3. the pairs that can still win (usually none behind step 2), packed; 64 at a time
     int base = 0;
+    if (rest)
     for (int j = 0; j * FB_SL < nF; ++j) { // (a loop on purpose: unrolled, with the eight bounds read ahead, the kernel needs 167 instead of 122 VGPRs)
         const int f = sl + j * FB_SL;
         const bool surv = want && w.lb[j][lane] <= thr && f != minf;
@@ -650,11 +670,11 @@ __device__ __forceinline__ void contact_finish_batch(const PhysDev& p, const Sta
             fb_wave_sync();
             R2S_BSTAMP(); // record + impulses done
             // mesh_collision (:295-421) — the arithmetic of finish_wave, expression for expression
-            float d2_1, d2_2;
+            float d2_1, d2_2, lm[3] = {3.0e38f, 0.f, 3.0e38f}; // lm: this lane's smallest bound, its triangle, its second smallest bound (first query)
             MeshHit q;
             {
                 const f3 x0 = mk(st[0], st[1], st[2]), vin = mk(st[3], st[4], st[5]);
-                q = batch_query<false>(p, sh, w, x0 + vin * p.dt, act, 0.f, d2_1 R2S_BP_ARG);
+                q = batch_query<false>(p, sh, w, x0 + vin * p.dt, act, 0.f, d2_1, lm R2S_BP_ARG);
             }
             R2S_BSTAMP(); // first query back
             bool requery = false;
@@ -720,7 +740,7 @@ __device__ __forceinline__ void contact_finish_batch(const PhysDev& p, const Sta
                 }
             }
             fb_wave_sync();
-            const MeshHit q2 = batch_query<true>(p, sh, w, next_x, requery, thr2, d2_2 R2S_BP_ARG);
+            const MeshHit q2 = batch_query<true>(p, sh, w, next_x, requery, thr2, d2_2, lm R2S_BP_ARG);
             R2S_BSTAMP(); // response + second query back
             if (act && sl == 0) { // the particle's storing lane
                 f3 x = mk(st[7], st[8], st[9]);
