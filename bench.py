@@ -43,8 +43,8 @@ for p in (ROOT, os.path.join(ROOT, "real2sim-eval_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = next((f for f in (os.path.join("profiles", "r5_pmc_summary.json"), os.path.join("profiles", "r4_pmc_summary.json")) if os.path.exists(os.path.join(ROOT, f))),
-                os.path.join("profiles", "r5_pmc_summary.json"))   # the newest committed counter summary (labelled STALE when collected on other kernel sources)
+PMC_FILE = next((f for f in (os.path.join("profiles", "r6_pmc_summary.json"), os.path.join("profiles", "r5_pmc_summary.json"), os.path.join("profiles", "r4_pmc_summary.json")) if os.path.exists(os.path.join(ROOT, f))),
+                os.path.join("profiles", "r6_pmc_summary.json"))   # the newest committed counter summary (labelled STALE when collected on other kernel sources)
 
 
 def pmc_summary(kernel, config):
@@ -600,6 +600,11 @@ def main():
                 "traffic_source": src if pmc_sub else None,
                 "hbm_actual_frac": (pmc_sub["hbm_bytes_per_launch"] / t_kernel / 1e9 / HBM_PEAK_GBS) if pmc_sub and ro.n_env == 32 and n_sub == 667 else None,
                 "valu_busy_frac": pmc_sub.get("valu_busy_frac") if pmc_sub else None,
+                # the kernel's own arithmetic bound: its VALU instructions x 4 issue cycles over the chip's 1024 SIMDs, as a share of the
+                # kernel's span — the same ratio as valu_busy_frac, named for what it says: 1 / valu_floor_frac is how far the kernel runs above its VALU floor
+                "valu_floor_frac": pmc_sub.get("valu_busy_frac") if pmc_sub else None,
+                "valu_floor_us": (pmc_sub["counters_mean_per_dispatch"]["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e3) if pmc_sub and "SQ_INSTS_VALU" in pmc_sub.get("counters_mean_per_dispatch", {}) else None,
+                "read_requests_reaching_dram_frac": pmc_sub.get("read_requests_reaching_dram_frac") if pmc_sub else None,
                 "counters_stale": pmc_sub.get("stale") if pmc_sub else None,
                 "kernel": ("k_steps_resident (small batch: all substeps of an env step in ONE launch; the figures below are per substep of it)" if resident_steps == args.steps
                            else "k_substep (fused spring gather + velocity + collisions + integrate)"),

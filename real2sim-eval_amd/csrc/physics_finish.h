@@ -619,18 +619,28 @@ __device__ __forceinline__ void contact_finish_batch(const PhysDev& p, const Sta
         // stage the substep's triangles, their boxes, the meshes' boxes and the gripper motion (index -> vertex: two dependent round trips, once per
         // workgroup) — with the two round trips of the first batch's candidate gathers issued next to them
         const int nF = p.nF;
+        const bool pre = p.tri_pre != nullptr; // uniform: the triangles were laid out for this by k_tri_pre — one coalesced round trip
         int ia = 0, ib = 0, ic = 0, mm = 0, fm = 0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
         if (tid < nF) {
-            ia = p.faces[3 * tid]; ib = p.faces[3 * tid + 1]; ic = p.faces[3 * tid + 2]; // stored order == caller order for small meshes
-            mm = p.mesh_map[tid]; fm = p.face_map[tid];
+            if (pre) {
+                const float4* tp = p.tri_pre + ((size_t)e * p.n_sub + step) * 5 * nF + tid;
+                r0 = tp[0]; r1 = tp[(size_t)nF]; r2 = tp[(size_t)2 * nF]; r3 = tp[(size_t)3 * nF]; r4 = tp[(size_t)4 * nF];
+            } else {
+                ia = p.faces[3 * tid]; ib = p.faces[3 * tid + 1]; ic = p.faces[3 * tid + 2]; // stored order == caller order for small meshes
+                mm = p.mesh_map[tid]; fm = p.face_map[tid];
+            }
         }
         ImpPre ip;
         ip.on = false;
         if (WITH_SELF) imp_pre1(p, eb, ra.y & 0x7fffffff, tb0 + pi < n_rec && ra.y < 0, sl, ra.x & 0x7ffff, ip);
         f3 a = mk(0.f, 0.f, 0.f), b = a, c = a;
-        if (tid < nF) { a = mesh_vertex(p, e, step, ia); b = mesh_vertex(p, e, step, ib); c = mesh_vertex(p, e, step, ic); }
+        if (tid < nF && !pre) { a = mesh_vertex(p, e, step, ia); b = mesh_vertex(p, e, step, ib); c = mesh_vertex(p, e, step, ic); }
         if (WITH_SELF) imp_pre2(p, po, eb, ip);
-        if (tid < nF) {
+        if (tid < nF && pre) {
+            sh.tri[tid][0] = r0; sh.tri[tid][1] = r1; sh.tri[tid][2] = r2;
+            sh.tbox[tid][0] = r3.x; sh.tbox[tid][1] = r3.y; sh.tbox[tid][2] = r3.z; sh.tbox[tid][3] = r3.w; sh.tbox[tid][4] = r4.x; sh.tbox[tid][5] = r4.y;
+        } else if (tid < nF) {
             int m = 0;
             for (int k = 1; k < p.n_mesh; ++k) m += tid >= p.mesh_face_off[k] ? 1 : 0;
             sh.tri[tid][0] = make_float4(a.x, a.y, a.z, b.x);

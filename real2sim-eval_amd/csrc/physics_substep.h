@@ -271,7 +271,21 @@ __device__ __forceinline__ bool resident_in_range(const ResidentIO& io, f3 next_
 // pre-impulse velocity and k_contact_finish applies the impulses first.
 __device__ __forceinline__ bool mesh_rec_push(const PhysDev& p, int e, int step, int i, int ncand, f3 x0, f3 v)
 {
-    const int slot = atomicAdd(p.rec_cnt + (size_t)e * p.n_sub + step, 1);
+    // One atomic per WAVEFRONT, not per listed lane (round 6): the lanes of a fused block share their environment, but `e` lives in a vector register,
+    // so the compiler cannot see the address is uniform and issued a returning atomic per lane — 20 serialised round trips to one L2 word in a block
+    // under a pad.  Lanes of different environments in one wavefront (k_self_finish's groups) keep the per-lane form.
+    int slot;
+    {
+        const unsigned long long act = __builtin_amdgcn_ballot_w64(true); // the lanes that push (this code runs under their branch)
+        const int e0 = __builtin_amdgcn_readfirstlane(e);
+        if (__builtin_amdgcn_ballot_w64(e != e0) == 0ull) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+            int base = 0;
+            if (rank == 0) base = atomicAdd(p.rec_cnt + (size_t)e0 * p.n_sub + step, (int)__builtin_popcountll(act));
+            slot = __builtin_amdgcn_readfirstlane(base) + rank;
+        } else
+            slot = atomicAdd(p.rec_cnt + (size_t)e * p.n_sub + step, 1);
+    }
     if (slot >= p.N) return false;
     int4* r = p.mesh_rec + 2 * (par_off(p, step) + (size_t)e * p.N + slot);
     const int hint = p.mq_hint ? p.mq_hint[(size_t)e * p.N + i] : -1; // the cluster of its closest face one substep ago rides in the record (bits 19..30)

@@ -8,7 +8,9 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = {"k_substep_pf<256, 1024, false, 1, 3>": "k_substep_pf", "k_substep_pf<256, 1024, true, 1, 3>": "k_substep_pf_contact",
+KERNELS = {"k_substep_pf<256, 1024, false, 1, 4>": "k_substep_pf", "k_substep_pf<256, 1024, true, 1, 4>": "k_substep_pf_contact",   # round 6: the batched small-scene finishers at the head
+           "k_contact_finish_batch<true>": "k_contact_finish", "k_contact_finish_batch<false>": "k_contact_finish_mesh_only",
+           "k_substep_pf<256, 1024, false, 1, 3>": "k_substep_pf", "k_substep_pf<256, 1024, true, 1, 3>": "k_substep_pf_contact",
            "k_substep_pf<256, 1024, false, 2, 2>": "k_substep_pf_large_mesh",
            "k_substep<256, 1024, false, 1>": "k_substep", "k_substep<256, 1024, true, 1>": "k_substep_contact", "k_contact_finish<3, true>": "k_contact_finish",
            "k_contact_finish<3, false>": "k_contact_finish_mesh_only", "k_composite": "k_composite", "k_steps_resident": "k_steps_resident", "k_emit_keys": "k_emit_keys", "k_preprocess": "k_preprocess",
@@ -51,12 +53,18 @@ def main():
             if "SQ_WAVE_CYCLES" in m:
                 ent["wave_cycles_waiting_frac"] = round(m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"], 4)
                 ent["wave_cycles_issue_stalled_frac"] = round(m.get("SQ_WAIT_INST_ANY", 0) / m["SQ_WAVE_CYCLES"], 4)
+        if "TCC_EA0_RDREQ_DRAM_sum" in m or "TCC_EA0_RDREQ_sum" in m:   # the L2's requests to the fabric, and the part of them that went on to DRAM (the rest hit the Infinity Cache)
+            ent["l2_fabric_requests"] = {c: m[c] for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_DRAM_sum") if c in m}
+            if m.get("TCC_EA0_RDREQ_sum", 0) > 0 and "TCC_EA0_RDREQ_DRAM_sum" in m:
+                ent["read_requests_reaching_dram_frac"] = round(m["TCC_EA0_RDREQ_DRAM_sum"] / m["TCC_EA0_RDREQ_sum"], 4)
+        if m.get("TCC_REQ_sum", 0) > 0 and "TCC_HIT_sum" in m:
+            ent["l2_hit_frac"] = round(m["TCC_HIT_sum"] / m["TCC_REQ_sum"], 4)
         out[key] = ent
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "real2sim-eval_amd"))
     from r2s_hip._lib import kernel_source_sha16
     res = {"source_sha16": kernel_source_sha16(), "git_head": os.environ.get("PMC_GIT_HEAD", "unknown (no .git on the GPU box; pass PMC_GIT_HEAD)"),
            "note": "rocprofv3 --pmc passes (tools/profiling/pmc_r3.sh / pmc_r4.sh) over tools/profiling/pmc_run.py on one MI355X: " + os.environ.get("PMC_CONFIG", "sloth_32env") + ", R2S_CHAINS=1 (a k_substep dispatch = "
-                   "one batched substep of all 32 envs), 2 free + 3 contact env steps.  hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
+                   "one batched substep of all 32 envs), " + (os.environ.get("PMC_STEPS", "5") + " env steps through the closing ramp into the held grasp (PMC_CLOSE_RATE)" if os.environ.get("PMC_CLOSE_RATE") else "2 free + 3 contact env steps") + ".  hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                    "(FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md; the 512 MiB calibration copy of the same run is listed).  "
                    "valu_busy_frac = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 shader engines): the share of SIMD issue cycles taken by VALU instructions (a floor: quarter-rate instructions count 4 cycles too), at most 1; lds_busy_frac = SQ_LDS_IDX_ACTIVE / 256 CUs "
                    "over the same span.",

@@ -17,8 +17,9 @@ def main():
     for _ in range(3):
         y.copy_(x)          # reads 512 MiB, writes 512 MiB per call
     torch.cuda.synchronize()
-    ro = BatchedRollout(os.environ.get("PMC_CONFIG", "sloth_32env"), close_at=2, settle_steps=int(os.environ.get("PMC_SETTLE", "12")))
-    for _ in range(5):
+    rate = float(os.environ.get("PMC_CLOSE_RATE", "0"))   # round 6: 0.1 = the closing ramp (the grasp latches around env step 11: PMC_STEPS=14 ends in the held grasp)
+    ro = BatchedRollout(os.environ.get("PMC_CONFIG", "sloth_32env"), close_at=2, settle_steps=int(os.environ.get("PMC_SETTLE", "12")), close_rate=rate if rate > 0 else None)
+    for _ in range(int(os.environ.get("PMC_STEPS", "5"))):
         ro.step()
     torch.cuda.synchronize()
     print("contact stats at the end:", ro.contact_stats())

@@ -1,6 +1,7 @@
 cd /root/repo
 export R2S_PARITY_LOG=gpurun_out/r6_parity.json
-timeout 900 python -m pytest tests/test_fin_batch_gpu.py tests/test_contact_flavours_gpu.py tests/test_flavour_pairs_gpu.py -m gpu -q -x 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_fin_batch_gpu.py tests/test_contact_flavours_gpu.py tests/test_flavour_pairs_gpu.py tests/test_episode_reset_gpu.py -m gpu -q -x 2>&1 | tail -3
 run() { echo "== $*"; env "$@" timeout 300 python tools/profiling/grasp_diag.py sloth_32env 32 3 18 0.1 2>&1 | grep -v "pad forces" | grep "step  2\|step  7\|step 17" | cut -c1-110; }
 run A=1
-R2S_HIP_LIB=scratch/variants/libr2s_probe.so timeout 300 python tools/probes/pf_probe.py sloth_32env 32 3 16 0.1 2>&1 | tail -28 > gpurun_out/r6_pf_probe_hold.txt; cat gpurun_out/r6_pf_probe_hold.txt
+run R2S_TRI_PRE=0
+run A=2
