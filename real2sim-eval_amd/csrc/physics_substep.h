@@ -603,6 +603,13 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
     // contact candidates (rare; the list is rebuilt once per env step) only publish their own v_before_collision
     // here and are finished by k_self_finish, which reads the partners' published values; everyone else is done.
     bool fin = valid;
+    // Per-environment record lists (large-mesh scenes; small scenes with batched finishing, round 6) in a flavour that defers: the two kinds of
+    // listed particles — with candidates (tagged, test widened by 2 mm) and without — are tested here and pushed TOGETHER, one atomic per
+    // wavefront for both (they were two dependent atomic round trips, the second inside finish_wave: the blocks under a pad ended 3 us after the
+    // others and with them the launch); what is left for finish_wave is "no mesh in reach" (NEED 2: advance, ground, store).
+    const bool rec_mode = PF && MESH != 0 && p.mesh_rec != nullptr && (p.mesh_defer || MESH == 2); // uniform; in the launches with the finishers at their head only (compiled
+                                                                                                   // into the plain k_substep too it cost the free flavour 8 VGPRs and a spill)
+    int tag_ncand = 0;
     if (SELF) {
         const int ncand = valid ? p.coll_num[eb + i] : 0;
         if (ncand > 0) {
@@ -610,7 +617,8 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
             p.vbc[po + eb + i] = make_float4(v.x, v.y, v.z, 0.f);
             p.xbc[po + eb + i] = make_float4(x0.x, x0.y, x0.z, 0.f);
             fin = false; // finished by k_self_finish / k_contact_finish
-            if (MESH != 0 && (p.mesh_defer || MESH == 2)) {
+            if (rec_mode) tag_ncand = ncand;
+            else if (MESH != 0 && (p.mesh_defer || MESH == 2)) {
                 // Will it also need a mesh query?  Its velocity is not final (the impulses come later), so the test is widened
                 // by 2 mm (= 40 m/s of velocity change in one substep); over-inclusion is harmless, the query itself is exact.
                 // Such a particle goes to the mesh list TAGGED: k_contact_finish applies its impulses and queries in one go.
@@ -633,7 +641,24 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
         }
     }
     R2S_QP_DECL(-1);
-    const bool done = finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
+    bool done;
+    if (rec_mode) {
+        bool near = false, need = false;
+        if (fin || tag_ncand > 0) need = mesh_need(p, e, step, x0 + v * p.dt, tag_ncand > 0 ? 0.002f : 0.f, near);
+        const unsigned long long nm = __builtin_amdgcn_ballot_w64(near);
+        if (nm && lane == __builtin_ctzll(nm)) p.mesh_cnt[p.n_sub] = 1;   // "anything near?" (the host picks a later step's flavour from it)
+        const unsigned long long qm = __builtin_amdgcn_ballot_w64(need);
+        if (qm && lane == __builtin_ctzll(qm)) p.fault[1] = 1;          // "a query was needed"
+        if (need && mesh_rec_push(p, e, step, i, tag_ncand, x0, v)) {
+            if (tag_ncand > 0) p.cand_mark[par_off(p, step) + eb + i] = step + 1;
+            fin = false;
+        } else if (need && tag_ncand == 0) {
+            // (the list cannot overflow — a particle is listed at most once per substep, N slots; kept for form: queried in place where the kernel can)
+            need = false;
+        }
+        done = finish_wave<MESH, false, 2>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
+    } else
+        done = finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
     if (PF && valid && !done) pf_mark(xv_out, eb + i); // left to the finishers at the head of the next launch
     R2S_STAMP(3);
 }
