@@ -513,7 +513,13 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
     // (round 5, measured and removed: XCD x owning the blocks b = x mod 8 instead of a contiguous range — so that the blocks of a contact
     // region, neighbours in Morton order, and with them the blocks that wait for a finisher in k_substep_pf, spread over all eight XCDs:
     // 22.8 vs 22.2 us per contact substep of the headline, 17.8 vs 17.0 free: the halo locality of contiguous ranges is worth more)
+#ifndef R2S_NO_SCALAR_ENV
+    // block and environment are the same in every lane, but the integer division leaves them in vector registers and everything indexed by them (mesh boxes,
+    // per-environment lists, the state base) was addressed per lane: named scalars, so those become scalar loads / scalar address arithmetic (round 6)
+    const int b = __builtin_amdgcn_readfirstlane(item / p.ne), e = __builtin_amdgcn_readfirstlane(p.e0 + (item - b * p.ne));
+#else
     const int b = item / p.ne, e = p.e0 + (item - b * p.ne);
+#endif
     R2S_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
