@@ -1,8 +1,2 @@
 cd /root/repo
-export R2S_PARITY_LOG=gpurun_out/r6_parity.json
-run() { echo "== $*"; env "$@" timeout 300 python tools/profiling/grasp_diag.py sloth_32env 32 3 18 0.1 2>&1 | grep -v "pad forces" | grep "step  0\|step  1:\|step  2\|step  7\|step 17" | cut -c1-110; }
-run A=1
-run R2S_HIP_LIB=scratch/variants/libr2s_noscal.so
-run A=2
-run R2S_HIP_LIB=scratch/variants/libr2s_noscal.so
-timeout 900 python -m pytest tests/test_physics_gpu.py tests/test_fin_batch_gpu.py tests/test_pf_gpu.py tests/test_parity_round2_gpu.py -m gpu -q -x 2>&1 | tail -3
+for n in 32 16 8 4; do NENV=$n python tools/profiling/raster_bench.py sloth_32env 2>/dev/null | tail -1; done

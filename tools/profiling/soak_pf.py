@@ -3,7 +3,7 @@ headline batch (32 environments, four chains) or the pusher's — each time next
 HBM; every run must end in the same bits as the first and none may run a poll into its limit (a sticky fault raises at the next step).
 `rope_fold_1env` puts the same soak on the resident stepper's self-collision flavour (two tagged hand-offs per substep, 3 000 particles
 with candidates).
-usage: soak_pf.py [config] [runs] [steps]"""
+usage: soak_pf.py [config] [runs] [steps] [close_rate]   (round 6: with a close_rate the grasp latches — the batched finishers and the held grasp are in the soak)"""
 import hashlib
 import os
 import sys
@@ -19,7 +19,8 @@ runs = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 side = torch.cuda.Stream()
 big = torch.empty(1 << 27, dtype=torch.float32, device="cuda")
-ro = BatchedRollout(cfg, close_at=2)
+rate = float(sys.argv[4]) if len(sys.argv) > 4 else None
+ro = BatchedRollout(cfg, close_at=2, close_rate=rate)
 x0, v0 = ro._init["x"].clone(), ro._init["v"].clone()
 ref, bad, substeps = None, 0, 0
 for r in range(runs):
