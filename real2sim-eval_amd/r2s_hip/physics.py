@@ -34,7 +34,7 @@ class R2SPhysDesc(C.Structure):
 
 
 class R2SFlavourIn(C.Structure):
-    """include/r2s_physics.h: the input of the flavour selection (counters of env step t - 2, capabilities, switches)."""
+    """include/r2s_physics.h: the input of the flavour selection (counters of env step t - lag — 2, small batches 1 —, capabilities, switches)."""
     _fields_ = [(n, C.c_int32) for n in (
         "have_counters", "near_mesh", "query_needed", "servers_ran_out", "srv_exhausted", "n_candidates", "n_substeps", "full_step",
         "n_faces", "any_large", "block", "split_ok", "resident_ok", "srv_ok", "pf_ok", "has_vx", "self_collision", "n_blocks", "n_env",

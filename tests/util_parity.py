@@ -1,8 +1,8 @@
 """Parity bookkeeping: every GPU parity comparison leaves its achieved error next to the tolerance it was held to.
 
 The `-m gpu` tests call `close()` / `record()`; the numbers are merged into one JSON file (default
-`gpurun_out/r5_parity.json` under the repository root, or `$R2S_PARITY_LOG`), so that the margin to the 1e-4 rel / 1e-5 abs
-gates of BASELINE.json is a number and not just a passed assertion.  `profiles/r5_parity.json` is a committed copy of the
+`gpurun_out/r6_parity.json` under the repository root, or `$R2S_PARITY_LOG`), so that the margin to the 1e-4 rel / 1e-5 abs
+gates of BASELINE.json is a number and not just a passed assertion.  `profiles/r6_parity.json` is a committed copy of the
 file a full `pytest -m gpu` run on the MI355X wrote."""
 import inspect
 import json
@@ -14,7 +14,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _path():
-    return os.environ.get("R2S_PARITY_LOG", os.path.join(_ROOT, "gpurun_out", "r5_parity.json"))
+    return os.environ.get("R2S_PARITY_LOG", os.path.join(_ROOT, "gpurun_out", "r6_parity.json"))
 
 
 def _test_id():
