@@ -901,6 +901,8 @@ void report_fault(const int* cnt)
                  "is shared with a kernel that never ends); the state is invalid [first fault: code %d, work item %d, substep %d of the launch, context %d %d %d %d %d %d]",
                  cnt[1] == 2 ? "a neighbour block's substep" : cnt[1] == 5 ? "a neighbour's record (server pair)" : cnt[1] == 6 ? "a particle finished by the head of its launch" : cnt[1] == 7 ? "a self-collision partner's record" : "a mesh-query server's result", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
         r2s::set_last_error_msg(buf);
+    } else if (cnt[1] == 8) {
+        r2s::set_last_error_msg("a per-environment list of particles left to the finishing code overflowed (more than N entries in one substep: cannot happen in a sound launch); the state is invalid");
     } else
         r2s::set_last_error_msg("a self-collision impulse changed a particle's velocity by more than 40 m/s within one substep: its mesh-contact "
                                 "test (widened by 2 mm) may have been skipped where the reference applies it (unsupported)");

@@ -269,7 +269,7 @@ __device__ __forceinline__ bool resident_in_range(const ResidentIO& io, f3 next_
 // Large-mesh scenes: hand a particle to the substep's finishing launch through its environment's list (a particle is listed at most
 // once per substep: N slots cannot overflow).  ncand > 0 = tagged: the particle also has self-collision candidates, `v` is its published
 // pre-impulse velocity and k_contact_finish applies the impulses first.
-__device__ __forceinline__ bool mesh_rec_push(const PhysDev& p, int e, int step, int i, int ncand, f3 x0, f3 v)
+__device__ __forceinline__ int mesh_rec_reserve(const PhysDev& p, int e, int step)
 {
     // One atomic per WAVEFRONT, not per listed lane (round 6): the lanes of a fused block share their environment, but `e` lives in a vector register,
     // so the compiler cannot see the address is uniform and issued a returning atomic per lane — 20 serialised round trips to one L2 word in a block
@@ -286,11 +286,20 @@ __device__ __forceinline__ bool mesh_rec_push(const PhysDev& p, int e, int step,
         } else
             slot = atomicAdd(p.rec_cnt + (size_t)e * p.n_sub + step, 1);
     }
-    if (slot >= p.N) return false;
+    return slot;
+}
+__device__ __forceinline__ void mesh_rec_write(const PhysDev& p, int e, int step, int slot, int i, int ncand, f3 x0, f3 v)
+{
     int4* r = p.mesh_rec + 2 * (par_off(p, step) + (size_t)e * p.N + slot);
     const int hint = p.mq_hint ? p.mq_hint[(size_t)e * p.N + i] : -1; // the cluster of its closest face one substep ago rides in the record (bits 19..30)
     r[0] = make_int4(ncand | ((hint + 1) << 19), ncand > 0 ? (i | (int)0x80000000) : i, __float_as_int(x0.x), __float_as_int(x0.y));
     r[1] = make_int4(__float_as_int(x0.z), __float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z));
+}
+__device__ __forceinline__ bool mesh_rec_push(const PhysDev& p, int e, int step, int i, int ncand, f3 x0, f3 v)
+{
+    const int slot = mesh_rec_reserve(p, e, step);
+    if (slot >= p.N) return false;
+    mesh_rec_write(p, e, step, slot, i, ncand, x0, v);
     return true;
 }
 
@@ -655,14 +664,19 @@ __device__ __forceinline__ void substep_body(const PhysDev& p, const StateC xv_i
         if (nm && lane == __builtin_ctzll(nm)) p.mesh_cnt[p.n_sub] = 1;   // "anything near?" (the host picks a later step's flavour from it)
         const unsigned long long qm = __builtin_amdgcn_ballot_w64(need);
         if (qm && lane == __builtin_ctzll(qm)) p.fault[1] = 1;          // "a query was needed"
-        if (need && mesh_rec_push(p, e, step, i, tag_ncand, x0, v)) {
-            if (tag_ncand > 0) p.cand_mark[par_off(p, step) + eb + i] = step + 1;
-            fin = false;
-        } else if (need && tag_ncand == 0) {
-            // (the list cannot overflow — a particle is listed at most once per substep, N slots; kept for form: queried in place where the kernel can)
-            need = false;
-        }
+        // the slot is reserved (one atomic per wavefront), the rest of the block's particles are finished WHILE it is on its way, the record is written
+        // behind that: the round trip to the counter was 1 - 1.5 us in series in the blocks under a pad, the ones that end the launch.  A particle is
+        // listed at most once per substep and the list has N slots: a slot beyond them cannot happen — if it does, the run ends with a fault
+        int slot = 0;
+        if (need) { slot = mesh_rec_reserve(p, e, step); fin = false; }
         done = finish_wave<MESH, false, 2>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
+        if (need) {
+            if (slot < p.N) {
+                mesh_rec_write(p, e, step, slot, i, tag_ncand, x0, v);
+                if (tag_ncand > 0) p.cand_mark[par_off(p, step) + eb + i] = step + 1;
+            } else
+                resident_fault(p, 8, item, step, (unsigned)(eb + i), (unsigned)slot, 0u, 0u, 0u, 0u);
+        }
     } else
         done = finish_wave<MESH, MESH != 0>(p, e, i, eb, step, write_forces, x0, v, fin, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
     if (PF && valid && !done) pf_mark(xv_out, eb + i); // left to the finishers at the head of the next launch

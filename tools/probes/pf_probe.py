@@ -79,3 +79,4 @@ print(f"blocks whose staging took > median + 2 us (waited for a finisher): {int(
 if w.any():
     print("  waiting blocks: entered at", pc(b[w, 0]), "staged at", pc(b[w, 1]), "ended at", pc(b[w, 3]), "gather + finish after staging", pc(b[w, 3] - b[w, 1]))
     print("  the others: ended at", pc(b[~w, 3]), "gather + finish after staging", pc(b[~w, 3] - b[~w, 1]))
+    print("  waiting blocks: gather", pc(b[w, 2] - b[w, 1]), "finish (tests, pushes, ground, store)", pc(b[w, 3] - b[w, 2]), "| the others: gather", pc(b[~w, 2] - b[~w, 1]), "finish", pc(b[~w, 3] - b[~w, 2]))
