@@ -530,7 +530,7 @@ void launch_fused(R2SPhys* h, const PhysDev& p, int in_buf, int step, int write_
 // substep of the held grasp with 16 / 20 / 24 / 32 slots (hovering: 19.3 / 19.4 / 19.5 / 19.7).
 int fin_batch_slots(bool with_self)
 {
-    int n = with_self ? 32 : 8;
+    int n = with_self ? 16 : 8;
     if (const char* ev = getenv("R2S_FIN_SLOTS")) n = std::max(1, atoi(ev));
     return n;
 }

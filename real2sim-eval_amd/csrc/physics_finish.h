@@ -230,6 +230,35 @@ __device__ __forceinline__ void contact_finish_body(const PhysDev& p, const Stat
     }
 }
 
+// Part 2 for the batched finisher, per ENVIRONMENT (round 6): the workgroups of an environment behind its part-1 workgroups (`slot_rel` of
+// `nslot_rel`) walk THAT environment's candidate list, 16 lanes per particle.  With the interleaved mapping above part 1 (from the first slot)
+// and part 2 (from the last) need twice the workgroups to stay apart — and every finishing workgroup of a launch holds one of the chip's
+// 1 024 slots for the 2 - 3 us it takes to find out it has nothing to do: the contact flavours are bound by exactly those slots.
+template <int FW, bool PFOUT>
+__device__ __forceinline__ void finish_candidates_env(const PhysDev& p, const StateM xv_out, int step, int write_forces, int e, int slot_rel, int nslot_rel, size_t po)
+{
+    constexpr int G = 16;
+    const int sub = (int)(threadIdx.x & (G - 1)), grp = (int)(threadIdx.x / G), gpb = 256 / G;
+    const size_t eb = (size_t)e * p.N;
+    const int t0g = slot_rel * gpb + grp, gstride = nslot_rel * gpb;
+    int2 ci = p.cand_list[eb + (size_t)min(max(t0g, 0), p.N - 1)];                 // speculative, with the count (one round trip)
+    const int n = slot_rel >= 0 ? p.cand_cnt_env[e] : 0;
+    for (int t = t0g; __builtin_amdgcn_ballot_w64(t < n) != 0ull; t += gstride) { // wave-uniform trip count (the group shuffles run with their lanes together)
+        if (t != t0g || t >= n) ci = p.cand_list[eb + (size_t)(t < n ? t : 0)];
+        const int i = ci.y, cnt = ci.x >> 12;
+        const bool act = t < n && p.cand_mark[po + eb + i] != step + 1; // not already done in part 1
+        const f3 x0 = xyz(p.xbc[po + eb + i]);
+        const f3 vpre = xyz(p.vbc[po + eb + i]);
+        const f3 v = self_impulse<G>(p, po, eb, i, act, x0, vpre, sub, cnt);
+        if (act && sub == 0) { // (the bound the skipped mesh test relies on: see finish_candidates)
+            const f3 dvi = v - vpre;
+            if (dot(dvi, dvi) * p.dt * p.dt > 0.002f * 0.002f) *p.fault = 1;
+        }
+        R2S_QP_DECL(-1);
+        finish_wave<FW, false, 2, false, false, PFOUT>(p, e, i, eb, step, write_forces, x0, v, act && sub == 0, xv_out, nullptr, nullptr, nullptr, nullptr, true, nullptr R2S_QP_ARG);
+    }
+}
+
 // ---- small scenes, BATCHED finishing (round 6; MESHQ 4) ---------------------------------------------------------------------------------
 // Until round 5 a listed particle of a small scene (every mesh small, <= 128 faces: two 44-face fingers + a box) was finished by a WORKGROUP
 // of its own — two wavefronts, one triangle per lane (MESHQ 3).  That form is latency-optimal for a handful of particles (the resident
@@ -633,10 +662,14 @@ __device__ __forceinline__ void contact_finish_batch(const PhysDev& p, const Sta
         }
         ImpPre ip;
         ip.on = false;
+#ifndef R2S_FB_NO_IMP_PREFETCH
         if (WITH_SELF) imp_pre1(p, eb, ra.y & 0x7fffffff, tb0 + pi < n_rec && ra.y < 0, sl, ra.x & 0x7ffff, ip);
+#endif
         f3 a = mk(0.f, 0.f, 0.f), b = a, c = a;
         if (tid < nF && !pre) { a = mesh_vertex(p, e, step, ia); b = mesh_vertex(p, e, step, ib); c = mesh_vertex(p, e, step, ic); }
+#ifndef R2S_FB_NO_IMP_PREFETCH
         if (WITH_SELF) imp_pre2(p, po, eb, ip);
+#endif
         if (tid < nF && pre) {
             sh.tri[tid][0] = r0; sh.tri[tid][1] = r1; sh.tri[tid][2] = r2;
             sh.tbox[tid][0] = r3.x; sh.tbox[tid][1] = r3.y; sh.tbox[tid][2] = r3.z; sh.tbox[tid][3] = r3.w; sh.tbox[tid][4] = r4.x; sh.tbox[tid][5] = r4.y;
@@ -666,7 +699,9 @@ __device__ __forceinline__ void contact_finish_batch(const PhysDev& p, const Sta
             const bool act = t < n_rec;
             if (tb != tb0) {
                 ra = rec[2 * min(t, p.N - 1)]; rc = rec[2 * min(t, p.N - 1) + 1];
+#ifndef R2S_FB_NO_IMP_PREFETCH
                 if (WITH_SELF) { imp_pre1(p, eb, ra.y & 0x7fffffff, act && ra.y < 0, sl, ra.x & 0x7ffff, ip); imp_pre2(p, po, eb, ip); }
+#endif
             }
             const bool tagged = act && ra.y < 0;
             float* st = w.st[pi]; // the particle's parked state: [0..2] x0, [3..5] v, [6] i | [7..9] next_x, [10..12] next_v, [13..15] per-face force, [16] margin, [17] flags, [18] face_map
@@ -674,7 +709,11 @@ __device__ __forceinline__ void contact_finish_batch(const PhysDev& p, const Sta
                 const int i = act ? (ra.y & 0x7fffffff) : 0, cnt = ra.x & 0x7ffff;
                 const f3 x0 = mk(__int_as_float(ra.z), __int_as_float(ra.w), __int_as_float(rc.x));
                 f3 v = mk(__int_as_float(rc.y), __int_as_float(rc.z), __int_as_float(rc.w));
+    #ifdef R2S_FB_NO_IMP_PREFETCH
+                if (WITH_SELF && __builtin_amdgcn_ballot_w64(tagged) != 0ull) v = self_impulse<16>(p, po, eb, i, tagged, x0, v, sl, cnt);
+#else
                 if (WITH_SELF && __builtin_amdgcn_ballot_w64(tagged) != 0ull) v = self_impulse_pre(p, po, eb, i, tagged, x0, v, sl, cnt, ip);
+#endif
                 if (sl == 0) { st[0] = x0.x; st[1] = x0.y; st[2] = x0.z; st[3] = v.x; st[4] = v.y; st[5] = v.z; st[6] = __int_as_float(i); }
             }
             fb_wave_sync();
@@ -812,11 +851,11 @@ __device__ __forceinline__ void contact_finish_batch(const PhysDev& p, const Sta
 #undef probe_n
 #ifndef R2S_FB_NO_PART2
     if (WITH_SELF) {
-#ifdef R2S_PHASE_PROBE
-        finish_candidates<1, PFOUT>(p, xv_out, step, write_forces, L, n_wg, 256, po, lane, wave, probe_entry);
-#else
-        finish_candidates<1, PFOUT>(p, xv_out, step, write_forces, L, n_wg, 256, po, lane, wave, 0);
-#endif
+        // part 2 behind part 1's workgroups of the same environment: slots [n1, nslot); if part 1 fills every slot (never in the scenes measured), all
+        // of them take part 2 behind their part-1 work
+        const int n1 = min((n_rec + 4 * FB_PW - 1) / (4 * FB_PW), nslot);
+        const bool all = n1 >= nslot;
+        finish_candidates_env<1, PFOUT>(p, xv_out, step, write_forces, e, slot >= nslot ? -1 : all ? slot : slot - n1, all ? nslot : nslot - n1, po);
     }
 #endif
 }
