@@ -530,6 +530,171 @@ __global__ void __launch_bounds__(256) k_tile_ranges(const uint32_t* __restrict_
     if (i == L - 1) ranges[cur].y = L;
 }
 
+// ---- tile binning in ONE pass (round 6) -----------------------------------------------------------------------------------------------------
+// Until round 6 the emitted (tile key, Gaussian) pairs went through rocPRIM's Onesweep radix sort — two passes of 9 bits over 35 M pairs,
+// 0.61 - 0.63 ms per 64 frames at 0.22 of the HBM peak, the front end's largest stage — and k_tile_ranges then read the sorted keys back to find
+// where each tile's list starts.  The emission order already is (frame, depth, index): what is left to do is a STABLE partition by tile id, and
+// within a frame there are only gx * gy tiles (1 200 at 640 x 480: one 11-bit digit).  So the list is cut into chunks of BIN_CHUNK instances that
+// never straddle a frame, and the partition is a counting sort with the (frame, tile) pair as its single digit:
+//   k_bin_plan     frame boundaries of the emission order (from the scan of the tile counts) -> chunk table {frame, first instance, length}
+//   k_bin_hist     per chunk: LDS histogram over the frame's tiles -> one row of hist[chunk][tile]
+//   k_bin_colscan  per (frame, tile): exclusive prefix over the frame's chunks (in place) + the tile's total
+//   k_tile_starts  exclusive scan of the totals over all (frame, tile) = the ranges array of identifyTileRanges (rasterizer_impl.cu:116-138),
+//                  without reading a key
+//   k_bin_scatter  per chunk: every wavefront ranks its 64 x BIN_STEPS consecutive instances — peers of a lane (same tile, same step) from one
+//                  ballot per key bit, earlier steps from the wavefront's own LDS counters — the counters of the eight wavefronts are chained
+//                  behind the chunk's prefix, and the Gaussian indices go to  start(tile) + prefix(chunk, tile) + rank.
+// Every instance keeps its emission order inside its tile: point_list is the one the two sorts of the reference produce (and the one the
+// rocPRIM path produced: tests/test_raster_gpu.py compares it with the oracle's).  Keys are read twice and never written again; the values are
+// written once.  Frames with more than BIN_MAX_TILES tiles (or more than BIN_MAX_FRAMES frames) keep the radix sort.
+constexpr int BIN_THREADS = 512, BIN_STEPS = 16, BIN_CHUNK = BIN_THREADS * BIN_STEPS;
+constexpr int BIN_MAX_TILES = 2048, BIN_MAX_FRAMES = 1024;
+
+__global__ void __launch_bounds__(1024) k_bin_plan(const FrameDev* __restrict__ frames, int F, const uint32_t* __restrict__ offsets, uint32_t cap,
+                                                   uint32_t nb_max, uint4* __restrict__ desc, uint32_t* __restrict__ chunk_first)
+{
+    __shared__ uint32_t s_end[BIN_MAX_FRAMES + 1], s_first[BIN_MAX_FRAMES + 1];
+    const int tid = (int)threadIdx.x;
+    // frame f's Gaussians sit at [base, base + P) of the (frame, depth) order: its instances end where the scan says (clamped to the capacity of
+    // the sync-free mode, like the emission)
+    if (tid < F) { const FrameDev& fr = frames[tid]; s_end[tid + 1] = fr.P > 0 ? min(offsets[(size_t)fr.base + fr.P - 1], cap) : 0u; }
+    if (tid == 0) s_end[0] = 0u;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0, nb = 0;
+        for (int f = 0; f < F; ++f) {
+            run = max(run, s_end[f + 1]); // a frame without Gaussians ends where its predecessor ends
+            s_end[f + 1] = run;
+            s_first[f] = nb;
+            nb += (run - s_end[f] + BIN_CHUNK - 1) / BIN_CHUNK;
+        }
+        s_first[F] = nb;
+    }
+    __syncthreads();
+    for (int f = tid; f <= F; f += 1024) chunk_first[f] = s_first[f];
+    for (int f = tid; f < F; f += 1024) {
+        const uint32_t start = s_end[f], cnt = s_end[f + 1] - start, first = s_first[f];
+        for (uint32_t k = 0; k * BIN_CHUNK < cnt; ++k) desc[first + k] = make_uint4((uint32_t)f, start + k * BIN_CHUNK, min((uint32_t)BIN_CHUNK, cnt - k * BIN_CHUNK), 0u);
+    }
+    for (uint32_t c = s_first[F] + (uint32_t)tid; c < nb_max; c += 1024) desc[c] = make_uint4(0u, 0u, 0u, 0u); // workgroups past the last chunk leave
+}
+
+__global__ void __launch_bounds__(BIN_THREADS) k_bin_hist(const uint4* __restrict__ desc, int tiles, const uint32_t* __restrict__ keys, uint32_t* __restrict__ hist)
+{
+    extern __shared__ uint32_t s_bin[];
+    const uint4 d = desc[blockIdx.x];
+    if (d.z == 0) return;
+    const int tid = (int)threadIdx.x;
+    for (int t = tid; t < tiles; t += BIN_THREADS) s_bin[t] = 0u;
+    __syncthreads();
+    const uint32_t kb = d.x * (uint32_t)tiles;
+    const uint32_t* k = keys + d.y;
+#pragma unroll 4
+    for (uint32_t i = (uint32_t)tid; i < d.z; i += BIN_THREADS) atomicAdd(&s_bin[k[i] - kb], 1u);
+    __syncthreads();
+    uint32_t* row = hist + (size_t)blockIdx.x * tiles;
+    for (int t = tid; t < tiles; t += BIN_THREADS) row[t] = s_bin[t];
+}
+
+__global__ void __launch_bounds__(256) k_bin_colscan(int F, int tiles, const uint32_t* __restrict__ chunk_first, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals)
+{
+    const uint32_t ft = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ft >= (uint32_t)F * (uint32_t)tiles) return;
+    const uint32_t f = ft / (uint32_t)tiles, t = ft - f * (uint32_t)tiles;
+    const uint32_t c0 = chunk_first[f], c1 = chunk_first[f + 1];
+    uint32_t run = 0;
+    uint32_t c = c0;
+    for (; c + 8 <= c1; c += 8) { // eight rows in flight
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = hist[(size_t)(c + k) * tiles + t];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { hist[(size_t)(c + k) * tiles + t] = run; run += v[k]; }
+    }
+    for (; c < c1; ++c) { const uint32_t v = hist[(size_t)c * tiles + t]; hist[(size_t)c * tiles + t] = run; run += v; }
+    totals[ft] = run;
+}
+
+// ranges[ft] = [start, start + total) of every (frame, tile) with instances, {0, 0} for the others (what the reference's zero-filled ranges hold for a
+// tile no key names).  One workgroup: FT is a few tens of thousands.
+__global__ void __launch_bounds__(1024) k_tile_starts(uint32_t FT, const uint32_t* __restrict__ totals, uint2* __restrict__ ranges)
+{
+    __shared__ uint32_t s_wave[16];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t per = (FT + 1023u) / 1024u, a = min((uint32_t)tid * per, FT), b = min(a + per, FT);
+    uint32_t sum = 0;
+    for (uint32_t i = a; i < b; ++i) sum += totals[i];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - sum;
+    for (int w = 0; w < wave; ++w) base += s_wave[w];
+    for (uint32_t i = a; i < b; ++i) {
+        const uint32_t n = totals[i];
+        ranges[i] = n ? make_uint2(base, base + n) : make_uint2(0u, 0u);
+        base += n;
+    }
+}
+
+__global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const uint4* __restrict__ desc, int tiles, int key_bits, const uint32_t* __restrict__ keys,
+                                                             const uint32_t* __restrict__ vals, const uint32_t* __restrict__ hist,
+                                                             const uint2* __restrict__ ranges, uint32_t* __restrict__ out)
+{
+    extern __shared__ uint32_t s_bin[]; // [wavefront][tile]: instances of the tile this wavefront has ranked so far; then: where its next one goes
+    const uint4 d = desc[blockIdx.x];
+    if (d.z == 0) return;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int WAVES = BIN_THREADS / 64;
+    const uint32_t kb = d.x * (uint32_t)tiles;
+    // this lane's instances: 64 consecutive ones per step and wavefront, all loads in flight before the first is needed
+    uint32_t pk[BIN_STEPS], vv[BIN_STEPS];
+#pragma unroll
+    for (int s = 0; s < BIN_STEPS; ++s) {
+        const uint32_t i = (uint32_t)(wave * (64 * BIN_STEPS) + s * 64 + lane);
+        const bool ok = i < d.z;
+        pk[s] = ok ? keys[d.y + i] - kb : 0x80000000u;
+        vv[s] = ok ? vals[d.y + i] : 0u;
+    }
+    for (int t = tid; t < WAVES * tiles; t += BIN_THREADS) s_bin[t] = 0u;
+    __syncthreads();
+    uint32_t* wh = s_bin + wave * tiles;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int s = 0; s < BIN_STEPS; ++s) {
+        const bool ok = !(pk[s] >> 31);
+        const uint32_t key = pk[s] & 0x7ffu;
+        unsigned long long peers = __builtin_amdgcn_ballot_w64(ok); // lanes of this step with my tile
+        for (int b = 0; b < key_bits; ++b) {
+            const bool bit = (key >> b) & 1u;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        if (!ok) peers = 0ull;
+        const uint32_t before = wh[ok ? key : 0u]; // read by every peer before the last of them books the step (one wavefront: in order)
+        __builtin_amdgcn_wave_barrier();
+        if (ok && (peers >> lane) <= 1ull) wh[key] = before + (uint32_t)__builtin_popcountll(peers);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        pk[s] = (pk[s] & 0x800007ffu) | ((before + (uint32_t)__builtin_popcountll(peers & lt)) << 11); // rank among the wavefront's instances of the tile
+    }
+    __syncthreads();
+    const uint32_t* row = hist + (size_t)blockIdx.x * tiles;
+    for (int t = tid; t < tiles; t += BIN_THREADS) { // the tile's list start + the chunks before this one + the wavefronts before each
+        uint32_t run = ranges[kb + t].x + row[t];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) { const uint32_t n = s_bin[w * tiles + t]; s_bin[w * tiles + t] = run; run += n; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < BIN_STEPS; ++s)
+        if (!(pk[s] >> 31)) out[wh[pk[s] & 0x7ffu] + ((pk[s] >> 11) & 0xfffffu)] = vv[s];
+}
+
 // Workgroup order of the compositor: tiles sorted by the length of their instance list, longest first.  On the benchmark
 // scene 5 % of the tiles (the object region) hold 85 % of the instances; started in tile order, the deep tiles of the last
 // frames run alone at the end of the kernel (1.26 ms); started first, the short ones fill the gaps (0.97 ms).
@@ -869,6 +1034,7 @@ struct R2SRasterCtx {
     int late_error = 0;          // error of a sync-free call, reported by the next poll        // a sync-free call whose words have not been looked at yet
     bool timing = false;
     int cull = 0; // exact-output tile culling of instances (batched API option)
+    bool bin_pass = getenv("R2S_RASTER_RADIX_SORT") == nullptr; // one-pass tile binning (k_bin_*) instead of the radix sort of the instances
     bool tile_order = true; // longest-first workgroup order of the compositor (R2S_NO_TILE_ORDER at context creation: A/B knob)
     hipEvent_t ev[7] = {};
     bool ev_ok = false;
@@ -1057,25 +1223,38 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     // the count changes by a fraction of a per cent per env step; 25 % headroom, and an overflow flag if it ever is not enough)
     const uint32_t cap = sync_free ? c->L_cap : L;
     const uint32_t bits = higher_msb((uint32_t)F * (uint32_t)tiles + (sync_free ? 1u : 0u)); // + 1: the sentinel key F * tiles
+    // one-pass binning (k_bin_*) wherever a frame's tiles fit its LDS counters; otherwise (and with R2S_RASTER_RADIX_SORT set: A/B knob) the radix sort
+    const bool bin_pass = c->bin_pass && tiles <= BIN_MAX_TILES && F <= BIN_MAX_FRAMES;
     uint32_t *keys_a = nullptr, *keys_b = nullptr;
     uint32_t *vals_a = nullptr, *vals_b = nullptr;
     const uint32_t* keys_sorted = nullptr;
     const uint32_t* vals_sorted = nullptr;
+    bool ranges_done = false;
     if (cap > 0 && G > 0) {
         rocprim::double_buffer<uint32_t> dk((uint32_t*)nullptr, (uint32_t*)nullptr);
         rocprim::double_buffer<uint32_t> dv((uint32_t*)nullptr, (uint32_t*)nullptr);
         size_t sort_bytes = 0;
-        R2S_HIP_TRY(rocprim::radix_sort_pairs<TileSortConfig>(nullptr, sort_bytes, dk, dv, (size_t)cap, 0u, bits, stream));
-        r2s::Carver sz(nullptr);
-        sz.take<uint32_t>(cap); sz.take<uint32_t>(cap); sz.take<uint32_t>(cap); sz.take<uint32_t>(cap); sz.take<char>(sort_bytes);
-        char* p = c->scratch(1, sz.bytes());
-        if (!p) return R2S_ERR_ALLOC;
-        r2s::Carver cv(p);
-        keys_a = cv.take<uint32_t>(cap); keys_b = cv.take<uint32_t>(cap);
-        vals_a = cv.take<uint32_t>(cap); vals_b = cv.take<uint32_t>(cap);
-        char* sort_tmp = cv.take<char>(sort_bytes);
+        if (!bin_pass) R2S_HIP_TRY(rocprim::radix_sort_pairs<TileSortConfig>(nullptr, sort_bytes, dk, dv, (size_t)cap, 0u, bits, stream));
+        const uint32_t nb_max = cap / BIN_CHUNK + (uint32_t)F; // every frame ends in at most one partial chunk
+        uint32_t *bin_hist = nullptr, *bin_first = nullptr, *bin_totals = nullptr;
+        uint4* bin_desc = nullptr;
+        char* sort_tmp = nullptr;
+        {
+            r2s::Carver sz(nullptr);
+            sz.take<uint32_t>(cap); sz.take<uint32_t>(cap); sz.take<uint32_t>(cap);
+            if (bin_pass) { sz.take<uint32_t>((size_t)nb_max * tiles); sz.take<uint4>(nb_max); sz.take<uint32_t>((size_t)F + 1); sz.take<uint32_t>(FT); }
+            else { sz.take<uint32_t>(cap); sz.take<char>(sort_bytes); }
+            char* p = c->scratch(1, sz.bytes());
+            if (!p) return R2S_ERR_ALLOC;
+            r2s::Carver cv(p);
+            keys_a = cv.take<uint32_t>(cap); vals_a = cv.take<uint32_t>(cap); vals_b = cv.take<uint32_t>(cap);
+            if (bin_pass) {
+                bin_hist = cv.take<uint32_t>((size_t)nb_max * tiles); bin_desc = cv.take<uint4>(nb_max); bin_first = cv.take<uint32_t>((size_t)F + 1);
+                bin_totals = cv.take<uint32_t>(FT);
+            } else { keys_b = cv.take<uint32_t>(cap); sort_tmp = cv.take<char>(sort_bytes); }
+        }
 
-        if (sync_free) // instances this batch does not produce: sentinel keys that sort behind every (frame, tile)
+        if (sync_free && !bin_pass) // instances this batch does not produce: sentinel keys that sort behind every (frame, tile)
             hipLaunchKernelGGL(k_fill_sentinel, dim3((cap + 255) / 256), dim3(256), 0, stream, offsets + (G - 1), cap, (uint32_t)F * (uint32_t)tiles, keys_a);
         if (G <= (size_t)1 << 18) { // small batch: large rectangles through the queue (see k_emit_keys)
             hipLaunchKernelGGL(k_emit_keys<true>, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
@@ -1086,18 +1265,33 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
             hipLaunchKernelGGL(k_emit_keys<false>, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
                                order, radii_all, geom, offsets, keys_a, vals_a, c->cull, cap, err_flag + 1, big_q, err_flag + 2);
         mark(3);
-        rocprim::double_buffer<uint32_t> dkey(keys_a, keys_b);
-        rocprim::double_buffer<uint32_t> dval(vals_a, vals_b);
-        R2S_HIP_TRY(rocprim::radix_sort_pairs<TileSortConfig>(sort_tmp, sort_bytes, dkey, dval, (size_t)cap, 0u, bits, stream));
-        keys_sorted = dkey.current();
-        vals_sorted = dval.current();
+        if (bin_pass) {
+            unsigned key_bits = 0;
+            while ((1u << key_bits) < (unsigned)tiles) ++key_bits;
+            hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(1024), 0, stream, c->d_frames, F, offsets, cap, nb_max, bin_desc, bin_first);
+            hipLaunchKernelGGL(k_bin_hist, dim3(nb_max), dim3(BIN_THREADS), sizeof(uint32_t) * tiles, stream, bin_desc, tiles, keys_a, bin_hist);
+            hipLaunchKernelGGL(k_bin_colscan, dim3((unsigned)((FT + 255) / 256)), dim3(256), 0, stream, F, tiles, bin_first, bin_hist, bin_totals);
+            hipLaunchKernelGGL(k_tile_starts, dim3(1), dim3(1024), 0, stream, (uint32_t)FT, bin_totals, ranges);
+            hipLaunchKernelGGL(k_bin_scatter, dim3(nb_max), dim3(BIN_THREADS), sizeof(uint32_t) * tiles * (BIN_THREADS / 64), stream, bin_desc, tiles, (int)key_bits,
+                               keys_a, vals_a, bin_hist, ranges, vals_b);
+            vals_sorted = vals_b;
+            ranges_done = true;
+        } else {
+            rocprim::double_buffer<uint32_t> dkey(keys_a, keys_b);
+            rocprim::double_buffer<uint32_t> dval(vals_a, vals_b);
+            R2S_HIP_TRY(rocprim::radix_sort_pairs<TileSortConfig>(sort_tmp, sort_bytes, dkey, dval, (size_t)cap, 0u, bits, stream));
+            keys_sorted = dkey.current();
+            vals_sorted = dval.current();
+        }
         mark(4);
     } else {
         mark(3); mark(4);
     }
-    R2S_HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)F * tiles, stream));
-    if (cap > 0 && G > 0)
-        hipLaunchKernelGGL(k_tile_ranges, dim3((cap + 255) / 256), dim3(256), 0, stream, offsets + (G - 1), cap, keys_sorted, ranges);
+    if (!ranges_done) {
+        R2S_HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)F * tiles, stream));
+        if (cap > 0 && G > 0)
+            hipLaunchKernelGGL(k_tile_ranges, dim3((cap + 255) / 256), dim3(256), 0, stream, offsets + (G - 1), cap, keys_sorted, ranges);
+    }
     if (sync_free) { // count, culling error and overflow words of THIS call land in pinned memory behind the pipeline
         R2S_HIP_TRY(hipMemcpyAsync(&c->h_read[2], err_flag + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
         L = cap;
