@@ -6,7 +6,7 @@
 //
 //   k_preprocess   one thread per (frame, Gaussian): cull, project, EWA conic, radius, tile rect, SH->RGB.
 //                  Writes ONE packed 48-byte record per Gaussian (what compositing gathers later).
-//   k_gauss_keys   (frame << 32 | depth bits, Gaussian index) per Gaussian; rocPRIM radix sort on 32 + log2(F) bits.
+//                  Also the key of the first sort: (frame << 32 | depth bits, Gaussian index); rocPRIM radix sort on 32 + log2(F) bits.
 //   rocPRIM scan   inclusive sum of tiles_touched in that (frame, depth) order, all frames at once.
 //   k_emit_keys    (frame-extended tile id, global Gaussian index) per overlapped tile, Gaussians walked in depth order.
 //   rocPRIM sort   radix_sort_pairs on ceil_log2(F * tiles) bits — stable, so a tile's list stays in depth order and
@@ -21,13 +21,11 @@
 #include <rocprim/rocprim.hpp>
 #include "../../include/r2s_raster.h"
 #include <vector>
+#include <type_traits>
 
 namespace {
 
 constexpr int TILE = 16;         // BLOCK_X == BLOCK_Y, cuda_rasterizer/config.h:15-16
-#ifndef R2S_TILE_CLASS_BITS
-#define R2S_TILE_CLASS_BITS 14   // workgroup order of the compositor: sort key = list length, 14 bits (see k_tile_len_keys)
-#endif
 constexpr int TILE_THREADS = 256;
 
 struct FrameDev {
@@ -169,12 +167,17 @@ struct RectJob {
 // measured on the benchmark scene (64 frames, wrist cameras on the grippers), per-lane limit 2 / 6 / 12 / 24 / 40 / 64 / 100 tiles:
 // count 0.80 / 0.57 / 0.47 / 0.43 / 0.41 / 0.43 / 0.47 ms, emit 0.86 / 0.60 / 0.47 / 0.44 / 0.47 / 0.51 / 0.54 ms (all per lane: 0.73 / 0.73)
 constexpr uint32_t RECT_SMALL_COUNT = 40, RECT_SMALL_EMIT = 24;
+#ifdef R2S_SURV_MASKS // experiment (measured, NOT the build: see rect_walk_flat): the counting walk leaves survivor masks for the emitting walk
+constexpr bool SURV_MASKS = true;
+#else
+constexpr bool SURV_MASKS = false;
+#endif
 // EMIT = false: returns the number of candidate tiles that can contribute (every lane of the wavefront must call it).
 // EMIT = true: writes (tile key, value) of the surviving tiles from offset `off` on, clamped to `cap`; `test` = apply the culling
 // test (off in the reference-exact mode, where every tile of the rectangle is an instance).
-template <bool EMIT>
+template <bool EMIT, typename KeyT = uint32_t>
 __device__ __forceinline__ uint32_t rect_walk(const RectJob& j, int W, int H, uint32_t off, uint32_t cap, uint32_t tile_base, uint32_t val,
-                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx = 0, bool test = true)
+                                              KeyT* __restrict__ keys, uint32_t* __restrict__ vals, int gx = 0, bool test = true)
 {
     const int lane = (int)(threadIdx.x & 63);
     const uint32_t w = j.x1 - j.x0, n = w * (j.y1 - j.y0);
@@ -184,7 +187,7 @@ __device__ __forceinline__ uint32_t rect_walk(const RectJob& j, int W, int H, ui
         for (uint32_t y = j.y0; y < j.y1; ++y)
             for (uint32_t x = j.x0; x < j.x1; ++x) {
                 if (test && !tile_can_contribute(j.mx, j.my, j.ca, j.cb, j.cc, j.rdy, j.rdx, j.lt, (int)x, (int)y, W, H)) continue;
-                if (EMIT) { if (off < cap) { keys[off] = tile_base + y * (uint32_t)gx + x; vals[off] = val; } ++off; }
+                if (EMIT) { if (off < cap) { keys[off] = (KeyT)(tile_base + y * (uint32_t)gx + x); vals[off] = val; } ++off; }
                 ++count;
             }
     }
@@ -206,7 +209,7 @@ __device__ __forceinline__ uint32_t rect_walk(const RectJob& j, int W, int H, ui
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(ok);
             if (EMIT) {
                 const uint32_t pos = base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
-                if (ok && pos < cap) { keys[pos] = tb + (y0 + ry) * (uint32_t)gx + (x0 + rx); vals[pos] = vL; }
+                if (ok && pos < cap) { keys[pos] = (KeyT)(tb + (y0 + ry) * (uint32_t)gx + (x0 + rx)); vals[pos] = vL; }
                 base += (uint32_t)__builtin_popcountll(bal);
             }
             total += (uint32_t)__builtin_popcountll(bal);
@@ -230,10 +233,17 @@ struct WalkShared {      // one per wavefront
     uint4 p2[64];        // x0, y0, w, first output slot (emit)
     uint2 p3[64];        // tile_base, value (emit)
     uint32_t cnt[64];    // passing tiles so far
+    unsigned long long mask[64]; // which candidate tiles of the Gaussian pass (rectangles of up to 64 tiles; see k_preprocess)
 };
-template <bool EMIT>
+// Survivor masks (round 6, -DR2S_SURV_MASKS; measured and NOT taken): the culling test is ~70 of the 240 instructions of a trip, and the counting walk
+// of k_preprocess already knows the answer the emitting walk of k_emit_keys asks for again.  With MASKS the counting walk leaves, for every Gaussian
+// whose rectangle has at most 64 candidate tiles, a 64-bit word — bit k = candidate k passes — and the emitting walk reads the bit instead of testing
+// (larger rectangles are tested again: a wavefront skips the test code unless one of its candidates needs it).  Lists and images identical; on the
+// 64-frame benchmark batch k_preprocess 308 -> 334 us (the word's bookkeeping + 41 MB), k_emit_keys 315 -> 304 us: a loss of 15 us.
+template <bool EMIT, typename KeyT = uint32_t, bool MASKS = false>
 __device__ __forceinline__ uint32_t rect_walk_flat(WalkShared& ws, const RectJob& j, int W, int H, uint32_t off, uint32_t cap, uint32_t tile_base,
-                                                   uint32_t val, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx, bool test)
+                                                   uint32_t val, KeyT* __restrict__ keys, uint32_t* __restrict__ vals, int gx, bool test,
+                                                   unsigned long long mask = 0ull)
 {
     const int lane = (int)(threadIdx.x & 63);
     const uint32_t w = j.x1 - j.x0, n = w * (j.y1 - j.y0);
@@ -249,6 +259,7 @@ __device__ __forceinline__ uint32_t rect_walk_flat(WalkShared& ws, const RectJob
     ws.p2[lane] = make_uint4(j.x0, j.y0, w, off);
     if (EMIT) ws.p3[lane] = make_uint2(tile_base, val);
     ws.cnt[lane] = 0u;
+    if (MASKS) ws.mask[lane] = EMIT ? mask : 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -267,10 +278,15 @@ __device__ __forceinline__ uint32_t rect_walk_flat(WalkShared& ws, const RectJob
         const uint4 q2 = ws.p2[g];
         const uint32_t k = c - start; // the k-th candidate tile of Gaussian g, row-major in its rectangle
         const uint32_t ry = (uint32_t)(((float)k + 0.5f) * (1.0f / (float)max(q2.z, 1u))), rx = k - ry * q2.z; // k < 2^11, w <= 2^7: exact
-        const bool ok = active && (!test || tile_can_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, q1.z, q1.w, q1.y, (int)(q2.x + rx), (int)(q2.y + ry), W, H));
+        const uint32_t pre_g = ws.pre[g];
+        bool ok = active;
+        if (test && active) {
+            if (MASKS && EMIT && pre_g - start <= 64u) ok = (ws.mask[g] >> k) & 1ull;
+            else ok = tile_can_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, q1.z, q1.w, q1.y, (int)(q2.x + rx), (int)(q2.y + ry), W, H);
+        }
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(ok);
         // this Gaussian's candidates of this trip sit in lanes [seg, seg_end)
-        const int seg = (int)max((int)start - (int)t0, 0), seg_end = (int)min(ws.pre[g] - t0, 64u);
+        const int seg = (int)max((int)start - (int)t0, 0), seg_end = (int)min(pre_g - t0, 64u);
         const unsigned long long upto = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         const unsigned long long from = (seg == 0) ? ~0ull : ~(~0ull >> (64 - seg));
         const uint32_t before = ws.cnt[g]; // passing tiles of g in earlier trips (read by every lane before any lane of this trip adds)
@@ -279,13 +295,15 @@ __device__ __forceinline__ uint32_t rect_walk_flat(WalkShared& ws, const RectJob
             const uint32_t pos = q2.w + before + (uint32_t)__builtin_popcountll(bal & upto & from);
             if (ok && pos < cap) {
                 const uint2 q3 = ws.p3[g];
-                keys[pos] = q3.x + (q2.y + ry) * (uint32_t)gx + (q2.x + rx);
+                keys[pos] = (KeyT)(q3.x + (q2.y + ry) * (uint32_t)gx + (q2.x + rx));
                 vals[pos] = q3.y;
             }
         }
         if (active && lane == seg_end - 1) { // the last lane of the segment books the segment's passing tiles
             const unsigned long long segmask = from & ((seg_end == 64) ? ~0ull : (~0ull >> (64 - seg_end)));
             ws.cnt[g] = before + (uint32_t)__builtin_popcountll(bal & segmask);
+            if (MASKS && !EMIT && pre_g - start <= 64u) // the segment's first lane holds candidate max(t0 - start, 0) of the Gaussian
+                ws.mask[g] |= ((bal & segmask) >> seg) << (uint32_t)max((int)t0 - (int)start, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -298,7 +316,8 @@ __device__ __forceinline__ uint32_t rect_walk_flat(WalkShared& ws, const RectJob
 __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__ frames, int gx, int gy, int W, int H,
                                                     float* __restrict__ depths, int* __restrict__ radii_all,
                                                     GeomRec* __restrict__ geom, uint32_t* __restrict__ tiles_touched,
-                                                    int* __restrict__ err_flag, int cull)
+                                                    int* __restrict__ err_flag, int cull, uint64_t* __restrict__ gkeys, uint32_t* __restrict__ gvals,
+                                                    unsigned long long* __restrict__ surv)
 {
 #pragma clang fp contract(off)
     const FrameDev& fr = frames[blockIdx.y];
@@ -307,6 +326,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
     const size_t g = (size_t)fr.base + (valid ? idx : 0);
     int radius_out = 0;
     uint32_t tiles = 0;
+    uint32_t depth_bits = 0xffffffffu; // a Gaussian that emits nothing sorts behind its frame's visible ones (where it sorts changes no list)
     RectJob job = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}; // candidate tiles still to be tested (exact-output culling)
     do {
         if (!valid) break;
@@ -398,6 +418,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
             sh_to_rgb(idx, fr.D, fr.M, fr.means3D, fr.campos, fr.shs, rgb);
         }
         depths[g] = pvz;
+        depth_bits = __float_as_uint(pvz);
         GeomRec rec;
         rec.q0 = make_float4(pix, piy, ca, cb);
         rec.q1 = make_float4(cc, fr.opac[idx], pvz, rgb[0]);
@@ -411,33 +432,27 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
         }
     } while (false);
     __shared__ WalkShared ws_s[4];
-    if (cull) tiles = rect_walk_flat<false>(ws_s[threadIdx.x >> 6], job, W, H, 0u, 0u, 0u, 0u, nullptr, nullptr, 0, true);
+    if (cull) tiles = rect_walk_flat<false, uint32_t, SURV_MASKS>(ws_s[threadIdx.x >> 6], job, W, H, 0u, 0u, 0u, 0u, nullptr, nullptr, 0, true);
     if (!valid) return;
+    if (SURV_MASKS && cull) surv[g] = ws_s[threadIdx.x >> 6].mask[threadIdx.x & 63];
     radii_all[g] = radius_out;
     if (fr.radii) fr.radii[idx] = radius_out;
     tiles_touched[g] = tiles;
+    // sort key of the first sort (see below): (frame, raw depth bits, unsigned like the reference's key), value = the Gaussian
+    gkeys[g] = ((uint64_t)blockIdx.y << 32) | depth_bits;
+    gvals[g] = (uint32_t)g;
 }
 
 // The reference sorts all instances once by (tile << 32 | depth bits) (rasterizer_impl.cu:70-111, :306-311).  The same
 // order comes out of two stable sorts that move 3.5x fewer bytes: first the GAUSSIANS by (frame, depth bits) —
-// k_gauss_keys — then their instances, emitted in that order, by tile id alone (17 bits for 64 frames x 1200 tiles
+// (frame, depth) keys of k_preprocess — then their instances, emitted in that order, by tile id alone (17 bits for 64 frames x 1200 tiles
 // instead of 48-49): inside a tile the stable second sort keeps the depth order, and equal depths keep ascending index.
-__global__ void __launch_bounds__(256) k_gauss_keys(const FrameDev* __restrict__ frames, const float* __restrict__ depths,
-                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
-{
-    const FrameDev& fr = frames[blockIdx.y];
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= fr.P) return;
-    const size_t g = (size_t)fr.base + idx;
-    keys[g] = ((uint64_t)blockIdx.y << 32) | __float_as_uint(depths[g]); // raw bits, unsigned, like the reference's key
-    vals[g] = (uint32_t)g;
-}
-__global__ void __launch_bounds__(256) k_gather_tiles(uint32_t G, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
-                                                      uint32_t* __restrict__ out)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < G) out[i] = tiles_touched[order[i]];
-}
+// (the keys are written by k_preprocess; the scan of the tile counts reads them through the sorted order: TilesInOrder)
+struct TilesInOrder {
+    const uint32_t* order;
+    const uint32_t* tiles_touched;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return tiles_touched[order[i]]; }
+};
 
 // duplicateWithKeys, rasterizer_impl.cu:70-111, walking the Gaussians in (frame, depth) order; key = frame-extended tile id.
 // Large rectangles (> RECT_SMALL_EMIT tiles) are walked by a whole wavefront.  Big batches (QUEUE = false): in place, by the wavefront
@@ -465,19 +480,20 @@ __device__ __forceinline__ EmitJob emit_job(uint32_t i, int gx, int gy, const ui
     }
     return e;
 }
-template <bool QUEUE>
+template <bool QUEUE, typename KeyT>
 __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ frames, uint32_t G, int gx, int gy, int W, int H,
                                                    const uint64_t* __restrict__ gkeys, const uint32_t* __restrict__ order,
                                                    const int* __restrict__ radii_all, const GeomRec* __restrict__ geom,
-                                                   const uint32_t* __restrict__ offsets, uint32_t* __restrict__ keys,
+                                                   const uint32_t* __restrict__ offsets, KeyT* __restrict__ keys,
                                                    uint32_t* __restrict__ vals, int cull, uint32_t cap, int* __restrict__ overflow,
-                                                   uint32_t* __restrict__ big_q, int* __restrict__ big_n)
+                                                   uint32_t* __restrict__ big_q, int* __restrict__ big_n, const unsigned long long* __restrict__ surv)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < G;
     if (valid && i == G - 1 && offsets[i] > cap) *overflow = 1; // sync-free mode: the scratch was sized from an earlier batch and is too small
     EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
     if (valid) e = emit_job(i, gx, gy, gkeys, order, radii_all, geom, offsets, cull);
+    if (sizeof(KeyT) == 2) e.tile_base = 0u; // 16-bit keys (one-pass binning): the tile inside its frame; the frame is the chunk's
     const bool big = QUEUE && (e.job.x1 - e.job.x0) * (e.job.y1 - e.job.y0) > RECT_SMALL_EMIT;
     const unsigned long long bm = __builtin_amdgcn_ballot_w64(big);
     if (QUEUE && bm) { // one atomic per wavefront
@@ -491,12 +507,15 @@ __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ 
         }
     }
     __shared__ WalkShared ws_s[4];
-    (void)rect_walk_flat<true>(ws_s[threadIdx.x >> 6], e.job, W, H, e.off, cap, e.tile_base, e.g, keys, vals, gx, cull != 0);
+    unsigned long long mask = 0ull;
+    if (SURV_MASKS && cull && valid) mask = surv[e.g];
+    (void)rect_walk_flat<true, KeyT, SURV_MASKS>(ws_s[threadIdx.x >> 6], e.job, W, H, e.off, cap, e.tile_base, e.g, keys, vals, gx, cull != 0, mask);
 }
+template <typename KeyT>
 __global__ void __launch_bounds__(256) k_emit_big(uint32_t G, int gx, int gy, int W, int H, const uint64_t* __restrict__ gkeys,
                                                   const uint32_t* __restrict__ order, const int* __restrict__ radii_all,
                                                   const GeomRec* __restrict__ geom, const uint32_t* __restrict__ offsets,
-                                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int cull, uint32_t cap,
+                                                  KeyT* __restrict__ keys, uint32_t* __restrict__ vals, int cull, uint32_t cap,
                                                   const uint32_t* __restrict__ big_q, const int* __restrict__ big_n)
 {
     const int n = *big_n;
@@ -505,7 +524,8 @@ __global__ void __launch_bounds__(256) k_emit_big(uint32_t G, int gx, int gy, in
     for (int q = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); q < n; q += waves) { // wave-uniform: one rectangle per trip
         EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
         if (lane == 0) e = emit_job(big_q[q], gx, gy, gkeys, order, radii_all, geom, offsets, cull); // rect_walk broadcasts lane 0's rectangle
-        (void)rect_walk<true>(e.job, W, H, e.off, cap, e.tile_base, e.g, keys, vals, gx, cull != 0);
+        if (sizeof(KeyT) == 2) e.tile_base = 0u;
+        (void)rect_walk<true, KeyT>(e.job, W, H, e.off, cap, e.tile_base, e.g, keys, vals, gx, cull != 0);
     }
 }
 
@@ -579,7 +599,7 @@ __global__ void __launch_bounds__(1024) k_bin_plan(const FrameDev* __restrict__ 
     for (uint32_t c = s_first[F] + (uint32_t)tid; c < nb_max; c += 1024) desc[c] = make_uint4(0u, 0u, 0u, 0u); // workgroups past the last chunk leave
 }
 
-__global__ void __launch_bounds__(BIN_THREADS) k_bin_hist(const uint4* __restrict__ desc, int tiles, const uint32_t* __restrict__ keys, uint32_t* __restrict__ hist)
+__global__ void __launch_bounds__(BIN_THREADS) k_bin_hist(const uint4* __restrict__ desc, int tiles, const uint16_t* __restrict__ keys, uint32_t* __restrict__ hist)
 {
     extern __shared__ uint32_t s_bin[];
     const uint4 d = desc[blockIdx.x];
@@ -587,44 +607,40 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_hist(const uint4* __restric
     const int tid = (int)threadIdx.x;
     for (int t = tid; t < tiles; t += BIN_THREADS) s_bin[t] = 0u;
     __syncthreads();
-    const uint32_t kb = d.x * (uint32_t)tiles;
-    const uint32_t* k = keys + d.y;
-#pragma unroll 4
-    for (uint32_t i = (uint32_t)tid; i < d.z; i += BIN_THREADS) atomicAdd(&s_bin[k[i] - kb], 1u);
+    const uint16_t* k = keys + d.y;
+    uint32_t kk[BIN_STEPS]; // the chunk's keys of this lane, all loads in flight
+#pragma unroll
+    for (int s = 0; s < BIN_STEPS; ++s) { const uint32_t i = (uint32_t)(s * BIN_THREADS + tid); kk[s] = i < d.z ? (uint32_t)k[i] : 0xffffffffu; }
+#pragma unroll
+    for (int s = 0; s < BIN_STEPS; ++s) if (kk[s] != 0xffffffffu) atomicAdd(&s_bin[kk[s]], 1u);
     __syncthreads();
     uint32_t* row = hist + (size_t)blockIdx.x * tiles;
     for (int t = tid; t < tiles; t += BIN_THREADS) row[t] = s_bin[t];
 }
 
-__global__ void __launch_bounds__(256) k_bin_colscan(int F, int tiles, const uint32_t* __restrict__ chunk_first, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals)
+__global__ void __launch_bounds__(256) k_bin_colscan(int F, int tiles, const uint32_t* __restrict__ chunk_first, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals,
+                                                     uint32_t* __restrict__ local_start, uint32_t* __restrict__ group_sum)
 {
     const uint32_t ft = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ft >= (uint32_t)F * (uint32_t)tiles) return;
-    const uint32_t f = ft / (uint32_t)tiles, t = ft - f * (uint32_t)tiles;
-    const uint32_t c0 = chunk_first[f], c1 = chunk_first[f + 1];
     uint32_t run = 0;
-    uint32_t c = c0;
-    for (; c + 8 <= c1; c += 8) { // eight rows in flight
-        uint32_t v[8];
+    if (ft < (uint32_t)F * (uint32_t)tiles) {
+        const uint32_t f = ft / (uint32_t)tiles, t = ft - f * (uint32_t)tiles;
+        const uint32_t c0 = chunk_first[f], c1 = chunk_first[f + 1];
+        uint32_t c = c0;
+        for (; c + 8 <= c1; c += 8) { // eight rows in flight
+            uint32_t v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = hist[(size_t)(c + k) * tiles + t];
+            for (int k = 0; k < 8; ++k) v[k] = hist[(size_t)(c + k) * tiles + t];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { hist[(size_t)(c + k) * tiles + t] = run; run += v[k]; }
+            for (int k = 0; k < 8; ++k) { hist[(size_t)(c + k) * tiles + t] = run; run += v[k]; }
+        }
+        for (; c < c1; ++c) { const uint32_t v = hist[(size_t)c * tiles + t]; hist[(size_t)c * tiles + t] = run; run += v; }
+        totals[ft] = run;
     }
-    for (; c < c1; ++c) { const uint32_t v = hist[(size_t)c * tiles + t]; hist[(size_t)c * tiles + t] = run; run += v; }
-    totals[ft] = run;
-}
-
-// ranges[ft] = [start, start + total) of every (frame, tile) with instances, {0, 0} for the others (what the reference's zero-filled ranges hold for a
-// tile no key names).  One workgroup: FT is a few tens of thousands.
-__global__ void __launch_bounds__(1024) k_tile_starts(uint32_t FT, const uint32_t* __restrict__ totals, uint2* __restrict__ ranges)
-{
-    __shared__ uint32_t s_wave[16];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t per = (FT + 1023u) / 1024u, a = min((uint32_t)tid * per, FT), b = min(a + per, FT);
-    uint32_t sum = 0;
-    for (uint32_t i = a; i < b; ++i) sum += totals[i];
-    uint32_t incl = sum;
+    // the tile's list starts behind the lists of the 256 (frame, tile) pairs of this workgroup before it (here) and of the workgroups before (k_tile_starts)
+    __shared__ uint32_t s_wave[4];
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    uint32_t incl = run;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
@@ -632,16 +648,53 @@ __global__ void __launch_bounds__(1024) k_tile_starts(uint32_t FT, const uint32_
     }
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    uint32_t base = incl - sum;
+    uint32_t base = incl - run;
     for (int w = 0; w < wave; ++w) base += s_wave[w];
-    for (uint32_t i = a; i < b; ++i) {
-        const uint32_t n = totals[i];
-        ranges[i] = n ? make_uint2(base, base + n) : make_uint2(0u, 0u);
-        base += n;
-    }
+    if (ft < (uint32_t)F * (uint32_t)tiles) local_start[ft] = base;
+    if (threadIdx.x == 255) group_sum[blockIdx.x] = base + run;
 }
 
-__global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const uint4* __restrict__ desc, int tiles, int key_bits, const uint32_t* __restrict__ keys,
+// ranges[ft] = [start, start + total) of every (frame, tile) with instances, {0, 0} for the others (what the reference's zero-filled ranges hold for a
+// tile no key names): the scan of the totals over all (frame, tile) pairs, finished per group of 256 — a group adds up the few hundred sums before it.
+constexpr int TILE_ORDER_BITS = 12; // length classes of the compositor's workgroup order (k_tile_order): four instances per class, 16 380+ in the first
+__device__ __forceinline__ uint32_t tile_len_class(uint32_t n) { return ((1u << TILE_ORDER_BITS) - 1u) - min(n >> 2, (1u << TILE_ORDER_BITS) - 1u); }
+// One more list of class `c` (valid lanes): counted in the workgroup's LDS first — most tiles of a batch are empty or short and share a handful of
+// classes, and 76 800 atomics on a handful of addresses take 0.18 ms — then one global atomic per class the workgroup has seen.
+__device__ __forceinline__ void tile_class_count(uint32_t* s_cls, bool valid, uint32_t c, uint32_t* __restrict__ cls_count)
+{
+    constexpr uint32_t NC = 1u << TILE_ORDER_BITS;
+    for (uint32_t k = threadIdx.x; k < NC; k += blockDim.x) s_cls[k] = 0u;
+    __syncthreads();
+    const bool first = valid && atomicAdd(&s_cls[c], 1u) == 0u;
+    __syncthreads();
+    if (first) atomicAdd(&cls_count[c], s_cls[c]);
+}
+
+__global__ void __launch_bounds__(256) k_tile_starts(uint32_t FT, const uint32_t* __restrict__ totals, const uint32_t* __restrict__ local_start,
+                                                     const uint32_t* __restrict__ group_sum, uint2* __restrict__ ranges, uint32_t* __restrict__ cls_count)
+{
+    __shared__ uint32_t s_part[256];
+    uint32_t part = 0;
+    for (uint32_t g = threadIdx.x; g < blockIdx.x; g += 256) part += group_sum[g];
+    s_part[threadIdx.x] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o];
+        __syncthreads();
+    }
+    const uint32_t ft = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = 0;
+    if (ft < FT) {
+        n = totals[ft];
+        const uint32_t st = s_part[0] + local_start[ft];
+        ranges[ft] = n ? make_uint2(st, st + n) : make_uint2(0u, 0u);
+    }
+    __shared__ uint32_t s_cls[1u << TILE_ORDER_BITS];
+    if (cls_count) tile_class_count(s_cls, ft < FT, tile_len_class(n), cls_count);
+}
+
+template <int KEY_BITS>
+__global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const uint4* __restrict__ desc, int tiles, const uint16_t* __restrict__ keys,
                                                              const uint32_t* __restrict__ vals, const uint32_t* __restrict__ hist,
                                                              const uint2* __restrict__ ranges, uint32_t* __restrict__ out)
 {
@@ -657,30 +710,45 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const uint4* __rest
     for (int s = 0; s < BIN_STEPS; ++s) {
         const uint32_t i = (uint32_t)(wave * (64 * BIN_STEPS) + s * 64 + lane);
         const bool ok = i < d.z;
-        pk[s] = ok ? keys[d.y + i] - kb : 0x80000000u;
+        pk[s] = ok ? (uint32_t)keys[d.y + i] : 0x80000000u;
         vv[s] = ok ? vals[d.y + i] : 0u;
     }
     for (int t = tid; t < WAVES * tiles; t += BIN_THREADS) s_bin[t] = 0u;
-    __syncthreads();
-    uint32_t* wh = s_bin + wave * tiles;
+    // the peers of every instance — lanes of its step with the same tile — from one ballot per key bit: the sixteen steps are independent chains
+    // (no LDS, no barrier: the compiler interleaves them).  pk = key | rank among the peers << 11 | number of peers << 17 | last peer << 24 | invalid << 31
     const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int s = 0; s < BIN_STEPS; ++s) {
         const bool ok = !(pk[s] >> 31);
         const uint32_t key = pk[s] & 0x7ffu;
-        unsigned long long peers = __builtin_amdgcn_ballot_w64(ok); // lanes of this step with my tile
-        for (int b = 0; b < key_bits; ++b) {
-            const bool bit = (key >> b) & 1u;
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(bit);
-            peers &= bit ? bal : ~bal;
+        uint32_t plo = 0xffffffffu, phi = 0xffffffffu;
+#pragma unroll
+        for (int b = 0; b < KEY_BITS; ++b) {
+            const int m = __builtin_amdgcn_sbfe((int)key, b, 1); // 0 or ~0
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(m != 0);
+            plo &= ~((uint32_t)bal ^ (uint32_t)m);               // bit set: bal, clear: ~bal
+            phi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)m);
         }
+        unsigned long long peers = (((unsigned long long)phi << 32) | plo) & __builtin_amdgcn_ballot_w64(ok);
         if (!ok) peers = 0ull;
-        const uint32_t before = wh[ok ? key : 0u]; // read by every peer before the last of them books the step (one wavefront: in order)
+#ifdef R2S_BIN_NOMATCH // experiment: every lane alone (wrong lists; what the ballots cost)
+        peers = ok ? 1ull << lane : 0ull;
+#endif
+        const uint32_t r = (uint32_t)__builtin_popcountll(peers & lt), n = (uint32_t)__builtin_popcountll(peers);
+        pk[s] = (pk[s] & 0x800007ffu) | (r << 11) | (n << 17) | ((peers >> lane) == 1ull ? 1u << 24 : 0u);
+    }
+    __syncthreads();
+    uint32_t* wh = s_bin + wave * tiles;
+#pragma unroll
+    for (int s = 0; s < BIN_STEPS; ++s) {
+        const bool ok = !(pk[s] >> 31);
+        const uint32_t key = pk[s] & 0x7ffu;
+        const uint32_t before = wh[key]; // read by every peer before the last of them books the step (one wavefront: its LDS operations stay in order)
         __builtin_amdgcn_wave_barrier();
-        if (ok && (peers >> lane) <= 1ull) wh[key] = before + (uint32_t)__builtin_popcountll(peers);
+        if (ok && ((pk[s] >> 24) & 1u)) wh[key] = before + ((pk[s] >> 17) & 0x7fu);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        pk[s] = (pk[s] & 0x800007ffu) | ((before + (uint32_t)__builtin_popcountll(peers & lt)) << 11); // rank among the wavefront's instances of the tile
+        pk[s] = (pk[s] & 0x800007ffu) | ((before + ((pk[s] >> 11) & 0x3fu)) << 11); // rank among the wavefront's instances of the tile
     }
     __syncthreads();
     const uint32_t* row = hist + (size_t)blockIdx.x * tiles;
@@ -692,7 +760,11 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const uint4* __rest
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < BIN_STEPS; ++s)
+#ifdef R2S_BIN_NOSCATTER // experiment: coalesced stores (wrong lists; what the scattered 4-byte stores cost)
+        if (!(pk[s] >> 31)) out[d.y + (uint32_t)(wave * (64 * BIN_STEPS) + s * 64 + lane) + ((wh[pk[s] & 0x7ffu] + (pk[s] >> 11)) & 1u)] = vv[s];
+#else
         if (!(pk[s] >> 31)) out[wh[pk[s] & 0x7ffu] + ((pk[s] >> 11) & 0xfffffu)] = vv[s];
+#endif
 }
 
 // Workgroup order of the compositor: tiles sorted by the length of their instance list, longest first.  On the benchmark
@@ -705,19 +777,52 @@ __global__ void __launch_bounds__(256) k_fill_sentinel(const uint32_t* __restric
     if (i < cap && i >= *last_offset) keys[i] = sentinel;
 }
 
-__global__ void __launch_bounds__(256) k_tile_len_keys(uint32_t n, const uint2* __restrict__ ranges, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+// (Until round 6: a key per tile + a two-pass rocPRIM sort of 76 800 pairs — five launches, 45 us.  The order only has to be by length CLASS and
+// nothing depends on the order inside a class, so it is a counting sort: the class counts come with the ranges (k_tile_starts; k_tile_classes
+// behind the radix-sort path), every workgroup scans them for itself, and the slots inside a class are handed out by atomics.  Which of two
+// equally long lists starts first may differ from run to run; no pixel depends on it.)
+__global__ void __launch_bounds__(256) k_tile_classes(uint32_t n, const uint2* __restrict__ ranges, uint32_t* __restrict__ cls_count)
 {
+    __shared__ uint32_t s_cls[1u << TILE_ORDER_BITS];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint2 r = ranges[i];
-    // Longest lists first.  Coarser length classes (64 classes of 128 instances, 256 of 32, 1024 of 8) — which keep neighbouring
-    // tiles next to each other inside a class for L2 reuse — were measured and are not faster (0.97 / 0.98 / 0.99 / 1.00 ms for
-    // 14 / 10 / 8 / 6 key bits on the benchmark scene): balance matters more than the 1.3x re-fetch, so the full length is the key.
-#ifndef R2S_TILE_CLASS_SHIFT
-#define R2S_TILE_CLASS_SHIFT 0
-#endif
-    keys[i] = ((1u << R2S_TILE_CLASS_BITS) - 1u) - min((r.y - r.x) >> R2S_TILE_CLASS_SHIFT, (1u << R2S_TILE_CLASS_BITS) - 1u);
-    vals[i] = i;
+    uint2 r = make_uint2(0u, 0u);
+    if (i < n) r = ranges[i];
+    tile_class_count(s_cls, i < n, tile_len_class(r.y - r.x), cls_count);
+}
+__global__ void __launch_bounds__(1024) k_tile_order(uint32_t n, const uint2* __restrict__ ranges, const uint32_t* __restrict__ cls_count,
+                                                     uint32_t* __restrict__ cls_cursor, uint32_t* __restrict__ order)
+{
+    constexpr uint32_t NC = 1u << TILE_ORDER_BITS;
+    __shared__ uint32_t s_start[NC]; // where the class starts in the order
+    __shared__ uint32_t s_cnt[NC];   // lists of the class in this workgroup; then: the workgroup's first slot inside the class
+    __shared__ uint32_t s_wave[16];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint2 r = make_uint2(0u, 0u);
+    if (i < n) r = ranges[i];
+    const uint32_t c = tile_len_class(r.y - r.x);
+    // exclusive scan of the class counts: 4 consecutive classes per thread
+    constexpr int PER = (int)(NC / 1024);
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { v[k] = cls_count[tid * PER + k]; sum += v[k]; s_cnt[tid * PER + k] = 0u; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - sum;
+    for (int w = 0; w < wave; ++w) base += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { s_start[tid * PER + k] = base; base += v[k]; }
+    const uint32_t local = i < n ? atomicAdd(&s_cnt[c], 1u) : 1u;
+    __syncthreads();
+    if (local == 0u) s_cnt[c] = atomicAdd(&cls_cursor[c], s_cnt[c]); // one global atomic per class and workgroup
+    __syncthreads();
+    if (i < n) order[s_start[c] + s_cnt[c] + local] = i;
 }
 
 // renderCUDA, forward.cu:262-394.  One workgroup per 16x16 tile; wavefront w owns the 8x8 quadrant
@@ -1117,8 +1222,9 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
 
     // ---- geometry scratch (GeometryState, rasterizer_impl.h:30-45) ----
     size_t scan_bytes = 0;
-    R2S_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, G ? G : 1,
-                                        rocprim::plus<uint32_t>(), stream));
+    R2S_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes,
+                                        rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), TilesInOrder{nullptr, nullptr}),
+                                        (uint32_t*)nullptr, G ? G : 1, rocprim::plus<uint32_t>(), stream));
     // first sort: Gaussians by (frame, depth bits)
     unsigned fbits = 0;
     while ((1u << fbits) < (unsigned)F) ++fbits;
@@ -1128,39 +1234,36 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         rocprim::double_buffer<uint32_t> dv((uint32_t*)nullptr, (uint32_t*)nullptr);
         R2S_HIP_TRY(rocprim::radix_sort_pairs<GaussSortConfig>(nullptr, gsort_bytes, dk, dv, G ? G : 1, 0u, 32u + fbits, stream));
     }
-    float* depths; int* radii_all; GeomRec* geom; uint32_t* tiles_touched; uint32_t* tiles_sorted; uint32_t* offsets; char* scan_tmp; int* err_flag; uint32_t* big_q;
-    uint64_t *gkeys_a, *gkeys_b; uint32_t *gvals_a, *gvals_b; char* gsort_tmp;
+    float* depths; int* radii_all; GeomRec* geom; uint32_t* tiles_touched; uint32_t* offsets; char* scan_tmp; int* err_flag; uint32_t* big_q;
+    uint64_t *gkeys_a, *gkeys_b; uint32_t *gvals_a, *gvals_b; char* gsort_tmp; unsigned long long* surv;
     {
         r2s::Carver sz(nullptr);
-        sz.take<float>(G); sz.take<int>(G); sz.take<GeomRec>(G); sz.take<uint32_t>(G); sz.take<uint32_t>(G); sz.take<uint32_t>(G);
+        sz.take<float>(G); sz.take<int>(G); sz.take<GeomRec>(G); sz.take<uint32_t>(G); sz.take<uint32_t>(G);
         sz.take<char>(scan_bytes); sz.take<int>(4); sz.take<uint32_t>(G);
-        sz.take<uint64_t>(G); sz.take<uint64_t>(G); sz.take<uint32_t>(G); sz.take<uint32_t>(G); sz.take<char>(gsort_bytes);
+        sz.take<uint64_t>(G); sz.take<uint64_t>(G); sz.take<uint32_t>(G); sz.take<uint32_t>(G); sz.take<char>(gsort_bytes); sz.take<unsigned long long>(SURV_MASKS && c->cull ? G : 0);
         char* p = c->scratch(0, sz.bytes());
         if (!p) return R2S_ERR_ALLOC;
         r2s::Carver cv(p);
         depths = cv.take<float>(G); radii_all = cv.take<int>(G); geom = cv.take<GeomRec>(G);
-        tiles_touched = cv.take<uint32_t>(G); tiles_sorted = cv.take<uint32_t>(G); offsets = cv.take<uint32_t>(G);
+        tiles_touched = cv.take<uint32_t>(G); offsets = cv.take<uint32_t>(G);
         scan_tmp = cv.take<char>(scan_bytes); err_flag = cv.take<int>(4); big_q = cv.take<uint32_t>(G);
         gkeys_a = cv.take<uint64_t>(G); gkeys_b = cv.take<uint64_t>(G); gvals_a = cv.take<uint32_t>(G); gvals_b = cv.take<uint32_t>(G);
         gsort_tmp = cv.take<char>(gsort_bytes);
+        surv = cv.take<unsigned long long>(SURV_MASKS && c->cull ? G : 0);
     }
     // ---- image scratch (ImageState: ranges; accum_alpha / n_contrib are backward-only) ----
     uint2* ranges;
-    uint32_t *tl_keys[2], *tl_vals[2];
-    char* tl_tmp;
-    size_t tl_bytes = 0;
+    uint32_t *tl_order, *tl_cls;
     const size_t FT = (size_t)F * tiles;
     {
-        rocprim::double_buffer<uint32_t> dk((uint32_t*)nullptr, (uint32_t*)nullptr), dv((uint32_t*)nullptr, (uint32_t*)nullptr);
-        R2S_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tl_bytes, dk, dv, FT, 0u, (unsigned)R2S_TILE_CLASS_BITS, stream));
         r2s::Carver sz(nullptr);
-        sz.take<uint2>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>(FT); sz.take<char>(tl_bytes);
+        sz.take<uint2>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>(2u << TILE_ORDER_BITS);
         char* p = c->scratch(2, sz.bytes());
         if (!p) return R2S_ERR_ALLOC;
         r2s::Carver cv(p);
         ranges = cv.take<uint2>(FT);
-        tl_keys[0] = cv.take<uint32_t>(FT); tl_keys[1] = cv.take<uint32_t>(FT); tl_vals[0] = cv.take<uint32_t>(FT); tl_vals[1] = cv.take<uint32_t>(FT);
-        tl_tmp = cv.take<char>(tl_bytes);
+        tl_order = cv.take<uint32_t>(FT);
+        tl_cls = cv.take<uint32_t>(2u << TILE_ORDER_BITS); // class counts | class cursors
     }
 
     R2S_HIP_TRY(hipMemcpyAsync(c->d_frames, c->h_frames, sizeof(FrameDev) * F, hipMemcpyHostToDevice, stream));
@@ -1192,17 +1295,17 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     if (G > 0) {
         dim3 grid((maxP + 255) / 256, F);
         hipLaunchKernelGGL(k_preprocess, grid, dim3(256), 0, stream, c->d_frames, gx, gy, W, H, depths, radii_all, geom,
-                           tiles_touched, err_flag, c->cull);
+                           tiles_touched, err_flag, c->cull, gkeys_a, gvals_a, surv);
         mark(1);
-        hipLaunchKernelGGL(k_gauss_keys, grid, dim3(256), 0, stream, c->d_frames, depths, gkeys_a, gvals_a);
         rocprim::double_buffer<uint64_t> dgk(gkeys_a, gkeys_b);
         rocprim::double_buffer<uint32_t> dgv(gvals_a, gvals_b);
         R2S_HIP_TRY(rocprim::radix_sort_pairs<GaussSortConfig>(gsort_tmp, gsort_bytes, dgk, dgv, G, 0u, 32u + fbits, stream));
         gkeys_sorted = dgk.current();
         order = dgv.current();
-        hipLaunchKernelGGL(k_gather_tiles, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, (uint32_t)G, order, tiles_touched, tiles_sorted);
         // offsets[i] = instances of the first i+1 Gaussians in (frame, depth) order; frames stay contiguous
-        R2S_HIP_TRY(rocprim::inclusive_scan(scan_tmp, scan_bytes, tiles_sorted, offsets, G, rocprim::plus<uint32_t>(), stream));
+        R2S_HIP_TRY(rocprim::inclusive_scan(scan_tmp, scan_bytes,
+                                            rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), TilesInOrder{order, tiles_touched}),
+                                            offsets, G, rocprim::plus<uint32_t>(), stream));
         mark(2);
         R2S_HIP_TRY(hipMemcpyAsync(&c->h_read[0], offsets + (G - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         R2S_HIP_TRY(hipMemcpyAsync(&c->h_read[1], err_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -1230,50 +1333,63 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     const uint32_t* keys_sorted = nullptr;
     const uint32_t* vals_sorted = nullptr;
     bool ranges_done = false;
+    const bool want_order = cap > 0 && G > 0 && FT >= 4096 && c->tile_order; // compositor workgroups longest list first (big batches)
+    if (want_order) R2S_HIP_TRY(hipMemsetAsync(tl_cls, 0, sizeof(uint32_t) * (2u << TILE_ORDER_BITS), stream));
     if (cap > 0 && G > 0) {
         rocprim::double_buffer<uint32_t> dk((uint32_t*)nullptr, (uint32_t*)nullptr);
         rocprim::double_buffer<uint32_t> dv((uint32_t*)nullptr, (uint32_t*)nullptr);
         size_t sort_bytes = 0;
         if (!bin_pass) R2S_HIP_TRY(rocprim::radix_sort_pairs<TileSortConfig>(nullptr, sort_bytes, dk, dv, (size_t)cap, 0u, bits, stream));
         const uint32_t nb_max = cap / BIN_CHUNK + (uint32_t)F; // every frame ends in at most one partial chunk
-        uint32_t *bin_hist = nullptr, *bin_first = nullptr, *bin_totals = nullptr;
+        uint32_t *bin_hist = nullptr, *bin_first = nullptr, *bin_totals = nullptr, *bin_local = nullptr, *bin_gsum = nullptr;
         uint4* bin_desc = nullptr;
         char* sort_tmp = nullptr;
         {
             r2s::Carver sz(nullptr);
-            sz.take<uint32_t>(cap); sz.take<uint32_t>(cap); sz.take<uint32_t>(cap);
-            if (bin_pass) { sz.take<uint32_t>((size_t)nb_max * tiles); sz.take<uint4>(nb_max); sz.take<uint32_t>((size_t)F + 1); sz.take<uint32_t>(FT); }
+            sz.take<uint32_t>(bin_pass ? (cap + 1) / 2 : cap); sz.take<uint32_t>(cap); sz.take<uint32_t>(cap);
+            if (bin_pass) { sz.take<uint32_t>((size_t)nb_max * tiles); sz.take<uint4>(nb_max); sz.take<uint32_t>((size_t)F + 1); sz.take<uint32_t>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>((FT + 255) / 256); }
             else { sz.take<uint32_t>(cap); sz.take<char>(sort_bytes); }
             char* p = c->scratch(1, sz.bytes());
             if (!p) return R2S_ERR_ALLOC;
             r2s::Carver cv(p);
-            keys_a = cv.take<uint32_t>(cap); vals_a = cv.take<uint32_t>(cap); vals_b = cv.take<uint32_t>(cap);
+            keys_a = cv.take<uint32_t>(bin_pass ? (cap + 1) / 2 : cap); vals_a = cv.take<uint32_t>(cap); vals_b = cv.take<uint32_t>(cap);
             if (bin_pass) {
                 bin_hist = cv.take<uint32_t>((size_t)nb_max * tiles); bin_desc = cv.take<uint4>(nb_max); bin_first = cv.take<uint32_t>((size_t)F + 1);
-                bin_totals = cv.take<uint32_t>(FT);
+                bin_totals = cv.take<uint32_t>(FT); bin_local = cv.take<uint32_t>(FT); bin_gsum = cv.take<uint32_t>((FT + 255) / 256);
             } else { keys_b = cv.take<uint32_t>(cap); sort_tmp = cv.take<char>(sort_bytes); }
         }
 
         if (sync_free && !bin_pass) // instances this batch does not produce: sentinel keys that sort behind every (frame, tile)
             hipLaunchKernelGGL(k_fill_sentinel, dim3((cap + 255) / 256), dim3(256), 0, stream, offsets + (G - 1), cap, (uint32_t)F * (uint32_t)tiles, keys_a);
-        if (G <= (size_t)1 << 18) { // small batch: large rectangles through the queue (see k_emit_keys)
-            hipLaunchKernelGGL(k_emit_keys<true>, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
-                               order, radii_all, geom, offsets, keys_a, vals_a, c->cull, cap, err_flag + 1, big_q, err_flag + 2);
-            hipLaunchKernelGGL(k_emit_big, dim3(1024), dim3(256), 0, stream, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
-                               order, radii_all, geom, offsets, keys_a, vals_a, c->cull, cap, big_q, err_flag + 2);
-        } else
-            hipLaunchKernelGGL(k_emit_keys<false>, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
-                               order, radii_all, geom, offsets, keys_a, vals_a, c->cull, cap, err_flag + 1, big_q, err_flag + 2);
+        auto emit = [&](auto* keys) { // 16-bit keys (tile inside the frame) for the one-pass binning, frame-extended 32-bit keys for the radix sort
+            using KeyT = std::remove_pointer_t<decltype(keys)>;
+            if (G <= (size_t)1 << 18) { // small batch: large rectangles through the queue (see k_emit_keys)
+                hipLaunchKernelGGL((k_emit_keys<true, KeyT>), dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
+                                   order, radii_all, geom, offsets, keys, vals_a, c->cull, cap, err_flag + 1, big_q, err_flag + 2, surv);
+                hipLaunchKernelGGL(k_emit_big<KeyT>, dim3(1024), dim3(256), 0, stream, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
+                                   order, radii_all, geom, offsets, keys, vals_a, c->cull, cap, big_q, err_flag + 2);
+            } else
+                hipLaunchKernelGGL((k_emit_keys<false, KeyT>), dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
+                                   order, radii_all, geom, offsets, keys, vals_a, c->cull, cap, err_flag + 1, big_q, err_flag + 2, surv);
+        };
+        const uint16_t* keys16 = reinterpret_cast<const uint16_t*>(keys_a);
+        if (bin_pass) emit(reinterpret_cast<uint16_t*>(keys_a));
+        else emit(keys_a);
         mark(3);
         if (bin_pass) {
             unsigned key_bits = 0;
             while ((1u << key_bits) < (unsigned)tiles) ++key_bits;
             hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(1024), 0, stream, c->d_frames, F, offsets, cap, nb_max, bin_desc, bin_first);
-            hipLaunchKernelGGL(k_bin_hist, dim3(nb_max), dim3(BIN_THREADS), sizeof(uint32_t) * tiles, stream, bin_desc, tiles, keys_a, bin_hist);
-            hipLaunchKernelGGL(k_bin_colscan, dim3((unsigned)((FT + 255) / 256)), dim3(256), 0, stream, F, tiles, bin_first, bin_hist, bin_totals);
-            hipLaunchKernelGGL(k_tile_starts, dim3(1), dim3(1024), 0, stream, (uint32_t)FT, bin_totals, ranges);
-            hipLaunchKernelGGL(k_bin_scatter, dim3(nb_max), dim3(BIN_THREADS), sizeof(uint32_t) * tiles * (BIN_THREADS / 64), stream, bin_desc, tiles, (int)key_bits,
-                               keys_a, vals_a, bin_hist, ranges, vals_b);
+            hipLaunchKernelGGL(k_bin_hist, dim3(nb_max), dim3(BIN_THREADS), sizeof(uint32_t) * tiles, stream, bin_desc, tiles, keys16, bin_hist);
+            hipLaunchKernelGGL(k_bin_colscan, dim3((unsigned)((FT + 255) / 256)), dim3(256), 0, stream, F, tiles, bin_first, bin_hist, bin_totals, bin_local, bin_gsum);
+            hipLaunchKernelGGL(k_tile_starts, dim3((unsigned)((FT + 255) / 256)), dim3(256), 0, stream, (uint32_t)FT, bin_totals, bin_local, bin_gsum, ranges, want_order ? tl_cls : nullptr);
+            const size_t sc_lds = sizeof(uint32_t) * tiles * (BIN_THREADS / 64);
+            if (key_bits <= 9)
+                hipLaunchKernelGGL(k_bin_scatter<9>, dim3(nb_max), dim3(BIN_THREADS), sc_lds, stream, bin_desc, tiles, keys16, vals_a, bin_hist, ranges, vals_b);
+            else if (key_bits == 10)
+                hipLaunchKernelGGL(k_bin_scatter<10>, dim3(nb_max), dim3(BIN_THREADS), sc_lds, stream, bin_desc, tiles, keys16, vals_a, bin_hist, ranges, vals_b);
+            else
+                hipLaunchKernelGGL(k_bin_scatter<11>, dim3(nb_max), dim3(BIN_THREADS), sc_lds, stream, bin_desc, tiles, keys16, vals_a, bin_hist, ranges, vals_b);
             vals_sorted = vals_b;
             ranges_done = true;
         } else {
@@ -1297,11 +1413,10 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         L = cap;
     }
     const uint32_t* tile_order = nullptr;
-    if (L > 0 && FT >= 4096 && c->tile_order) { // big batches: start the deepest tiles first
-        hipLaunchKernelGGL(k_tile_len_keys, dim3((unsigned)((FT + 255) / 256)), dim3(256), 0, stream, (uint32_t)FT, ranges, tl_keys[0], tl_vals[0]);
-        rocprim::double_buffer<uint32_t> dk(tl_keys[0], tl_keys[1]), dv(tl_vals[0], tl_vals[1]);
-        R2S_HIP_TRY(rocprim::radix_sort_pairs(tl_tmp, tl_bytes, dk, dv, FT, 0u, (unsigned)R2S_TILE_CLASS_BITS, stream));
-        tile_order = dv.current();
+    if (want_order) { // big batches: start the deepest tiles first
+        if (!ranges_done) hipLaunchKernelGGL(k_tile_classes, dim3((unsigned)((FT + 255) / 256)), dim3(256), 0, stream, (uint32_t)FT, ranges, tl_cls);
+        hipLaunchKernelGGL(k_tile_order, dim3((unsigned)((FT + 1023) / 1024)), dim3(1024), 0, stream, (uint32_t)FT, ranges, tl_cls, tl_cls + (1u << TILE_ORDER_BITS), tl_order);
+        tile_order = tl_order;
     }
     mark(5);
     if (c->aux_T || c->aux_n) // the backward-only auxiliaries (final_T, n_contrib) cost two VALU instructions per blend: only on request
