@@ -316,7 +316,7 @@ __device__ __forceinline__ uint32_t rect_walk_flat(WalkShared& ws, const RectJob
 __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__ frames, int gx, int gy, int W, int H,
                                                     float* __restrict__ depths, int* __restrict__ radii_all,
                                                     GeomRec* __restrict__ geom, uint32_t* __restrict__ tiles_touched,
-                                                    int* __restrict__ err_flag, int cull, uint64_t* __restrict__ gkeys, uint32_t* __restrict__ gvals,
+                                                    int* __restrict__ err_flag, int cull, uint64_t* __restrict__ gkeys, int idx_bits,
                                                     unsigned long long* __restrict__ surv)
 {
 #pragma clang fp contract(off)
@@ -438,9 +438,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
     radii_all[g] = radius_out;
     if (fr.radii) fr.radii[idx] = radius_out;
     tiles_touched[g] = tiles;
-    // sort key of the first sort (see below): (frame, raw depth bits, unsigned like the reference's key), value = the Gaussian
-    gkeys[g] = ((uint64_t)blockIdx.y << 32) | depth_bits;
-    gvals[g] = (uint32_t)g;
+    // key of the first sort (see below): frame | raw depth bits (unsigned, like the reference's key) | index inside the frame.  Only the upper two
+    // fields are sorted on; the index rides in the key's low bits, so the sort moves 8 bytes per Gaussian instead of a key-value pair's 12.
+    gkeys[g] = ((uint64_t)blockIdx.y << (32 + idx_bits)) | ((uint64_t)depth_bits << idx_bits) | (uint64_t)(uint32_t)idx;
 }
 
 // The reference sorts all instances once by (tile << 32 | depth bits) (rasterizer_impl.cu:70-111, :306-311).  The same
@@ -448,10 +448,21 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
 // (frame, depth) keys of k_preprocess — then their instances, emitted in that order, by tile id alone (17 bits for 64 frames x 1200 tiles
 // instead of 48-49): inside a tile the stable second sort keeps the depth order, and equal depths keep ascending index.
 // (the keys are written by k_preprocess; the scan of the tile counts reads them through the sorted order: TilesInOrder)
+struct DepthOrder { // the Gaussians in (frame, depth, index) order: entry i of the sorted keys
+    const uint64_t* keys;
+    const FrameDev* frames;
+    int idx_bits;
+    __device__ __forceinline__ uint32_t frame(uint32_t i) const { return (uint32_t)(keys[i] >> (32 + idx_bits)); }
+    __device__ __forceinline__ uint32_t gaussian(uint32_t i) const
+    {
+        const uint64_t k = keys[i];
+        return frames[(uint32_t)(k >> (32 + idx_bits))].base + (uint32_t)(k & ((1ull << idx_bits) - 1ull));
+    }
+};
 struct TilesInOrder {
-    const uint32_t* order;
+    DepthOrder order;
     const uint32_t* tiles_touched;
-    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return tiles_touched[order[i]]; }
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return tiles_touched[order.gaussian(i)]; }
 };
 
 // duplicateWithKeys, rasterizer_impl.cu:70-111, walking the Gaussians in (frame, depth) order; key = frame-extended tile id.
@@ -462,12 +473,12 @@ struct TilesInOrder {
 // instance lands is fixed by the scan of the tile counts, so the drain order does not matter.  (The queue for big batches too: 2.0 - 2.6
 // ms instead of 0.40 for the 64-frame benchmark batch — several 100 k appends through one counter, even one atomic per wavefront.)
 struct EmitJob { RectJob job; uint32_t off, tile_base, g; };
-__device__ __forceinline__ EmitJob emit_job(uint32_t i, int gx, int gy, const uint64_t* __restrict__ gkeys, const uint32_t* __restrict__ order,
+__device__ __forceinline__ EmitJob emit_job(uint32_t i, int gx, int gy, const DepthOrder& order,
                                             const int* __restrict__ radii_all, const GeomRec* __restrict__ geom,
                                             const uint32_t* __restrict__ offsets, int cull)
 {
     EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
-    e.g = order[i];
+    e.g = order.gaussian(i);
     const int r = radii_all[e.g];
     if (r > 0) {
         e.off = (i == 0) ? 0u : offsets[i - 1];
@@ -475,14 +486,14 @@ __device__ __forceinline__ EmitJob emit_job(uint32_t i, int gx, int gy, const ui
         const float4 q1 = geom[e.g].q1;
         uint32_t x0, y0, x1, y1;
         tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
-        e.tile_base = (uint32_t)(gkeys[i] >> 32) * (uint32_t)(gx * gy);
+        e.tile_base = order.frame(i) * (uint32_t)(gx * gy);
         e.job = {q0.x, q0.y, q0.z, q0.w, q1.x, cull ? logf(1.0f / (255.0f * q1.y)) : 0.f, -q0.w / q1.x, -q0.w / q0.z, x0, y0, x1, y1};
     }
     return e;
 }
 template <bool QUEUE, typename KeyT>
 __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ frames, uint32_t G, int gx, int gy, int W, int H,
-                                                   const uint64_t* __restrict__ gkeys, const uint32_t* __restrict__ order,
+                                                   const DepthOrder order,
                                                    const int* __restrict__ radii_all, const GeomRec* __restrict__ geom,
                                                    const uint32_t* __restrict__ offsets, KeyT* __restrict__ keys,
                                                    uint32_t* __restrict__ vals, int cull, uint32_t cap, int* __restrict__ overflow,
@@ -492,7 +503,7 @@ __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ 
     const bool valid = i < G;
     if (valid && i == G - 1 && offsets[i] > cap) *overflow = 1; // sync-free mode: the scratch was sized from an earlier batch and is too small
     EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
-    if (valid) e = emit_job(i, gx, gy, gkeys, order, radii_all, geom, offsets, cull);
+    if (valid) e = emit_job(i, gx, gy, order, radii_all, geom, offsets, cull);
     if (sizeof(KeyT) == 2) e.tile_base = 0u; // 16-bit keys (one-pass binning): the tile inside its frame; the frame is the chunk's
     const bool big = QUEUE && (e.job.x1 - e.job.x0) * (e.job.y1 - e.job.y0) > RECT_SMALL_EMIT;
     const unsigned long long bm = __builtin_amdgcn_ballot_w64(big);
@@ -512,8 +523,7 @@ __global__ void __launch_bounds__(256) k_emit_keys(const FrameDev* __restrict__ 
     (void)rect_walk_flat<true, KeyT, SURV_MASKS>(ws_s[threadIdx.x >> 6], e.job, W, H, e.off, cap, e.tile_base, e.g, keys, vals, gx, cull != 0, mask);
 }
 template <typename KeyT>
-__global__ void __launch_bounds__(256) k_emit_big(uint32_t G, int gx, int gy, int W, int H, const uint64_t* __restrict__ gkeys,
-                                                  const uint32_t* __restrict__ order, const int* __restrict__ radii_all,
+__global__ void __launch_bounds__(256) k_emit_big(uint32_t G, int gx, int gy, int W, int H, const DepthOrder order, const int* __restrict__ radii_all,
                                                   const GeomRec* __restrict__ geom, const uint32_t* __restrict__ offsets,
                                                   KeyT* __restrict__ keys, uint32_t* __restrict__ vals, int cull, uint32_t cap,
                                                   const uint32_t* __restrict__ big_q, const int* __restrict__ big_n)
@@ -523,7 +533,7 @@ __global__ void __launch_bounds__(256) k_emit_big(uint32_t G, int gx, int gy, in
     const int waves = (int)(gridDim.x * (blockDim.x >> 6));
     for (int q = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); q < n; q += waves) { // wave-uniform: one rectangle per trip
         EmitJob e = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u}, 0u, 0u, 0u};
-        if (lane == 0) e = emit_job(big_q[q], gx, gy, gkeys, order, radii_all, geom, offsets, cull); // rect_walk broadcasts lane 0's rectangle
+        if (lane == 0) e = emit_job(big_q[q], gx, gy, order, radii_all, geom, offsets, cull); // rect_walk broadcasts lane 0's rectangle
         if (sizeof(KeyT) == 2) e.tile_base = 0u;
         (void)rect_walk<true, KeyT>(e.job, W, H, e.off, cap, e.tile_base, e.g, keys, vals, gx, cull != 0);
     }
@@ -693,8 +703,13 @@ __global__ void __launch_bounds__(256) k_tile_starts(uint32_t FT, const uint32_t
     if (cls_count) tile_class_count(s_cls, ft < FT, tile_len_class(n), cls_count);
 }
 
+#ifdef R2S_BIN_WAVES
+#define R2S_BIN_OCC __attribute__((amdgpu_waves_per_eu(R2S_BIN_WAVES, R2S_BIN_WAVES)))
+#else
+#define R2S_BIN_OCC
+#endif
 template <int KEY_BITS>
-__global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const uint4* __restrict__ desc, int tiles, const uint16_t* __restrict__ keys,
+__global__ void __launch_bounds__(BIN_THREADS) R2S_BIN_OCC k_bin_scatter(const uint4* __restrict__ desc, int tiles, const uint16_t* __restrict__ keys,
                                                              const uint32_t* __restrict__ vals, const uint32_t* __restrict__ hist,
                                                              const uint2* __restrict__ ranges, uint32_t* __restrict__ out)
 {
@@ -705,13 +720,18 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const uint4* __rest
     constexpr int WAVES = BIN_THREADS / 64;
     const uint32_t kb = d.x * (uint32_t)tiles;
     // this lane's instances: 64 consecutive ones per step and wavefront, all loads in flight before the first is needed
-    uint32_t pk[BIN_STEPS], vv[BIN_STEPS];
+    uint32_t pk[BIN_STEPS];
+#ifndef R2S_BIN_LATE_VALS
+    uint32_t vv[BIN_STEPS];
+#endif
 #pragma unroll
     for (int s = 0; s < BIN_STEPS; ++s) {
         const uint32_t i = (uint32_t)(wave * (64 * BIN_STEPS) + s * 64 + lane);
         const bool ok = i < d.z;
         pk[s] = ok ? (uint32_t)keys[d.y + i] : 0x80000000u;
+#ifndef R2S_BIN_LATE_VALS
         vv[s] = ok ? vals[d.y + i] : 0u;
+#endif
     }
     for (int t = tid; t < WAVES * tiles; t += BIN_THREADS) s_bin[t] = 0u;
     // the peers of every instance — lanes of its step with the same tile — from one ballot per key bit: the sixteen steps are independent chains
@@ -731,11 +751,11 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const uint4* __rest
         }
         unsigned long long peers = (((unsigned long long)phi << 32) | plo) & __builtin_amdgcn_ballot_w64(ok);
         if (!ok) peers = 0ull;
-#ifdef R2S_BIN_NOMATCH // experiment: every lane alone (wrong lists; what the ballots cost)
-        peers = ok ? 1ull << lane : 0ull;
-#endif
         const uint32_t r = (uint32_t)__builtin_popcountll(peers & lt), n = (uint32_t)__builtin_popcountll(peers);
         pk[s] = (pk[s] & 0x800007ffu) | (r << 11) | (n << 17) | ((peers >> lane) == 1ull ? 1u << 24 : 0u);
+#ifdef R2S_BIN_GROUP // experiment: at most R2S_BIN_GROUP chains interleaved (registers)
+        if ((s + 1) % R2S_BIN_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     __syncthreads();
     uint32_t* wh = s_bin + wave * tiles;
@@ -760,8 +780,8 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const uint4* __rest
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < BIN_STEPS; ++s)
-#ifdef R2S_BIN_NOSCATTER // experiment: coalesced stores (wrong lists; what the scattered 4-byte stores cost)
-        if (!(pk[s] >> 31)) out[d.y + (uint32_t)(wave * (64 * BIN_STEPS) + s * 64 + lane) + ((wh[pk[s] & 0x7ffu] + (pk[s] >> 11)) & 1u)] = vv[s];
+#ifdef R2S_BIN_LATE_VALS // experiment: the values loaded behind the ranking (16 registers less)
+        if (!(pk[s] >> 31)) out[wh[pk[s] & 0x7ffu] + ((pk[s] >> 11) & 0xfffffu)] = vals[d.y + (uint32_t)(wave * (64 * BIN_STEPS) + s * 64 + lane)];
 #else
         if (!(pk[s] >> 31)) out[wh[pk[s] & 0x7ffu] + ((pk[s] >> 11) & 0xfffffu)] = vv[s];
 #endif
@@ -1223,31 +1243,34 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     // ---- geometry scratch (GeometryState, rasterizer_impl.h:30-45) ----
     size_t scan_bytes = 0;
     R2S_HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes,
-                                        rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), TilesInOrder{nullptr, nullptr}),
+                                        rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), TilesInOrder{DepthOrder{nullptr, nullptr, 0}, nullptr}),
                                         (uint32_t*)nullptr, G ? G : 1, rocprim::plus<uint32_t>(), stream));
     // first sort: Gaussians by (frame, depth bits)
     unsigned fbits = 0;
     while ((1u << fbits) < (unsigned)F) ++fbits;
+    // the key carries the Gaussian's index inside its frame below the sorted bits (keys only: 8 bytes per Gaussian and pass instead of 12)
+    unsigned idx_bits = 1;
+    while ((1ull << idx_bits) < (unsigned long long)maxP) ++idx_bits;
+    if (fbits + 32u + idx_bits > 64u) return R2S_ERR_OVERFLOW; // frames x Gaussians per frame beyond 2^32: not a batch this library renders
     size_t gsort_bytes = 0;
     {
         rocprim::double_buffer<uint64_t> dk((uint64_t*)nullptr, (uint64_t*)nullptr);
-        rocprim::double_buffer<uint32_t> dv((uint32_t*)nullptr, (uint32_t*)nullptr);
-        R2S_HIP_TRY(rocprim::radix_sort_pairs<GaussSortConfig>(nullptr, gsort_bytes, dk, dv, G ? G : 1, 0u, 32u + fbits, stream));
+        R2S_HIP_TRY(rocprim::radix_sort_keys<GaussSortConfig>(nullptr, gsort_bytes, dk, G ? G : 1, idx_bits, idx_bits + 32u + fbits, stream));
     }
     float* depths; int* radii_all; GeomRec* geom; uint32_t* tiles_touched; uint32_t* offsets; char* scan_tmp; int* err_flag; uint32_t* big_q;
-    uint64_t *gkeys_a, *gkeys_b; uint32_t *gvals_a, *gvals_b; char* gsort_tmp; unsigned long long* surv;
+    uint64_t *gkeys_a, *gkeys_b; char* gsort_tmp; unsigned long long* surv;
     {
         r2s::Carver sz(nullptr);
         sz.take<float>(G); sz.take<int>(G); sz.take<GeomRec>(G); sz.take<uint32_t>(G); sz.take<uint32_t>(G);
         sz.take<char>(scan_bytes); sz.take<int>(4); sz.take<uint32_t>(G);
-        sz.take<uint64_t>(G); sz.take<uint64_t>(G); sz.take<uint32_t>(G); sz.take<uint32_t>(G); sz.take<char>(gsort_bytes); sz.take<unsigned long long>(SURV_MASKS && c->cull ? G : 0);
+        sz.take<uint64_t>(G); sz.take<uint64_t>(G); sz.take<char>(gsort_bytes); sz.take<unsigned long long>(SURV_MASKS && c->cull ? G : 0);
         char* p = c->scratch(0, sz.bytes());
         if (!p) return R2S_ERR_ALLOC;
         r2s::Carver cv(p);
         depths = cv.take<float>(G); radii_all = cv.take<int>(G); geom = cv.take<GeomRec>(G);
         tiles_touched = cv.take<uint32_t>(G); offsets = cv.take<uint32_t>(G);
         scan_tmp = cv.take<char>(scan_bytes); err_flag = cv.take<int>(4); big_q = cv.take<uint32_t>(G);
-        gkeys_a = cv.take<uint64_t>(G); gkeys_b = cv.take<uint64_t>(G); gvals_a = cv.take<uint32_t>(G); gvals_b = cv.take<uint32_t>(G);
+        gkeys_a = cv.take<uint64_t>(G); gkeys_b = cv.take<uint64_t>(G);
         gsort_tmp = cv.take<char>(gsort_bytes);
         surv = cv.take<unsigned long long>(SURV_MASKS && c->cull ? G : 0);
     }
@@ -1290,18 +1313,15 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     }
     mark(0);
     uint32_t L = 0;
-    const uint64_t* gkeys_sorted = nullptr;
-    const uint32_t* order = nullptr;
+    DepthOrder order{nullptr, c->d_frames, (int)idx_bits};
     if (G > 0) {
         dim3 grid((maxP + 255) / 256, F);
         hipLaunchKernelGGL(k_preprocess, grid, dim3(256), 0, stream, c->d_frames, gx, gy, W, H, depths, radii_all, geom,
-                           tiles_touched, err_flag, c->cull, gkeys_a, gvals_a, surv);
+                           tiles_touched, err_flag, c->cull, gkeys_a, (int)idx_bits, surv);
         mark(1);
         rocprim::double_buffer<uint64_t> dgk(gkeys_a, gkeys_b);
-        rocprim::double_buffer<uint32_t> dgv(gvals_a, gvals_b);
-        R2S_HIP_TRY(rocprim::radix_sort_pairs<GaussSortConfig>(gsort_tmp, gsort_bytes, dgk, dgv, G, 0u, 32u + fbits, stream));
-        gkeys_sorted = dgk.current();
-        order = dgv.current();
+        R2S_HIP_TRY(rocprim::radix_sort_keys<GaussSortConfig>(gsort_tmp, gsort_bytes, dgk, G, idx_bits, idx_bits + 32u + fbits, stream));
+        order.keys = dgk.current();
         // offsets[i] = instances of the first i+1 Gaussians in (frame, depth) order; frames stay contiguous
         R2S_HIP_TRY(rocprim::inclusive_scan(scan_tmp, scan_bytes,
                                             rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), TilesInOrder{order, tiles_touched}),
@@ -1364,12 +1384,12 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         auto emit = [&](auto* keys) { // 16-bit keys (tile inside the frame) for the one-pass binning, frame-extended 32-bit keys for the radix sort
             using KeyT = std::remove_pointer_t<decltype(keys)>;
             if (G <= (size_t)1 << 18) { // small batch: large rectangles through the queue (see k_emit_keys)
-                hipLaunchKernelGGL((k_emit_keys<true, KeyT>), dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
+                hipLaunchKernelGGL((k_emit_keys<true, KeyT>), dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H,
                                    order, radii_all, geom, offsets, keys, vals_a, c->cull, cap, err_flag + 1, big_q, err_flag + 2, surv);
-                hipLaunchKernelGGL(k_emit_big<KeyT>, dim3(1024), dim3(256), 0, stream, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
+                hipLaunchKernelGGL(k_emit_big<KeyT>, dim3(1024), dim3(256), 0, stream, (uint32_t)G, gx, gy, W, H,
                                    order, radii_all, geom, offsets, keys, vals_a, c->cull, cap, big_q, err_flag + 2);
             } else
-                hipLaunchKernelGGL((k_emit_keys<false, KeyT>), dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H, gkeys_sorted,
+                hipLaunchKernelGGL((k_emit_keys<false, KeyT>), dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, c->d_frames, (uint32_t)G, gx, gy, W, H,
                                    order, radii_all, geom, offsets, keys, vals_a, c->cull, cap, err_flag + 1, big_q, err_flag + 2, surv);
         };
         const uint16_t* keys16 = reinterpret_cast<const uint16_t*>(keys_a);
