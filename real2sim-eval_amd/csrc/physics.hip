@@ -59,6 +59,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <vector>
+#include <functional>
 
 namespace {
 
@@ -383,6 +384,9 @@ struct R2SPhys {
     static constexpr int MAX_CHAINS = 8;
     hipGraph_t graph[MAX_CHAINS][12] = {};      // [mesh_defer * 4 + variant * 2 + parity]; [8 + 2 + parity]: the resident self-collision flavour WITH servers (self_srv)
     hipGraphExec_t graph_exec[MAX_CHAINS][12] = {};
+    hipGraph_t graph_tail[MAX_CHAINS][12] = {};      // chains captured as head + tail (capture_graph): the tail; null where the capture was not split
+    hipGraphExec_t graph_exec_tail[MAX_CHAINS][12] = {};
+    int graph_head = 64;                             // substeps in the head graph (R2S_GRAPH_HEAD; 0: one graph per chain)
     hipEvent_t chain_fork = nullptr, chain_join[MAX_CHAINS] = {};
     // timing
     bool timing = false;
@@ -614,7 +618,8 @@ bool resident_flavour(const R2SPhys* h, bool with_self, int mesh_defer, int n) {
 constexpr int RES_MAX_ITEMS = 256; // (block, env) work items of a resident launch: one 512-thread workgroup per CU (two wavefronts per SIMD, each
                                    // with its 2 + 2 adjacency groups in registers), all on the chip at once
 
-int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, hipStream_t s, int e0 = 0, int ne = -1, bool zero_forces = true, int chain_id = 0)
+int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, hipStream_t s, int e0 = 0, int ne = -1, bool zero_forces = true, int chain_id = 0,
+                  int split_at = 0, const std::function<int()>* on_split = nullptr)
 {
     PhysDev p = h->dev();
     if (ne < 0) ne = h->E;
@@ -681,6 +686,7 @@ int enqueue_steps(R2SPhys* h, int first, int n, int start_buf, bool with_self, h
     }
     for (int k = 0; k < n; ++k) {
         const int last = (k == n - 1);
+        if (on_split && k == split_at && k > 0) { if (const int rc = (*on_split)()) return rc; } // graph capture: the launches from here on go to the tail graph
         if (last && h->nF > 0 && zero_forces) { // this chain's slice of the accumulator
             const size_t cnt = 3 * (size_t)ne * h->nF;
             hipLaunchKernelGGL(k_zero_f32, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, h->d_coll_forces + 3 * (size_t)e0 * h->nF, cnt);
@@ -704,7 +710,9 @@ void drop_graph(R2SPhys* h)
         for (int v = 0; v < 12; ++v) {
             if (h->graph_exec[c][v]) (void)hipGraphExecDestroy(h->graph_exec[c][v]);
             if (h->graph[c][v]) (void)hipGraphDestroy(h->graph[c][v]);
-            h->graph_exec[c][v] = nullptr; h->graph[c][v] = nullptr;
+            if (h->graph_exec_tail[c][v]) (void)hipGraphExecDestroy(h->graph_exec_tail[c][v]);
+            if (h->graph_tail[c][v]) (void)hipGraphDestroy(h->graph_tail[c][v]);
+            h->graph_exec[c][v] = nullptr; h->graph[c][v] = nullptr; h->graph_exec_tail[c][v] = nullptr; h->graph_tail[c][v] = nullptr;
         }
 }
 
@@ -729,19 +737,38 @@ int capture_graph(R2SPhys* h, int variant, int start_buf)
     for (int c = 0; c < chains; ++c) {
         if (h->graph_exec[c][slot]) (void)hipGraphExecDestroy(h->graph_exec[c][slot]);
         if (h->graph[c][slot]) (void)hipGraphDestroy(h->graph[c][slot]);
-        h->graph_exec[c][slot] = nullptr; h->graph[c][slot] = nullptr;
+        if (h->graph_exec_tail[c][slot]) (void)hipGraphExecDestroy(h->graph_exec_tail[c][slot]);
+        if (h->graph_tail[c][slot]) (void)hipGraphDestroy(h->graph_tail[c][slot]);
+        h->graph_exec[c][slot] = nullptr; h->graph[c][slot] = nullptr; h->graph_exec_tail[c][slot] = nullptr; h->graph_tail[c][slot] = nullptr;
         const int e0 = (int)((int64_t)h->E * c / chains), e1 = (int)((int64_t)h->E * (c + 1) / chains);
         hipStream_t cs;
         R2S_HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         if (const hipError_t eb = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal); eb != hipSuccess) { (void)hipStreamDestroy(cs); R2S_HIP_TRY(eb); }
-        const int rc = enqueue_steps(h, 0, h->prm.num_substeps, start_buf, variant == 1, cs, e0, e1 - e0, true, c);
+        // Head and tail (round 6): hipGraphLaunch of a 667-node chain takes 0.2 ms of host time and the chain starts when the call is through —
+        // in the closed loop (the policy waits for the observation before the next step is launched) the four chains started 0.2 ms apart and the
+        // step paid 0.6 ms for it.  Each chain is therefore two graphs: a head of HEAD substeps that is launched in microseconds — all chains' heads
+        // first — and the tail, enqueued behind it on the same stream while the heads run.  The same launches in the same order on the same stream.
+        hipGraph_t g_head = nullptr;
+        const std::function<int()> split = [&]() -> int {
+            R2S_HIP_TRY(hipStreamEndCapture(cs, &g_head));
+            R2S_HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+            return R2S_OK;
+        };
+        const int head = h->graph_head < h->prm.num_substeps ? h->graph_head : 0;
+        const int rc = enqueue_steps(h, 0, h->prm.num_substeps, start_buf, variant == 1, cs, e0, e1 - e0, true, c, head, head > 0 ? &split : nullptr);
         hipGraph_t g = nullptr;
         const hipError_t e = hipStreamEndCapture(cs, &g);
         (void)hipStreamDestroy(cs);
-        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (rc) { if (g) (void)hipGraphDestroy(g); if (g_head) (void)hipGraphDestroy(g_head); return rc; }
         R2S_HIP_TRY(e);
-        h->graph[c][slot] = g;
-        R2S_HIP_TRY(hipGraphInstantiate(&h->graph_exec[c][slot], g, nullptr, nullptr, 0));
+        if (g_head) { // the capture was split: `g` is the tail
+            h->graph[c][slot] = g_head; h->graph_tail[c][slot] = g;
+            R2S_HIP_TRY(hipGraphInstantiate(&h->graph_exec[c][slot], g_head, nullptr, nullptr, 0));
+            R2S_HIP_TRY(hipGraphInstantiate(&h->graph_exec_tail[c][slot], g, nullptr, nullptr, 0));
+        } else {
+            h->graph[c][slot] = g;
+            R2S_HIP_TRY(hipGraphInstantiate(&h->graph_exec[c][slot], g, nullptr, nullptr, 0));
+        }
     }
     return R2S_OK;
 }
@@ -804,15 +831,20 @@ int launch_graphs(R2SPhys* h, int slot, hipStream_t s)
         if (!h->chain_fork) R2S_HIP_TRY(hipEventCreateWithFlags(&h->chain_fork, hipEventDisableTiming));
         R2S_HIP_TRY(hipEventRecord(h->chain_fork, s));
     }
-    for (int c = 1; c < chains; ++c) {
+    for (int c = 1; c < chains; ++c) { // every chain's head first (or its only graph) ...
         hipStream_t sc = chain_side_stream(c);
         if (!sc) return R2S_ERR_HIP;
         if (!h->chain_join[c]) R2S_HIP_TRY(hipEventCreateWithFlags(&h->chain_join[c], hipEventDisableTiming));
         R2S_HIP_TRY(hipStreamWaitEvent(sc, h->chain_fork, 0));
         R2S_HIP_TRY(hipGraphLaunch(h->graph_exec[c][slot], sc));
-        R2S_HIP_TRY(hipEventRecord(h->chain_join[c], sc));
     }
     R2S_HIP_TRY(hipGraphLaunch(h->graph_exec[0][slot], s));
+    for (int c = 1; c < chains; ++c) { // ... then the tails, behind their heads on the same streams
+        hipStream_t sc = chain_side_stream(c);
+        if (h->graph_exec_tail[c][slot]) R2S_HIP_TRY(hipGraphLaunch(h->graph_exec_tail[c][slot], sc));
+        R2S_HIP_TRY(hipEventRecord(h->chain_join[c], sc));
+    }
+    if (h->graph_exec_tail[0][slot]) R2S_HIP_TRY(hipGraphLaunch(h->graph_exec_tail[0][slot], s));
     for (int c = 1; c < chains; ++c) R2S_HIP_TRY(hipStreamWaitEvent(s, h->chain_join[c], 0));
     return R2S_OK;
 }
@@ -952,6 +984,7 @@ int r2s_phys_create(const R2SPhysDesc* d, R2SPhys** out, r2s_stream_t stream_)
         h->pb = sizes[pick]; h->rcap = caps[pick];
         // the remaining tuning knobs are also read here, ONCE per handle (r2s_phys_set_tuning changes them afterwards)
         if (const char* ev = getenv("R2S_CHAINS")) h->chains_override = atoi(ev);
+        if (const char* ev = getenv("R2S_GRAPH_HEAD")) h->graph_head = std::max(0, atoi(ev)); // substeps in a chain's head graph (0: one graph per chain)
         if (const char* ev = getenv("R2S_MESH_DEFER")) h->force_defer = atoi(ev) != 0;
     }
     const int PB = h->pb, SL = SLICE;
