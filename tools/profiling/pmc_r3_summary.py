@@ -15,6 +15,7 @@ KERNELS = {"k_substep_pf<256, 1024, false, 1, 4>": "k_substep_pf", "k_substep_pf
            "k_substep<256, 1024, false, 1>": "k_substep", "k_substep<256, 1024, true, 1>": "k_substep_contact", "k_contact_finish<3, true>": "k_contact_finish",
            "k_contact_finish<3, false>": "k_contact_finish_mesh_only", "k_composite": "k_composite", "k_steps_resident": "k_steps_resident", "k_emit_keys": "k_emit_keys", "k_preprocess": "k_preprocess",
            "k_skin": "k_skin", "k_bone_fit": "k_bone_fit", "k_candidates_fine": "k_candidates_fine", "k_tile_ranges": "k_tile_ranges",
+           "k_bin_scatter": "k_bin_scatter", "k_bin_hist": "k_bin_hist",   # round 6: one-pass tile binning
            "direct_copy_kernel": "calibration_copy_512MiB", "__amd_rocclr_copyBuffer": "calibration_copy_512MiB"}
 
 

@@ -15,5 +15,8 @@ grep -v amdgpu.ids $s/phase_probe_free.txt > $d/r6_phase_probe_free.txt
 cp $s/variant_sloth.txt $d/r6_variant_bench.txt
 cp $s/onset_sloth_1env.txt $d/r6_onset_sloth_1env.txt
 grep -v amdgpu.ids $s/soak_pf.txt > $d/r6_soak_pf.txt
+cp $s/raster_kernels.md $d/r6_raster_kernels.md
+cp $s/raster_stage_ab.txt $d/r6_raster_stage_ab.txt
+cp $s/graph_head_ab.txt $d/r6_graph_head_ab.txt
 tail -2 $s/pytest.log
 ls -la $d/r6_*

@@ -43,3 +43,12 @@ db=$(find $out/trace_pusher -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $db $out/kernel_stats_pusher.md > /dev/null 2>&1 || echo stats-failed
 head -6 $out/kernel_stats_pusher.md | cut -c1-70,150-240
 rm -rf $out/trace_pusher
+# raster path alone: per-kernel table of the 64-frame batch, stage times with the one-pass binning and with the radix sort (A/B knob), images hashed
+cd $R
+bash tools/profiling/r6_raster_trace.sh > $out/raster_trace.log 2>&1; cp gpurun_out/r6_raster_kernels.md $out/raster_kernels.md
+{ echo "== one-pass binning (build)"; timeout 300 python tools/profiling/raster_bench.py sloth_32env 2>&1 | tail -1;
+  echo "== radix sort of the instances (R2S_RASTER_RADIX_SORT=1)"; R2S_RASTER_RADIX_SORT=1 timeout 300 python tools/profiling/raster_bench.py sloth_32env 2>&1 | tail -1;
+  echo "== one environment (rope_1env), both"; timeout 300 python tools/profiling/raster_bench.py rope_1env 2>&1 | tail -1; R2S_RASTER_RADIX_SORT=1 timeout 300 python tools/profiling/raster_bench.py rope_1env 2>&1 | tail -1; } > $out/raster_stage_ab.txt
+cat $out/raster_stage_ab.txt | cut -c1-250
+# closed-loop cost of launching the chains: one graph per chain vs head + tail
+bash tools/profiling/r6_head_ab.sh 2>&1 | grep "^head" > $out/graph_head_ab.txt; cat $out/graph_head_ab.txt
