@@ -111,10 +111,12 @@ void r2s_raster_ctx_destroy(R2SRasterCtx* ctx);
 /* Bytes of device scratch currently held by the context. */
 size_t r2s_raster_ctx_scratch_bytes(const R2SRasterCtx* ctx);
 
-/* All frames share width x height.  One preprocess / scan / key-emit / radix sort /
- * tile-range / composite pass covers every frame (the tile id in the sort key is extended by
- * the frame index).  `num_rendered_per_frame` (host, may be NULL) receives each frame's
- * instance count.  Returns the total instance count or a negative error. */
+/* All frames share width x height.  One preprocess / depth sort / scan / key-emit / tile binning /
+ * composite pass covers every frame (instances are binned by (frame, tile); frames of more than 2 048
+ * tiles take a radix sort on frame-extended tile keys instead, with identical lists).
+ * `num_rendered_per_frame` (host, may be NULL) receives each frame's instance count.  Returns the total
+ * instance count or a negative error (R2S_ERR_OVERFLOW also when log2(frames) + log2(largest set) > 32:
+ * the first sort's key holds frame, depth bits and the Gaussian's index inside its frame in 64 bits). */
 int64_t r2s_raster_forward_batch(
     R2SRasterCtx* ctx,
     const R2SGaussianSet* sets, int n_sets,
@@ -126,7 +128,7 @@ int64_t r2s_raster_forward_batch(
 /* Sync-free mode (off by default).  The reference reads the instance count back between the scan and the key emission
  * (a blocking cudaMemcpy, rasterizer_impl.cu:284) to size its binning buffer; r2s_raster_forward_batch normally does the
  * same once per batch.  With this mode on, only the FIRST batch does: later batches size the binning scratch from the last
- * known count + 12.5 % (+ 4096), pad the sort with sentinel keys, take the count on the device where a kernel needs it, and return
+ * known count + 12.5 % (+ 4096), bin over that capacity (the count is taken on the device where a kernel needs it), and return
  * without touching the host — the return value is then the most recent count the host has seen (an earlier batch's).
  * r2s_raster_ctx_poll(ctx, wait, &num_rendered, &overflows) looks at the last batch without blocking (wait = 0: returns 1
  * while it is still running) or blocking (wait = 1): its count, the number of batches so far whose capacity was too small

@@ -5,13 +5,16 @@
 // (forward only, median-depth output).  Pipeline for a batch of F frames (environment x camera view):
 //
 //   k_preprocess   one thread per (frame, Gaussian): cull, project, EWA conic, radius, tile rect, SH->RGB.
-//                  Writes ONE packed 48-byte record per Gaussian (what compositing gathers later).
-//                  Also the key of the first sort: (frame << 32 | depth bits, Gaussian index); rocPRIM radix sort on 32 + log2(F) bits.
-//   rocPRIM scan   inclusive sum of tiles_touched in that (frame, depth) order, all frames at once.
-//   k_emit_keys    (frame-extended tile id, global Gaussian index) per overlapped tile, Gaussians walked in depth order.
-//   rocPRIM sort   radix_sort_pairs on ceil_log2(F * tiles) bits — stable, so a tile's list stays in depth order and
-//                  ties keep index order: the order of the reference's single 64-bit sort, for 3.5x fewer bytes.
-//   k_tile_ranges  per (frame, tile) [start, end) in the sorted list.
+//                  Writes ONE packed 48-byte record per Gaussian (what compositing gathers later) and the key of the first sort:
+//                  frame | depth bits | index inside the frame.
+//   rocPRIM sort   radix_sort_keys on the (frame, depth bits) fields: 32 + log2(F) bits, stable; the index rides in the key.
+//   rocPRIM scan   inclusive sum of tiles_touched read through that order (TilesInOrder), all frames at once.
+//   k_emit_keys    (tile inside the frame u16, global Gaussian index) per overlapped tile, Gaussians walked in depth order.
+//   k_bin_*        ONE-pass stable partition of the instances by (frame, tile) — chunk histograms, column scan, ranked scatter — so a
+//                  tile's list stays in depth order and ties keep index order: the order of the reference's single 64-bit sort.  The scan
+//                  of the histograms IS the per-tile [start, end) table.  (Frames of more than 2 048 tiles: two-pass rocPRIM sort on
+//                  frame-extended 32-bit keys + k_tile_ranges, the form of rounds 1-5.)
+//   k_tile_order   compositor workgroups longest list first (counting sort over length classes).
 //   k_composite    one 256-thread workgroup per 16x16 tile, each of its 4 wavefronts owns an 8x8 pixel
 //                  quadrant; 256 instance records per round are staged through LDS and broadcast-read.
 //
@@ -234,6 +237,7 @@ struct WalkShared {      // one per wavefront
     uint2 p3[64];        // tile_base, value (emit)
     uint32_t cnt[64];    // passing tiles so far
     unsigned long long mask[64]; // which candidate tiles of the Gaussian pass (rectangles of up to 64 tiles; see k_preprocess)
+    float inv_w[64];     // 1 / rectangle width (one IEEE division per Gaussian instead of one per candidate tile)
 };
 // Survivor masks (round 6, -DR2S_SURV_MASKS; measured and NOT taken): the culling test is ~70 of the 240 instructions of a trip, and the counting walk
 // of k_preprocess already knows the answer the emitting walk of k_emit_keys asks for again.  With MASKS the counting walk leaves, for every Gaussian
@@ -259,6 +263,7 @@ __device__ __forceinline__ uint32_t rect_walk_flat(WalkShared& ws, const RectJob
     ws.p2[lane] = make_uint4(j.x0, j.y0, w, off);
     if (EMIT) ws.p3[lane] = make_uint2(tile_base, val);
     ws.cnt[lane] = 0u;
+    ws.inv_w[lane] = 1.0f / (float)max(w, 1u);
     if (MASKS) ws.mask[lane] = EMIT ? mask : 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -277,7 +282,7 @@ __device__ __forceinline__ uint32_t rect_walk_flat(WalkShared& ws, const RectJob
         const float4 q0 = ws.p0[g], q1 = ws.p1[g];
         const uint4 q2 = ws.p2[g];
         const uint32_t k = c - start; // the k-th candidate tile of Gaussian g, row-major in its rectangle
-        const uint32_t ry = (uint32_t)(((float)k + 0.5f) * (1.0f / (float)max(q2.z, 1u))), rx = k - ry * q2.z; // k < 2^11, w <= 2^7: exact
+        const uint32_t ry = (uint32_t)(((float)k + 0.5f) * ws.inv_w[g]), rx = k - ry * q2.z; // k < 2^11, w <= 2^7: exact
         const uint32_t pre_g = ws.pre[g];
         bool ok = active;
         if (test && active) {
