@@ -90,6 +90,12 @@ class ObservationSink:
         except Exception:
             self._registered = False   # copies still work, they just synchronise
         self._dev = [torch.empty(self.E, self.V, self.H, self.W, 3, dtype=torch.uint8, device=self.device) for _ in range(self.slots)]
+        # Round 6: the D2H copies (59 MB of frames + the state per 32-environment step) run on a stream of their own.  On the rollout's stream
+        # they sat between two env steps — the next step's graphs waited 2 ms for a DMA they have nothing to do with (sustained episodes ran at
+        # 0.89 of the closed-loop figure).  The state is snapshotted into the slot's device staging on the rollout's stream first (the next
+        # step overwrites it), then frames and state leave from the staging.
+        self._dev_state = [torch.empty(max(self._slot_bytes - self._px_bytes, 1), dtype=torch.uint8, device=self.device) for _ in range(self.slots)]
+        self._copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._free: "queue.Queue[int]" = queue.Queue()
         for k in range(self.slots):
             self._free.put(k)
@@ -137,18 +143,27 @@ class ObservationSink:
             k = self._free.get()
         base = k * self._slot_bytes
         pack_u8(color.reshape(self.E, self.V, 3, self.H, self.W), bgr=True, out=self._dev[k])
-        self._host[base: base + self._px_bytes].copy_(self._dev[k].reshape(-1), non_blocking=self._registered)
-        desc, off = [], base + self._px_bytes
+        desc, off, staged = [], base + self._px_bytes, []
         for name, t in (state or {}).items():
             t = t.detach().contiguous()
             nbytes = t.numel() * t.element_size()
             if off + nbytes > base + self._slot_bytes:
                 raise ValueError("state does not fit the ring slot: pass state_bytes >= the total size of the state tensors")
-            self._host[off: off + nbytes].copy_(t.reshape(-1).view(torch.uint8), non_blocking=self._registered)
+            so = off - (base + self._px_bytes)
+            self._dev_state[k][so: so + nbytes].copy_(t.reshape(-1).view(torch.uint8))   # D2D on the rollout's stream: a snapshot
+            staged.append((so, off, nbytes))
             desc.append((name, str(t.dtype).replace("torch.", ""), tuple(t.shape), off))
             off = (off + nbytes + 63) // 64 * 64
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
+        main = torch.cuda.current_stream(self.device)
+        cs = self._copy_stream if (self._copy_stream is not None and self._registered) else main
+        if cs is not main:
+            cs.wait_stream(main)
+        with torch.cuda.stream(cs):
+            self._host[base: base + self._px_bytes].copy_(self._dev[k].reshape(-1), non_blocking=self._registered)
+            for so, ho, nbytes in staged:
+                self._host[ho: ho + nbytes].copy_(self._dev_state[k][so: so + nbytes], non_blocking=self._registered)
+            ev = torch.cuda.Event()
+            ev.record(cs)
         self._work.put((k, ev, int(cnt), desc, robot, bool(final)))
 
     def make_videos(self, frame_rate: int = 10):
