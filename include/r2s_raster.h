@@ -148,7 +148,10 @@ float r2s_raster_ctx_stage_ms(const R2SRasterCtx* ctx, int stage);
  * 3-sigma bounding square (duplicateWithKeys, rasterizer_impl.cu:70-111); with culling on, instances that provably
  * cannot reach alpha >= 1/255 at any pixel of the tile are not emitted.  out_color / out_depth are unchanged (such
  * instances are skipped per pixel at forward.cu:351 anyway); the returned instance count and the backward-only
- * n_contrib become smaller.  Never applied by r2s_raster_forward. */
+ * n_contrib become smaller.  With culling on, the debug taps `tiles_touched` / `point_offsets` hold a Gaussian's emission
+ * SLOTS (its candidate tiles: the reference's rectangle cut to the bounding box of its alpha >= 1/255 ellipse), not its
+ * surviving instances; `num_rendered`, `point_list` and `ranges` are those of the survivors.  A sync-free batch that
+ * overflowed reports the slots it needed.  Never applied by r2s_raster_forward. */
 void r2s_raster_ctx_set_tile_culling(R2SRasterCtx* ctx, int enable);
 
 /* Debug taps for parity tests: copies of the last batch call's intermediates

@@ -163,6 +163,35 @@ __device__ __forceinline__ void sh_to_rgb(int idx, int deg, int M, const float* 
 // per lane; the larger ones are taken ONE AT A TIME BY THE WHOLE WAVEFRONT, 64 candidate tiles per trip: the count is a ballot,
 // and the emitted run of a Gaussian is written with consecutive lanes at consecutive offsets (the per-lane walk scatters
 // 4-byte stores: 8x the payload in HBM traffic, profiles/r2_pmc_summary.json).  Order and content of the lists are unchanged.
+// Candidate tiles under the culling test (round 6): the reference's rectangle — the bounding square of 3 sigma of the LARGER axis (getRect) —
+// cut down to the tiles that the bounding box of the alpha >= 1/255 ellipse can reach: half-widths sqrt(2 (ln(255 o) + margin) Sigma_xx / yy).
+// tile_can_contribute drops every tile outside that box anyway (its bound is the same quadratic form, with 0.01 of slack in the log domain:
+// here 0.02 and a pixel on top), so the survivors and their row-major order are unchanged; what shrinks is the walk — on the benchmark batch
+// the square holds 63 M candidate tiles for 36 M survivors (elongated and faint splats) — and, on the binning path, the emission slots.
+// Computed from the STORED record (k_preprocess and k_emit_keys must agree to the bit: contraction off).
+__device__ __forceinline__ void cull_rect(float mx, float my, float ca, float cb, float cc, float opac, int gx, int gy, uint32_t& x0, uint32_t& y0,
+                                          uint32_t& x1, uint32_t& y1)
+{
+#pragma clang fp contract(off)
+    const float lr = logf(255.0f * opac) + 0.02f;
+    const float det = ca * cc - cb * cb;
+    if (!(det > 0.f) || !(lr == lr)) return; // an odd conic or opacity keeps the reference's rectangle (the test itself keeps anything odd)
+    if (!(lr > 0.f)) { x1 = x0; y1 = y0; return; } // fainter than 1/255 at its centre
+    const float hx = sqrtf(2.f * lr * cc / det) + 1.0f, hy = sqrtf(2.f * lr * ca / det) + 1.0f;
+    const float ax = floorf((mx - hx - 15.f) * (1.0f / (float)TILE)), bx = floorf((mx + hx) * (1.0f / (float)TILE)) + 1.f;
+    const float ay = floorf((my - hy - 15.f) * (1.0f / (float)TILE)), by = floorf((my + hy) * (1.0f / (float)TILE)) + 1.f;
+    const uint32_t cx0 = (uint32_t)fminf(fmaxf(ax, 0.f), (float)gx), cx1 = (uint32_t)fminf(fmaxf(bx, 0.f), (float)gx);
+    const uint32_t cy0 = (uint32_t)fminf(fmaxf(ay, 0.f), (float)gy), cy1 = (uint32_t)fminf(fmaxf(by, 0.f), (float)gy);
+    x0 = max(x0, cx0); x1 = max(min(x1, cx1), x0);
+    y0 = max(y0, cy0); y1 = max(min(y1, cy1), y0);
+}
+
+// Binning path (16-bit keys, round 6): a Gaussian's candidate tile k owns emission slot `offset + k`, whether it passes the culling test or
+// not — a culled candidate leaves KEY_NONE there and the binning skips it.  So the slots follow from the RECTANGLES alone: k_preprocess does
+// not walk the candidates to count the survivors (63 % of its instructions), and the emitting walk needs no rank among the survivors.  The
+// instance count is the total of the tile histograms instead of the last scan element; the scan is the capacity the slots need (at most the
+// reference's count, ~5 % above the culled one).
+constexpr uint32_t KEY_NONE = 0xffffu;
 struct RectJob {
     float mx, my, ca, cb, cc, lt, rdy, rdx; // rdy = -cb / cc, rdx = -cb / ca
     uint32_t x0, y0, x1, y1; // empty (x1 == x0) for lanes without a visible Gaussian
@@ -185,12 +214,15 @@ __device__ __forceinline__ uint32_t rect_walk(const RectJob& j, int W, int H, ui
     const int lane = (int)(threadIdx.x & 63);
     const uint32_t w = j.x1 - j.x0, n = w * (j.y1 - j.y0);
     uint32_t count = 0;
+    constexpr bool SLOTS = EMIT && sizeof(KeyT) == 2; // binning path: candidate k of a Gaussian owns slot off + k (see rect_walk_flat)
     const bool big = n > (EMIT ? RECT_SMALL_EMIT : RECT_SMALL_COUNT);
     if (n > 0 && !big) {
         for (uint32_t y = j.y0; y < j.y1; ++y)
             for (uint32_t x = j.x0; x < j.x1; ++x) {
-                if (test && !tile_can_contribute(j.mx, j.my, j.ca, j.cb, j.cc, j.rdy, j.rdx, j.lt, (int)x, (int)y, W, H)) continue;
-                if (EMIT) { if (off < cap) { keys[off] = (KeyT)(tile_base + y * (uint32_t)gx + x); vals[off] = val; } ++off; }
+                const bool pass = !test || tile_can_contribute(j.mx, j.my, j.ca, j.cb, j.cc, j.rdy, j.rdx, j.lt, (int)x, (int)y, W, H);
+                if (SLOTS) { if (off < cap) { keys[off] = pass ? (KeyT)(y * (uint32_t)gx + x) : (KeyT)KEY_NONE; if (pass) vals[off] = val; } ++off; }
+                if (!pass) continue;
+                if (EMIT && !SLOTS) { if (off < cap) { keys[off] = (KeyT)(tile_base + y * (uint32_t)gx + x); vals[off] = val; } ++off; }
                 ++count;
             }
     }
@@ -210,7 +242,10 @@ __device__ __forceinline__ uint32_t rect_walk(const RectJob& j, int W, int H, ui
             const uint32_t ry = t / wL, rx = t - ry * wL;
             const bool ok = t < nL && (!test || tile_can_contribute(mx, my, ca, cb, cc, rdy, rdx, lt, (int)(x0 + rx), (int)(y0 + ry), W, H));
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(ok);
-            if (EMIT) {
+            if (SLOTS) {
+                const uint32_t pos = base + t;
+                if (t < nL && pos < cap) { keys[pos] = ok ? (KeyT)((y0 + ry) * (uint32_t)gx + (x0 + rx)) : (KeyT)KEY_NONE; if (ok) vals[pos] = vL; }
+            } else if (EMIT) {
                 const uint32_t pos = base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
                 if (ok && pos < cap) { keys[pos] = (KeyT)(tb + (y0 + ry) * (uint32_t)gx + (x0 + rx)); vals[pos] = vL; }
                 base += (uint32_t)__builtin_popcountll(bal);
@@ -289,6 +324,14 @@ __device__ __forceinline__ uint32_t rect_walk_flat(WalkShared& ws, const RectJob
             if (MASKS && EMIT && pre_g - start <= 64u) ok = (ws.mask[g] >> k) & 1ull;
             else ok = tile_can_contribute(q0.x, q0.y, q0.z, q0.w, q1.x, q1.z, q1.w, q1.y, (int)(q2.x + rx), (int)(q2.y + ry), W, H);
         }
+        if (EMIT && sizeof(KeyT) == 2) { // binning path: the candidate's own slot, a culled one leaves KEY_NONE (no rank, no bookkeeping)
+            const uint32_t pos = q2.w + k;
+            if (active && pos < cap) {
+                keys[pos] = ok ? (KeyT)((q2.y + ry) * (uint32_t)gx + (q2.x + rx)) : (KeyT)KEY_NONE;
+                if (ok) vals[pos] = ws.p3[g].y; // (the value of an empty slot is never looked at)
+            }
+            continue;
+        }
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(ok);
         // this Gaussian's candidates of this trip sit in lanes [seg, seg_end)
         const int seg = (int)max((int)start - (int)t0, 0), seg_end = (int)min(pre_g - t0, 64u);
@@ -321,7 +364,7 @@ __device__ __forceinline__ uint32_t rect_walk_flat(WalkShared& ws, const RectJob
 __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__ frames, int gx, int gy, int W, int H,
                                                     float* __restrict__ depths, int* __restrict__ radii_all,
                                                     GeomRec* __restrict__ geom, uint32_t* __restrict__ tiles_touched,
-                                                    int* __restrict__ err_flag, int cull, uint64_t* __restrict__ gkeys, int idx_bits,
+                                                    int* __restrict__ err_flag, int cull, int count_exact, uint64_t* __restrict__ gkeys, int idx_bits,
                                                     unsigned long long* __restrict__ surv)
 {
 #pragma clang fp contract(off)
@@ -430,16 +473,17 @@ __global__ void __launch_bounds__(256) k_preprocess(const FrameDev* __restrict__
         rec.q2 = make_float4(rgb[1], rgb[2], 0.f, 0.f);
         geom[g] = rec;
         radius_out = (int)my_radius;
-        tiles = (y1 - y0) * (x1 - x0);
-        if (cull) { // a Gaussian whose every tile is culled keeps its radius (the reference reports it) but emits nothing
+        if (cull) cull_rect(pix, piy, ca, cb, cc, fr.opac[idx], gx, gy, x0, y0, x1, y1); // (a Gaussian whose every tile is culled keeps its radius — the reference reports it — but emits nothing)
+        tiles = (y1 - y0) * (x1 - x0); // binning path: the emission slots (KEY_NONE); reference mode: the instances
+        if (count_exact) { // radix-sort path with culling: the survivors are counted here
             job = {pix, piy, ca, cb, cc, logf(1.0f / (255.0f * fr.opac[idx])), -cb / cc, -cb / ca, x0, y0, x1, y1};
             tiles = 0;
         }
     } while (false);
     __shared__ WalkShared ws_s[4];
-    if (cull) tiles = rect_walk_flat<false, uint32_t, SURV_MASKS>(ws_s[threadIdx.x >> 6], job, W, H, 0u, 0u, 0u, 0u, nullptr, nullptr, 0, true);
+    if (count_exact) tiles = rect_walk_flat<false, uint32_t, SURV_MASKS>(ws_s[threadIdx.x >> 6], job, W, H, 0u, 0u, 0u, 0u, nullptr, nullptr, 0, true);
     if (!valid) return;
-    if (SURV_MASKS && cull) surv[g] = ws_s[threadIdx.x >> 6].mask[threadIdx.x & 63];
+    if (SURV_MASKS && count_exact) surv[g] = ws_s[threadIdx.x >> 6].mask[threadIdx.x & 63];
     radii_all[g] = radius_out;
     if (fr.radii) fr.radii[idx] = radius_out;
     tiles_touched[g] = tiles;
@@ -491,6 +535,7 @@ __device__ __forceinline__ EmitJob emit_job(uint32_t i, int gx, int gy, const De
         const float4 q1 = geom[e.g].q1;
         uint32_t x0, y0, x1, y1;
         tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
+        if (cull) cull_rect(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, gx, gy, x0, y0, x1, y1);
         e.tile_base = order.frame(i) * (uint32_t)(gx * gy);
         e.job = {q0.x, q0.y, q0.z, q0.w, q1.x, cull ? logf(1.0f / (255.0f * q1.y)) : 0.f, -q0.w / q1.x, -q0.w / q0.z, x0, y0, x1, y1};
     }
@@ -627,7 +672,7 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_hist(const uint4* __restric
 #pragma unroll
     for (int s = 0; s < BIN_STEPS; ++s) { const uint32_t i = (uint32_t)(s * BIN_THREADS + tid); kk[s] = i < d.z ? (uint32_t)k[i] : 0xffffffffu; }
 #pragma unroll
-    for (int s = 0; s < BIN_STEPS; ++s) if (kk[s] != 0xffffffffu) atomicAdd(&s_bin[kk[s]], 1u);
+    for (int s = 0; s < BIN_STEPS; ++s) if (kk[s] < (uint32_t)tiles) atomicAdd(&s_bin[kk[s]], 1u); // (KEY_NONE: a culled candidate's slot)
     __syncthreads();
     uint32_t* row = hist + (size_t)blockIdx.x * tiles;
     for (int t = tid; t < tiles; t += BIN_THREADS) row[t] = s_bin[t];
@@ -686,7 +731,8 @@ __device__ __forceinline__ void tile_class_count(uint32_t* s_cls, bool valid, ui
 }
 
 __global__ void __launch_bounds__(256) k_tile_starts(uint32_t FT, const uint32_t* __restrict__ totals, const uint32_t* __restrict__ local_start,
-                                                     const uint32_t* __restrict__ group_sum, uint2* __restrict__ ranges, uint32_t* __restrict__ cls_count)
+                                                     const uint32_t* __restrict__ group_sum, uint2* __restrict__ ranges, uint32_t* __restrict__ cls_count,
+                                                     uint32_t tiles, uint32_t* __restrict__ frame_start)
 {
     __shared__ uint32_t s_part[256];
     uint32_t part = 0;
@@ -703,6 +749,10 @@ __global__ void __launch_bounds__(256) k_tile_starts(uint32_t FT, const uint32_t
         n = totals[ft];
         const uint32_t st = s_part[0] + local_start[ft];
         ranges[ft] = n ? make_uint2(st, st + n) : make_uint2(0u, 0u);
+        // instances before each frame and, behind the last, of the whole batch: the instance COUNT on the binning path (the scan of the
+        // rectangles is only the capacity of the emission slots)
+        if (ft % tiles == 0u) frame_start[ft / tiles] = st;
+        if (ft == FT - 1u) frame_start[FT / tiles] = st + n;
     }
     __shared__ uint32_t s_cls[1u << TILE_ORDER_BITS];
     if (cls_count) tile_class_count(s_cls, ft < FT, tile_len_class(n), cls_count);
@@ -732,10 +782,11 @@ __global__ void __launch_bounds__(BIN_THREADS) R2S_BIN_OCC k_bin_scatter(const u
 #pragma unroll
     for (int s = 0; s < BIN_STEPS; ++s) {
         const uint32_t i = (uint32_t)(wave * (64 * BIN_STEPS) + s * 64 + lane);
-        const bool ok = i < d.z;
-        pk[s] = ok ? (uint32_t)keys[d.y + i] : 0x80000000u;
+        const uint32_t key = i < d.z ? (uint32_t)keys[d.y + i] : KEY_NONE;
+        const bool ok = key < (uint32_t)tiles; // (KEY_NONE: a culled candidate's slot)
+        pk[s] = ok ? key : 0x80000000u;
 #ifndef R2S_BIN_LATE_VALS
-        vv[s] = ok ? vals[d.y + i] : 0u;
+        vv[s] = i < d.z ? vals[d.y + i] : 0u;
 #endif
     }
     for (int t = tid; t < WAVES * tiles; t += BIN_THREADS) s_bin[t] = 0u;
@@ -792,9 +843,6 @@ __global__ void __launch_bounds__(BIN_THREADS) R2S_BIN_OCC k_bin_scatter(const u
 #endif
 }
 
-// Workgroup order of the compositor: tiles sorted by the length of their instance list, longest first.  On the benchmark
-// scene 5 % of the tiles (the object region) hold 85 % of the instances; started in tile order, the deep tiles of the last
-// frames run alone at the end of the kernel (1.26 ms); started first, the short ones fill the gaps (0.97 ms).
 // sync-free mode: the tail of the key array (instances the batch did not produce) sorts behind every real tile
 __global__ void __launch_bounds__(256) k_fill_sentinel(const uint32_t* __restrict__ last_offset, uint32_t cap, uint32_t sentinel, uint32_t* __restrict__ keys)
 {
@@ -802,6 +850,9 @@ __global__ void __launch_bounds__(256) k_fill_sentinel(const uint32_t* __restric
     if (i < cap && i >= *last_offset) keys[i] = sentinel;
 }
 
+// Workgroup order of the compositor: tiles sorted by the length of their instance list, longest first.  On the benchmark
+// scene 5 % of the tiles (the object region) hold 85 % of the instances; started in tile order, the deep tiles of the last
+// frames run alone at the end of the kernel (1.26 ms); started first, the short ones fill the gaps (0.97 ms).
 // (Until round 6: a key per tile + a two-pass rocPRIM sort of 76 800 pairs — five launches, 45 us.  The order only has to be by length CLASS and
 // nothing depends on the order inside a class, so it is a counting sort: the class counts come with the ranges (k_tile_starts; k_tile_classes
 // behind the radix-sort path), every workgroup scans them for itself, and the slots inside a class are handed out by atomics.  Which of two
@@ -1152,12 +1203,15 @@ struct R2SRasterCtx {
     FrameDev* d_frames = nullptr;
     FrameDev* h_frames = nullptr; // pinned
     int frames_cap = 0;
-    uint64_t* h_read = nullptr; // pinned: [0] last offset, [1] error flag, [2] overflow flag (sync-free mode)
+    uint64_t* h_read = nullptr; // pinned: [0] last offset, [1] error flag, [2] overflow flag (sync-free mode), [3] instance count of the binning path
     // sync-free mode (r2s_raster_ctx_set_async): the instance count is NOT read back between scan and emit; the binning
     // scratch is sized from the last known count x 1.25 and the count / error / overflow words of a call are read later
     bool async_mode = false;
     uint32_t L_cap = 0;          // capacity the binning scratch was sized for; 0 = not known yet (next call synchronises once)
     int64_t last_L = 0;          // most recent count the host has seen
+    int64_t last_slots = 0;      // ... and the emission slots that batch needed (= the count, except on the binning path with culling: see KEY_NONE)
+    bool pending_true = false;   // the pending sync-free batch reports its count in h_read[3] (binning path)
+    hipEvent_t cnt_ev = nullptr; // synchronous calls: behind the copy of the binning path's count
     hipEvent_t done_ev = nullptr;
     bool pending = false;
     int overflows = 0;           // sync-free batches whose capacity was too small (their images miss instances)
@@ -1304,25 +1358,30 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     if (c->pending) {
         R2S_HIP_TRY(hipEventSynchronize(c->done_ev)); // long finished: it was recorded a whole env step ago
         c->pending = false;
-        c->last_L = (int64_t)(c->h_read[0] & 0xFFFFFFFFull);
+        c->last_slots = (int64_t)(c->h_read[0] & 0xFFFFFFFFull);
+        c->last_L = c->pending_true ? (int64_t)(c->h_read[3] & 0xFFFFFFFFull) : c->last_slots;
         if ((int)(c->h_read[1] & 0xFFFFFFFFull) != 0) c->late_error = R2S_ERR_PREFILTERED;
-        if ((int)(c->h_read[2] & 0xFFFFFFFFull) != 0) { c->overflows++; c->L_cap = 0; sync_free = false; }
+        if ((int)(c->h_read[2] & 0xFFFFFFFFull) != 0) { c->overflows++; c->L_cap = 0; sync_free = false; c->last_L = c->last_slots; } // (its histograms cover the slots that fitted: report what it needed)
         else if (c->L_cap > 0) {
             // follow the scene BOTH ways, one batch late: everything behind the emission (sentinel fill, tile sort, ranges) runs over the
             // capacity, not over the count, so slack is paid for on every step — 12.5 % + 4096 (a rollout's count moves by a percent or two
             // per step; a bigger jump is an overflow: reported, and the closed loop renders that step again).  Growing-only with 25 % of
             // slack had the tile sort work on 1.25 x the PEAK count of the episode.
-            const uint64_t want = (uint64_t)c->last_L + c->last_L / 8 + 4096;
+            const uint64_t want = (uint64_t)c->last_slots + c->last_slots / 8 + 4096;
             c->L_cap = (uint32_t)std::min<uint64_t>(want, 0xFFFFFFF0ull);
         }
     }
     mark(0);
     uint32_t L = 0;
+    // one-pass binning (k_bin_*) wherever a frame's tiles fit its LDS counters; otherwise (and with R2S_RASTER_RADIX_SORT set: A/B knob) the radix sort
+    const bool bin_pass = c->bin_pass && !SURV_MASKS && tiles <= BIN_MAX_TILES && F <= BIN_MAX_FRAMES; // (the survivor-mask experiment needs the exact counts: radix path)
+    // ... on which the emission slots follow from the rectangles (KEY_NONE): k_preprocess counts the survivors of the culling test only for the radix sort
+    const int count_exact = (c->cull && !bin_pass) ? 1 : 0;
     DepthOrder order{nullptr, c->d_frames, (int)idx_bits};
     if (G > 0) {
         dim3 grid((maxP + 255) / 256, F);
         hipLaunchKernelGGL(k_preprocess, grid, dim3(256), 0, stream, c->d_frames, gx, gy, W, H, depths, radii_all, geom,
-                           tiles_touched, err_flag, c->cull, gkeys_a, (int)idx_bits, surv);
+                           tiles_touched, err_flag, c->cull, count_exact, gkeys_a, (int)idx_bits, surv);
         mark(1);
         rocprim::double_buffer<uint64_t> dgk(gkeys_a, gkeys_b);
         R2S_HIP_TRY(rocprim::radix_sort_keys<GaussSortConfig>(gsort_tmp, gsort_bytes, dgk, G, idx_bits, idx_bits + 32u + fbits, stream));
@@ -1339,7 +1398,7 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
             R2S_HIP_TRY(hipStreamSynchronize(stream));
             L = (uint32_t)(c->h_read[0] & 0xFFFFFFFFull);
             if ((int)(c->h_read[1] & 0xFFFFFFFFull) != 0) return R2S_ERR_PREFILTERED;
-            c->last_L = L;
+            c->last_L = L; c->last_slots = L;
             if (c->async_mode) c->L_cap = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 8 + 4096, 0xFFFFFFF0ull); // first call of the mode
         }
     } else {
@@ -1351,13 +1410,12 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     // the count changes by a fraction of a per cent per env step; 25 % headroom, and an overflow flag if it ever is not enough)
     const uint32_t cap = sync_free ? c->L_cap : L;
     const uint32_t bits = higher_msb((uint32_t)F * (uint32_t)tiles + (sync_free ? 1u : 0u)); // + 1: the sentinel key F * tiles
-    // one-pass binning (k_bin_*) wherever a frame's tiles fit its LDS counters; otherwise (and with R2S_RASTER_RADIX_SORT set: A/B knob) the radix sort
-    const bool bin_pass = c->bin_pass && tiles <= BIN_MAX_TILES && F <= BIN_MAX_FRAMES;
     uint32_t *keys_a = nullptr, *keys_b = nullptr;
     uint32_t *vals_a = nullptr, *vals_b = nullptr;
     const uint32_t* keys_sorted = nullptr;
     const uint32_t* vals_sorted = nullptr;
-    bool ranges_done = false;
+    bool ranges_done = false, count_pending = false;
+    const uint32_t* frame_start_dev = nullptr;
     const bool want_order = cap > 0 && G > 0 && FT >= 4096 && c->tile_order; // compositor workgroups longest list first (big batches)
     if (want_order) R2S_HIP_TRY(hipMemsetAsync(tl_cls, 0, sizeof(uint32_t) * (2u << TILE_ORDER_BITS), stream));
     if (cap > 0 && G > 0) {
@@ -1367,12 +1425,13 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         if (!bin_pass) R2S_HIP_TRY(rocprim::radix_sort_pairs<TileSortConfig>(nullptr, sort_bytes, dk, dv, (size_t)cap, 0u, bits, stream));
         const uint32_t nb_max = cap / BIN_CHUNK + (uint32_t)F; // every frame ends in at most one partial chunk
         uint32_t *bin_hist = nullptr, *bin_first = nullptr, *bin_totals = nullptr, *bin_local = nullptr, *bin_gsum = nullptr;
+        uint32_t* bin_fstart = nullptr; // instances before each frame; [F]: of the batch
         uint4* bin_desc = nullptr;
         char* sort_tmp = nullptr;
         {
             r2s::Carver sz(nullptr);
             sz.take<uint32_t>(bin_pass ? (cap + 1) / 2 : cap); sz.take<uint32_t>(cap); sz.take<uint32_t>(cap);
-            if (bin_pass) { sz.take<uint32_t>((size_t)nb_max * tiles); sz.take<uint4>(nb_max); sz.take<uint32_t>((size_t)F + 1); sz.take<uint32_t>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>((FT + 255) / 256); }
+            if (bin_pass) { sz.take<uint32_t>((size_t)nb_max * tiles); sz.take<uint4>(nb_max); sz.take<uint32_t>((size_t)F + 1); sz.take<uint32_t>(FT); sz.take<uint32_t>(FT); sz.take<uint32_t>((FT + 255) / 256); sz.take<uint32_t>((size_t)F + 1); }
             else { sz.take<uint32_t>(cap); sz.take<char>(sort_bytes); }
             char* p = c->scratch(1, sz.bytes());
             if (!p) return R2S_ERR_ALLOC;
@@ -1380,7 +1439,7 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
             keys_a = cv.take<uint32_t>(bin_pass ? (cap + 1) / 2 : cap); vals_a = cv.take<uint32_t>(cap); vals_b = cv.take<uint32_t>(cap);
             if (bin_pass) {
                 bin_hist = cv.take<uint32_t>((size_t)nb_max * tiles); bin_desc = cv.take<uint4>(nb_max); bin_first = cv.take<uint32_t>((size_t)F + 1);
-                bin_totals = cv.take<uint32_t>(FT); bin_local = cv.take<uint32_t>(FT); bin_gsum = cv.take<uint32_t>((FT + 255) / 256);
+                bin_totals = cv.take<uint32_t>(FT); bin_local = cv.take<uint32_t>(FT); bin_gsum = cv.take<uint32_t>((FT + 255) / 256); bin_fstart = cv.take<uint32_t>((size_t)F + 1);
             } else { keys_b = cv.take<uint32_t>(cap); sort_tmp = cv.take<char>(sort_bytes); }
         }
 
@@ -1407,7 +1466,14 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
             hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(1024), 0, stream, c->d_frames, F, offsets, cap, nb_max, bin_desc, bin_first);
             hipLaunchKernelGGL(k_bin_hist, dim3(nb_max), dim3(BIN_THREADS), sizeof(uint32_t) * tiles, stream, bin_desc, tiles, keys16, bin_hist);
             hipLaunchKernelGGL(k_bin_colscan, dim3((unsigned)((FT + 255) / 256)), dim3(256), 0, stream, F, tiles, bin_first, bin_hist, bin_totals, bin_local, bin_gsum);
-            hipLaunchKernelGGL(k_tile_starts, dim3((unsigned)((FT + 255) / 256)), dim3(256), 0, stream, (uint32_t)FT, bin_totals, bin_local, bin_gsum, ranges, want_order ? tl_cls : nullptr);
+            hipLaunchKernelGGL(k_tile_starts, dim3((unsigned)((FT + 255) / 256)), dim3(256), 0, stream, (uint32_t)FT, bin_totals, bin_local, bin_gsum, ranges, want_order ? tl_cls : nullptr, (uint32_t)tiles, bin_fstart);
+            R2S_HIP_TRY(hipMemcpyAsync(&c->h_read[3], bin_fstart + F, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)); // the instance count
+            if (!sync_free && c->cull) { // a synchronous call returns the count: wait for it (not for the kernels behind it) at the end
+                if (!c->cnt_ev) R2S_HIP_TRY(hipEventCreateWithFlags(&c->cnt_ev, hipEventDisableTiming));
+                R2S_HIP_TRY(hipEventRecord(c->cnt_ev, stream));
+                count_pending = true;
+            }
+            frame_start_dev = bin_fstart;
             const size_t sc_lds = sizeof(uint32_t) * tiles * (BIN_THREADS / 64);
             if (key_bits <= 9)
                 hipLaunchKernelGGL(k_bin_scatter<9>, dim3(nb_max), dim3(BIN_THREADS), sc_lds, stream, bin_desc, tiles, keys16, vals_a, bin_hist, ranges, vals_b);
@@ -1456,6 +1522,7 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         if (!c->done_ev) R2S_HIP_TRY(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
         R2S_HIP_TRY(hipEventRecord(c->done_ev, stream));
         c->pending = true;
+        c->pending_true = ranges_done;
     }
 
     // per-frame instance counts: offsets at frame boundaries are not read back (that would add syncs);
@@ -1469,15 +1536,28 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
             c->stage_ms[k] = ms;
         }
     }
+    int64_t L_report = sync_free ? c->last_L : (int64_t)L;
+    if (count_pending) { // binning path with culling: the count is the histograms' total, not the slots' scan
+        R2S_HIP_TRY(hipEventSynchronize(c->cnt_ev));
+        L_report = (int64_t)(c->h_read[3] & 0xFFFFFFFFull);
+        c->last_L = L_report;
+    }
     if (per_frame_out) {
-        // one small D2H per frame boundary, only when asked for
         std::vector<uint32_t> ends(F, 0);
-        for (int f = 0; f < F; ++f) {
-            const uint64_t endg = (uint64_t)c->h_frames[f].base + (uint64_t)c->h_frames[f].P;
-            if (endg == 0) { ends[f] = 0; continue; }
-            R2S_HIP_TRY(hipMemcpyAsync(&ends[f], offsets + (endg - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (frame_start_dev) { // binning path: the scan of the tile totals at the frame boundaries
+            std::vector<uint32_t> fs((size_t)F + 1, 0);
+            R2S_HIP_TRY(hipMemcpyAsync(fs.data(), frame_start_dev, sizeof(uint32_t) * ((size_t)F + 1), hipMemcpyDeviceToHost, stream));
+            R2S_HIP_TRY(hipStreamSynchronize(stream));
+            for (int f = 0; f < F; ++f) ends[f] = fs[(size_t)f + 1];
+        } else {
+            // one small D2H per frame boundary, only when asked for
+            for (int f = 0; f < F; ++f) {
+                const uint64_t endg = (uint64_t)c->h_frames[f].base + (uint64_t)c->h_frames[f].P;
+                if (endg == 0) { ends[f] = 0; continue; }
+                R2S_HIP_TRY(hipMemcpyAsync(&ends[f], offsets + (endg - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            }
+            R2S_HIP_TRY(hipStreamSynchronize(stream));
         }
-        R2S_HIP_TRY(hipStreamSynchronize(stream));
         uint32_t prev = 0;
         for (int f = 0; f < F; ++f) {
             per_frame_out[f] = (int64_t)(ends[f] - prev);
@@ -1485,7 +1565,7 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
         }
     }
     c->dbg.total_gaussians = (int64_t)G;
-    c->dbg.num_rendered = sync_free ? c->last_L : (int64_t)L;
+    c->dbg.num_rendered = L_report;
     c->dbg.depths = depths;
     c->dbg.radii = radii_all;
     c->dbg.geom = reinterpret_cast<const float*>(geom);
@@ -1494,7 +1574,7 @@ int64_t forward_impl(R2SRasterCtx* c, const R2SGaussianSet* sets, int n_sets, co
     c->dbg.keys_sorted = keys_sorted;
     c->dbg.point_list = vals_sorted;
     c->dbg.ranges = reinterpret_cast<const uint32_t*>(ranges);
-    return sync_free ? c->last_L : (int64_t)L; // sync-free: the most recent count the host has seen (an earlier batch's)
+    return L_report; // sync-free: the most recent count the host has seen (an earlier batch's)
 }
 
 } // namespace
@@ -1518,6 +1598,7 @@ void r2s_raster_ctx_destroy(R2SRasterCtx* c)
     if (c->h_frames) (void)hipHostFree(c->h_frames);
     if (c->h_read) (void)hipHostFree(c->h_read);
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
+    if (c->cnt_ev) (void)hipEventDestroy(c->cnt_ev);
     if (c->ev_ok) for (auto& e : c->ev) (void)hipEventDestroy(e);
     delete c;
 }
@@ -1536,9 +1617,10 @@ int r2s_raster_ctx_poll(R2SRasterCtx* c, int wait, int64_t* num_rendered, int32_
     if (c->pending && (wait || hipEventQuery(c->done_ev) == hipSuccess)) {
         R2S_HIP_TRY(hipEventSynchronize(c->done_ev));
         c->pending = false;
-        c->last_L = (int64_t)(c->h_read[0] & 0xFFFFFFFFull);
+        c->last_slots = (int64_t)(c->h_read[0] & 0xFFFFFFFFull);
+        c->last_L = c->pending_true ? (int64_t)(c->h_read[3] & 0xFFFFFFFFull) : c->last_slots;
         if ((int)(c->h_read[1] & 0xFFFFFFFFull) != 0) c->late_error = R2S_ERR_PREFILTERED;
-        if ((int)(c->h_read[2] & 0xFFFFFFFFull) != 0) { c->overflows++; c->L_cap = 0; }
+        if ((int)(c->h_read[2] & 0xFFFFFFFFull) != 0) { c->overflows++; c->L_cap = 0; c->last_L = c->last_slots; }
     }
     if (num_rendered) *num_rendered = c->last_L;
     if (overflows) *overflows = c->overflows;

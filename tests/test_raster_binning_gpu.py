@@ -159,13 +159,26 @@ def test_sync_free_batches_bin_with_a_capacity_and_report_an_overflow():
     big_c = torch.empty(2, 3, H, W, device=dev); big_d = torch.empty(2, 1, H, W, device=dev)
     big_args = frames_for(rb, big, big_c, big_d)
     rb.forward(*big_args, W, H)    # four times the instances: beyond the capacity
-    rc, n_big, over = rb.poll(wait=True)
+    rc, n_big, over = rb.poll(wait=True)       # an overflowing batch reports the emission slots it needed (>= its instance count)
     assert over == 1 and n_big > n_small * 2
     rb.forward(*big_args, W, H)    # re-sized by synchronising once
     rc, n2, over2 = rb.poll(wait=True)
-    assert over2 == 1 and n2 == n_big
     exp_c = torch.empty(2, 3, H, W, device=dev); exp_d = torch.empty(2, 1, H, W, device=dev)
     rb2 = _ctx(dev, True); rb2.set_tile_culling(True)
-    rb2.forward(*frames_for(rb2, big, exp_c, exp_d), W, H)
+    n_exact = rb2.forward(*frames_for(rb2, big, exp_c, exp_d), W, H)   # radix-sort path: the survivors are counted before the emission
     torch.cuda.synchronize()
+    assert over2 == 1 and n2 == n_exact and n_big >= n_exact
     assert torch.equal(big_c, exp_c) and torch.equal(big_d, exp_d)
+
+
+def test_binning_with_poisoned_allocations_in_a_fresh_process():
+    """R2S_POISON=1 (every device allocation of the library filled with 0xFF, read once per process): the binning must not read a histogram
+    row, chunk descriptor or class counter it never wrote — the batch comparison above, run again in a poisoned subprocess."""
+    import subprocess
+    import sys
+
+    here = os.path.abspath(__file__)
+    env = dict(os.environ, R2S_POISON="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-m", "gpu", "-k", "equals_radix_sort_path and 640", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0 and "2 passed" in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-800:])

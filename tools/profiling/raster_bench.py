@@ -13,5 +13,6 @@ for i in range(6):
     st = ro.raster.stage_ms()
     if i: 
         for k, v in st.items(): acc[k] = acc.get(k, 0) + v / 5
+d = ro.raster.debug(); slots = int(d["point_offsets"][-1]) if len(d["point_offsets"]) else 0
 h = hashlib.sha1(ro.out_color.cpu().numpy().tobytes() + ro.out_depth.cpu().numpy().tobytes()).hexdigest()[:12]
-print(json.dumps({"cfg": cfg, "n_env": ro.n_env, "L": int(ro.last_num_rendered), "sha": h, "total": sum(acc.values()), **{k: round(v, 4) for k, v in acc.items()}}))
+print(json.dumps({"cfg": cfg, "n_env": ro.n_env, "L": int(ro.last_num_rendered), "slots": slots, "sha": h, "total": sum(acc.values()), **{k: round(v, 4) for k, v in acc.items()}}))
