@@ -182,3 +182,28 @@ def test_binning_with_poisoned_allocations_in_a_fresh_process():
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-m", "gpu", "-k", "equals_radix_sort_path and 640", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(here)))
     assert r.returncode == 0 and "2 passed" in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-800:])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_binning_equals_radix_sort_path_on_random_shapes(seed):
+    """Odd shapes: widths / heights that are no multiple of the tile, one to seven frames, sets of 1 to a few thousand Gaussians (frames far
+    below one chunk, sets of different sizes in one batch), culling on and off — both paths, identical counts, lists, ranges and pixels."""
+    import torch
+    from r2s_hip import synth
+
+    rng = np.random.default_rng(1000 + seed)
+    dev = torch.device("cuda:0")
+    W, H = int(rng.integers(40, 700)), int(rng.integers(30, 500))
+    cams = [synth.side_camera(W, H), synth.wrist_camera(W, H)]
+    sizes = [int(rng.choice([1, 7, 64, 300, 2500, 6000])) for _ in range(int(rng.integers(1, 4)))]
+    scenes = [synth.gaussian_scene(max(p, 3), 200 + 10 * seed + k) for k, p in enumerate(sizes)]
+    for sc, p in zip(scenes, sizes):      # cut to the drawn size (gaussian_scene needs a few points to lay out its table)
+        for key in ("means3D", "opacities", "shs", "scales", "rotations"):
+            sc[key] = np.ascontiguousarray(sc[key][:p])
+    frame_of = [(int(rng.integers(0, len(scenes))), int(rng.integers(0, 2)), None) for _ in range(int(rng.integers(1, 8)))]
+    for cull in (False, True):
+        a = _render(_ctx(dev, False), scenes, cams, frame_of, W, H, dev, cull)
+        b = _render(_ctx(dev, True), scenes, cams, frame_of, W, H, dev, cull)
+        assert a[0] == b[0], (W, H, sizes, frame_of, cull)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (W, H, sizes, frame_of, cull)
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]), (W, H, sizes, frame_of, cull)
