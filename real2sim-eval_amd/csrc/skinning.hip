@@ -142,11 +142,7 @@ __global__ void __launch_bounds__(256) k_skin(int E, int N, int P, int k_wgt, co
     const float x = xyz[ep], y = xyz[ep + 1], z = xyz[ep + 2];
     const bool ident = ident_flag[e] != 0;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for (int k = 0; k < k_wgt; ++k) {
-        const int j = widx[(size_t)k * P + t];
-        const float w = weights[(size_t)k * P + t];
-        const float4* q = reinterpret_cast<const float4*>(rec + (size_t)e * N + j);
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3]; // r0..r3 | r4..r7 | r8 b0 b1 b2 | m0 m1 m2 pad
+    auto blend = [&](const float4 q0, const float4 q1, const float4 q2, const float4 q3, const float w) { // r0..r3 | r4..r7 | r8 b0 b1 b2 | m0 m1 m2 pad
         const float dx = x - q2.y, dy = y - q2.z, dz = z - q2.w;
         float tx, ty, tz;
         if (ident) { tx = dx; ty = dy; tz = dz; }
@@ -157,6 +153,31 @@ __global__ void __launch_bounds__(256) k_skin(int E, int N, int P, int k_wgt, co
         }
         tx = tx + q3.x + q2.y; ty = ty + q3.y + q2.z; tz = tz + q3.z + q2.w;
         ax += tx * w; ay += ty * w; az += tz * w;
+    };
+    // The kernel waits for its gathers (VALU busy 0.12): four bones at a time — their indices, then their sixteen 16-byte gathers, are in
+    // flight together; the sums run in the reference's order (bone 0 first).
+#ifndef R2S_SKIN_BATCH
+#define R2S_SKIN_BATCH 8 // bones whose gathers are in flight together: 1 (the loop until round 6) 208 us per 32-environment call, 2: 167, 4: 157, 8: 148 (two wavefronts per SIMD)
+#endif
+    constexpr int SB = R2S_SKIN_BATCH;
+    int k = 0;
+    for (; k + SB <= k_wgt; k += SB) {
+        int j[SB]; float w[SB]; float4 r[SB][4];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) { j[u] = widx[(size_t)(k + u) * P + t]; w[u] = weights[(size_t)(k + u) * P + t]; }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const float4* q = reinterpret_cast<const float4*>(rec + (size_t)e * N + j[u]);
+            r[u][0] = q[0]; r[u][1] = q[1]; r[u][2] = q[2]; r[u][3] = q[3];
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) blend(r[u][0], r[u][1], r[u][2], r[u][3], w[u]);
+    }
+    for (; k < k_wgt; ++k) {
+        const int j = widx[(size_t)k * P + t];
+        const float w = weights[(size_t)k * P + t];
+        const float4* q = reinterpret_cast<const float4*>(rec + (size_t)e * N + j);
+        blend(q[0], q[1], q[2], q[3], w);
     }
     out[eo] = ax; out[eo + 1] = ay; out[eo + 2] = az;
 }
