@@ -113,3 +113,33 @@ def test_hand_offs_under_uneven_load_a_second_stream_streaming_through_hbm():
     assert sa["mesh_contacts"] > 0 and sa["self_collision_candidates"] > 0
     for k in range(steps):
         assert np.array_equal(xa[k], xb[k]) and np.array_equal(va[k], vb[k]), (k, float(np.abs(xa[k] - xb[k]).max()))
+
+
+def test_chains_captured_as_head_and_tail_graphs_equal_one_graph_per_chain_bit_for_bit():
+    """Round 6: every chain is captured as a head graph (R2S_GRAPH_HEAD substeps, default 64) and a tail graph, all heads launched before any
+    tail (csrc/physics.hip capture_graph / launch_graphs) — the same launches in the same order on the same streams.  The grasp of the toy
+    (two chains, finishers at the head of the next launch, candidates) with one graph per chain (0), the default, and a head of 7 substeps
+    (odd: the tail starts on the other parity of the state buffer): every env step the same bits."""
+    import os
+
+    steps = 5
+    runs = {}
+    old = os.environ.get("R2S_GRAPH_HEAD")
+    try:
+        for head in ("0", "64", "7"):
+            os.environ["R2S_GRAPH_HEAD"] = head          # read once per handle, at create
+            runs[head] = _rollout("sloth_32env", 9, True, steps)
+    finally:
+        if old is None:
+            os.environ.pop("R2S_GRAPH_HEAD", None)
+        else:
+            os.environ["R2S_GRAPH_HEAD"] = old
+    xa, va, fa, sa, da, ta = runs["0"]
+    assert fa[-1]["finishers_at_head_of_next_launch"] and fa[-1]["chains"] == 2 and sa["mesh_contacts"] > 0 and sa["self_collision_candidates"] > 0
+    for head in ("64", "7"):
+        xb, vb, fb, sb, db, tb = runs[head]
+        assert [f["kernel"] for f in fa] == [f["kernel"] for f in fb]
+        assert np.array_equal(da, db) and ta == tb
+        for k in range(steps):
+            assert np.array_equal(xa[k], xb[k]) and np.array_equal(va[k], vb[k]), (head, k, float(np.abs(xa[k] - xb[k]).max()))
+    record("chains as head + tail graphs vs one graph per chain", env_steps=steps, envs=9, heads=[0, 64, 7], x_max_abs=0.0, tol=0)
